@@ -1,0 +1,250 @@
+"""CPU oracle: NumPy restatement of the reference Monte Carlo hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``optionslab_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` use it, and there only as the checker / the timed CPU
+baseline, never as the thing shipped.
+
+Parity status: PINNED.  Every function below is checked bit-for-bit against
+vectors captured by importing the reference itself in the build container
+(``tests/golden/make_golden.py`` -> ``tests/golden/reference_vectors.json``,
+NumPy 2.2.6 / SciPy 1.15.3); see ``tests/test_oracle_golden.py``.
+
+The arithmetic order of every expression is the reference's, because fp64
+results are compared with ``==``.  Citations are ``/root/reference`` paths.
+"""
+
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import numpy as np
+from scipy.stats import norm
+from scipy.stats.qmc import Sobol
+
+SOBOL_MAX_DIM = 21201  # src/simulation/gbm_qmc.py:29-30
+
+
+# --------------------------------------------------------------------------
+# a13  Black-Scholes-Merton closed form (src/pricing_models/black_scholes.py:9-52)
+# --------------------------------------------------------------------------
+def bs_price(S, K, T, r, sigma, option_type="call", q=0.0):
+    if S <= 0 or K <= 0 or T < 0 or sigma < 0:  # :31-34
+        raise ValueError("Invalid input: all inputs must be positive, and T, sigma >= 0")
+    if T == 0:  # :37-38
+        return max(S - K, 0.0) if option_type == "call" else max(K - S, 0.0)
+    sq = sigma * np.sqrt(T)
+    d1 = (np.log(S / K) + (r - q + 0.5 * sigma**2) * T) / sq  # :40
+    d2 = d1 - sq  # :41
+    if option_type == "call":  # :43-44
+        return S * np.exp(-q * T) * norm.cdf(d1) - K * np.exp(-r * T) * norm.cdf(d2)
+    if option_type == "put":  # :46-47
+        return K * np.exp(-r * T) * norm.cdf(-d2) - S * np.exp(-q * T) * norm.cdf(-d1)
+    raise ValueError("option_type must be 'call' or 'put'")
+
+
+def bs_greeks(S, K, T, r, sigma, option_type="call", q=0.0):
+    """Analytic BSM Greeks (not in the reference; SURVEY G0' accuracy anchor)."""
+    sq = sigma * math.sqrt(T)
+    d1 = (math.log(S / K) + (r - q + 0.5 * sigma * sigma) * T) / sq
+    d2 = d1 - sq
+    pdf = math.exp(-0.5 * d1 * d1) / math.sqrt(2.0 * math.pi)
+    eq, er = math.exp(-q * T), math.exp(-r * T)
+    sign = 1.0 if option_type == "call" else -1.0
+    Nd1, Nd2 = float(norm.cdf(sign * d1)), float(norm.cdf(sign * d2))
+    return OrderedDict(
+        delta=sign * eq * Nd1,
+        gamma=eq * pdf / (S * sq),
+        vega=S * eq * pdf * math.sqrt(T),
+        theta=(-S * eq * pdf * sigma / (2.0 * math.sqrt(T)) - sign * r * K * er * Nd2 + sign * q * S * eq * Nd1),
+        rho=sign * K * T * er * Nd2,
+    )
+
+
+# --------------------------------------------------------------------------
+# a4/a5/a10  terminal-price backends (src/simulation/*.py)
+# --------------------------------------------------------------------------
+def terminal_multistep(S, T, r, sigma, q, n_paths, n_steps, seed, antithetic=True):
+    """src/simulation/gbm_numpy.py:15-53 -- PCG64 normals (N, M), row sums."""
+    gen = np.random.default_rng(seed)  # :32
+    dt = T / n_steps  # :35
+    drift = (r - q - 0.5 * sigma * sigma) * dt  # :36
+    vol = sigma * np.sqrt(dt)  # :37
+    total_drift = drift * n_steps  # :38
+    log_S0 = np.log(S)  # :39
+    Z = gen.standard_normal((n_paths, n_steps))  # :43
+    up = log_S0 + total_drift + vol * np.sum(Z, axis=1)  # :46
+    if not antithetic:
+        return np.exp(up)  # :53
+    dn = log_S0 + total_drift - vol * np.sum(Z, axis=1)  # :50
+    return np.concatenate([np.exp(up), np.exp(dn)])  # :51  layout [pos | neg]
+
+
+def terminal_singlestep(S, T, r, sigma, q, n_paths, seed):
+    """src/simulation/gbm_numpy.py:56-83 -- closed-form single draw per path."""
+    gen = np.random.default_rng(seed)  # :71
+    drift = (r - q - 0.5 * sigma * sigma) * T  # :73
+    vol = sigma * np.sqrt(T)  # :74
+    log_S0 = np.log(S)  # :75
+    Z = gen.standard_normal(n_paths)  # :77
+    return np.concatenate([np.exp(log_S0 + drift + vol * Z), np.exp(log_S0 + drift - vol * Z)])  # :80-83
+
+
+def terminal_sobol(S, T, r, sigma, q, n_paths, n_steps, seed):
+    """src/simulation/gbm_qmc.py:14-46 -- scrambled Sobol, no antithetic."""
+    dims = min(n_steps, SOBOL_MAX_DIM)  # :30
+    u = Sobol(d=dims, scramble=True, seed=seed).random(n_paths)  # :32-33
+    z = norm.ppf(np.clip(u, 1e-10, 1 - 1e-10))  # :36
+    dt = T / dims  # :38
+    drift = (r - q - 0.5 * sigma * sigma) * dt
+    vol = sigma * np.sqrt(dt)
+    log_S0 = np.log(S)
+    return np.exp(log_S0 + drift * dims + vol * np.sum(z, axis=1))  # :44-46
+
+
+# --------------------------------------------------------------------------
+# a1-a3, a6-a8  the pricer (src/pricing_models/monte_carlo.py:28-186)
+# --------------------------------------------------------------------------
+@dataclass
+class OracleResult:  # MCResult, monte_carlo.py:37-43
+    price: float
+    std_error: float = 0.0
+    n_paths: int = 0
+
+
+class OraclePricer:
+    """MonteCarloPricer restated (monte_carlo.py:46-186); method is a plain
+    string in {"numpy", "numba", "qmc", "fast"} (MCMethod values, :28-34)."""
+
+    def __init__(self, num_simulations=100000, num_steps=1, seed=None, method="numpy"):
+        if num_simulations < 1:  # :63-64
+            raise ValueError("num_simulations must be >= 1")
+        self.num_simulations = num_simulations
+        self.num_steps = num_steps
+        self.seed = seed if seed is not None else np.random.default_rng().integers(0, 2**31)  # :68-70
+        self.method = method
+
+    def terminal(self, S, T, r, sigma, q, seed=None):  # _simulate, :74-106
+        s = seed if seed is not None else self.seed  # :84
+        if self.method == "fast" or (self.num_steps == 1 and self.method == "numpy"):  # :87-92
+            return terminal_singlestep(S, T, r, sigma, q, self.num_simulations, s)
+        if self.method == "qmc":  # :94-97
+            return terminal_sobol(S, T, r, sigma, q, self.num_simulations, self.num_steps, s)
+        # numba is absent wherever this oracle runs => silent NumPy path (:72, :99-106)
+        return terminal_multistep(S, T, r, sigma, q, self.num_simulations, self.num_steps, s)
+
+    def price(self, S, K, T, r, sigma, option_type, q=0.0, seed=None, return_error=False):  # :108-152
+        if T <= 0:  # :133-135
+            intrinsic = max(S - K, 0) if option_type == "call" else max(K - S, 0)
+            return OracleResult(intrinsic, 0.0, 0) if return_error else intrinsic
+        st = self.terminal(S, T, r, sigma, q, seed)
+        x = np.maximum(st - K, 0.0) if option_type == "call" else np.maximum(K - st, 0.0)  # :140-143
+        disc = np.exp(-r * T)
+        value = float(disc * np.mean(x))  # :145-146
+        if return_error:  # :148-150  naive ddof=0 estimator over all 2N samples
+            return OracleResult(value, float(disc * np.std(x) / np.sqrt(len(x))), len(x))
+        return value
+
+    def price_with_control_variate(self, S, K, T, r, sigma, option_type, q=0.0, seed=None):  # :154-186
+        st = self.terminal(S, T, r, sigma, q, seed)
+        x = np.maximum(st - K, 0.0) if option_type == "call" else np.maximum(K - st, 0.0)
+        d = np.exp(-r * T) * x  # :175
+        fwd = S * np.exp((r - q) * T)  # :179
+        c = np.cov(d, st)  # :181  (ddof=1)
+        beta = c[0, 1] / c[1, 1] if c[1, 1] > 1e-10 else 0.0  # :182
+        return float(np.mean(d) - beta * (np.mean(st) - fwd))  # :184
+
+
+# --------------------------------------------------------------------------
+# a11  finite-difference Greeks driver (src/greeks/unified_greeks.py:235-367)
+# --------------------------------------------------------------------------
+FD_H_RATE = 1e-4  # :276
+FD_H_TIME = 1 / 365.0  # :277
+
+
+def fd_steps(S):
+    """(h_S, h_sigma, h_r, h_T) -- unified_greeks.py:274-277."""
+    return max(1e-4, 0.01 * S), max(1e-4, 0.01), FD_H_RATE, FD_H_TIME
+
+
+def fd_greeks(price_fn: Callable[..., float], S, K, T, r, sigma, option_type="call", q=0.0,
+              include_second_order=True, **kw):
+    """``price_fn(S,K,T,r,sigma,option_type,q,**kw)``; bump-and-reprice with a
+    memo on the parameter tuple (:280-288).  Returns the same OrderedDict."""
+    h_S, h_v, h_r, h_T = fd_steps(S)
+    memo = {}
+
+    def P(S_=S, T_=T, r_=r, v_=sigma):
+        k = (S_, K, T_, r_, v_, q)
+        if k not in memo:
+            memo[k] = price_fn(S_, K, T_, r_, v_, option_type, q, **kw)
+        return memo[k]
+
+    mid = P()  # :295
+    su, sd = P(S_=S + h_S), P(S_=S - h_S)  # :298-299
+    delta = (su - sd) / (2 * h_S)  # :301
+    gamma = (su - 2 * mid + sd) / (h_S**2)  # :302
+    vu, vd = P(v_=sigma + h_v), P(v_=sigma - h_v)  # :305-306
+    vega = (vu - vd) / (2 * h_v)  # :307
+    if T > h_T:  # :310-314
+        theta = (P(T_=T - h_T) - mid) / h_T
+    else:
+        theta = -mid / max(T, 1e-6)
+    ru, rd = P(r_=r + h_r), P(r_=r - h_r)  # :317-318
+    rho = (ru - rd) / (2 * h_r)  # :319
+    out = OrderedDict(price=mid, delta=delta, gamma=gamma, vega=vega, theta=theta, rho=rho)
+    if include_second_order:  # :336-362
+        uu, ud = P(S_=S + h_S, v_=sigma + h_v), P(S_=S + h_S, v_=sigma - h_v)
+        du, dd = P(S_=S - h_S, v_=sigma + h_v), P(S_=S - h_S, v_=sigma - h_v)
+        out["vanna"] = (uu - ud - du + dd) / (4 * h_S * h_v)  # :343-345
+        if T > h_T:  # :348-354
+            d_down = (P(S_=S + h_S, T_=T - h_T) - P(S_=S - h_S, T_=T - h_T)) / (2 * h_S)
+            out["charm"] = (d_down - delta) / h_T
+        else:
+            out["charm"] = 0.0
+        out["vomma"] = (vu - 2 * mid + vd) / (h_v**2)  # :357
+    return out
+
+
+# --------------------------------------------------------------------------
+# a12  Asian option on full paths (src/pricing_models/exotic_options.py:40-160)
+# --------------------------------------------------------------------------
+def asian_paths(S, T, r, sigma, q, n_paths, n_steps, seed: Optional[int]):
+    """exotic_options.py:40-67 -- legacy global RandomState (MT19937), no antithetic."""
+    if seed is not None:  # :51-52
+        np.random.seed(seed)
+    dt = T / n_steps
+    drift = (r - q - 0.5 * sigma**2) * dt  # :55
+    diffusion = sigma * np.sqrt(dt)  # :56
+    Z = np.random.standard_normal((n_paths, n_steps))  # :59
+    steps = drift + diffusion * Z  # :62
+    log_S = np.zeros((n_paths, n_steps + 1))
+    log_S[:, 0] = np.log(S)
+    log_S[:, 1:] = np.log(S) + np.cumsum(steps, axis=1)  # :65
+    return np.exp(log_S)  # :67
+
+
+def asian_price(S, K, T, r, sigma, q=0.0, seed=None, n_paths=100000, n_steps=252,
+                avg_type="arithmetic", option_type="call"):
+    """exotic_options.py:97-131 -- average over t=1..M (t=0 excluded)."""
+    paths = asian_paths(S, T, r, sigma, q, n_paths, n_steps, seed)
+    if avg_type == "arithmetic":  # :119-120
+        avg = np.mean(paths[:, 1:], axis=1)
+    else:  # :121-122
+        avg = np.exp(np.mean(np.log(paths[:, 1:]), axis=1))
+    x = np.maximum(avg - K, 0) if option_type == "call" else np.maximum(K - avg, 0)  # :125-128
+    return np.exp(-r * T) * np.mean(x)  # :131  (np.float64)
+
+
+def asian_geometric_closed_form(S, K, T, r, sigma, q=0.0, option_type="call"):
+    """exotic_options.py:133-160 (continuous-monitoring lognormal approximation)."""
+    v = sigma / np.sqrt(3)  # :145
+    b = 0.5 * (r - q - sigma**2 / 6)  # :146
+    d1 = (np.log(S / K) + (b + 0.5 * v**2) * T) / (v * np.sqrt(T))  # :148-150
+    d2 = d1 - v * np.sqrt(T)  # :151
+    if option_type == "call":  # :153-156
+        return S * np.exp((b - r) * T) * norm.cdf(d1) - K * np.exp(-r * T) * norm.cdf(d2)
+    return K * np.exp(-r * T) * norm.cdf(-d2) - S * np.exp((b - r) * T) * norm.cdf(-d1)  # :158-160

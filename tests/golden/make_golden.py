@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/reference_vectors.json by RUNNING the reference.
+
+Run only in the build container, where /root/reference is mounted read-only:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference never travels: this script imports it in place, records inputs
+and outputs (data only) and writes a small JSON fixture.  `import src` the
+normal way fails here (its package __init__ files pull numba / streamlit,
+which are absent), so empty parent packages are registered first and only the
+hot-path modules -- which need NumPy/SciPy alone -- are imported.
+"""
+
+import json
+import os
+import sys
+import types
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_vectors.json")
+
+
+def load_reference():
+    for name, rel in (("src", "src"), ("src.pricing_models", "src/pricing_models"), ("src.greeks", "src/greeks")):
+        pkg = types.ModuleType(name)
+        pkg.__path__ = [os.path.join(REF, rel)]
+        sys.modules[name] = pkg
+    sys.path.insert(0, REF)
+    from src.greeks.unified_greeks import ExoticAdapter, compute_greeks_unified
+    from src.pricing_models.black_scholes import black_scholes
+    from src.pricing_models.exotic_options import AsianOption, price_asian
+    from src.pricing_models.monte_carlo import MCMethod, MonteCarloPricer
+
+    return dict(MonteCarloPricer=MonteCarloPricer, MCMethod=MCMethod, black_scholes=black_scholes,
+                AsianOption=AsianOption, price_asian=price_asian,
+                compute_greeks_unified=compute_greeks_unified, ExoticAdapter=ExoticAdapter)
+
+
+ATM = dict(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2)
+
+
+def main():
+    import numpy as np
+    import scipy
+
+    ref = load_reference()
+    MCP, MCMethod = ref["MonteCarloPricer"], ref["MCMethod"]
+    bs = ref["black_scholes"]
+    doc = {
+        "generator": "tests/golden/make_golden.py",
+        "reference": "Diegotistical/OptionsLab @ /root/reference (snapshot 2026-01-30)",
+        "numpy": np.__version__,
+        "scipy": scipy.__version__,
+    }
+
+    # -- Black-Scholes ------------------------------------------------------
+    doc["black_scholes"] = []
+    for S, K, T, r, v, q in [(100, 100, 1.0, 0.05, 0.2, 0.0), (110, 100, 1.0, 0.05, 0.2, 0.0),
+                             (90, 100, 1.0, 0.05, 0.2, 0.0), (100, 100, 0.25, 0.05, 0.2, 0.0),
+                             (100, 100, 2.0, 0.05, 0.4, 0.02), (100, 95, 0.5, 0.03, 0.3, 0.02),
+                             (100, 100, 0.0, 0.05, 0.2, 0.0), (120, 100, 0.0, 0.05, 0.2, 0.0)]:
+        doc["black_scholes"].append(dict(args=[S, K, T, r, v, q],
+                                         call=float(bs(S, K, T, r, v, "call", q)),
+                                         put=float(bs(S, K, T, r, v, "put", q))))
+
+    # -- pricer.price -------------------------------------------------------
+    cases = []
+
+    def add_price(N, M, seed, method, S, K, T, r, sigma, typ, q=0.0, call_seed=None):
+        v = sigma
+        p = MCP(N, M, seed, getattr(MCMethod, method))
+        kw = {} if call_seed is None else {"seed": call_seed}
+        res = p.price(S, K, T, r, v, typ, q, return_error=True, **kw)
+        plain = p.price(S, K, T, r, v, typ, q, **kw)
+        assert plain == res.price
+        st = p._simulate(S, T, r, v, q, call_seed)
+        cases.append(dict(ctor=[N, M, seed, method.lower()], args=[S, K, T, r, v, typ, q], call_seed=call_seed,
+                          price=res.price, std_error=res.std_error, n_paths=int(res.n_paths),
+                          plain_is_float=type(plain) is float,
+                          terminal_head=[float(x) for x in st[:4]],
+                          terminal_mid=[float(x) for x in st[len(st) // 2: len(st) // 2 + 4]],
+                          terminal_len=int(len(st))))
+
+    for typ in ("call", "put"):
+        add_price(10000, 50, 42, "NUMPY", typ=typ, **ATM)                 # G1/G2
+        add_price(10000, 50, 42, "NUMPY", typ=typ, q=0.02, **ATM)         # G9
+        add_price(100000, 1, 42, "NUMPY", typ=typ, **ATM)                 # G5
+        add_price(100000, 252, 42, "NUMPY", typ=typ, **ATM)               # G3 (config 1)
+    add_price(1000000, 252, 42, "NUMPY", typ="call", **ATM)               # G4
+    add_price(10000, 50, 42, "NUMBA", typ="call", **ATM)                  # numba absent => numpy path
+    add_price(10000, 50, 7, "FAST", typ="call", **ATM)                    # FAST forces single step
+    add_price(10000, 50, 42, "NUMPY", typ="call", call_seed=123, **ATM)   # per-call seed override
+    add_price(2**14, 16, 42, "QMC", typ="call", **ATM)                    # G10
+    add_price(2**12, 8, 5, "QMC", typ="put", **ATM)
+    for S, K, T, r, v in [(110, 100, 1.0, 0.05, 0.2), (90, 100, 1.0, 0.05, 0.2), (100, 100, 1.0, 0.05, 0.1),
+                          (100, 100, 1.0, 0.05, 0.4), (100, 100, 0.25, 0.05, 0.2), (100, 100, 2.0, 0.05, 0.2)]:
+        add_price(10000, 50, 42, "NUMPY", S, K, T, r, v, "call")          # tests/test_monte_carlo.py:523-546
+    add_price(7, 3, 1, "NUMPY", typ="call", **ATM)                        # tiny ragged case
+    add_price(1, 1, 0, "NUMPY", typ="put", **ATM)                         # minimum size
+    doc["price"] = cases
+
+    # -- T <= 0 early-out (monte_carlo.py:133-135) ---------------------------
+    p = MCP(1000, 10, 1)
+    r0 = p.price(120, 100, 0.0, 0.05, 0.2, "call", return_error=True)
+    doc["expired"] = [dict(args=[120, 100, 0.0, 0.05, 0.2, "call"], price=r0.price, std_error=r0.std_error,
+                           n_paths=r0.n_paths, plain=p.price(120, 100, 0.0, 0.05, 0.2, "call")),
+                      dict(args=[80, 100, -1.0, 0.05, 0.2, "put"], price=p.price(80, 100, -1.0, 0.05, 0.2, "put"),
+                           std_error=0.0, n_paths=0, plain=p.price(80, 100, -1.0, 0.05, 0.2, "put"))]
+
+    # -- control variate (G8) ----------------------------------------------
+    doc["control_variate"] = []
+    for N, M, seed, typ, q in [(100000, 252, 42, "call", 0.0), (10000, 50, 42, "put", 0.02), (100000, 1, 42, "call", 0.0)]:
+        doc["control_variate"].append(dict(ctor=[N, M, seed, "numpy"], args=[100.0, 100.0, 1.0, 0.05, 0.2, typ, q],
+                                           value=MCP(N, M, seed).price_with_control_variate(100.0, 100.0, 1.0, 0.05, 0.2, typ, q)))
+
+    # -- unified FD Greeks (G6/G7) -----------------------------------------
+    doc["greeks"] = []
+    cgu = ref["compute_greeks_unified"]
+    for N, M, seed, typ, q, second in [(100000, 1, 42, "call", 0.0, False), (100000, 252, 42, "call", 0.0, False),
+                                       (100000, 252, 42, "call", 0.0, True), (20000, 50, 42, "put", 0.02, True)]:
+        g = cgu(MCP(N, M, seed), 100.0, 100.0, 1.0, 0.05, 0.2, typ, q, include_second_order=second)
+        doc["greeks"].append(dict(ctor=[N, M, seed, "numpy"], args=[100.0, 100.0, 1.0, 0.05, 0.2, typ, q],
+                                  include_second_order=second, keys=list(g.keys()),
+                                  values={k: float(x) for k, x in g.items()}))
+    # short-dated branch T <= h_T (unified_greeks.py:313-314, 353-354)
+    g = cgu(MCP(20000, 4, 42), 100.0, 100.0, 0.002, 0.05, 0.2, "call", 0.0, include_second_order=True)
+    doc["greeks"].append(dict(ctor=[20000, 4, 42, "numpy"], args=[100.0, 100.0, 0.002, 0.05, 0.2, "call", 0.0],
+                              include_second_order=True, keys=list(g.keys()), values={k: float(x) for k, x in g.items()}))
+
+    # -- Asian (G11/G12) ----------------------------------------------------
+    doc["asian"] = []
+    A = ref["AsianOption"]
+    for n, m, seed, avg, typ, q in [(100000, 252, 42, "arithmetic", "call", 0.0), (100000, 252, 42, "geometric", "call", 0.0),
+                                    (10000, 252, 42, "arithmetic", "put", 0.0), (10000, 64, 7, "arithmetic", "call", 0.02),
+                                    (10000, 64, 7, "geometric", "put", 0.02), (1000, 252, 42, "arithmetic", "call", 0.0)]:
+        o = A(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, q=q, seed=seed)
+        doc["asian"].append(dict(params=[100.0, 100.0, 1.0, 0.05, 0.2, q], seed=seed, n_paths=n, n_steps=m, avg_type=avg,
+                                 option_type=typ, price=float(o.price(n, m, avg, typ)),
+                                 geometric_closed_form=float(o.price_geometric_closed_form(typ))))
+    doc["price_asian_helper"] = dict(args=[100.0, 100.0, 1.0, 0.05, 0.2, "arithmetic", "call", 20000, 42],
+                                     value=float(ref["price_asian"](100.0, 100.0, 1.0, 0.05, 0.2, "arithmetic", "call", 20000, 42)))
+    # ExoticAdapter Greeks on an Asian (unified_greeks.py:177-227)
+    ad = ref["ExoticAdapter"](A(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, seed=42), n_paths=20000, n_steps=64, avg_type="arithmetic")
+    g = cgu(ad, 100.0, 100.0, 1.0, 0.05, 0.2, "call", 0.0, include_second_order=False)
+    doc["asian_greeks"] = dict(n_paths=20000, n_steps=64, seed=42, values={k: float(x) for k, x in g.items()})
+
+    with open(OUT, "w") as f:
+        json.dump(doc, f, indent=1)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()

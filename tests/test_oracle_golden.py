@@ -1,0 +1,98 @@
+"""The NumPy oracle must equal the reference bit-for-bit on every golden vector
+(vectors captured by running the reference: tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+from oracle import numpy_reference as orc
+
+BIG = 500_000  # cases above this many paths are marked slow-ish but still run (seconds)
+
+
+def test_fixture_environment_matches(golden):
+    # PCG64/ziggurat streams are stable since NumPy 1.17 but not contractually frozen
+    assert golden["numpy"].split(".")[0] == np.__version__.split(".")[0]
+
+
+def test_black_scholes(golden):
+    for row in golden["black_scholes"]:
+        S, K, T, r, v, q = row["args"]
+        assert float(orc.bs_price(S, K, T, r, v, "call", q)) == row["call"]
+        assert float(orc.bs_price(S, K, T, r, v, "put", q)) == row["put"]
+    with pytest.raises(ValueError):
+        orc.bs_price(-1, 100, 1, 0.05, 0.2)
+    with pytest.raises(ValueError):
+        orc.bs_price(100, 100, 1, 0.05, 0.2, "straddle")
+
+
+def test_price_bitwise(golden):
+    for c in golden["price"]:
+        N, M, seed, method = c["ctor"]
+        S, K, T, r, v, typ, q = c["args"]
+        p = orc.OraclePricer(N, M, seed, method)
+        kw = {} if c["call_seed"] is None else {"seed": c["call_seed"]}
+        res = p.price(S, K, T, r, v, typ, q, return_error=True, **kw)
+        assert (res.price, res.std_error, res.n_paths) == (c["price"], c["std_error"], c["n_paths"]), c["ctor"]
+        if N <= BIG:
+            plain = p.price(S, K, T, r, v, typ, q, **kw)
+            assert type(plain) is float and plain == c["price"]
+            st = p.terminal(S, T, r, v, q, c["call_seed"])
+            assert len(st) == c["terminal_len"]
+            assert [float(x) for x in st[:4]] == c["terminal_head"]
+            h = len(st) // 2
+            assert [float(x) for x in st[h:h + 4]] == c["terminal_mid"]
+
+
+def test_expired(golden):
+    p = orc.OraclePricer(1000, 10, 1)
+    for e in golden["expired"]:
+        S, K, T, r, v, typ = e["args"]
+        res = p.price(S, K, T, r, v, typ, return_error=True)
+        assert (res.price, res.std_error, res.n_paths) == (e["price"], 0.0, 0)
+        assert p.price(S, K, T, r, v, typ) == e["plain"]
+
+
+def test_ctor_validation():
+    for bad in (0, -100):
+        with pytest.raises(ValueError):
+            orc.OraclePricer(num_simulations=bad)
+    p = orc.OraclePricer(10)  # seed drawn once, then fixed
+    assert p.price(100, 100, 1, 0.05, 0.2, "call") == p.price(100, 100, 1, 0.05, 0.2, "call")
+
+
+def test_control_variate(golden):
+    for c in golden["control_variate"]:
+        N, M, seed, method = c["ctor"]
+        assert orc.OraclePricer(N, M, seed, method).price_with_control_variate(*c["args"]) == c["value"]
+
+
+def test_fd_greeks(golden):
+    for c in golden["greeks"]:
+        N, M, seed, method = c["ctor"]
+        S, K, T, r, v, typ, q = c["args"]
+        g = orc.fd_greeks(orc.OraclePricer(N, M, seed, method).price, S, K, T, r, v, typ, q,
+                          include_second_order=c["include_second_order"])
+        assert list(g.keys()) == c["keys"]
+        for k in c["keys"]:
+            assert float(g[k]) == c["values"][k], (c["ctor"], k)
+
+
+def test_asian(golden):
+    for c in golden["asian"]:
+        S, K, T, r, v, q = c["params"]
+        got = orc.asian_price(S, K, T, r, v, q, c["seed"], c["n_paths"], c["n_steps"], c["avg_type"], c["option_type"])
+        assert float(got) == c["price"]
+        assert float(orc.asian_geometric_closed_form(S, K, T, r, v, q, c["option_type"])) == c["geometric_closed_form"]
+    h = golden["price_asian_helper"]
+    S, K, T, r, v, avg, typ, n, seed = h["args"]
+    assert float(orc.asian_price(S, K, T, r, v, 0.0, seed, n, 252, avg, typ)) == h["value"]
+
+
+def test_asian_greeks_via_adapter(golden):
+    c = golden["asian_greeks"]
+
+    def price(S, K, T, r, v, typ, q=0.0):
+        return orc.asian_price(S, K, T, r, v, q, c["seed"], c["n_paths"], c["n_steps"], "arithmetic", typ)
+
+    g = orc.fd_greeks(price, 100.0, 100.0, 1.0, 0.05, 0.2, "call", 0.0, include_second_order=False)
+    for k, x in c["values"].items():
+        assert float(g[k]) == x, k

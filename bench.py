@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: GBM path-steps/s, European call, 1M paths x 252 steps
+per GPU (BASELINE.json configs[1]), antithetic on, on-device reduction.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete pricing of the contract over this rank's block of
+1,000,000 global paths x 252 steps: path kernel -> on-device reduction -> (N > 1:
+one all-reduce of the 24-byte (sum, sumsq, n) triple over RCCL/xGMI) -> the triple
+lands in a per-step device slot.  Steps are enqueued back to back on the stream
+(pricing requests in flight); the timed region ends with a full synchronise and
+includes the D2H copy of all K results, each of which is then checked (every
+step's price must be within 3 sigma of Black-Scholes).  Inputs are scalars, so
+nothing but the results crosses PCIe.  The JSON line also carries `sync_call`:
+the same workload through the blocking MonteCarloPricer.price() API, one host
+round trip per call.
+
+torch is plumbing here (device result slots, stream handle, process group); the
+compute is libolmc.so through its C ABI.  With N > 1 launch as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N`.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORK = dict(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, q=0.0, option_type="call")
+PATHS_PER_GPU = 1_000_000
+N_STEPS = 252
+SEED = 42
+LANE_OPS_PER_PATH_STEP = 32          # algorithmic VALU lane-ops per path-step
+PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 (MI355X_MICROARCH.md: 157.3 TF fp32 = 2 flop/FMA)
+
+
+def cpu_baseline():
+    """Reference-pinned NumPy oracle (oracle/numpy_reference.py) timed on this host: 1 core
+    (NumPy's Generator is serial).  Bounded sample: warm-up at 100k x 252, then one full
+    1M x 252 pricing (about 5-15 s)."""
+    from oracle import numpy_reference as orc
+    p = orc.OraclePricer(100_000, N_STEPS, SEED)
+    p.price(WORK["S"], WORK["K"], WORK["T"], WORK["r"], WORK["sigma"], "call")
+    n = 1_000_000
+    t0 = time.perf_counter()
+    res = orc.OraclePricer(n, N_STEPS, SEED).price(WORK["S"], WORK["K"], WORK["T"], WORK["r"], WORK["sigma"], "call",
+                                                   return_error=True)
+    dt = time.perf_counter() - t0
+    return dict(value=n * N_STEPS / dt, unit="path-steps/s", cores=1, kind="port",
+                sample=f"1 x price() at {n} paths x {N_STEPS} steps, NumPy oracle pinned bitwise to the reference "
+                       f"(price {res.price:.6f}); host has {os.cpu_count()} logical cores, NumPy RNG uses 1",
+                seconds=dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    os.environ["OLMC_DEVICE"] = str(local_rank)
+
+    import torch
+    import torch.distributed as dist
+
+    import optionslab_amd as ol
+    from optionslab_amd import _hip, sharding
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    info = _hip.device_info()
+
+    n_global = PATHS_PER_GPU * world
+    lo, hi = sharding.shard_bounds(n_global, rank, world)
+    S, K, T, r, sigma, q = (WORK[k] for k in ("S", "K", "T", "r", "sigma", "q"))
+    stream = torch.cuda.current_stream()
+    K_steps, W = args.steps, args.warmup
+    slots = torch.zeros((max(K_steps, W, 1), 3), dtype=torch.float64, device="cuda")
+
+    def enqueue(k, seed):
+        _hip.european_shard_dev(S, K, T, r, sigma, q, True, lo, hi - lo, N_STEPS, seed, True,
+                                slots[k].data_ptr(), stream.cuda_stream)
+        if world > 1:
+            return dist.all_reduce(slots[k], op=dist.ReduceOp.SUM, async_op=True)
+        return None
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up (untimed)
+    pend = [enqueue(k, SEED + 1000 + k) for k in range(W)]
+    for w in pend:
+        if w is not None:
+            w.wait()
+    fence()
+
+    _hip.profile_enable(True)
+    _hip.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    pend = [enqueue(k, SEED + k) for k in range(K_steps)]
+    for w in pend:
+        if w is not None:
+            w.wait()
+    results = slots[:K_steps].cpu()          # D2H of the K triples, inside the timed region
+    fence()
+    elapsed = time.perf_counter() - t0
+    launches, kernel_ms = _hip.kernel_time()
+    _hip.profile_enable(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # every step's result must be a valid price
+    bs = ol.black_scholes(S, K, T, r, sigma, "call", q)
+    worst = 0.0
+    for row in results.tolist():
+        price, se = sharding.finalize(row[0], row[1], int(row[2]), r, T)
+        assert int(row[2]) == 2 * n_global, row
+        worst = max(worst, abs(price - bs) / se)
+    assert worst <= 4.5, f"a step's price is {worst:.2f} sigma from Black-Scholes"   # max of K draws of |N(0,1)|
+
+    out = None
+    if rank == 0:
+        path_steps = n_global * N_STEPS
+        value = path_steps * K_steps / elapsed
+        avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
+        achieved = (hi - lo) * N_STEPS * LANE_OPS_PER_PATH_STEP / avg_kernel_s / 1e12
+        out = {
+            "metric": "MC path-steps/sec (1M paths x 252 steps Euro call); price vs BS |err|/sigma",
+            "value": value, "unit": "path-steps/s", "n_gpus": world, "steps": K_steps, "warmup": W,
+            "ms_per_step": elapsed / K_steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 normals / f64 prices", "data": "synthetic",
+            "config": {"workload": "European call S0=100 K=100 sigma=0.2 r=0.05 T=1, 1,000,000 paths x 252 steps per GPU, "
+                                   "antithetic on (2M payoffs per GPU), Philox4x32-10 + Box-Muller in registers, on-device reduction",
+                       "paths_per_gpu": PATHS_PER_GPU, "n_steps": N_STEPS, "global_paths": n_global,
+                       "parallelism": f"path-sharded x{world}" + (", 1 RCCL all-reduce of (sum,sumsq,n) per step" if world > 1 else "")},
+            "accuracy": {"bs_price": bs, "max_abs_err_over_sigma": worst, "payoffs_per_step": 2 * n_global},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_TLANEOPS, "unit": "Tlane-op/s",
+                         "frac": achieved / PEAK_TLANEOPS, "traffic": None,
+                         "kernel": "european_kernel<1,true,kReduce>", "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "launches_timed": launches, "lane_ops_per_path_step": LANE_OPS_PER_PATH_STEP,
+                         "note": "VALU-issue bound (not HBM, not MFMA): HBM traffic is 16 B per block partial; "
+                                 "traffic measured with rocprofv3 --pmc is in profiles/ and DESIGN.md"},
+            "device": info,
+        }
+        # blocking API at the same size (one host round trip per price() call)
+        if world == 1:
+            pricer = ol.MonteCarloPricer(PATHS_PER_GPU, N_STEPS, SEED)
+            for _ in range(3):
+                pricer.price(S, K, T, r, sigma, "call")
+            reps = max(10, min(K_steps, 50))
+            t1 = time.perf_counter()
+            for i in range(reps):
+                res = pricer.price(S, K, T, r, sigma, "call", seed=SEED + i, return_error=True)
+            dt = (time.perf_counter() - t1) / reps
+            out["sync_call"] = {"value": PATHS_PER_GPU * N_STEPS / dt, "unit": "path-steps/s", "ms_per_call": dt * 1e3,
+                                "what": "MonteCarloPricer.price(return_error=True), blocking, result on host"}
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline()
+                out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

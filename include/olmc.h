@@ -1,0 +1,195 @@
+/*
+ * olmc.h -- C ABI of libolmc.so, the MI355X (gfx950) Monte Carlo path engine.
+ *
+ * This is the drop-in boundary for the OptionsLab hot path: every entry point
+ * names the reference interface it replaces (paths relative to the reference
+ * repository root).  The reference is pure Python, so the binding a maintainer
+ * adds is a ctypes stub (INTEGRATION.md shows it); the signatures therefore
+ * use only plain C scalars, pointers and sizes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; the message
+ *     for the calling thread's last failure is olmc_last_error();
+ *   - the caller owns every buffer it passes in; the library owns its device
+ *     scratch (grown lazily, freed by olmc_shutdown) and returns no pointer
+ *     that outlives the call except the thread-local error string;
+ *   - entry points are re-entrant: a per-device mutex guards scratch + stream;
+ *   - there is NO CPU fallback: without a usable HIP device every compute
+ *     entry point fails with OLMC_ERR_HIP.
+ *
+ * Random stream (identical whatever the grid shape / GPU count):
+ *   Philox4x32-10, key = (seed_lo32, seed_hi32),
+ *   counter = (path_lo32, path_hi32, block, stream_tag), `path` = GLOBAL path
+ *   index, `block` = step/4.  The four output words give the four normals of
+ *   steps 4*block .. 4*block+3 by two Box-Muller transforms:
+ *     u = (x + 0.5) * 2^-32 (fp32),  rad = sqrt(-2 ln u_a),
+ *     z_even = rad * cos(2 pi u_b),  z_odd = rad * sin(2 pi u_b),
+ *   pair (x0,x1) -> steps 4b,4b+1; pair (x2,x3) -> steps 4b+2,4b+3.
+ *   Normals are fp32; every quantity that depends on S, K, T, r, sigma, q is
+ *   fp64 (finite-difference Greeks under common random numbers stay smooth).
+ */
+#ifndef OLMC_H
+#define OLMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OLMC_ABI_VERSION 1
+
+enum {
+    OLMC_OK = 0,
+    OLMC_ERR_ARG = 1,     /* bad argument (n_paths < 1, n_steps < 1, null pointer, k out of range) */
+    OLMC_ERR_HIP = 2,     /* HIP runtime / device failure                                         */
+    OLMC_ERR_STATE = 3,   /* olmc_init not called / wrong device                                   */
+    OLMC_ERR_RCCL = 4     /* RCCL failure in the multi-GPU entry points                            */
+};
+
+enum { OLMC_STREAM_GBM = 0 };                    /* counter word 3 (stream_tag)          */
+enum { OLMC_AVG_ARITHMETIC = 0, OLMC_AVG_GEOMETRIC = 1 };
+#define OLMC_MAX_BATCH 16                        /* parameter sets per fused launch      */
+
+/* Result of one reduction.  Mirrors what MonteCarloPricer.price() derives from
+ * the 2N payoffs (src/pricing_models/monte_carlo.py:140-150):
+ *   price     = exp(-rT) * sum / n
+ *   std_error = exp(-rT) * sqrt(sumsq/n - (sum/n)^2) / sqrt(n)      (ddof = 0)
+ * sum / sumsq are UNdiscounted payoff moments so shards can be added. */
+typedef struct olmc_stats {
+    double  sum;
+    double  sumsq;
+    int64_t n;          /* payoff samples = n_paths * (1 + antithetic)  (MCResult.n_paths) */
+    double  price;
+    double  std_error;
+} olmc_stats;
+
+/* One European contract; `is_call` != 0 -> max(S_T-K,0), else max(K-S_T,0)
+ * (monte_carlo.py:140-143: anything that is not "call" prices as a put). */
+typedef struct olmc_option {
+    double  S, K, T, r, sigma, q;
+    int32_t is_call;
+    int32_t reserved;
+} olmc_option;
+
+/* Five moments of the control-variate estimator
+ * (monte_carlo.py:154-186): d = discounted payoff, s = terminal price. */
+typedef struct olmc_cv_moments {
+    double  sum_d, sum_s, sum_dd, sum_ss, sum_ds;
+    int64_t n;
+    double  value;      /* mean(d) - beta * (mean(s) - S e^{(r-q)T}), beta = cov/var (ddof=1) */
+} olmc_cv_moments;
+
+typedef struct olmc_devinfo {
+    char    name[128];
+    char    arch[32];
+    int32_t compute_units;
+    int32_t clock_mhz;
+    int32_t wavefront;
+    int32_t device;
+    int64_t hbm_bytes;
+} olmc_devinfo;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int         olmc_abi_version(void);
+int         olmc_init(int device);             /* idempotent per device; selects it for the calling thread */
+int         olmc_shutdown(void);               /* frees scratch + streams of every initialised device      */
+const char* olmc_last_error(void);             /* thread-local, never NULL                                 */
+int         olmc_device_info(olmc_devinfo* out);
+
+/* ---- European terminal payoff: GBM paths + payoff + on-device reduction --
+ * Replaces MonteCarloPricer._simulate + the payoff/mean/std tail of .price()
+ * (monte_carlo.py:74-106, 137-150) and simulate_gbm_numpy / _fast
+ * (src/simulation/gbm_numpy.py:15-53, 56-83).  n_steps == 1 is the reference's
+ * single-step closed form.  Only (sum, sumsq) leave the device. */
+int olmc_european(double S, double K, double T, double r, double sigma, double q, int is_call,
+                  int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
+                  olmc_stats* out);
+
+/* Same for the global path range [path_offset, path_offset + n_local): the unit a
+ * rank owns when independent path batches are sharded over GPUs.
+ * out->price / std_error are those of the shard alone; combine with
+ * olmc_combine_stats after summing (sum, sumsq, n) over ranks. */
+int olmc_european_shard(double S, double K, double T, double r, double sigma, double q, int is_call,
+                        int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
+                        int antithetic, olmc_stats* out);
+
+/* Device-resident variant for one-process-per-GPU jobs: writes the raw triple
+ * {sum, sumsq, (double)n} to `d_triple` (3 doubles of DEVICE memory owned by
+ * the caller, e.g. a torch tensor handed to an RCCL all-reduce) on `hip_stream`
+ * (a hipStream_t, NULL = the library's stream) and does not synchronise. */
+int olmc_european_shard_dev(double S, double K, double T, double r, double sigma, double q, int is_call,
+                            int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
+                            int antithetic, double* d_triple, void* hip_stream);
+
+/* k <= OLMC_MAX_BATCH contracts priced on the SAME normals (common random
+ * numbers) in one pass: one RNG stream, k payoffs per path, 2k sums.  This is
+ * the fused form of the 8 / 14 price() calls compute_greeks_unified makes
+ * (src/greeks/unified_greeks.py:280-358).  All contracts share n_steps, so
+ * they share sum_t Z exactly as the reference's re-seeded calls do. */
+int olmc_european_batch(const olmc_option* opts, int32_t k,
+                        int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
+                        int antithetic, olmc_stats* out /* [k] */);
+
+/* Finite-difference Greeks, bumps exactly as unified_greeks.py:274-277, 295-362.
+ * out9 = {price, delta, gamma, vega, theta, rho, vanna, charm, vomma}; the last
+ * three are written only when second_order != 0.  `evals` (nullable) receives
+ * the 8 or 14 per-evaluation stats in the reference's call order. */
+int olmc_european_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call,
+                            int64_t n_paths, int32_t n_steps, uint64_t seed, int second_order,
+                            double* out9, olmc_stats* evals /* [14] or NULL */);
+
+/* Terminal prices to caller-owned HOST memory, length n_paths*(1+antithetic),
+ * layout [pos(0..N-1) | neg(0..N-1)] (gbm_numpy.py:51).  This is the backend
+ * contract simulate_*(S,T,r,sigma,q,n_paths,n_steps,seed) -> ndarray
+ * (src/simulation/__init__.py:5-6). */
+int olmc_european_terminal(double S, double T, double r, double sigma, double q,
+                           int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
+                           double* out_host);
+
+/* Control-variate estimator, five moments reduced on device
+ * (MonteCarloPricer.price_with_control_variate, monte_carlo.py:154-186). */
+int olmc_european_cv(double S, double K, double T, double r, double sigma, double q, int is_call,
+                     int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
+                     olmc_cv_moments* out);
+
+/* ---- Asian (average over t = 1..M, t = 0 excluded) ------------------------
+ * Replaces ExoticOptionBase._generate_paths + AsianOption.price
+ * (src/pricing_models/exotic_options.py:40-67, 97-131): running sum of S_t
+ * (arithmetic) or of log S_t (geometric) in registers, no path matrix. */
+int olmc_asian(double S, double K, double T, double r, double sigma, double q, int is_call,
+               int avg_kind, int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
+               int antithetic, olmc_stats* out);
+
+/* ---- multi-GPU, single process ------------------------------------------
+ * n_paths split into n_gpus contiguous global path ranges, one host thread and
+ * one stream per device, ONE RCCL all-reduce of {sum, sumsq, n} (3 x fp64)
+ * over xGMI, identical finalisation on every rank. */
+int olmc_multi_gpu_european(double S, double K, double T, double r, double sigma, double q, int is_call,
+                            int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
+                            int n_gpus, olmc_stats* out);
+
+/* Host-side finalisation shared by every path: fills price / std_error from
+ * (sum, sumsq, n) with discount exp(-rT).  Pure function, no device needed. */
+int olmc_combine_stats(const olmc_stats* parts, int32_t n_parts, double r, double T, olmc_stats* out);
+
+/* ---- validation taps (tests, not the product path) ------------------------ */
+/* Raw Philox4x32-10 words: out[(p*n_blocks + b)*4 + w], p < n_paths, b < n_blocks. */
+int olmc_philox_words(uint64_t seed, int64_t path_offset, int64_t n_paths,
+                      int32_t block0, int32_t n_blocks, uint32_t stream_tag, uint32_t* out_host);
+/* The fp32 normal stream: out[p*n_steps + t]. */
+int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps,
+                 float* out_host);
+
+/* ---- measurement ----------------------------------------------------------
+ * When enabled, every path-kernel launch is bracketed by HIP events on the
+ * stream it runs on; olmc_kernel_time returns the number of launches timed and
+ * their total milliseconds since the last reset. */
+int olmc_profile_enable(int on);
+int olmc_profile_reset(void);
+int olmc_kernel_time(int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OLMC_H */

@@ -1,0 +1,22 @@
+"""optionslab_amd -- MI355X-native Monte Carlo path engine behind the OptionsLab
+``MonteCarloPricer.price()`` / ``compute_greeks_unified()`` API.
+
+Importing the package touches neither the GPU nor libolmc.so; the first compute
+call loads the library and raises ``AccelerationError(backend="hip")`` if it (or
+a device) is missing -- there is no CPU fallback.
+"""
+from .black_scholes import black_scholes
+from .exceptions import AccelerationError, ConvergenceError, GreeksError, InputValidationError, MonteCarloError
+from .exotic import AsianOption, price_asian
+from .greeks import ExoticAdapter, PricerProtocol, compute_greeks_unified
+from .monte_carlo import NUMBA_AVAILABLE, MCMethod, MCResult, MonteCarloPricer
+from .simulation import hip_available, simulate_gbm_hip, simulate_gbm_hip_fast
+from . import sharding  # noqa: E402  (torch is imported lazily inside)
+
+__version__ = "0.1.0"
+
+__all__ = [
+    "MonteCarloPricer", "MCMethod", "MCResult", "NUMBA_AVAILABLE", "compute_greeks_unified", "PricerProtocol",
+    "ExoticAdapter", "AsianOption", "price_asian", "black_scholes", "simulate_gbm_hip", "simulate_gbm_hip_fast",
+    "hip_available", "MonteCarloError", "InputValidationError", "ConvergenceError", "AccelerationError", "GreeksError",
+]

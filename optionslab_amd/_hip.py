@@ -1,0 +1,238 @@
+"""ctypes binding of libolmc.so (C ABI: include/olmc.h).
+
+The library is loaded on first use and there is no CPU fallback: if the shared
+object is missing, or no HIP device answers, every call raises
+``AccelerationError(..., backend="hip")`` (the reference defines that exception
+for exactly this, src/exceptions/montecarlo_exceptions.py:105-131).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .exceptions import AccelerationError
+
+LIBRARY_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libolmc.so")
+MAX_BATCH = 16
+AVG_ARITHMETIC, AVG_GEOMETRIC = 0, 1
+_U64 = (1 << 64) - 1
+
+
+class Stats(C.Structure):
+    _fields_ = [("sum", C.c_double), ("sumsq", C.c_double), ("n", C.c_int64),
+                ("price", C.c_double), ("std_error", C.c_double)]
+
+
+class Option(C.Structure):
+    _fields_ = [("S", C.c_double), ("K", C.c_double), ("T", C.c_double), ("r", C.c_double),
+                ("sigma", C.c_double), ("q", C.c_double), ("is_call", C.c_int32), ("reserved", C.c_int32)]
+
+
+class CvMoments(C.Structure):
+    _fields_ = [("sum_d", C.c_double), ("sum_s", C.c_double), ("sum_dd", C.c_double), ("sum_ss", C.c_double),
+                ("sum_ds", C.c_double), ("n", C.c_int64), ("value", C.c_double)]
+
+
+class DevInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("arch", C.c_char * 32), ("compute_units", C.c_int32),
+                ("clock_mhz", C.c_int32), ("wavefront", C.c_int32), ("device", C.c_int32), ("hbm_bytes", C.c_int64)]
+
+
+_D, _I, _I32, _I64, _U64T, _P = C.c_double, C.c_int, C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
+_SIX = [_D] * 6
+
+# name -> (restype, argtypes); must list every symbol include/olmc.h declares
+PROTOTYPES = {
+    "olmc_abi_version": (_I, []),
+    "olmc_init": (_I, [_I]),
+    "olmc_shutdown": (_I, []),
+    "olmc_last_error": (C.c_char_p, []),
+    "olmc_device_info": (_I, [C.POINTER(DevInfo)]),
+    "olmc_european": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
+    "olmc_european_shard": (_I, _SIX + [_I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
+    "olmc_european_shard_dev": (_I, _SIX + [_I, _I64, _I64, _I32, _U64T, _I, _P, _P]),
+    "olmc_european_batch": (_I, [C.POINTER(Option), _I32, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
+    "olmc_european_greeks_fd": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(_D), C.POINTER(Stats)]),
+    "olmc_european_terminal": (_I, [_D] * 5 + [_I64, _I32, _U64T, _I, C.POINTER(_D)]),
+    "olmc_european_cv": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(CvMoments)]),
+    "olmc_asian": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
+    "olmc_multi_gpu_european": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(Stats)]),
+    "olmc_combine_stats": (_I, [C.POINTER(Stats), _I32, _D, _D, C.POINTER(Stats)]),
+    "olmc_philox_words": (_I, [_U64T, _I64, _I64, _I32, _I32, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "olmc_normals": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(C.c_float)]),
+    "olmc_profile_enable": (_I, [_I]),
+    "olmc_profile_reset": (_I, []),
+    "olmc_kernel_time": (_I, [C.POINTER(_I64), C.POINTER(_D)]),
+}
+
+_lock = threading.Lock()
+_lib: Optional[C.CDLL] = None
+_initialised = False
+
+
+def load_library() -> C.CDLL:
+    """dlopen libolmc.so and bind every prototype (no device is touched)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIBRARY_PATH):
+                raise AccelerationError(
+                    f"{LIBRARY_PATH} is not built (run `python -m optionslab_amd.build`); there is no CPU fallback",
+                    backend="hip")
+            try:
+                lib = C.CDLL(LIBRARY_PATH)
+            except OSError as e:
+                raise AccelerationError(f"cannot load {LIBRARY_PATH}: {e}", backend="hip") from e
+            for name, (res, args) in PROTOTYPES.items():
+                fn = getattr(lib, name)
+                fn.restype, fn.argtypes = res, args
+            _lib = lib
+        return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        msg = load_library().olmc_last_error().decode("utf-8", "replace")
+        raise AccelerationError(f"libolmc error {rc}: {msg}", backend="hip")
+
+
+def lib() -> C.CDLL:
+    """Loaded library with the device initialised (device = $OLMC_DEVICE, else $LOCAL_RANK, else 0)."""
+    global _initialised
+    l = load_library()
+    if not _initialised:
+        dev = int(os.environ.get("OLMC_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _check(l.olmc_init(dev))
+        _initialised = True
+    return l
+
+
+def hip_available() -> bool:
+    try:
+        lib()
+        return True
+    except AccelerationError:
+        return False
+
+
+def shutdown() -> None:
+    global _initialised
+    if _lib is not None:
+        _lib.olmc_shutdown()
+    _initialised = False
+
+
+def seed64(seed: int) -> int:
+    return int(seed) & _U64
+
+
+def device_info() -> dict:
+    info = DevInfo()
+    _check(lib().olmc_device_info(C.byref(info)))
+    return dict(name=info.name.decode(), arch=info.arch.decode(), compute_units=info.compute_units,
+                clock_mhz=info.clock_mhz, wavefront=info.wavefront, device=info.device, hbm_bytes=info.hbm_bytes)
+
+
+def european(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int, seed: int, antithetic: bool = True,
+             path_offset: int = 0) -> Stats:
+    out = Stats()
+    _check(lib().olmc_european_shard(S, K, T, r, sigma, q, int(is_call), int(path_offset), int(n_paths), int(n_steps),
+                                     seed64(seed), int(antithetic), C.byref(out)))
+    return out
+
+
+def european_shard_dev(S, K, T, r, sigma, q, is_call: bool, path_offset: int, n_local: int, n_steps: int, seed: int,
+                       antithetic: bool, d_triple_ptr: int, stream_ptr: int = 0) -> None:
+    _check(lib().olmc_european_shard_dev(S, K, T, r, sigma, q, int(is_call), int(path_offset), int(n_local), int(n_steps),
+                                         seed64(seed), int(antithetic), C.c_void_p(d_triple_ptr),
+                                         C.c_void_p(stream_ptr) if stream_ptr else None))
+
+
+def european_batch(options: Sequence[Tuple[float, float, float, float, float, float, bool]], n_paths: int, n_steps: int,
+                   seed: int, antithetic: bool = True, path_offset: int = 0) -> List[Stats]:
+    k = len(options)
+    arr = (Option * k)(*[Option(S, K, T, r, v, q, int(c), 0) for (S, K, T, r, v, q, c) in options])
+    out = (Stats * k)()
+    _check(lib().olmc_european_batch(arr, k, int(path_offset), int(n_paths), int(n_steps), seed64(seed), int(antithetic), out))
+    return list(out)
+
+
+def european_greeks_fd(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int, seed: int,
+                       second_order: bool) -> Tuple[List[float], List[Stats]]:
+    out9 = (C.c_double * 9)()
+    evals = (Stats * 14)()
+    _check(lib().olmc_european_greeks_fd(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(n_steps), seed64(seed),
+                                         int(second_order), out9, evals))
+    return list(out9), list(evals)
+
+
+def european_terminal(S, T, r, sigma, q, n_paths: int, n_steps: int, seed: int, antithetic: bool = True) -> np.ndarray:
+    out = np.empty(int(n_paths) * (2 if antithetic else 1), dtype=np.float64)
+    _check(lib().olmc_european_terminal(S, T, r, sigma, q, int(n_paths), int(n_steps), seed64(seed), int(antithetic),
+                                        out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def european_cv(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int, seed: int,
+                antithetic: bool = True) -> CvMoments:
+    out = CvMoments()
+    _check(lib().olmc_european_cv(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(n_steps), seed64(seed),
+                                  int(antithetic), C.byref(out)))
+    return out
+
+
+def asian(S, K, T, r, sigma, q, is_call: bool, geometric: bool, n_paths: int, n_steps: int, seed: int,
+          antithetic: bool = False, path_offset: int = 0) -> Stats:
+    out = Stats()
+    _check(lib().olmc_asian(S, K, T, r, sigma, q, int(is_call), AVG_GEOMETRIC if geometric else AVG_ARITHMETIC,
+                            int(path_offset), int(n_paths), int(n_steps), seed64(seed), int(antithetic), C.byref(out)))
+    return out
+
+
+def multi_gpu_european(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int, seed: int, antithetic: bool,
+                       n_gpus: int) -> Stats:
+    out = Stats()
+    _check(lib().olmc_multi_gpu_european(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(n_steps), seed64(seed),
+                                         int(antithetic), int(n_gpus), C.byref(out)))
+    return out
+
+
+def combine_stats(parts: Sequence[Tuple[float, float, int]], r: float, T: float) -> Stats:
+    """Pure host function: needs the library but no device."""
+    k = len(parts)
+    arr = (Stats * k)(*[Stats(s, ss, int(n), 0.0, 0.0) for (s, ss, n) in parts])
+    out = Stats()
+    _check(load_library().olmc_combine_stats(arr, k, r, T, C.byref(out)))
+    return out
+
+
+def philox_words(seed: int, path_offset: int, n_paths: int, block0: int, n_blocks: int, tag: int = 0) -> np.ndarray:
+    out = np.empty((int(n_paths), int(n_blocks), 4), dtype=np.uint32)
+    _check(lib().olmc_philox_words(seed64(seed), int(path_offset), int(n_paths), int(block0), int(n_blocks), int(tag),
+                                   out.ctypes.data_as(C.POINTER(C.c_uint32))))
+    return out
+
+
+def normals(seed: int, path_offset: int, n_paths: int, n_steps: int) -> np.ndarray:
+    out = np.empty((int(n_paths), int(n_steps)), dtype=np.float32)
+    _check(lib().olmc_normals(seed64(seed), int(path_offset), int(n_paths), int(n_steps),
+                              out.ctypes.data_as(C.POINTER(C.c_float))))
+    return out
+
+
+def profile_enable(on: bool) -> None:
+    _check(lib().olmc_profile_enable(int(on)))
+
+
+def profile_reset() -> None:
+    _check(lib().olmc_profile_reset())
+
+
+def kernel_time() -> Tuple[int, float]:
+    n, ms = C.c_int64(0), C.c_double(0.0)
+    _check(lib().olmc_kernel_time(C.byref(n), C.byref(ms)))
+    return n.value, ms.value

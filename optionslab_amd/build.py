@@ -1,0 +1,41 @@
+"""Builds libolmc.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+SOURCES = [os.path.join(PKG, "csrc", "olmc.hip")]
+HEADERS = [os.path.join(PKG, "csrc", "olmc_kernels.h"), os.path.join(ROOT, "include", "olmc.h")]
+LIBRARY = os.path.join(PKG, "libolmc.so")
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIBRARY):
+        return True
+    built = os.path.getmtime(LIBRARY)
+    return any(os.path.getmtime(p) > built for p in SOURCES + HEADERS)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIBRARY
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"),
+           "-o", LIBRARY, *SOURCES, "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIBRARY
+
+
+if __name__ == "__main__":
+    print(build_library(force=True, verbose=True))

@@ -1,0 +1,722 @@
+// olmc.hip -- host side of libolmc.so: the C ABI declared in include/olmc.h.
+//
+// One context per HIP device (stream, device scratch for per-block partials,
+// a pinned host landing buffer).  Every compute entry point is
+//   host: derive the per-contract constants in fp64 (reference order)
+//   device: path kernel -> finalize kernel -> 8*NV bytes D2H
+// and fails loudly when no HIP device is usable -- there is no CPU fallback.
+#include "olmc.h"
+#include "olmc_kernels.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+using namespace olmc;
+
+thread_local std::string t_error = "";
+thread_local int t_device = -1;
+
+int fail(int code, const std::string& msg) {
+    t_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(OLMC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+constexpr int kMaxDevices = 16;
+constexpr int kMaxNV = 2 * OLMC_MAX_BATCH;       // values per block partial
+constexpr int kBlocksPerCU = 8;                  // 8 blocks x 4 waves = 32 waves/CU (the hardware cap)
+
+struct EventPair {
+    hipEvent_t start, stop;
+};
+
+struct DeviceCtx {
+    int device = -1;
+    int cus = 0;
+    hipStream_t stream = nullptr;
+    double* d_partials = nullptr;    // [partial_blocks][kMaxNV]
+    int32_t partial_blocks = 0;
+    double* d_result = nullptr;      // [kMaxNV]
+    double* h_result = nullptr;      // pinned [kMaxNV]
+    void* d_bulk = nullptr;          // terminal prices / validation taps
+    size_t bulk_bytes = 0;
+    std::mutex mu;
+    // profiling
+    std::vector<EventPair> ev_free, ev_pending;
+    int64_t prof_launches = 0;
+    double prof_ms = 0.0;
+};
+
+std::mutex g_mu;
+DeviceCtx* g_ctx[kMaxDevices] = {};
+int g_default_device = -1;
+bool g_profile = false;
+
+int ctx_create(int device, DeviceCtx** out) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(OLMC_ERR_HIP, std::string("no HIP device available: ") + hipGetErrorString(e));
+    if (device < 0 || device >= count || device >= kMaxDevices)
+        return fail(OLMC_ERR_ARG, "device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    DeviceCtx* c = new DeviceCtx();
+    c->device = device;
+    c->cus = prop.multiProcessorCount;
+    c->partial_blocks = c->cus * kBlocksPerCU;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc(&c->d_partials, sizeof(double) * kMaxNV * c->partial_blocks));
+    HIP_TRY(hipMalloc(&c->d_result, sizeof(double) * kMaxNV));
+    HIP_TRY(hipHostMalloc(&c->h_result, sizeof(double) * kMaxNV, hipHostMallocDefault));
+    *out = c;
+    return OLMC_OK;
+}
+
+int ctx_get(DeviceCtx** out) {
+    int dev = t_device >= 0 ? t_device : g_default_device;
+    if (dev < 0) {
+        // lazy init on device 0 so a bare compute call still works (or fails loudly)
+        int rc = olmc_init(0);
+        if (rc) return rc;
+        dev = t_device;
+    }
+    DeviceCtx* c = g_ctx[dev];
+    if (!c) return fail(OLMC_ERR_STATE, "device not initialised (call olmc_init)");
+    HIP_TRY(hipSetDevice(dev));
+    *out = c;
+    return OLMC_OK;
+}
+
+int bulk_reserve(DeviceCtx* c, size_t bytes) {
+    if (bytes <= c->bulk_bytes) return OLMC_OK;
+    if (c->d_bulk) HIP_TRY(hipFree(c->d_bulk));
+    c->d_bulk = nullptr;
+    c->bulk_bytes = 0;
+    HIP_TRY(hipMalloc(&c->d_bulk, bytes));
+    c->bulk_bytes = bytes;
+    return OLMC_OK;
+}
+
+int32_t grid_for(const DeviceCtx* c, int64_t n_paths) {
+    const int64_t tiles = (n_paths + kBlock - 1) / kBlock;
+    return static_cast<int32_t>(std::min<int64_t>(tiles, c->partial_blocks));
+}
+
+// ---- profiling brackets ---------------------------------------------------
+int prof_begin(DeviceCtx* c, hipStream_t s, EventPair* ep) {
+    if (c->ev_free.empty()) {
+        HIP_TRY(hipEventCreate(&ep->start));
+        HIP_TRY(hipEventCreate(&ep->stop));
+    } else {
+        *ep = c->ev_free.back();
+        c->ev_free.pop_back();
+    }
+    HIP_TRY(hipEventRecord(ep->start, s));
+    return OLMC_OK;
+}
+
+int prof_end(DeviceCtx* c, hipStream_t s, const EventPair& ep) {
+    HIP_TRY(hipEventRecord(ep.stop, s));
+    c->ev_pending.push_back(ep);
+    return OLMC_OK;
+}
+
+int prof_drain(DeviceCtx* c) {
+    for (const EventPair& ep : c->ev_pending) {
+        HIP_TRY(hipEventSynchronize(ep.stop));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ep.start, ep.stop));
+        c->prof_ms += ms;
+        c->prof_launches += 1;
+        c->ev_free.push_back(ep);
+    }
+    c->ev_pending.clear();
+    return OLMC_OK;
+}
+
+// ---- host-side constants (reference arithmetic order) ----------------------
+// gbm_numpy.py:35-39 (multi-step) and :73-75 (single-step; identical when M == 1
+// up to the exact product drift*1).
+Contract make_contract(const olmc_option& o, int32_t n_steps) {
+    const double dt = o.T / n_steps;
+    const double drift = (o.r - o.q - 0.5 * o.sigma * o.sigma) * dt;
+    const double vol = o.sigma * std::sqrt(dt);
+    const double total_drift = drift * n_steps;
+    Contract c;
+    c.a = std::log(o.S) + total_drift;
+    c.vol = vol;
+    c.strike = o.K;
+    c.sign = o.is_call ? 1.0 : -1.0;
+    return c;
+}
+
+void finish_stats(double sum, double sumsq, int64_t n, double r, double T, olmc_stats* out) {
+    const double disc = std::exp(-r * T);
+    const double mean = sum / static_cast<double>(n);
+    double var = sumsq / static_cast<double>(n) - mean * mean;   // ddof = 0, monte_carlo.py:149
+    if (var < 0.0) var = 0.0;
+    out->sum = sum;
+    out->sumsq = sumsq;
+    out->n = n;
+    out->price = disc * mean;
+    out->std_error = disc * std::sqrt(var) / std::sqrt(static_cast<double>(n));
+}
+
+int check_paths(int64_t path_offset, int64_t n_local, int32_t n_steps) {
+    if (n_local < 1) return fail(OLMC_ERR_ARG, "n_paths must be >= 1");
+    if (n_steps < 1) return fail(OLMC_ERR_ARG, "n_steps must be >= 1");
+    if (path_offset < 0) return fail(OLMC_ERR_ARG, "path_offset must be >= 0");
+    return OLMC_OK;
+}
+
+PathRange make_range(int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed) {
+    PathRange pr;
+    pr.first = static_cast<uint64_t>(path_offset);
+    pr.count = n_local;
+    pr.n_steps = n_steps;
+    pr.key0 = static_cast<uint32_t>(seed);
+    pr.key1 = static_cast<uint32_t>(seed >> 32);
+    return pr;
+}
+
+template <int NSETS, int MODE>
+void launch_european(bool anti, int32_t grid, hipStream_t s, const PathRange& pr, const ContractSet<NSETS>& cs,
+                     double* partials, double* terminal) {
+    if (anti)
+        hipLaunchKernelGGL((european_kernel<NSETS, true, MODE>), dim3(grid), dim3(kBlock), 0, s, pr, cs, partials, terminal);
+    else
+        hipLaunchKernelGGL((european_kernel<NSETS, false, MODE>), dim3(grid), dim3(kBlock), 0, s, pr, cs, partials, terminal);
+}
+
+// Path kernel + finalize for k contracts on stream `s`; leaves 2k doubles in d_out.
+int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32_t k, int64_t path_offset,
+                     int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic, double* d_out) {
+    const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
+    const int32_t grid = grid_for(c, n_local);
+    const bool anti = antithetic != 0;
+    EventPair ep{};
+    if (g_profile) { int rc = prof_begin(c, s, &ep); if (rc) return rc; }
+    int nsets;
+    if (k == 1) {
+        ContractSet<1> cs;
+        cs.c[0] = make_contract(opts[0], n_steps);
+        launch_european<1, kReduce>(anti, grid, s, pr, cs, c->d_partials, nullptr);
+        nsets = 1;
+    } else if (k <= 8) {
+        ContractSet<8> cs;
+        for (int i = 0; i < 8; ++i) cs.c[i] = make_contract(opts[i < k ? i : 0], n_steps);
+        launch_european<8, kReduce>(anti, grid, s, pr, cs, c->d_partials, nullptr);
+        nsets = 8;
+    } else {
+        ContractSet<16> cs;
+        for (int i = 0; i < 16; ++i) cs.c[i] = make_contract(opts[i < k ? i : 0], n_steps);
+        launch_european<16, kReduce>(anti, grid, s, pr, cs, c->d_partials, nullptr);
+        nsets = 16;
+    }
+    HIP_TRY(hipGetLastError());
+    if (g_profile) { int rc = prof_end(c, s, ep); if (rc) return rc; }
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, s, c->d_partials, grid, 2 * nsets, d_out);
+    HIP_TRY(hipGetLastError());
+    return OLMC_OK;
+}
+
+int run_batch(const olmc_option* opts, int32_t k, int64_t path_offset, int64_t n_local, int32_t n_steps,
+              uint64_t seed, int antithetic, olmc_stats* out) {
+    if (!opts || !out) return fail(OLMC_ERR_ARG, "null pointer");
+    if (k < 1 || k > OLMC_MAX_BATCH) return fail(OLMC_ERR_ARG, "batch size must be in [1, OLMC_MAX_BATCH]");
+    int rc = check_paths(path_offset, n_local, n_steps);
+    if (rc) return rc;
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    rc = run_batch_device(c, c->stream, opts, k, path_offset, n_local, n_steps, seed, antithetic, c->d_result);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 2 * k, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int64_t n = n_local * (antithetic ? 2 : 1);
+    for (int i = 0; i < k; ++i)
+        finish_stats(c->h_result[2 * i], c->h_result[2 * i + 1], n, opts[i].r, opts[i].T, &out[i]);
+    return OLMC_OK;
+}
+
+olmc_option make_option(double S, double K, double T, double r, double sigma, double q, int is_call) {
+    olmc_option o;
+    o.S = S; o.K = K; o.T = T; o.r = r; o.sigma = sigma; o.q = q;
+    o.is_call = is_call ? 1 : 0;
+    o.reserved = 0;
+    return o;
+}
+
+}  // namespace
+
+// =============================================================== lifetime ====
+extern "C" int olmc_abi_version(void) { return OLMC_ABI_VERSION; }
+
+extern "C" const char* olmc_last_error(void) { return t_error.c_str(); }
+
+extern "C" int olmc_init(int device) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (device < 0 || device >= kMaxDevices) return fail(OLMC_ERR_ARG, "device index out of range");
+    if (!g_ctx[device]) {
+        DeviceCtx* c = nullptr;
+        int rc = ctx_create(device, &c);
+        if (rc) return rc;
+        g_ctx[device] = c;
+    } else {
+        HIP_TRY(hipSetDevice(device));
+    }
+    t_device = device;
+    if (g_default_device < 0) g_default_device = device;
+    return OLMC_OK;
+}
+
+extern "C" int olmc_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (int d = 0; d < kMaxDevices; ++d) {
+        DeviceCtx* c = g_ctx[d];
+        if (!c) continue;
+        if (hipSetDevice(d) == hipSuccess) {
+            (void)hipStreamSynchronize(c->stream);
+            for (auto& ep : c->ev_pending) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
+            for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
+            if (c->d_bulk) (void)hipFree(c->d_bulk);
+            (void)hipFree(c->d_partials);
+            (void)hipFree(c->d_result);
+            (void)hipHostFree(c->h_result);
+            (void)hipStreamDestroy(c->stream);
+        }
+        delete c;
+        g_ctx[d] = nullptr;
+    }
+    g_default_device = -1;
+    t_device = -1;
+    return OLMC_OK;
+}
+
+extern "C" int olmc_device_info(olmc_devinfo* out) {
+    if (!out) return fail(OLMC_ERR_ARG, "null pointer");
+    DeviceCtx* c = nullptr;
+    int rc = ctx_get(&c);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, c->device));
+    std::memset(out, 0, sizeof(*out));
+    std::snprintf(out->name, sizeof(out->name), "%s", prop.name);
+    std::snprintf(out->arch, sizeof(out->arch), "%s", prop.gcnArchName);
+    out->compute_units = prop.multiProcessorCount;
+    out->clock_mhz = prop.clockRate / 1000;
+    out->wavefront = prop.warpSize;
+    out->device = c->device;
+    out->hbm_bytes = static_cast<int64_t>(prop.totalGlobalMem);
+    return OLMC_OK;
+}
+
+// ===================================================== European reductions ====
+extern "C" int olmc_european(double S, double K, double T, double r, double sigma, double q, int is_call,
+                             int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic, olmc_stats* out) {
+    const olmc_option o = make_option(S, K, T, r, sigma, q, is_call);
+    return run_batch(&o, 1, 0, n_paths, n_steps, seed, antithetic, out);
+}
+
+extern "C" int olmc_european_shard(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                   int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
+                                   int antithetic, olmc_stats* out) {
+    const olmc_option o = make_option(S, K, T, r, sigma, q, is_call);
+    return run_batch(&o, 1, path_offset, n_local, n_steps, seed, antithetic, out);
+}
+
+namespace olmc {
+__global__ void triple_kernel(const double* __restrict__ two, double n, double* __restrict__ triple) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        triple[0] = two[0];
+        triple[1] = two[1];
+        triple[2] = n;
+    }
+}
+}  // namespace olmc
+
+extern "C" int olmc_european_shard_dev(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                       int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
+                                       int antithetic, double* d_triple, void* hip_stream) {
+    if (!d_triple) return fail(OLMC_ERR_ARG, "null pointer");
+    int rc = check_paths(path_offset, n_local, n_steps);
+    if (rc) return rc;
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    const olmc_option o = make_option(S, K, T, r, sigma, q, is_call);
+    rc = run_batch_device(c, s, &o, 1, path_offset, n_local, n_steps, seed, antithetic, c->d_result);
+    if (rc) return rc;
+    const double n = static_cast<double>(n_local * (antithetic ? 2 : 1));
+    hipLaunchKernelGGL(olmc::triple_kernel, dim3(1), dim3(64), 0, s, c->d_result, n, d_triple);
+    HIP_TRY(hipGetLastError());
+    return OLMC_OK;
+}
+
+extern "C" int olmc_european_batch(const olmc_option* opts, int32_t k, int64_t path_offset, int64_t n_local,
+                                   int32_t n_steps, uint64_t seed, int antithetic, olmc_stats* out) {
+    return run_batch(opts, k, path_offset, n_local, n_steps, seed, antithetic, out);
+}
+
+extern "C" int olmc_combine_stats(const olmc_stats* parts, int32_t n_parts, double r, double T, olmc_stats* out) {
+    if (!parts || !out || n_parts < 1) return fail(OLMC_ERR_ARG, "bad arguments");
+    double sum = 0.0, sumsq = 0.0;
+    int64_t n = 0;
+    for (int i = 0; i < n_parts; ++i) {   // fixed rank order => bitwise stable
+        sum += parts[i].sum;
+        sumsq += parts[i].sumsq;
+        n += parts[i].n;
+    }
+    if (n < 1) return fail(OLMC_ERR_ARG, "no samples");
+    finish_stats(sum, sumsq, n, r, T, out);
+    return OLMC_OK;
+}
+
+// ================================================== finite-difference Greeks ====
+extern "C" int olmc_european_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                       int64_t n_paths, int32_t n_steps, uint64_t seed, int second_order,
+                                       double* out9, olmc_stats* evals) {
+    if (!out9) return fail(OLMC_ERR_ARG, "null pointer");
+    if (!(T > 0.0)) return fail(OLMC_ERR_ARG, "T must be > 0 (price() returns intrinsic value without simulating)");
+    // unified_greeks.py:274-277
+    const double h_S = std::max(1e-4, 0.01 * S);
+    const double h_v = std::max(1e-4, 0.01);
+    const double h_r = 1e-4;
+    const double h_T = 1 / 365.0;
+    const bool has_T = T > h_T;                                  // :310
+    olmc_option o[OLMC_MAX_BATCH];
+    int k = 0;
+    auto add = [&](double S_, double T_, double r_, double v_) { o[k] = make_option(S_, K, T_, r_, v_, q, is_call); return k++; };
+    // evaluation order = the reference's get_price() call order (:295-358)
+    const int i_mid = add(S, T, r, sigma);
+    const int i_su = add(S + h_S, T, r, sigma), i_sd = add(S - h_S, T, r, sigma);
+    const int i_vu = add(S, T, r, sigma + h_v), i_vd = add(S, T, r, sigma - h_v);
+    const int i_td = has_T ? add(S, T - h_T, r, sigma) : -1;
+    const int i_ru = add(S, T, r + h_r, sigma), i_rd = add(S, T, r - h_r, sigma);
+    int i_uu = -1, i_ud = -1, i_du = -1, i_dd = -1, i_ut = -1, i_dt = -1;
+    if (second_order) {
+        i_uu = add(S + h_S, T, r, sigma + h_v); i_ud = add(S + h_S, T, r, sigma - h_v);
+        i_du = add(S - h_S, T, r, sigma + h_v); i_dd = add(S - h_S, T, r, sigma - h_v);
+        if (has_T) { i_ut = add(S + h_S, T - h_T, r, sigma); i_dt = add(S - h_S, T - h_T, r, sigma); }
+    }
+    olmc_stats st[OLMC_MAX_BATCH];
+    int rc = run_batch(o, k, 0, n_paths, n_steps, seed, 1, st);
+    if (rc) return rc;
+    auto P = [&](int i) { return st[i].price; };
+    const double mid = P(i_mid);
+    const double delta = (P(i_su) - P(i_sd)) / (2 * h_S);                       // :301
+    out9[0] = mid;
+    out9[1] = delta;
+    out9[2] = (P(i_su) - 2 * mid + P(i_sd)) / (h_S * h_S);                       // :302
+    out9[3] = (P(i_vu) - P(i_vd)) / (2 * h_v);                                   // :307
+    out9[4] = has_T ? (P(i_td) - mid) / h_T : -mid / std::max(T, 1e-6);          // :310-314
+    out9[5] = (P(i_ru) - P(i_rd)) / (2 * h_r);                                   // :319
+    if (second_order) {
+        out9[6] = (P(i_uu) - P(i_ud) - P(i_du) + P(i_dd)) / (4 * h_S * h_v);    // :343-345
+        out9[7] = has_T ? ((P(i_ut) - P(i_dt)) / (2 * h_S) - delta) / h_T : 0.0; // :348-354
+        out9[8] = (P(i_vu) - 2 * mid + P(i_vd)) / (h_v * h_v);                   // :357
+    }
+    if (evals) {
+        for (int i = 0; i < k; ++i) evals[i] = st[i];
+        for (int i = k; i < 14; ++i) std::memset(&evals[i], 0, sizeof(olmc_stats));
+    }
+    return OLMC_OK;
+}
+
+// ============================================================ terminal array ====
+extern "C" int olmc_european_terminal(double S, double T, double r, double sigma, double q, int64_t n_paths,
+                                      int32_t n_steps, uint64_t seed, int antithetic, double* out_host) {
+    if (!out_host) return fail(OLMC_ERR_ARG, "null pointer");
+    int rc = check_paths(0, n_paths, n_steps);
+    if (rc) return rc;
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const size_t bytes = sizeof(double) * static_cast<size_t>(n_paths) * (antithetic ? 2 : 1);
+    rc = bulk_reserve(c, bytes);
+    if (rc) return rc;
+    const PathRange pr = make_range(0, n_paths, n_steps, seed);
+    ContractSet<1> cs;
+    cs.c[0] = make_contract(make_option(S, 0.0, T, r, sigma, q, 1), n_steps);
+    launch_european<1, kTerminal>(antithetic != 0, grid_for(c, n_paths), c->stream, pr, cs, nullptr,
+                                  static_cast<double*>(c->d_bulk));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_host, c->d_bulk, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OLMC_OK;
+}
+
+// =========================================================== control variate ====
+extern "C" int olmc_european_cv(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
+                                olmc_cv_moments* out) {
+    if (!out) return fail(OLMC_ERR_ARG, "null pointer");
+    int rc = check_paths(0, n_paths, n_steps);
+    if (rc) return rc;
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const PathRange pr = make_range(0, n_paths, n_steps, seed);
+    const int32_t grid = grid_for(c, n_paths);
+    ContractSet<1> cs;
+    cs.c[0] = make_contract(make_option(S, K, T, r, sigma, q, is_call), n_steps);
+    launch_european<1, kControlVariate>(antithetic != 0, grid, c->stream, pr, cs, c->d_partials, nullptr);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->d_partials, grid, 5, c->d_result);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // device moments are of the UNdiscounted payoff x; d = disc * x (monte_carlo.py:175)
+    const double disc = std::exp(-r * T);
+    const double n = static_cast<double>(n_paths * (antithetic ? 2 : 1));
+    const double sx = c->h_result[0], ss = c->h_result[1], sxx = c->h_result[2], sss = c->h_result[3], sxs = c->h_result[4];
+    out->sum_d = disc * sx;
+    out->sum_s = ss;
+    out->sum_dd = disc * disc * sxx;
+    out->sum_ss = sss;
+    out->sum_ds = disc * sxs;
+    out->n = static_cast<int64_t>(n);
+    const double mean_d = out->sum_d / n, mean_s = ss / n;
+    // np.cov default ddof = 1 (monte_carlo.py:181); the n-1 cancels in beta but not in the 1e-10 guard
+    const double cov_ds = (out->sum_ds - n * mean_d * mean_s) / (n - 1.0);
+    const double var_s = (sss - n * mean_s * mean_s) / (n - 1.0);
+    const double beta = (n > 1.0 && var_s > 1e-10) ? cov_ds / var_s : 0.0;        // :182
+    const double forward = S * std::exp((r - q) * T);                              // :179
+    out->value = mean_d - beta * (mean_s - forward);                               // :184
+    return OLMC_OK;
+}
+
+// ===================================================================== Asian ====
+extern "C" int olmc_asian(double S, double K, double T, double r, double sigma, double q, int is_call, int avg_kind,
+                          int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic,
+                          olmc_stats* out) {
+    if (!out) return fail(OLMC_ERR_ARG, "null pointer");
+    if (avg_kind != OLMC_AVG_ARITHMETIC && avg_kind != OLMC_AVG_GEOMETRIC) return fail(OLMC_ERR_ARG, "bad avg_kind");
+    int rc = check_paths(path_offset, n_local, n_steps);
+    if (rc) return rc;
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
+    const int32_t grid = grid_for(c, n_local);
+    AsianContract ac;
+    const double dt = T / n_steps;                               // exotic_options.py:54-56
+    ac.log_s0 = std::log(S);
+    ac.drift = (r - q - 0.5 * sigma * sigma) * dt;
+    ac.vol = sigma * std::sqrt(dt);
+    ac.strike = K;
+    ac.sign = is_call ? 1.0 : -1.0;
+    ac.inv_steps = 1.0 / n_steps;
+    EventPair ep{};
+    if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
+    const bool anti = antithetic != 0, geo = avg_kind == OLMC_AVG_GEOMETRIC;
+    if (anti && geo) hipLaunchKernelGGL((asian_kernel<true, true>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, c->d_partials);
+    else if (anti) hipLaunchKernelGGL((asian_kernel<true, false>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, c->d_partials);
+    else if (geo) hipLaunchKernelGGL((asian_kernel<false, true>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, c->d_partials);
+    else hipLaunchKernelGGL((asian_kernel<false, false>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, c->d_partials);
+    HIP_TRY(hipGetLastError());
+    if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->d_partials, grid, 2, c->d_result);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r, T, out);
+    return OLMC_OK;
+}
+
+// ======================================================== multi-GPU (RCCL) ====
+// librccl is resolved lazily so single-GPU users never load it.
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    int (*CommInitAll)(void**, int, const int*) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::vector<void*> comms;      // cached communicator set
+    int n_comms = 0;
+};
+Rccl g_rccl;
+constexpr int kNcclFloat64 = 8;    // ncclDouble (rccl.h: ncclFloat64 = 8)
+constexpr int kNcclSum = 0;        // ncclSum
+
+int rccl_load() {
+    if (g_rccl.lib) return OLMC_OK;
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(OLMC_ERR_RCCL, std::string("cannot load librccl: ") + dlerror());
+    g_rccl.CommInitAll = reinterpret_cast<decltype(g_rccl.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!g_rccl.CommInitAll || !g_rccl.AllReduce || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.CommDestroy)
+        return fail(OLMC_ERR_RCCL, "librccl is missing required symbols");
+    g_rccl.lib = h;
+    return OLMC_OK;
+}
+
+#define RCCL_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        int r_ = (expr);                                                                                 \
+        if (r_ != 0)                                                                                     \
+            return fail(OLMC_ERR_RCCL, std::string(#expr) + ": " +                                       \
+                                           (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error")); \
+    } while (0)
+}  // namespace
+
+extern "C" int olmc_multi_gpu_european(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                       int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic, int n_gpus,
+                                       olmc_stats* out) {
+    if (!out) return fail(OLMC_ERR_ARG, "null pointer");
+    if (n_gpus < 1 || n_gpus > kMaxDevices) return fail(OLMC_ERR_ARG, "n_gpus out of range");
+    int rc = check_paths(0, n_paths, n_steps);
+    if (rc) return rc;
+    if (n_paths < n_gpus) return fail(OLMC_ERR_ARG, "fewer paths than GPUs");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count < n_gpus)
+        return fail(OLMC_ERR_HIP, "requested " + std::to_string(n_gpus) + " GPUs, " + std::to_string(count) + " visible");
+    const int saved_device = t_device;
+    for (int d = 0; d < n_gpus; ++d) { rc = olmc_init(d); if (rc) return rc; }
+    t_device = saved_device >= 0 ? saved_device : 0;
+    static std::mutex multi_mu;
+    std::lock_guard<std::mutex> lock(multi_mu);
+    rc = rccl_load();
+    if (rc) return rc;
+    if (g_rccl.n_comms != n_gpus) {
+        for (void* cm : g_rccl.comms) g_rccl.CommDestroy(cm);
+        g_rccl.comms.assign(n_gpus, nullptr);
+        g_rccl.n_comms = 0;
+        std::vector<int> devs(n_gpus);
+        for (int d = 0; d < n_gpus; ++d) devs[d] = d;
+        RCCL_TRY(g_rccl.CommInitAll(g_rccl.comms.data(), n_gpus, devs.data()));
+        g_rccl.n_comms = n_gpus;
+    }
+    // contiguous global path ranges: rank d owns [d*N/P, (d+1)*N/P)  
+    std::vector<double*> triples(n_gpus, nullptr);
+    for (int d = 0; d < n_gpus; ++d) {
+        DeviceCtx* c = g_ctx[d];
+        HIP_TRY(hipSetDevice(d));
+        rc = bulk_reserve(c, 3 * sizeof(double));
+        if (rc) return rc;
+        triples[d] = static_cast<double*>(c->d_bulk);
+        const int64_t lo = n_paths * d / n_gpus, hi = n_paths * (d + 1) / n_gpus;
+        t_device = d;
+        rc = olmc_european_shard_dev(S, K, T, r, sigma, q, is_call, lo, hi - lo, n_steps, seed, antithetic, triples[d], nullptr);
+        if (rc) return rc;
+    }
+    RCCL_TRY(g_rccl.GroupStart());
+    for (int d = 0; d < n_gpus; ++d)
+        RCCL_TRY(g_rccl.AllReduce(triples[d], triples[d], 3, kNcclFloat64, kNcclSum, g_rccl.comms[d], g_ctx[d]->stream));
+    RCCL_TRY(g_rccl.GroupEnd());
+    double host[3] = {0, 0, 0};
+    for (int d = n_gpus - 1; d >= 0; --d) {
+        HIP_TRY(hipSetDevice(d));
+        if (d == 0) HIP_TRY(hipMemcpyAsync(host, triples[0], sizeof(host), hipMemcpyDeviceToHost, g_ctx[0]->stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx[d]->stream));
+    }
+    t_device = saved_device >= 0 ? saved_device : 0;
+    HIP_TRY(hipSetDevice(t_device));
+    finish_stats(host[0], host[1], static_cast<int64_t>(host[2]), r, T, out);
+    return OLMC_OK;
+}
+
+// ============================================================ validation taps ====
+extern "C" int olmc_philox_words(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t block0, int32_t n_blocks,
+                                 uint32_t stream_tag, uint32_t* out_host) {
+    if (!out_host || n_paths < 1 || n_blocks < 1 || block0 < 0 || path_offset < 0) return fail(OLMC_ERR_ARG, "bad arguments");
+    DeviceCtx* c = nullptr;
+    int rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const size_t bytes = sizeof(uint32_t) * 4 * static_cast<size_t>(n_paths) * n_blocks;
+    rc = bulk_reserve(c, bytes);
+    if (rc) return rc;
+    const int64_t total = n_paths * n_blocks;
+    const int grid = static_cast<int>(std::min<int64_t>((total + 255) / 256, 4096));
+    hipLaunchKernelGGL(philox_words_kernel, dim3(grid), dim3(256), 0, c->stream, static_cast<uint64_t>(path_offset), n_paths,
+                       block0, n_blocks, stream_tag, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32),
+                       static_cast<uint32_t*>(c->d_bulk));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_host, c->d_bulk, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OLMC_OK;
+}
+
+extern "C" int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps, float* out_host) {
+    if (!out_host || n_paths < 1 || n_steps < 1 || path_offset < 0) return fail(OLMC_ERR_ARG, "bad arguments");
+    DeviceCtx* c = nullptr;
+    int rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const size_t bytes = sizeof(float) * static_cast<size_t>(n_paths) * n_steps;
+    rc = bulk_reserve(c, bytes);
+    if (rc) return rc;
+    const int64_t total = n_paths * ((n_steps + 3) / 4);
+    const int grid = static_cast<int>(std::min<int64_t>((total + 255) / 256, 4096));
+    hipLaunchKernelGGL(normals_kernel, dim3(grid), dim3(256), 0, c->stream, static_cast<uint64_t>(path_offset), n_paths,
+                       n_steps, static_cast<uint32_t>(seed), static_cast<uint32_t>(seed >> 32),
+                       static_cast<float*>(c->d_bulk));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_host, c->d_bulk, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OLMC_OK;
+}
+
+// ================================================================ measurement ====
+extern "C" int olmc_profile_enable(int on) {
+    g_profile = on != 0;
+    return OLMC_OK;
+}
+
+extern "C" int olmc_profile_reset(void) {
+    DeviceCtx* c = nullptr;
+    int rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    rc = prof_drain(c);
+    c->prof_launches = 0;
+    c->prof_ms = 0.0;
+    return rc;
+}
+
+extern "C" int olmc_kernel_time(int64_t* launches, double* total_ms) {
+    if (!launches || !total_ms) return fail(OLMC_ERR_ARG, "null pointer");
+    DeviceCtx* c = nullptr;
+    int rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    rc = prof_drain(c);
+    if (rc) return rc;
+    *launches = c->prof_launches;
+    *total_ms = c->prof_ms;
+    return OLMC_OK;
+}

@@ -1,0 +1,60 @@
+"""AsianOption on the device step loop (reference: ExoticOptionBase._generate_paths
++ AsianOption, src/pricing_models/exotic_options.py:28-160, price_asian :558-572).
+
+Same dataclass fields and ``price(n_paths, n_steps, avg_type, option_type)``
+signature; the running average lives in registers, no (n_paths, n_steps) matrix
+exists.  Like the reference there is no antithetic mirror unless asked for, and
+the return value is a ``numpy.float64``.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Literal, Optional
+
+import numpy as np
+
+from . import _hip
+from .black_scholes import _ncdf
+
+
+@dataclass
+class AsianOption:
+    S: float
+    K: float
+    T: float
+    r: float
+    sigma: float
+    q: float = 0.0
+    seed: Optional[int] = None
+
+    def price(self, n_paths: int = 100000, n_steps: int = 252,
+              avg_type: Literal["arithmetic", "geometric"] = "arithmetic",
+              option_type: Literal["call", "put"] = "call", antithetic: bool = False,
+              return_error: bool = False):
+        if n_paths < 1 or n_steps < 1:
+            raise ValueError("n_paths and n_steps must be >= 1")
+        # seed=None: the reference leaves the global RandomState unseeded (:51-52) => fresh draw
+        seed = self.seed if self.seed is not None else int(np.random.default_rng().integers(0, 2**31))
+        st = _hip.asian(self.S, self.K, self.T, self.r, self.sigma, self.q, option_type == "call",
+                        avg_type != "arithmetic", n_paths, n_steps, seed, antithetic)
+        if return_error:
+            return np.float64(st.price), float(st.std_error)
+        return np.float64(st.price)
+
+    def price_geometric_closed_form(self, option_type: Literal["call", "put"] = "call") -> float:
+        """exotic_options.py:133-160"""
+        v = self.sigma / math.sqrt(3)
+        b = 0.5 * (self.r - self.q - self.sigma**2 / 6)
+        d1 = (math.log(self.S / self.K) + (b + 0.5 * v**2) * self.T) / (v * math.sqrt(self.T))
+        d2 = d1 - v * math.sqrt(self.T)
+        grow, disc = math.exp((b - self.r) * self.T), math.exp(-self.r * self.T)
+        if option_type == "call":
+            return self.S * grow * _ncdf(d1) - self.K * disc * _ncdf(d2)
+        return self.K * disc * _ncdf(-d2) - self.S * grow * _ncdf(-d1)
+
+
+def price_asian(S: float, K: float, T: float, r: float, sigma: float, avg_type: str = "arithmetic",
+                option_type: str = "call", n_paths: int = 100000, seed: int = None) -> float:
+    return AsianOption(S=S, K=K, T=T, r=r, sigma=sigma, seed=seed).price(
+        n_paths=n_paths, avg_type=avg_type, option_type=option_type)

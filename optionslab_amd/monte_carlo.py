@@ -1,0 +1,119 @@
+"""MonteCarloPricer on the MI355X path engine.
+
+Same constructor, attributes, method signatures, return types and error
+behaviour as the reference class (src/pricing_models/monte_carlo.py:28-186), so
+it drops into the Streamlit page (streamlit_app/pages/1_MonteCarlo_Basic.py:139-160),
+``compute_greeks_unified`` and tests/test_monte_carlo.py unchanged.  Every
+``MCMethod`` executes on the GPU through libolmc; nothing here computes paths
+on the CPU.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from dataclasses import dataclass
+from enum import Enum
+from typing import Literal, Optional, Union
+
+import numpy as np
+
+from . import _hip
+from .exceptions import AccelerationError
+
+NUMBA_AVAILABLE = False          # kept for `from ...monte_carlo import NUMBA_AVAILABLE` (monte_carlo.py:189)
+GREEK_KEYS = ("price", "delta", "gamma", "vega", "theta", "rho", "vanna", "charm", "vomma")
+
+
+class MCMethod(Enum):
+    """Backend selector (monte_carlo.py:28-34) plus the new member HIP.  NUMPY,
+    NUMBA and HIP all mean "multi-step on the device"; FAST forces a single step
+    (monte_carlo.py:87); QMC has no device implementation yet and raises."""
+
+    NUMPY = "numpy"
+    NUMBA = "numba"
+    QMC = "qmc"
+    FAST = "fast"
+    HIP = "hip"
+
+
+@dataclass
+class MCResult:
+    """monte_carlo.py:37-43"""
+
+    price: float
+    std_error: float = 0.0
+    n_paths: int = 0
+
+
+class MonteCarloPricer:
+    __slots__ = ("num_simulations", "num_steps", "seed", "method", "_use_numba")
+
+    def __init__(self, num_simulations: int = 100000, num_steps: int = 1, seed: Optional[int] = None,
+                 method: MCMethod = MCMethod.NUMPY):
+        if num_simulations < 1:
+            raise ValueError("num_simulations must be >= 1")
+        self.num_simulations = num_simulations
+        self.num_steps = num_steps
+        # one 31-bit draw at construction, then fixed: repeated price() calls and
+        # all FD bumps share the normals (monte_carlo.py:68-70)
+        self.seed = seed if seed is not None else int(np.random.default_rng().integers(0, 2**31))
+        self.method = method
+        self._use_numba = False
+
+    # ------------------------------------------------------------------ helpers
+    def _steps(self) -> int:
+        if self.method == MCMethod.QMC:
+            raise AccelerationError("MCMethod.QMC (scrambled Sobol) is not implemented on the device", backend="hip")
+        if self.method == MCMethod.FAST:
+            return 1
+        if self.num_steps < 1:
+            raise ValueError("num_steps must be >= 1")
+        return int(self.num_steps)
+
+    def _simulate(self, S: float, T: float, r: float, sigma: float, q: float, seed: Optional[int] = None) -> np.ndarray:
+        """Terminal prices, length 2*num_simulations, [pos | neg] (monte_carlo.py:74-106)."""
+        actual_seed = seed if seed is not None else self.seed
+        return _hip.european_terminal(S, T, r, sigma, q, self.num_simulations, self._steps(), actual_seed, True)
+
+    # -------------------------------------------------------------------- price
+    def price(self, S: float, K: float, T: float, r: float, sigma: float, option_type: Literal["call", "put"],
+              q: float = 0.0, seed: Optional[int] = None, return_error: bool = False) -> Union[float, MCResult]:
+        if T <= 0:  # monte_carlo.py:133-135
+            intrinsic = max(S - K, 0) if option_type == "call" else max(K - S, 0)
+            return MCResult(intrinsic, 0.0, 0) if return_error else intrinsic
+        actual_seed = seed if seed is not None else self.seed
+        st = _hip.european(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(),
+                           actual_seed, True)
+        if return_error:
+            return MCResult(float(st.price), float(st.std_error), int(st.n))
+        return float(st.price)
+
+    def price_with_control_variate(self, S: float, K: float, T: float, r: float, sigma: float,
+                                   option_type: Literal["call", "put"], q: float = 0.0,
+                                   seed: Optional[int] = None) -> float:
+        """Terminal spot as control, E[S_T] = S e^{(r-q)T} (monte_carlo.py:154-186)."""
+        actual_seed = seed if seed is not None else self.seed
+        m = _hip.european_cv(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(),
+                             actual_seed, True)
+        return float(m.value)
+
+    # ------------------------------------------------------------------- greeks
+    def greeks(self, S: float, K: float, T: float, r: float, sigma: float,
+               option_type: Literal["call", "put"] = "call", q: float = 0.0, seed: Optional[int] = None,
+               include_second_order: bool = True) -> "OrderedDict[str, float]":
+        """Additive convenience: the OrderedDict compute_greeks_unified(self, ...)
+        returns (src/greeks/unified_greeks.py:235-367), from ONE fused launch that
+        draws the normals once and evaluates all 8 / 14 bumped contracts per path."""
+        from .greeks import compute_greeks_unified
+
+        kw = {} if seed is None else {"seed": seed}
+        return compute_greeks_unified(self, S, K, T, r, sigma, option_type, q, include_second_order, **kw)
+
+    def _fused_greeks(self, S, K, T, r, sigma, option_type, q, include_second_order, seed=None):
+        actual_seed = seed if seed is not None else self.seed
+        vals, _ = _hip.european_greeks_fd(S, K, T, r, sigma, q, option_type == "call", self.num_simulations,
+                                          self._steps(), actual_seed, include_second_order)
+        n = 9 if include_second_order else 6
+        return OrderedDict((k, float(v)) for k, v in zip(GREEK_KEYS[:n], vals[:n]))
+
+
+__all__ = ["MonteCarloPricer", "MCMethod", "MCResult", "NUMBA_AVAILABLE"]

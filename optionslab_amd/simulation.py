@@ -1,0 +1,26 @@
+"""HIP simulation backend with the reference's backend contract
+``simulate_*(S, T, r, sigma, q, n_paths, n_steps, seed) -> ndarray[float64]``
+(src/simulation/__init__.py:5-6): terminal prices, antithetic => length
+2*n_paths ordered [pos | neg] (src/simulation/gbm_numpy.py:51)."""
+import numpy as np
+
+from . import _hip
+
+__all__ = ["simulate_gbm_hip", "simulate_gbm_hip_fast", "hip_available"]
+
+hip_available = _hip.hip_available
+
+
+def simulate_gbm_hip(S: float, T: float, r: float, sigma: float, q: float, n_paths: int, n_steps: int, seed: int,
+                     antithetic: bool = True) -> np.ndarray:
+    """Multi-step terminal prices (counterpart of simulate_gbm_numpy, gbm_numpy.py:15-53)."""
+    if n_paths < 1:
+        raise ValueError("n_paths must be >= 1")
+    if n_steps < 1:
+        raise ValueError("n_steps must be >= 1")
+    return _hip.european_terminal(S, T, r, sigma, q, n_paths, n_steps, seed, antithetic)
+
+
+def simulate_gbm_hip_fast(S: float, T: float, r: float, sigma: float, q: float, n_paths: int, seed: int) -> np.ndarray:
+    """Single-step closed form (counterpart of simulate_gbm_numpy_fast, gbm_numpy.py:56-83)."""
+    return simulate_gbm_hip(S, T, r, sigma, q, n_paths, 1, seed, True)

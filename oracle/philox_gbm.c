@@ -1,0 +1,149 @@
+/*
+ * philox_gbm.c -- CPU restatement (plain C, libm) of the DEVICE algorithm of
+ * libolmc: Philox4x32-10 counters -> Box-Muller normals -> GBM payoffs.
+ *
+ * TEST INFRASTRUCTURE ONLY: used by tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py as a checker; the product never links or calls it.
+ *
+ * Why a second oracle: the reference (oracle/numpy_reference.py, pinned bitwise
+ * to the reference's own outputs) draws PCG64 + ziggurat normals, so the GPU can
+ * match it only statistically (within 3 sigma of the Monte Carlo error).  This
+ * file consumes the SAME counter-based stream as the GPU, so GPU results must
+ * agree with it to rounding (the GPU's v_log/v_sin/v_cos approximations, ~1e-6
+ * relative on a normal), which is a far tighter gate on indexing, antithetic
+ * layout, remainder handling, sharding offsets and the reduction.
+ *
+ * Pinning: the Philox core is checked against the Random123 known-answer
+ * vectors (tests/test_philox_oracle.py); the payoff arithmetic follows
+ * src/simulation/gbm_numpy.py:35-51 and src/pricing_models/exotic_options.py:54-67,119-131
+ * of the reference and is cross-checked against the NumPy oracle statistically.
+ *
+ * Stream contract (include/olmc.h): key = (seed lo, seed hi); counter =
+ * (path lo, path hi, step/4, tag); words (x0,x1) -> normals of steps 4b, 4b+1
+ * (cos, sin), (x2,x3) -> steps 4b+2, 4b+3; u = fmaf((float)x, 2^-32, 2^-33).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#define M0 0xD2511F53u
+#define M1 0xCD9E8D57u
+#define W0 0x9E3779B9u
+#define W1 0xBB67AE85u
+
+void ol_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int i = 0; i < 10; ++i) {
+        uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+static float unit_open(uint32_t x) { return fmaf((float)x, 0x1p-32f, 0x1p-33f); }
+
+/* Box-Muller evaluated in double on the fp32 uniforms, rounded once to fp32. */
+static void box_muller(uint32_t xa, uint32_t xb, float* zc, float* zs) {
+    const double ua = unit_open(xa), ub = unit_open(xb);
+    const double rad = sqrt(-2.0 * log(ua)), ang = 6.283185307179586476925 * ub;
+    *zc = (float)(rad * cos(ang));
+    *zs = (float)(rad * sin(ang));
+}
+
+static void normals4(uint64_t path, uint32_t block, uint64_t seed, float z[4]) {
+    uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), block, 0u};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, w[4];
+    ol_philox4x32_10(ctr, key, w);
+    box_muller(w[0], w[1], &z[0], &z[1]);
+    box_muller(w[2], w[3], &z[2], &z[3]);
+}
+
+/* out[p*n_steps + t] */
+void ol_normals(uint64_t seed, int64_t path0, int64_t n_paths, int32_t n_steps, float* out) {
+    for (int64_t p = 0; p < n_paths; ++p)
+        for (int32_t b = 0; 4 * b < n_steps; ++b) {
+            float z[4];
+            normals4((uint64_t)(path0 + p), (uint32_t)b, seed, z);
+            for (int j = 0; j < 4 && 4 * b + j < n_steps; ++j) out[p * n_steps + 4 * b + j] = z[j];
+        }
+}
+
+/* sum_t Z: fp32 inside a block of four, fp64 across blocks (device order). */
+static double path_normal_sum(uint64_t path, int32_t n_steps, uint64_t seed) {
+    double acc = 0.0;
+    float z[4];
+    int32_t full = n_steps >> 2, rem = n_steps & 3;
+    for (int32_t b = 0; b < full; ++b) {
+        normals4(path, (uint32_t)b, seed, z);
+        acc += (double)((z[0] + z[1]) + (z[2] + z[3]));
+    }
+    if (rem) {
+        normals4(path, (uint32_t)full, seed, z);
+        float s = z[0];
+        if (rem > 1) s += z[1];
+        if (rem > 2) s += z[2];
+        acc += (double)s;
+    }
+    return acc;
+}
+
+/* Terminal prices [pos | neg] for global paths path0 .. path0+n-1 (gbm_numpy.py:35-51). */
+void ol_european_terminal(double S, double T, double r, double sigma, double q, int64_t path0, int64_t n,
+                          int32_t n_steps, uint64_t seed, int antithetic, double* out) {
+    const double dt = T / n_steps, drift = (r - q - 0.5 * sigma * sigma) * dt, vol = sigma * sqrt(dt);
+    const double a = log(S) + drift * n_steps;
+    for (int64_t i = 0; i < n; ++i) {
+        const double dz = vol * path_normal_sum((uint64_t)(path0 + i), n_steps, seed);
+        out[i] = exp(a + dz);
+        if (antithetic) out[n + i] = exp(a - dz);
+    }
+}
+
+/* moments[0..4] = sum x, sum x^2, sum s, sum s^2, sum x*s over all payoff samples
+ * (x = UNdiscounted payoff, s = terminal price); long double accumulation. */
+void ol_european_moments(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t path0,
+                         int64_t n, int32_t n_steps, uint64_t seed, int antithetic, double moments[5]) {
+    const double dt = T / n_steps, drift = (r - q - 0.5 * sigma * sigma) * dt, vol = sigma * sqrt(dt);
+    const double a = log(S) + drift * n_steps, sign = is_call ? 1.0 : -1.0;
+    long double m[5] = {0, 0, 0, 0, 0};
+    for (int64_t i = 0; i < n; ++i) {
+        const double dz = vol * path_normal_sum((uint64_t)(path0 + i), n_steps, seed);
+        for (int leg = 0; leg < (antithetic ? 2 : 1); ++leg) {
+            const double s = exp(leg ? a - dz : a + dz), x = fmax(sign * (s - K), 0.0);
+            m[0] += x; m[1] += x * x; m[2] += s; m[3] += s * s; m[4] += x * s;
+        }
+    }
+    for (int j = 0; j < 5; ++j) moments[j] = (double)m[j];
+}
+
+/* Asian: average over t = 1..M of S_t (arithmetic) or exp(mean ln S_t) (geometric)
+ * (exotic_options.py:54-67, 119-131).  moments[0..1] = sum x, sum x^2. */
+void ol_asian_moments(double S, double K, double T, double r, double sigma, double q, int is_call, int geometric,
+                      int64_t path0, int64_t n, int32_t n_steps, uint64_t seed, int antithetic, double moments[2]) {
+    const double dt = T / n_steps, drift = (r - q - 0.5 * sigma * sigma) * dt, vol = sigma * sqrt(dt);
+    const double log_s0 = log(S), sign = is_call ? 1.0 : -1.0;
+    long double m0 = 0, m1 = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double cum[2] = {0, 0}, run[2] = {0, 0};
+        for (int32_t b = 0; 4 * b < n_steps; ++b) {
+            float z[4];
+            normals4((uint64_t)(path0 + i), (uint32_t)b, seed, z);
+            for (int j = 0; j < 4 && 4 * b + j < n_steps; ++j) {
+                const double dz = vol * (double)z[j];
+                cum[0] += drift + dz;
+                cum[1] += drift - dz;
+                for (int leg = 0; leg < 2; ++leg) run[leg] += geometric ? log_s0 + cum[leg] : exp(log_s0 + cum[leg]);
+            }
+        }
+        for (int leg = 0; leg < (antithetic ? 2 : 1); ++leg) {
+            double avg = run[leg] / n_steps;
+            if (geometric) avg = exp(avg);
+            const double x = fmax(sign * (avg - K), 0.0);
+            m0 += x; m1 += x * x;
+        }
+    }
+    moments[0] = (double)m0; moments[1] = (double)m1;
+}

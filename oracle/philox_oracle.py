@@ -1,0 +1,88 @@
+"""ctypes wrapper of oracle/philox_gbm.c (CPU restatement of the device stream).
+TEST INFRASTRUCTURE ONLY -- see the header of philox_gbm.c."""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libphilox_oracle.so")
+_U64 = (1 << 64) - 1
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(HERE, "philox_gbm.c")
+    if force or not os.path.exists(LIB) or os.path.getmtime(src) > os.path.getmtime(LIB):
+        subprocess.run(["make", "-s", "-C", HERE, "-B"], check=True)
+    return LIB
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+def philox(ctr, key):
+    c, k, o = (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), (C.c_uint32 * 4)()
+    _load().ol_philox4x32_10(c, k, o)
+    return list(o)
+
+
+def philox_words(seed, path0, n_paths, block0, n_blocks, tag=0):
+    """Same layout as olmc_philox_words: out[p, b, w]."""
+    out = np.empty((n_paths, n_blocks, 4), dtype=np.uint32)
+    s = int(seed) & _U64
+    key = (s & 0xFFFFFFFF, s >> 32)
+    for p in range(n_paths):
+        g = path0 + p
+        for b in range(n_blocks):
+            out[p, b] = philox((g & 0xFFFFFFFF, g >> 32, block0 + b, tag), key)
+    return out
+
+
+def normals(seed, path0, n_paths, n_steps):
+    out = np.empty((n_paths, n_steps), dtype=np.float32)
+    _load().ol_normals(C.c_uint64(int(seed) & _U64), C.c_int64(path0), C.c_int64(n_paths), C.c_int32(n_steps),
+                       out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def european_terminal(S, T, r, sigma, q, n_paths, n_steps, seed, antithetic=True, path0=0):
+    out = np.empty(n_paths * (2 if antithetic else 1), dtype=np.float64)
+    _load().ol_european_terminal(C.c_double(S), C.c_double(T), C.c_double(r), C.c_double(sigma), C.c_double(q),
+                                 C.c_int64(path0), C.c_int64(n_paths), C.c_int32(n_steps),
+                                 C.c_uint64(int(seed) & _U64), C.c_int(int(antithetic)),
+                                 out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
+def european_moments(S, K, T, r, sigma, q, is_call, n_paths, n_steps, seed, antithetic=True, path0=0):
+    """-> (sum_x, sum_xx, sum_s, sum_ss, sum_xs, n)"""
+    m = (C.c_double * 5)()
+    _load().ol_european_moments(C.c_double(S), C.c_double(K), C.c_double(T), C.c_double(r), C.c_double(sigma),
+                                C.c_double(q), C.c_int(int(is_call)), C.c_int64(path0), C.c_int64(n_paths),
+                                C.c_int32(n_steps), C.c_uint64(int(seed) & _U64), C.c_int(int(antithetic)), m)
+    return (*list(m), n_paths * (2 if antithetic else 1))
+
+
+def asian_moments(S, K, T, r, sigma, q, is_call, geometric, n_paths, n_steps, seed, antithetic=False, path0=0):
+    m = (C.c_double * 2)()
+    _load().ol_asian_moments(C.c_double(S), C.c_double(K), C.c_double(T), C.c_double(r), C.c_double(sigma),
+                             C.c_double(q), C.c_int(int(is_call)), C.c_int(int(geometric)), C.c_int64(path0),
+                             C.c_int64(n_paths), C.c_int32(n_steps), C.c_uint64(int(seed) & _U64),
+                             C.c_int(int(antithetic)), m)
+    return m[0], m[1], n_paths * (2 if antithetic else 1)
+
+
+def price_and_error(sum_x, sum_xx, n, r, T):
+    """monte_carlo.py:145-150 on the moments."""
+    disc, mean = math.exp(-r * T), sum_x / n
+    var = max(sum_xx / n - mean * mean, 0.0)
+    return disc * mean, disc * math.sqrt(var) / math.sqrt(n)

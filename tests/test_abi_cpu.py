@@ -1,0 +1,95 @@
+"""CPU checks of the C-ABI boundary: libolmc.so builds/loads, exports every
+symbol include/olmc.h declares, the ctypes prototypes cover them all, struct
+layouts match, the pure host function works, and -- without a GPU -- compute
+entry points fail loudly instead of falling back."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from optionslab_amd import _hip
+from optionslab_amd.build import LIBRARY, build_library
+from optionslab_amd.exceptions import AccelerationError
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "olmc.h")
+
+
+def declared_symbols():
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(olmc_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def library():
+    build_library()
+    return _hip.load_library()
+
+
+def test_header_declares_the_expected_surface():
+    names = declared_symbols()
+    for must in ("olmc_init", "olmc_european", "olmc_european_batch", "olmc_european_greeks_fd", "olmc_european_terminal",
+                 "olmc_european_cv", "olmc_asian", "olmc_multi_gpu_european", "olmc_last_error", "olmc_shutdown"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(library):
+    for name in declared_symbols():
+        assert hasattr(library, name), f"{name} declared in include/olmc.h but not exported"
+    out = subprocess.run(["nm", "-D", "--defined-only", LIBRARY], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (olmc_[a-z0-9_]+)", out))
+    assert set(declared_symbols()) <= exported
+
+
+def test_ctypes_prototypes_cover_the_header():
+    assert sorted(_hip.PROTOTYPES) == declared_symbols()
+
+
+def test_library_carries_gfx950_code_object():
+    blob = open(LIBRARY, "rb").read()
+    assert b"gfx950" in blob
+
+
+def test_struct_layouts_match_the_header():
+    assert C.sizeof(_hip.Stats) == 40
+    assert C.sizeof(_hip.Option) == 56
+    assert C.sizeof(_hip.CvMoments) == 56
+    assert _hip.Stats.n.offset == 16 and _hip.Stats.price.offset == 24
+
+
+def test_abi_version_and_error_string(library):
+    assert library.olmc_abi_version() == 1
+    assert isinstance(library.olmc_last_error(), bytes)
+
+
+def test_combine_stats_is_a_pure_host_function(library):
+    # two shards of payoffs {1,2,3} and {4}: mean 2.5, var(ddof=0) 1.25
+    st = _hip.combine_stats([(6.0, 14.0, 3), (4.0, 16.0, 1)], r=0.0, T=1.0)
+    assert st.n == 4 and st.sum == 10.0 and st.sumsq == 30.0
+    assert st.price == 2.5
+    assert abs(st.std_error - (1.25 ** 0.5) / 2.0) < 1e-15
+    with pytest.raises(AccelerationError):
+        _hip.combine_stats([], 0.0, 1.0)
+
+
+def _no_gpu():
+    return not os.path.exists("/dev/kfd")
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="GPU present: loud-failure path not reachable")
+def test_compute_fails_loudly_without_a_gpu():
+    with pytest.raises(AccelerationError) as e:
+        _hip.european(100, 100, 1.0, 0.05, 0.2, 0.0, True, 1000, 4, 1)
+    assert e.value.backend == "hip"
+    import optionslab_amd as ol
+    with pytest.raises(AccelerationError):
+        ol.MonteCarloPricer(1000, 4, 1).price(100, 100, 1.0, 0.05, 0.2, "call")
+    with pytest.raises(ol.GreeksError):
+        ol.compute_greeks_unified(ol.MonteCarloPricer(1000, 4, 1), 100, 100, 1.0, 0.05, 0.2)
+    with pytest.raises(AccelerationError):
+        ol.AsianOption(100, 100, 1.0, 0.05, 0.2, seed=1).price(100, 8)
+    with pytest.raises(AccelerationError):
+        ol.simulate_gbm_hip(100, 1.0, 0.05, 0.2, 0.0, 100, 4, 1)
+    assert ol.hip_available() is False

@@ -1,0 +1,313 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`).  Every call goes
+through the C ABI of libolmc.so (ctypes).  Three gates:
+
+  1. bit-exact Philox words vs the C checker (integer work);
+  2. tight agreement with the C checker, which consumes the same counter stream
+     (tolerances below are set by the hardware log2/sin/cos approximations);
+  3. statistical agreement with the reference: golden vectors captured from the
+     reference itself, 3 sigma of the Monte Carlo standard error (north_star's
+     stated floating-point tolerance), plus the reference's own test assertions.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import optionslab_amd as ol
+from optionslab_amd import _hip
+from oracle import numpy_reference as orc
+from oracle import philox_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+ATM = (100.0, 100.0, 1.0, 0.05, 0.2)
+BS_CALL = 10.450583572185565
+Z_ABS_TOL = 2e-5        # |z_gpu - z_checker| per normal (fp32 normals, hardware transcendentals)
+REL_STREAM_TOL = 2e-6   # price vs the same-stream C checker
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    info = _hip.device_info()
+    assert info["arch"].startswith("gfx950"), info
+    yield
+    _hip.shutdown()
+
+
+# ------------------------------------------------------------------ RNG stream
+def test_philox_words_bit_exact():
+    for seed, path0, n_paths, block0, n_blocks, tag in [(42, 0, 300, 0, 5, 0), (2**63 + 12345, (1 << 32) - 7, 20, 1000, 3, 0),
+                                                        (0, 0, 1, 0, 1, 0), (7, 5, 9, 62, 2, 3)]:
+        got = _hip.philox_words(seed, path0, n_paths, block0, n_blocks, tag)
+        assert np.array_equal(got, po.philox_words(seed, path0, n_paths, block0, n_blocks, tag))
+    kat = _hip.philox_words(0, 0, 1, 0, 1, 0)[0, 0]
+    assert [int(x) for x in kat] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]   # Random123 KAT
+
+
+@pytest.mark.parametrize("n_steps", [1, 2, 3, 4, 5, 252])
+def test_normals_match_checker(n_steps):
+    z = _hip.normals(42, 1000, 513, n_steps)
+    want = po.normals(42, 1000, 513, n_steps)
+    assert z.shape == want.shape and np.isfinite(z).all()
+    assert np.abs(z.astype(np.float64) - want.astype(np.float64)).max() < Z_ABS_TOL
+
+
+def test_normals_distribution():
+    from scipy import stats
+    z = _hip.normals(123, 0, 200000, 10).astype(np.float64).ravel()
+    n = z.size
+    assert abs(z.mean()) < 4 / math.sqrt(n)
+    assert abs(z.var() - 1) < 4 * math.sqrt(2 / n)
+    assert abs(stats.skew(z)) < 4 * math.sqrt(6 / n)
+    assert abs(stats.kurtosis(z)) < 4 * math.sqrt(24 / n)
+    assert stats.kstest(z[:200000], "norm").pvalue > 1e-3
+
+
+# ------------------------------------------------------------------ European
+@pytest.mark.parametrize("N,M,seed,typ,q,anti", [
+    (10000, 50, 42, "call", 0.0, True), (10000, 50, 42, "put", 0.02, True), (100000, 252, 42, "call", 0.0, True),
+    (100000, 1, 42, "put", 0.0, True), (4097, 7, 3, "call", 0.0, True), (1, 1, 0, "put", 0.0, True),
+    (255, 3, 9, "call", 0.0, False), (70001, 13, 5, "put", 0.01, False),
+])
+def test_european_matches_same_stream_checker(N, M, seed, typ, q, anti):
+    S, K, T, r, v = ATM
+    st = _hip.european(S, K, T, r, v, q, typ == "call", N, M, seed, anti)
+    sx, sxx, *_m, n = po.european_moments(S, K, T, r, v, q, typ == "call", N, M, seed, anti)
+    price, se = po.price_and_error(sx, sxx, n, r, T)
+    assert st.n == n
+    assert st.sum == pytest.approx(sx, rel=REL_STREAM_TOL, abs=1e-9)
+    assert st.sumsq == pytest.approx(sxx, rel=4 * REL_STREAM_TOL, abs=1e-9)
+    assert st.price == pytest.approx(price, rel=REL_STREAM_TOL, abs=1e-9)
+    assert st.std_error == pytest.approx(se, rel=1e-4, abs=1e-9)
+
+
+def test_golden_reference_prices_within_3_sigma(golden):
+    for c in golden["price"]:
+        N, M, seed, method = c["ctor"]
+        if method == "qmc":
+            continue
+        S, K, T, r, v, typ, q = c["args"]
+        kw = {} if c["call_seed"] is None else {"seed": c["call_seed"]}
+        res = ol.MonteCarloPricer(N, M, seed, ol.MCMethod(method)).price(S, K, T, r, v, typ, q, return_error=True, **kw)
+        assert res.n_paths == c["n_paths"]
+        if N < 100:      # tiny cases: only sanity (se of 2..14 samples is meaningless)
+            assert res.price >= 0
+            continue
+        assert abs(res.price - c["price"]) <= 3 * math.hypot(res.std_error, c["std_error"]), c["ctor"]
+        assert abs(res.std_error / c["std_error"] - 1) < 0.05, c["ctor"]
+        bs = ol.black_scholes(S, K, T, r, v, typ, q)
+        assert abs(res.price - bs) <= 3.5 * res.std_error, c["ctor"]
+
+
+def test_headline_config_1m_x_252_within_3_sigma_of_bs_and_reference(golden):
+    g4 = next(c for c in golden["price"] if c["ctor"][0] == 1000000)
+    for seed in (42, 43, 44):
+        res = ol.MonteCarloPricer(1_000_000, 252, seed).price(*ATM, "call", return_error=True)
+        assert res.n_paths == 2_000_000
+        assert abs(res.price - BS_CALL) <= 3 * res.std_error
+        assert abs(res.price - g4["price"]) <= 3 * math.hypot(res.std_error, g4["std_error"])
+        assert abs(res.std_error / g4["std_error"] - 1) < 0.02
+
+
+def test_reference_test_suite_assertions():
+    """tests/test_monte_carlo.py of the reference, re-run against the device pricer."""
+    p = ol.MonteCarloPricer(num_simulations=10000, num_steps=50, seed=42)
+    call = p.price(S=100, K=100, T=1.0, r=0.05, sigma=0.2, option_type="call", q=0.0)
+    assert type(call) is float and 0 < call < 100 and abs(call - BS_CALL) < 1.0               # :119-131
+    put = p.price(S=100, K=100, T=1.0, r=0.05, sigma=0.2, option_type="put", q=0.0)
+    assert put > 0 and abs(put - ol.black_scholes(100, 100, 1.0, 0.05, 0.2, "put")) < 1.0        # :133-141
+    assert p.price(100, 100, 1.0, 0.05, 0.2, "call", seed=42) == p.price(100, 100, 1.0, 0.05, 0.2, "call", seed=42)  # :153-158
+    res = p.price(100, 100, 1.0, 0.05, 0.2, "call", return_error=True)
+    assert res.price > 0 and 0 < res.std_error < res.price                                    # :160-168
+    c, q_ = p.price(100, 100, 1.0, 0.05, 0.2, "call", 0.02), p.price(100, 100, 1.0, 0.05, 0.2, "put", 0.02)
+    assert abs((c - q_) - (100 * math.exp(-0.02) - 100 * math.exp(-0.05))) < 2.0              # :509-521
+    assert p.price(110, 100, 1.0, 0.05, 0.2, "call") > p.price(100, 100, 1.0, 0.05, 0.2, "call") > p.price(90, 100, 1.0, 0.05, 0.2, "call")
+    assert p.price(100, 100, 1.0, 0.05, 0.4, "call") > p.price(100, 100, 1.0, 0.05, 0.1, "call")
+    assert p.price(100, 100, 2.0, 0.05, 0.2, "call") > p.price(100, 100, 0.25, 0.05, 0.2, "call")
+    assert p.price(100, 100, 1.0, 0.05, 0.2, "call", seed=1) != p.price(100, 100, 1.0, 0.05, 0.2, "call", seed=2)
+    assert p.price(100, 100, 1.0, 0.05, 0.2, "banana") == p.price(100, 100, 1.0, 0.05, 0.2, "put")   # :140-143
+
+
+def test_unseeded_pricer_is_self_consistent():
+    p = ol.MonteCarloPricer(5000, 4)            # seed drawn once at construction
+    assert p.price(*ATM, "call") == p.price(*ATM, "call")
+
+
+def test_fast_method_forces_single_step():
+    a = ol.MonteCarloPricer(20000, 50, 7, ol.MCMethod.FAST).price(*ATM, "call")
+    b = ol.MonteCarloPricer(20000, 1, 7, ol.MCMethod.NUMPY).price(*ATM, "call")
+    assert a == b
+    with pytest.raises(ol.AccelerationError):
+        ol.MonteCarloPricer(1024, 8, 1, ol.MCMethod.QMC).price(*ATM, "call")
+
+
+def test_argument_errors():
+    with pytest.raises(ol.AccelerationError):
+        _hip.european(*ATM, 0.0, True, 0, 4, 1)
+    with pytest.raises(ol.AccelerationError):
+        _hip.european(*ATM, 0.0, True, 10, 0, 1)
+    with pytest.raises(ValueError):
+        ol.MonteCarloPricer(10, 0, 1).price(*ATM, "call")
+
+
+# ------------------------------------------------------------------ terminal array (backend contract)
+@pytest.mark.parametrize("N,M", [(1000, 12), (257, 1), (5000, 6)])
+def test_terminal_array_layout_and_values(N, M):
+    st = ol.simulate_gbm_hip(100.0, 1.0, 0.05, 0.2, 0.01, N, M, 3)
+    want = po.european_terminal(100.0, 1.0, 0.05, 0.2, 0.01, N, M, 3)
+    assert st.dtype == np.float64 and st.shape == (2 * N,)
+    assert np.allclose(st, want, rtol=2e-5, atol=0)
+    one_leg = ol.simulate_gbm_hip(100.0, 1.0, 0.05, 0.2, 0.01, N, M, 3, antithetic=False)
+    assert np.array_equal(one_leg, st[:N])
+    p = ol.MonteCarloPricer(N, M, 3)
+    assert np.array_equal(p._simulate(100.0, 1.0, 0.05, 0.2, 0.01), st)
+    # price() == the reference tail applied to the returned array (monte_carlo.py:140-150)
+    x = np.maximum(st - 100.0, 0.0)
+    res = p.price(100.0, 100.0, 1.0, 0.05, 0.2, "call", 0.01, return_error=True)
+    assert res.price == pytest.approx(float(np.exp(-0.05) * np.mean(x)), rel=1e-12)
+    assert res.std_error == pytest.approx(float(np.exp(-0.05) * np.std(x) / np.sqrt(len(x))), rel=1e-9)
+    assert np.array_equal(ol.simulate_gbm_hip_fast(100.0, 1.0, 0.05, 0.2, 0.0, N, 9),
+                          ol.simulate_gbm_hip(100.0, 1.0, 0.05, 0.2, 0.0, N, 1, 9))
+
+
+# ------------------------------------------------------------------ sharding (size-independent property)
+def test_shards_add_up_to_the_whole():
+    S, K, T, r, v = ATM
+    N, M, seed = 300_001, 21, 11
+    whole = _hip.european(S, K, T, r, v, 0.0, True, N, M, seed)
+    for world in (2, 3, 8):
+        parts = []
+        for k in range(world):
+            lo, hi = ol.sharding.shard_bounds(N, k, world)
+            st = _hip.european(S, K, T, r, v, 0.0, True, hi - lo, M, seed, True, path_offset=lo)
+            parts.append((st.sum, st.sumsq, st.n))
+        comb = _hip.combine_stats(parts, r, T)
+        assert comb.n == whole.n
+        assert comb.price == pytest.approx(whole.price, rel=1e-12)
+        assert comb.std_error == pytest.approx(whole.std_error, rel=1e-9)
+
+
+def test_large_path_offsets_use_the_high_counter_word():
+    S, K, T, r, v = ATM
+    off = (1 << 32) - 100
+    st = _hip.european(S, K, T, r, v, 0.0, True, 1000, 5, 1, True, path_offset=off)
+    sx, sxx, *_m, n = po.european_moments(S, K, T, r, v, 0.0, True, 1000, 5, 1, True, off)
+    assert st.sum == pytest.approx(sx, rel=REL_STREAM_TOL)
+
+
+def test_single_process_multi_gpu_entry_point_on_one_gpu():
+    S, K, T, r, v = ATM
+    a = _hip.multi_gpu_european(S, K, T, r, v, 0.0, True, 200_000, 16, 5, True, 1)    # RCCL all-reduce, 1 rank
+    b = _hip.european(S, K, T, r, v, 0.0, True, 200_000, 16, 5, True)
+    assert (a.sum, a.sumsq, a.n, a.price, a.std_error) == (b.sum, b.sumsq, b.n, b.price, b.std_error)
+    with pytest.raises(ol.AccelerationError):
+        _hip.multi_gpu_european(S, K, T, r, v, 0.0, True, 1000, 4, 5, True, 64)
+
+
+# ------------------------------------------------------------------ Greeks
+def test_batch_equals_separate_launches():
+    opts = [(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, True), (101.0, 100.0, 1.0, 0.05, 0.2, 0.0, True),
+            (99.0, 95.0, 0.5, 0.03, 0.25, 0.01, False)]
+    for k in (1, 2, 3):
+        got = _hip.european_batch(opts[:k], 50_000, 10, 42)
+        for o, st in zip(opts[:k], got):
+            S, K, T, r, v, q, c = o
+            one = _hip.european(S, K, T, r, v, q, c, 50_000, 10, 42)
+            assert st.price == pytest.approx(one.price, rel=1e-13) and st.n == one.n
+    many = [(100.0 + i, 100.0, 1.0, 0.05, 0.2, 0.0, True) for i in range(16)]
+    got = _hip.european_batch(many, 20_000, 6, 1)
+    assert all(a.price < b.price for a, b in zip(got, got[1:]))
+    with pytest.raises(ol.AccelerationError):
+        _hip.european_batch(many + many[:1], 100, 2, 1)
+
+
+@pytest.mark.parametrize("second", [False, True])
+def test_fused_greeks_equal_literal_bump_and_reprice(second):
+    p = ol.MonteCarloPricer(200_000, 52, 42)
+    fused = ol.compute_greeks_unified(p, *ATM, "call", 0.0, include_second_order=second)
+    literal = ol.compute_greeks_unified(p, *ATM, "call", 0.0, include_second_order=second, fused=False)
+    assert list(fused) == list(literal)
+    assert list(fused) == ["price", "delta", "gamma", "vega", "theta", "rho"] + (["vanna", "charm", "vomma"] if second else [])
+    for k in fused:
+        assert fused[k] == pytest.approx(literal[k], rel=1e-8, abs=1e-8), k
+    assert fused == p.greeks(*ATM, "call", 0.0, include_second_order=second)
+
+
+def test_greeks_against_reference_golden_and_black_scholes(golden):
+    exact = orc.bs_greeks(*ATM, "call")
+    g7 = next(c for c in golden["greeks"] if c["ctor"][:2] == [100000, 252] and not c["include_second_order"])
+    # tolerances: SURVEY §8c -- the BS-vs-reference gaps at N=1e5 scaled by sqrt(1e5/N), x3
+    N = 1_000_000
+    scale = 3 * math.sqrt(1e5 / N)
+    tol = dict(delta=3e-4 * scale * 3, gamma=4e-4 * scale * 3, vega=0.07 * scale * 3, theta=0.012 * scale * 3, rho=0.03 * scale * 3)
+    g = ol.MonteCarloPricer(N, 252, 42).greeks(*ATM, "call", include_second_order=False)
+    for k, t in tol.items():
+        assert abs(g[k] - exact[k]) <= t, (k, g[k], exact[k])
+        assert abs(g[k] - g7["values"][k]) <= 4 * abs(g7["values"][k] - exact[k]) + t, k
+    put = ol.MonteCarloPricer(N, 252, 42).greeks(*ATM, "put", include_second_order=False)
+    assert put["delta"] == pytest.approx(g["delta"] - 1.0, abs=2e-3)      # put-call parity of delta (q = 0)
+    assert put["gamma"] == pytest.approx(g["gamma"], abs=1e-3)
+
+
+def test_greeks_short_dated_branch():
+    p = ol.MonteCarloPricer(50_000, 4, 42)
+    g = p.greeks(100.0, 100.0, 0.002, 0.05, 0.2, "call")
+    lit = ol.compute_greeks_unified(p, 100.0, 100.0, 0.002, 0.05, 0.2, "call", fused=False)
+    assert g["charm"] == 0.0 and g["theta"] == pytest.approx(-g["price"] / 0.002, rel=1e-12)
+    for k in g:
+        assert g[k] == pytest.approx(lit[k], rel=1e-8, abs=1e-8)
+
+
+# ------------------------------------------------------------------ control variate
+def test_control_variate(golden):
+    for c in golden["control_variate"]:
+        N, M, seed, _ = c["ctor"]
+        S, K, T, r, v, typ, q = c["args"]
+        p = ol.MonteCarloPricer(N, M, seed)
+        got = p.price_with_control_variate(S, K, T, r, v, typ, q)
+        assert type(got) is float
+        # same-stream checker: rebuild the estimator from its five moments
+        sx, sxx, ss, sss, sxs, n = po.european_moments(S, K, T, r, v, q, typ == "call", N, M, seed, True)
+        disc = math.exp(-r * T)
+        md, ms = disc * sx / n, ss / n
+        beta = ((disc * sxs - n * md * ms) / (n - 1)) / ((sss - n * ms * ms) / (n - 1))
+        assert got == pytest.approx(md - beta * (ms - S * math.exp((r - q) * T)), rel=5e-6)
+        plain = p.price(S, K, T, r, v, typ, q, return_error=True)
+        bs = ol.black_scholes(S, K, T, r, v, typ, q)
+        assert abs(got - bs) <= 3 * plain.std_error and abs(got - c["value"]) <= 3 * plain.std_error
+
+
+# ------------------------------------------------------------------ Asian
+@pytest.mark.parametrize("geometric,typ,anti,N,M", [(False, "call", False, 20000, 64), (True, "put", False, 20000, 64),
+                                                    (False, "put", True, 5001, 13), (True, "call", True, 777, 252)])
+def test_asian_matches_same_stream_checker(geometric, typ, anti, N, M):
+    st = _hip.asian(100.0, 100.0, 1.0, 0.05, 0.2, 0.02, typ == "call", geometric, N, M, 7, anti)
+    sx, sxx, n = po.asian_moments(100.0, 100.0, 1.0, 0.05, 0.2, 0.02, typ == "call", geometric, N, M, 7, anti)
+    assert st.n == n
+    assert st.sum == pytest.approx(sx, rel=REL_STREAM_TOL) and st.sumsq == pytest.approx(sxx, rel=4 * REL_STREAM_TOL)
+
+
+def test_asian_against_reference_golden_and_reference_tests(golden):
+    for c in golden["asian"]:
+        S, K, T, r, v, q = c["params"]
+        o = ol.AsianOption(S, K, T, r, v, q, seed=c["seed"])
+        price, se = o.price(c["n_paths"], c["n_steps"], c["avg_type"], c["option_type"], return_error=True)
+        assert isinstance(price, np.float64) and price > 0                                   # test_exotic_options.py:56-76
+        assert abs(price - c["price"]) <= 3 * math.sqrt(2) * se, c
+        if c["avg_type"] == "geometric":                                                    # :92-101 (closed form is continuous-monitoring)
+            assert abs(price - c["geometric_closed_form"]) / c["geometric_closed_form"] < 0.05
+    a = ol.AsianOption(100, 100, 1.0, 0.05, 0.2, seed=42)
+    assert a.price(50000, avg_type="arithmetic", option_type="call") < BS_CALL               # :78-90
+    assert a.price(n_paths=1000) == ol.AsianOption(100, 100, 1.0, 0.05, 0.2, seed=42).price(n_paths=1000)  # :103-114
+    assert ol.price_asian(100, 100, 1.0, 0.05, 0.2, n_paths=1000, seed=42) == a.price(n_paths=1000)
+
+
+def test_asian_greeks_through_exotic_adapter(golden):
+    c = golden["asian_greeks"]
+    ad = ol.ExoticAdapter(ol.AsianOption(100.0, 100.0, 1.0, 0.05, 0.2, seed=42), n_paths=200_000, n_steps=64, avg_type="arithmetic")
+    g = ol.compute_greeks_unified(ad, 100.0, 100.0, 1.0, 0.05, 0.2, "call", 0.0, include_second_order=False)
+    want = c["values"]      # reference at 20k paths: loose gates, CRN keeps FD noise small
+    assert g["price"] == pytest.approx(want["price"], abs=0.15)
+    assert g["delta"] == pytest.approx(want["delta"], abs=0.02)
+    assert g["vega"] == pytest.approx(want["vega"], rel=0.05)
+    assert g["rho"] == pytest.approx(want["rho"], rel=0.05)

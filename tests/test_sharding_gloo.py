@@ -1,0 +1,83 @@
+"""N > 1 path on CPU: two gloo ranks each reduce their contiguous global path
+block (the C checker stands in for the per-rank kernel -- same counters as the
+GPU), all-reduce the (sum, sumsq, n) triple, and must reproduce the unsharded
+result.  Covers shard_bounds, allreduce_triple and finalize."""
+import math
+import os
+import socket
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = dict(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, q=0.0)
+N, M, SEED = 4001, 13, 77          # odd on purpose: ragged shards, step remainder
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from optionslab_amd import sharding
+    from oracle import philox_oracle as po
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lo, hi = sharding.shard_bounds(N, rank, world)
+    sx, sxx, *_rest, n = po.european_moments(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], ARGS["q"],
+                                             True, hi - lo, M, SEED, True, lo)
+    t = torch.tensor([sx, sxx, float(n)], dtype=torch.float64)
+    sharding.allreduce_triple(t)
+    price, se = sharding.finalize(t[0].item(), t[1].item(), int(t[2].item()), ARGS["r"], ARGS["T"])
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(repr((lo, hi, price, se, int(t[2].item()))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_tile_the_range():
+    from optionslab_amd.sharding import shard_bounds
+    for n, w in [(10, 3), (4001, 2), (64_000_000, 8), (8, 8), (1_000_003, 7)]:
+        cuts = [shard_bounds(n, k, w) for k in range(w)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        assert max(h - l for l, h in cuts) - min(h - l for l, h in cuts) <= 1
+    with pytest.raises(ValueError):
+        shard_bounds(3, 0, 4)
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
+
+
+def test_two_rank_gloo_allreduce_reproduces_unsharded_price(tmp_path):
+    import torch.multiprocessing as mp
+
+    from oracle import philox_oracle as po
+
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [eval(open(tmp_path / f"rank{k}.txt").read()) for k in range(2)]
+    assert got[0][:2] == (0, 2000) and got[1][:2] == (2000, 4001)
+    assert got[0][2:] == got[1][2:]                      # identical finalisation on every rank
+    sx, sxx, *_r, n = po.european_moments(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], ARGS["q"],
+                                          True, N, M, SEED, True, 0)
+    price, se = po.price_and_error(sx, sxx, n, ARGS["r"], ARGS["T"])
+    assert got[0][4] == n == 2 * N
+    assert got[0][2] == pytest.approx(price, rel=1e-13)
+    assert got[0][3] == pytest.approx(se, rel=1e-10)
+
+
+def test_finalize_matches_reference_formula():
+    from optionslab_amd.sharding import finalize
+    xs = [0.0, 1.0, 4.0, 7.0]
+    n, s, ss = len(xs), sum(xs), sum(x * x for x in xs)
+    price, se = finalize(s, ss, n, 0.05, 2.0)
+    mean = s / n
+    sd = math.sqrt(sum((x - mean) ** 2 for x in xs) / n)      # np.std, ddof=0
+    assert price == pytest.approx(math.exp(-0.1) * mean, rel=1e-15)
+    assert se == pytest.approx(math.exp(-0.1) * sd / math.sqrt(n), rel=1e-14)

@@ -85,7 +85,8 @@ def main():
     n_global = PATHS_PER_GPU * world
     lo, hi = sharding.shard_bounds(n_global, rank, world)
     S, K, T, r, sigma, q = (WORK[k] for k in ("S", "K", "T", "r", "sigma", "q"))
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream()          # one explicit stream: kernels, collectives' dependencies and D2H are ordered on it
+    torch.cuda.set_stream(stream)
     K_steps, W = args.steps, args.warmup
     slots = torch.zeros((max(K_steps, W, 1), 3), dtype=torch.float64, device="cuda")
 

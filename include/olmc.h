@@ -117,7 +117,10 @@ int olmc_european_shard(double S, double K, double T, double r, double sigma, do
 /* Device-resident variant for one-process-per-GPU jobs: writes the raw triple
  * {sum, sumsq, (double)n} to `d_triple` (3 doubles of DEVICE memory owned by
  * the caller, e.g. a torch tensor handed to an RCCL all-reduce) on `hip_stream`
- * (a hipStream_t, NULL = the library's stream) and does not synchronise. */
+ * (a hipStream_t used as given; NULL = the HIP null stream, which is torch's
+ * default stream) and does not synchronise: later work on that stream is
+ * ordered after it.  Calls sharing one device serialise on the library's
+ * per-device scratch, so use ONE stream per device for these calls. */
 int olmc_european_shard_dev(double S, double K, double T, double r, double sigma, double q, int is_call,
                             int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
                             int antithetic, double* d_triple, void* hip_stream);

@@ -133,7 +133,8 @@ def seed64(seed: int) -> int:
 def device_info() -> dict:
     info = DevInfo()
     _check(lib().olmc_device_info(C.byref(info)))
-    return dict(name=info.name.decode(), arch=info.arch.decode(), compute_units=info.compute_units,
+    arch = info.arch.decode()
+    return dict(name=info.name.decode() or f"AMD Instinct ({arch.split(':')[0]})", arch=arch, compute_units=info.compute_units,
                 clock_mhz=info.clock_mhz, wavefront=info.wavefront, device=info.device, hbm_bytes=info.hbm_bytes)
 
 

@@ -363,7 +363,7 @@ extern "C" int olmc_european_shard_dev(double S, double K, double T, double r, d
     rc = ctx_get(&c);
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(c->mu);
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);   // used as given: NULL is the HIP null stream
     const olmc_option o = make_option(S, K, T, r, sigma, q, is_call);
     rc = run_batch_device(c, s, &o, 1, path_offset, n_local, n_steps, seed, antithetic, c->d_result);
     if (rc) return rc;
@@ -630,7 +630,7 @@ extern "C" int olmc_multi_gpu_european(double S, double K, double T, double r, d
         triples[d] = static_cast<double*>(c->d_bulk);
         const int64_t lo = n_paths * d / n_gpus, hi = n_paths * (d + 1) / n_gpus;
         t_device = d;
-        rc = olmc_european_shard_dev(S, K, T, r, sigma, q, is_call, lo, hi - lo, n_steps, seed, antithetic, triples[d], nullptr);
+        rc = olmc_european_shard_dev(S, K, T, r, sigma, q, is_call, lo, hi - lo, n_steps, seed, antithetic, triples[d], c->stream);
         if (rc) return rc;
     }
     RCCL_TRY(g_rccl.GroupStart());

@@ -22,9 +22,13 @@
  *   counter = (path_lo32, path_hi32, block, stream_tag), `path` = GLOBAL path
  *   index, `block` = step/4.  The four output words give the four normals of
  *   steps 4*block .. 4*block+3 by two Box-Muller transforms:
- *     u = (x + 0.5) * 2^-32 (fp32),  rad = sqrt(-2 ln u_a),
+ *     u_a = (x_a + 0.5) * 2^-32 (fp32),  rad = sqrt(-2 ln u_a),
+ *     u_b = (x_b & 0x7fffff) * 2^-23     (turn fraction, 23 bits),
  *     z_even = rad * cos(2 pi u_b),  z_odd = rad * sin(2 pi u_b),
  *   pair (x0,x1) -> steps 4b,4b+1; pair (x2,x3) -> steps 4b+2,4b+3.
+ *   sum_t Z of a path is formed as 4 chunk sums of contiguous Philox blocks
+ *   (fp32 within 16 normals, fp64 across), added in chunk order -- the same bits
+ *   whichever kernel form or grid shape computes it.
  *   Normals are fp32; every quantity that depends on S, K, T, r, sigma, q is
  *   fp64 (finite-difference Greeks under common random numbers stay smooth).
  */
@@ -189,6 +193,10 @@ int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_
  * stream it runs on; olmc_kernel_time returns the number of launches timed and
  * their total milliseconds since the last reset. */
 int olmc_profile_enable(int on);
+/* Tuning knob for A/B measurements (results never change, only the launch shape):
+ *   OLMC_TUNE_GRID_CAP  max workgroups per launch, 0 = default (larger jobs grid-stride) */
+enum { OLMC_TUNE_GRID_CAP = 2 };
+int olmc_tune(int knob, int value);
 int olmc_profile_reset(void);
 int olmc_kernel_time(int64_t* launches, double* total_ms);
 

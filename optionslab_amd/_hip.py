@@ -16,7 +16,8 @@ import numpy as np
 
 from .exceptions import AccelerationError
 
-LIBRARY_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libolmc.so")
+# $OLMC_LIBRARY overrides the in-tree build (A/B measurements of alternative builds)
+LIBRARY_PATH = os.environ.get("OLMC_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libolmc.so")
 MAX_BATCH = 16
 AVG_ARITHMETIC, AVG_GEOMETRIC = 0, 1
 _U64 = (1 << 64) - 1
@@ -65,6 +66,7 @@ PROTOTYPES = {
     "olmc_philox_words": (_I, [_U64T, _I64, _I64, _I32, _I32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "olmc_normals": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(C.c_float)]),
     "olmc_profile_enable": (_I, [_I]),
+    "olmc_tune": (_I, [_I, _I]),
     "olmc_profile_reset": (_I, []),
     "olmc_kernel_time": (_I, [C.POINTER(_I64), C.POINTER(_D)]),
 }
@@ -223,6 +225,13 @@ def normals(seed: int, path_offset: int, n_paths: int, n_steps: int) -> np.ndarr
     _check(lib().olmc_normals(seed64(seed), int(path_offset), int(n_paths), int(n_steps),
                               out.ctypes.data_as(C.POINTER(C.c_float))))
     return out
+
+
+TUNE_GRID_CAP = 2
+
+
+def tune(knob: int, value: int) -> None:
+    _check(load_library().olmc_tune(int(knob), int(value)))
 
 
 def profile_enable(on: bool) -> None:

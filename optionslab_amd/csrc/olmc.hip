@@ -1,9 +1,9 @@
 // olmc.hip -- host side of libolmc.so: the C ABI declared in include/olmc.h.
 //
-// One context per HIP device (stream, device scratch for per-block partials,
+// One context per HIP device (stream, workspace of the fused grid reduction,
 // a pinned host landing buffer).  Every compute entry point is
 //   host: derive the per-contract constants in fp64 (reference order)
-//   device: path kernel -> finalize kernel -> 8*NV bytes D2H
+//   device: ONE path kernel (its last workgroup writes the reduced sums) -> 8*NV bytes D2H
 // and fails loudly when no HIP device is usable -- there is no CPU fallback.
 #include "olmc.h"
 #include "olmc_kernels.h"
@@ -38,8 +38,9 @@ int fail(int code, const std::string& msg) {
     } while (0)
 
 constexpr int kMaxDevices = 16;
-constexpr int kMaxNV = 2 * OLMC_MAX_BATCH;       // values per block partial
-constexpr int kBlocksPerCU = 8;                  // 8 blocks x 4 waves = 32 waves/CU (the hardware cap)
+constexpr int kMaxNV = 2 * OLMC_MAX_BATCH;       // values per workgroup row
+constexpr int32_t kMaxGrid = 1 << 18;            // workgroups per launch; larger jobs grid-stride
+constexpr int32_t kMaxGroups = kMaxGrid / kGroupBlocks + 1;
 
 struct EventPair {
     hipEvent_t start, stop;
@@ -49,10 +50,12 @@ struct DeviceCtx {
     int device = -1;
     int cus = 0;
     hipStream_t stream = nullptr;
-    double* d_partials = nullptr;    // [partial_blocks][kMaxNV]
-    int32_t partial_blocks = 0;
-    double* d_result = nullptr;      // [kMaxNV]
-    double* h_result = nullptr;      // pinned [kMaxNV]
+    double* d_block_rows = nullptr;  // [block_rows_cap] doubles, grown on demand (grid x NV)
+    size_t block_rows_cap = 0;
+    double* d_group_rows = nullptr;  // [kMaxGroups][kMaxNV]
+    uint32_t* d_counters = nullptr;  // [kMaxGroups + 1], zero between launches (self-resetting)
+    double* d_result = nullptr;      // [kMaxNV + 1]
+    double* h_result = nullptr;      // pinned [kMaxNV + 1]
     void* d_bulk = nullptr;          // terminal prices / validation taps
     size_t bulk_bytes = 0;
     std::mutex mu;
@@ -80,11 +83,12 @@ int ctx_create(int device, DeviceCtx** out) {
     DeviceCtx* c = new DeviceCtx();
     c->device = device;
     c->cus = prop.multiProcessorCount;
-    c->partial_blocks = c->cus * kBlocksPerCU;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc(&c->d_partials, sizeof(double) * kMaxNV * c->partial_blocks));
-    HIP_TRY(hipMalloc(&c->d_result, sizeof(double) * kMaxNV));
-    HIP_TRY(hipHostMalloc(&c->h_result, sizeof(double) * kMaxNV, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&c->d_group_rows, sizeof(double) * kMaxNV * kMaxGroups));
+    HIP_TRY(hipMalloc(&c->d_counters, sizeof(uint32_t) * (kMaxGroups + 1)));
+    HIP_TRY(hipMemset(c->d_counters, 0, sizeof(uint32_t) * (kMaxGroups + 1)));
+    HIP_TRY(hipMalloc(&c->d_result, sizeof(double) * (kMaxNV + 1)));
+    HIP_TRY(hipHostMalloc(&c->h_result, sizeof(double) * (kMaxNV + 1), hipHostMallocDefault));
     *out = c;
     return OLMC_OK;
 }
@@ -114,9 +118,41 @@ int bulk_reserve(DeviceCtx* c, size_t bytes) {
     return OLMC_OK;
 }
 
-int32_t grid_for(const DeviceCtx* c, int64_t n_paths) {
-    const int64_t tiles = (n_paths + kBlock - 1) / kBlock;
-    return static_cast<int32_t>(std::min<int64_t>(tiles, c->partial_blocks));
+// Tuning knob (olmc_tune): 0 = automatic.
+int g_grid_cap = 0;          // OLMC_TUNE_GRID_CAP: max workgroups per launch (0 = kMaxGrid)
+
+// Launch geometry: one workgroup per 256 paths, handed out by the hardware dispatcher
+// (measured faster than a fixed 8-workgroups-per-CU grid-stride); beyond kMaxGrid
+// workgroups the kernels grid-stride.
+int32_t grid_for(int64_t n_paths) {
+    const int64_t cap = g_grid_cap > 0 ? std::min<int64_t>(g_grid_cap, kMaxGrid) : kMaxGrid;
+    return static_cast<int32_t>(std::min<int64_t>((n_paths + kBlock - 1) / kBlock, cap));
+}
+
+// Workspace of the fused grid reduction for a launch of `grid` workgroups x nv values.
+int make_ws(DeviceCtx* c, int32_t grid, int nv, double* d_out, double tail, ReduceWs* ws) {
+    const size_t need = static_cast<size_t>(grid) * nv;
+    if (need > c->block_rows_cap) {
+        if (c->d_block_rows) HIP_TRY(hipFree(c->d_block_rows));
+        c->d_block_rows = nullptr;
+        c->block_rows_cap = 0;
+        const size_t cap = std::max<size_t>(need, size_t(1) << 16);
+        HIP_TRY(hipMalloc(&c->d_block_rows, sizeof(double) * cap));
+        c->block_rows_cap = cap;
+    }
+    ws->block_rows = c->d_block_rows;
+    ws->group_rows = c->d_group_rows;
+    ws->counters = c->d_counters;
+    ws->out = d_out;
+    ws->tail = tail;
+    return OLMC_OK;
+}
+
+// After a failed launch the self-resetting counters may be left dirty.
+void ws_recover(DeviceCtx* c) {
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    (void)hipMemset(c->d_counters, 0, sizeof(uint32_t) * (kMaxGroups + 1));
 }
 
 // ---- profiling brackets ---------------------------------------------------
@@ -198,42 +234,46 @@ PathRange make_range(int64_t path_offset, int64_t n_local, int32_t n_steps, uint
 
 template <int NSETS, int MODE>
 void launch_european(bool anti, int32_t grid, hipStream_t s, const PathRange& pr, const ContractSet<NSETS>& cs,
-                     double* partials, double* terminal) {
-    if (anti)
-        hipLaunchKernelGGL((european_kernel<NSETS, true, MODE>), dim3(grid), dim3(kBlock), 0, s, pr, cs, partials, terminal);
-    else
-        hipLaunchKernelGGL((european_kernel<NSETS, false, MODE>), dim3(grid), dim3(kBlock), 0, s, pr, cs, partials, terminal);
+                     const ReduceWs& ws, double* terminal) {
+    if (anti) hipLaunchKernelGGL((european_path_kernel<NSETS, true, MODE>), dim3(grid), dim3(kBlock), 0, s, pr, cs, ws, terminal);
+    else hipLaunchKernelGGL((european_path_kernel<NSETS, false, MODE>), dim3(grid), dim3(kBlock), 0, s, pr, cs, ws, terminal);
 }
 
-// Path kernel + finalize for k contracts on stream `s`; leaves 2k doubles in d_out.
+// ONE launch on stream `s` for k contracts: leaves {sum, sumsq} x k in d_out[0 .. 2k)
+// (padded to the kernel's NSETS) and, when tail >= 0, `tail` in d_out[2 * nsets].
 int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32_t k, int64_t path_offset,
-                     int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic, double* d_out) {
+                     int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic, double* d_out, double tail) {
     const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
-    const int32_t grid = grid_for(c, n_local);
+    const int32_t grid = grid_for(n_local);
     const bool anti = antithetic != 0;
+    const int nsets = k == 1 ? 1 : (k <= 8 ? 8 : 16);
+    ReduceWs ws;
+    int rc = make_ws(c, grid, 2 * nsets, d_out, tail, &ws);
+    if (rc) return rc;
     EventPair ep{};
-    if (g_profile) { int rc = prof_begin(c, s, &ep); if (rc) return rc; }
-    int nsets;
-    if (k == 1) {
+    if (g_profile) { rc = prof_begin(c, s, &ep); if (rc) return rc; }
+    if (nsets == 1) {
         ContractSet<1> cs;
         cs.c[0] = make_contract(opts[0], n_steps);
-        launch_european<1, kReduce>(anti, grid, s, pr, cs, c->d_partials, nullptr);
-        nsets = 1;
-    } else if (k <= 8) {
+        launch_european<1, kReduce>(anti, grid, s, pr, cs, ws, nullptr);
+    } else if (nsets == 8) {
         ContractSet<8> cs;
         for (int i = 0; i < 8; ++i) cs.c[i] = make_contract(opts[i < k ? i : 0], n_steps);
-        launch_european<8, kReduce>(anti, grid, s, pr, cs, c->d_partials, nullptr);
-        nsets = 8;
+        launch_european<8, kReduce>(anti, grid, s, pr, cs, ws, nullptr);
     } else {
         ContractSet<16> cs;
         for (int i = 0; i < 16; ++i) cs.c[i] = make_contract(opts[i < k ? i : 0], n_steps);
-        launch_european<16, kReduce>(anti, grid, s, pr, cs, c->d_partials, nullptr);
-        nsets = 16;
+        launch_european<16, kReduce>(anti, grid, s, pr, cs, ws, nullptr);
     }
-    HIP_TRY(hipGetLastError());
-    if (g_profile) { int rc = prof_end(c, s, ep); if (rc) return rc; }
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, s, c->d_partials, grid, 2 * nsets, d_out);
-    HIP_TRY(hipGetLastError());
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
+    if (g_profile) { rc = prof_end(c, s, ep); if (rc) return rc; }
+    return OLMC_OK;
+}
+
+int sync_or_recover(DeviceCtx* c, hipStream_t s) {
+    hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)); }
     return OLMC_OK;
 }
 
@@ -247,10 +287,11 @@ int run_batch(const olmc_option* opts, int32_t k, int64_t path_offset, int64_t n
     rc = ctx_get(&c);
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(c->mu);
-    rc = run_batch_device(c, c->stream, opts, k, path_offset, n_local, n_steps, seed, antithetic, c->d_result);
+    rc = run_batch_device(c, c->stream, opts, k, path_offset, n_local, n_steps, seed, antithetic, c->d_result, -1.0);
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 2 * k, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = sync_or_recover(c, c->stream);
+    if (rc) return rc;
     const int64_t n = n_local * (antithetic ? 2 : 1);
     for (int i = 0; i < k; ++i)
         finish_stats(c->h_result[2 * i], c->h_result[2 * i + 1], n, opts[i].r, opts[i].T, &out[i]);
@@ -298,7 +339,9 @@ extern "C" int olmc_shutdown(void) {
             for (auto& ep : c->ev_pending) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
             for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
             if (c->d_bulk) (void)hipFree(c->d_bulk);
-            (void)hipFree(c->d_partials);
+            if (c->d_block_rows) (void)hipFree(c->d_block_rows);
+            (void)hipFree(c->d_group_rows);
+            (void)hipFree(c->d_counters);
             (void)hipFree(c->d_result);
             (void)hipHostFree(c->h_result);
             (void)hipStreamDestroy(c->stream);
@@ -343,16 +386,6 @@ extern "C" int olmc_european_shard(double S, double K, double T, double r, doubl
     return run_batch(&o, 1, path_offset, n_local, n_steps, seed, antithetic, out);
 }
 
-namespace olmc {
-__global__ void triple_kernel(const double* __restrict__ two, double n, double* __restrict__ triple) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        triple[0] = two[0];
-        triple[1] = two[1];
-        triple[2] = n;
-    }
-}
-}  // namespace olmc
-
 extern "C" int olmc_european_shard_dev(double S, double K, double T, double r, double sigma, double q, int is_call,
                                        int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
                                        int antithetic, double* d_triple, void* hip_stream) {
@@ -365,12 +398,9 @@ extern "C" int olmc_european_shard_dev(double S, double K, double T, double r, d
     std::lock_guard<std::mutex> lock(c->mu);
     hipStream_t s = static_cast<hipStream_t>(hip_stream);   // used as given: NULL is the HIP null stream
     const olmc_option o = make_option(S, K, T, r, sigma, q, is_call);
-    rc = run_batch_device(c, s, &o, 1, path_offset, n_local, n_steps, seed, antithetic, c->d_result);
-    if (rc) return rc;
     const double n = static_cast<double>(n_local * (antithetic ? 2 : 1));
-    hipLaunchKernelGGL(olmc::triple_kernel, dim3(1), dim3(64), 0, s, c->d_result, n, d_triple);
-    HIP_TRY(hipGetLastError());
-    return OLMC_OK;
+    // the path kernel's last workgroup writes {sum, sumsq, n} straight into the caller's buffer
+    return run_batch_device(c, s, &o, 1, path_offset, n_local, n_steps, seed, antithetic, d_triple, n);
 }
 
 extern "C" int olmc_european_batch(const olmc_option* opts, int32_t k, int64_t path_offset, int64_t n_local,
@@ -459,7 +489,8 @@ extern "C" int olmc_european_terminal(double S, double T, double r, double sigma
     const PathRange pr = make_range(0, n_paths, n_steps, seed);
     ContractSet<1> cs;
     cs.c[0] = make_contract(make_option(S, 0.0, T, r, sigma, q, 1), n_steps);
-    launch_european<1, kTerminal>(antithetic != 0, grid_for(c, n_paths), c->stream, pr, cs, nullptr,
+    ReduceWs ws{};   // unused in kTerminal mode
+    launch_european<1, kTerminal>(antithetic != 0, grid_for(n_paths), c->stream, pr, cs, ws,
                                   static_cast<double*>(c->d_bulk));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_host, c->d_bulk, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -479,15 +510,20 @@ extern "C" int olmc_european_cv(double S, double K, double T, double r, double s
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(c->mu);
     const PathRange pr = make_range(0, n_paths, n_steps, seed);
-    const int32_t grid = grid_for(c, n_paths);
+    const int32_t grid = grid_for(n_paths);
     ContractSet<1> cs;
     cs.c[0] = make_contract(make_option(S, K, T, r, sigma, q, is_call), n_steps);
-    launch_european<1, kControlVariate>(antithetic != 0, grid, c->stream, pr, cs, c->d_partials, nullptr);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->d_partials, grid, 5, c->d_result);
-    HIP_TRY(hipGetLastError());
+    ReduceWs ws;
+    rc = make_ws(c, grid, 5, c->d_result, -1.0, &ws);
+    if (rc) return rc;
+    launch_european<1, kControlVariate>(antithetic != 0, grid, c->stream, pr, cs, ws, nullptr);
+    {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
+    }
     HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = sync_or_recover(c, c->stream);
+    if (rc) return rc;
     // device moments are of the UNdiscounted payoff x; d = disc * x (monte_carlo.py:175)
     const double disc = std::exp(-r * T);
     const double n = static_cast<double>(n_paths * (antithetic ? 2 : 1));
@@ -521,28 +557,34 @@ extern "C" int olmc_asian(double S, double K, double T, double r, double sigma, 
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(c->mu);
     const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
-    const int32_t grid = grid_for(c, n_local);
+    const int32_t grid = grid_for(n_local);
     AsianContract ac;
     const double dt = T / n_steps;                               // exotic_options.py:54-56
     ac.log_s0 = std::log(S);
+    ac.s0 = S;
     ac.drift = (r - q - 0.5 * sigma * sigma) * dt;
     ac.vol = sigma * std::sqrt(dt);
     ac.strike = K;
     ac.sign = is_call ? 1.0 : -1.0;
     ac.inv_steps = 1.0 / n_steps;
+    ReduceWs ws;
+    rc = make_ws(c, grid, 2, c->d_result, -1.0, &ws);
+    if (rc) return rc;
     EventPair ep{};
     if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
     const bool anti = antithetic != 0, geo = avg_kind == OLMC_AVG_GEOMETRIC;
-    if (anti && geo) hipLaunchKernelGGL((asian_kernel<true, true>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, c->d_partials);
-    else if (anti) hipLaunchKernelGGL((asian_kernel<true, false>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, c->d_partials);
-    else if (geo) hipLaunchKernelGGL((asian_kernel<false, true>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, c->d_partials);
-    else hipLaunchKernelGGL((asian_kernel<false, false>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, c->d_partials);
-    HIP_TRY(hipGetLastError());
+    if (anti && geo) hipLaunchKernelGGL((asian_kernel<true, true>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, ws);
+    else if (anti) hipLaunchKernelGGL((asian_kernel<true, false>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, ws);
+    else if (geo) hipLaunchKernelGGL((asian_kernel<false, true>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, ws);
+    else hipLaunchKernelGGL((asian_kernel<false, false>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, ws);
+    {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
+    }
     if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kBlock), 0, c->stream, c->d_partials, grid, 2, c->d_result);
-    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    rc = sync_or_recover(c, c->stream);
+    if (rc) return rc;
     finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r, T, out);
     return OLMC_OK;
 }
@@ -692,6 +734,11 @@ extern "C" int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths,
 }
 
 // ================================================================ measurement ====
+extern "C" int olmc_tune(int knob, int value) {
+    if (knob == OLMC_TUNE_GRID_CAP && value >= 0) { g_grid_cap = value; return OLMC_OK; }
+    return fail(OLMC_ERR_ARG, "unknown tuning knob or value");
+}
+
 extern "C" int olmc_profile_enable(int on) {
     g_profile = on != 0;
     return OLMC_OK;

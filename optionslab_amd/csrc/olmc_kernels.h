@@ -27,17 +27,32 @@ struct Words4 {
     uint32_t x0, x1, x2, x3;
 };
 
-// Philox4x32-10 (Salmon et al., SC'11).  The key (k0,k1) is wave-uniform, so the
-// ten bumped round keys live in SGPRs; each round is two 32x32->64 multiplies
-// (v_mad_u64_u32) and two three-input XORs.
+// Philox4x32-10 (Salmon et al., SC'11).  The key is wave-uniform; each round is two
+// 32x32->64 multiplies (v_mad_u64_u32: hi and lo from one instruction) and two 3-input XORs.
+// (Pinning the round keys in VGPRs to avoid SGPR-source XORs was measured: no gain --
+// in this mix every non-transcendental VALU instruction costs ~4 cycles of SIMD issue.)
+// a ^ b ^ c in ONE instruction: gfx950's v_bitop3_b32 with truth table 0x96.  hipcc does not
+// form it from `a ^ b ^ c` on its own (it emits two v_xor_b32), and the XORs are the largest
+// instruction class of a Philox call, so this removes ~18 of ~80 instructions per 4 normals.
+#ifndef OLMC_USE_BITOP3
+#define OLMC_USE_BITOP3 1
+#endif
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if OLMC_USE_BITOP3
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
+
 __device__ __forceinline__ Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                 uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int round = 0; round < 10; ++round) {
         const uint64_t p0 = static_cast<uint64_t>(kPhiloxM0) * c0;
         const uint64_t p1 = static_cast<uint64_t>(kPhiloxM1) * c2;
-        const uint32_t n0 = static_cast<uint32_t>(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = static_cast<uint32_t>(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n0 = xor3(static_cast<uint32_t>(p1 >> 32), c1, k0);
+        const uint32_t n2 = xor3(static_cast<uint32_t>(p0 >> 32), c3, k1);
         c1 = static_cast<uint32_t>(p1);
         c3 = static_cast<uint32_t>(p0);
         c0 = n0;
@@ -49,48 +64,108 @@ __device__ __forceinline__ Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32
 }
 
 // ------------------------------------------------------------ Box-Muller ----
-// u = (x + 0.5) * 2^-32 in fp32 (never 0, so the log is finite; may round to 1).
-// v_log_f32 is log2, v_sin_f32 / v_cos_f32 take their argument in revolutions,
-// so 2*pi*u needs no multiply.  |z| <= sqrt(2*33*ln 2) = 6.76.
-__device__ __forceinline__ void box_muller(uint32_t xa, uint32_t xb, float& z_cos, float& z_sin) {
+// Radius word:  u_a = (x_a + 0.5) * 2^-32 in fp32 (never 0, so the log is finite; may
+//               round to 1); |z| <= sqrt(2*33*ln 2) = 6.76.
+// Angle word:   the low 23 bits of x_b become the mantissa of a float in [1, 2);
+//               v_sin_f32 / v_cos_f32 take revolutions and are periodic, so that float IS
+//               the angle (turn fraction (x_b & 0x7fffff) * 2^-23): one v_and_or_b32.
+// v_log_f32 is log2, so sqrt(-2 ln u) = sqrt(2 ln 2) * sqrt(-log2 u).  The kernels work
+// with the RAW normals z' = sqrt(-log2 u_a) * {cos, sin}(2 pi u_b) and apply the constant
+// kZScale = sqrt(2 ln 2) once per path (to sum z') or once per thread (to vol): two
+// multiplies fewer per pair, and the negation is a free source modifier of v_sqrt_f32.
+constexpr double kZScale = 1.1774100225154747;     // sqrt(2 ln 2)
+constexpr float kZScaleF = 1.17741002f;
+
+__device__ __forceinline__ void box_muller_raw(uint32_t xa, uint32_t xb, float& z_cos, float& z_sin) {
     constexpr float kTwoM32 = 2.3283064365386963e-10f;   // 2^-32
     constexpr float kTwoM33 = 1.1641532182693481e-10f;   // 2^-33
-    constexpr float kMinus2Ln2 = -1.3862943611198906f;   // -2 ln 2
     const float ua = __builtin_fmaf(static_cast<float>(xa), kTwoM32, kTwoM33);
-    const float ub = __builtin_fmaf(static_cast<float>(xb), kTwoM32, kTwoM33);
-    const float rad = __builtin_amdgcn_sqrtf(kMinus2Ln2 * __builtin_amdgcn_logf(ua));
-    z_cos = rad * __builtin_amdgcn_cosf(ub);
-    z_sin = rad * __builtin_amdgcn_sinf(ub);
+    const float turns = __uint_as_float((xb & 0x007FFFFFu) | 0x3F800000u);
+    const float rad = __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(ua));
+    z_cos = rad * __builtin_amdgcn_cosf(turns);
+    z_sin = rad * __builtin_amdgcn_sinf(turns);
 }
 
-// Four normals of steps 4*block .. 4*block+3 of global path `g`.
-__device__ __forceinline__ void normals4(uint32_t g_lo, uint32_t g_hi, uint32_t block, uint32_t tag,
-                                         uint32_t k0, uint32_t k1, float (&z)[4]) {
+// Four RAW normals of steps 4*block .. 4*block+3 of global path `g`.
+__device__ __forceinline__ void raw_normals4(uint32_t g_lo, uint32_t g_hi, uint32_t block, uint32_t tag,
+                                             uint32_t k0, uint32_t k1, float (&z)[4]) {
     const Words4 w = philox4x32_10(g_lo, g_hi, block, tag, k0, k1);
-    box_muller(w.x0, w.x1, z[0], z[1]);
-    box_muller(w.x2, w.x3, z[2], z[3]);
+    box_muller_raw(w.x0, w.x1, z[0], z[1]);
+    box_muller_raw(w.x2, w.x3, z[2], z[3]);
 }
 
-// sum_t Z_t over n_steps for one path: fp32 inside a block of four, fp64 across
-// blocks.  A trailing partial block uses the first n_steps % 4 normals.
-__device__ __forceinline__ double path_normal_sum(uint32_t g_lo, uint32_t g_hi, int32_t n_steps,
-                                                  uint32_t k0, uint32_t k1) {
-    const int32_t full = n_steps >> 2;
+// Sum of the four RAW normals of one Philox block, factored so that it costs one packed add,
+// one packed multiply and one add:  rad_a (cos_a + sin_a) + rad_b (cos_b + sin_b).
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float raw_block_sum4(uint32_t g_lo, uint32_t g_hi, uint32_t block, uint32_t k0, uint32_t k1) {
+    constexpr float kTwoM32 = 2.3283064365386963e-10f;   // 2^-32
+    constexpr float kTwoM33 = 1.1641532182693481e-10f;   // 2^-33
+    const Words4 w = philox4x32_10(g_lo, g_hi, block, 0u, k0, k1);
+    const float ua = __builtin_fmaf(static_cast<float>(w.x0), kTwoM32, kTwoM33);
+    const float ub = __builtin_fmaf(static_cast<float>(w.x2), kTwoM32, kTwoM33);
+    const float ta = __uint_as_float((w.x1 & 0x007FFFFFu) | 0x3F800000u);
+    const float tb = __uint_as_float((w.x3 & 0x007FFFFFu) | 0x3F800000u);
+    const float2v rad = {__builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(ua)), __builtin_amdgcn_sqrtf(-__builtin_amdgcn_logf(ub))};
+    const float2v c = {__builtin_amdgcn_cosf(ta), __builtin_amdgcn_cosf(tb)};
+    const float2v sn = {__builtin_amdgcn_sinf(ta), __builtin_amdgcn_sinf(tb)};
+    const float2v p = rad * (c + sn);
+    return p.x + p.y;
+}
+
+// The Philox blocks of a path are cut into kChunks contiguous chunks (chunk w gets
+// n/4 blocks, the first n%4 chunks one more) and sum_t z' = ((c0 + c1) + c2) + c3: four
+// independent fp64 accumulation chains per thread.
+constexpr int kChunks = 4;
+constexpr int kGroup = 4;   // blocks summed in fp32 (16 normals) before one fp64 add
+
+__device__ __forceinline__ void chunk_range(int32_t n_blocks, int w, int32_t& b_begin, int32_t& b_end) {
+    const int32_t q = n_blocks / kChunks, r = n_blocks % kChunks;
+    b_begin = w * q + min(w, r);
+    b_end = b_begin + q + (w < r ? 1 : 0);
+}
+
+// sum of RAW normals over Philox blocks [b_begin, b_end) of one path; block b covers steps
+// 4b..4b+3 and only steps < n_steps count.  fp32 within a group of kGroup blocks, fp64 across.
+__device__ __forceinline__ double chunk_normal_sum(uint32_t g_lo, uint32_t g_hi, int32_t b_begin, int32_t b_end,
+                                                   int32_t n_steps, uint32_t k0, uint32_t k1) {
+    const int32_t full_end = min(b_end, n_steps >> 2);     // blocks whose four steps all count
     double acc = 0.0;
-    float z[4];
-    for (int32_t b = 0; b < full; ++b) {
-        normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, k0, k1, z);
-        acc += static_cast<double>((z[0] + z[1]) + (z[2] + z[3]));
+    int32_t b = b_begin;
+    for (; b + kGroup <= full_end; b += kGroup) {
+        float s = raw_block_sum4(g_lo, g_hi, static_cast<uint32_t>(b), k0, k1);
+#pragma unroll
+        for (int j = 1; j < kGroup; ++j) s += raw_block_sum4(g_lo, g_hi, static_cast<uint32_t>(b + j), k0, k1);
+        acc += static_cast<double>(s);
+    }
+    if (b < full_end) {
+        float s = raw_block_sum4(g_lo, g_hi, static_cast<uint32_t>(b), k0, k1);
+        for (++b; b < full_end; ++b) s += raw_block_sum4(g_lo, g_hi, static_cast<uint32_t>(b), k0, k1);
+        acc += static_cast<double>(s);
     }
     const int32_t rem = n_steps & 3;
-    if (rem) {
-        normals4(g_lo, g_hi, static_cast<uint32_t>(full), 0u, k0, k1, z);
+    if (rem && b < b_end) {                                  // trailing partial block: first `rem` normals
+        float z[4];
+        raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, k0, k1, z);
         float s = z[0];
         if (rem > 1) s += z[1];
         if (rem > 2) s += z[2];
         acc += static_cast<double>(s);
     }
     return acc;
+}
+
+// sum_t Z_t (true normals) of one path, one thread walking all chunks.
+__device__ __forceinline__ double path_normal_sum(uint32_t g_lo, uint32_t g_hi, int32_t n_steps, uint32_t k0, uint32_t k1) {
+    const int32_t n_blocks = (n_steps + 3) >> 2;
+    double part[kChunks];
+#pragma unroll
+    for (int w = 0; w < kChunks; ++w) {
+        int32_t b0, b1;
+        chunk_range(n_blocks, w, b0, b1);
+        part[w] = chunk_normal_sum(g_lo, g_hi, b0, b1, n_steps, k0, k1);
+    }
+    return (((part[0] + part[1]) + part[2]) + part[3]) * kZScale;
 }
 
 // ------------------------------------------------------------ reductions ----
@@ -100,10 +175,94 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// Sum NV per-thread values over the block in a fixed order and let thread 0
-// store them to dst[0..NV).  LDS-staged across the four waves.
+// Grid-wide reduction fused into the path kernels: no second launch.
+//   level 0  every workgroup stores its NV block sums (write-through `sc1` stores), drains
+//            them (s_waitcnt vmcnt(0)) and takes a ticket on its group's counter
+//            (agent-scope atomic add).  A group = kGroupBlocks consecutive workgroups.
+//   level 1  the workgroup whose ticket is last in its group acquires, sums the group's
+//            rows in index order, stores the group row the same way and takes a ticket on
+//            the top counter;
+//   level 2  the last group finisher sums the group rows in index order and writes out[].
+// Sums run in INDEX order, never arrival order, so equal inputs give equal bits
+// (tests/test_monte_carlo.py:153-158 of the reference needs price1 == price2).  Counters
+// are zero on entry and each finisher re-zeroes the one it consumed, so back-to-back
+// launches on one stream need no memset.  Protocol per cdna_hip_programming.md G16:
+// sc1 payload + drained vmcnt before the agent-scope add on the producer, agent acquire
+// fence after the returned add on the consumer.  Only wave 0 of a workgroup takes part.
+constexpr int kGroupBlocks = 256;
+
+struct ReduceWs {
+    double* block_rows;     // [gridDim.x][NV]
+    double* group_rows;     // [n_groups][NV]
+    uint32_t* counters;     // [n_groups + 1], last = top counter
+    double* out;            // [NV] (+1 when tail >= 0)
+    double tail;            // if >= 0, written to out[NV] (the sample count of the triple)
+};
+
+__device__ __forceinline__ void store_sc1(double* p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_sc1(const double* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Lanes c < NV return sum_{row < rows} src[row * NV + c], rows taken in a fixed order:
+// lane = sub * NVP + c sums rows == sub (mod 64/NVP) ascending, then the sub-sums are
+// folded by a shuffle tree.  Call with all 64 lanes of a wave active.
 template <int NV>
-__device__ __forceinline__ void block_sum_store(const double (&v)[NV], double* __restrict__ dst) {
+__device__ __forceinline__ double wave_rows_sum(const double* src, int32_t rows) {
+    constexpr int NVP = NV <= 2 ? 2 : NV <= 8 ? 8 : NV <= 16 ? 16 : 32;
+    constexpr int SUBS = kWave / NVP;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int c = lane % NVP, sub = lane / NVP;
+    double v = 0.0;
+    if (c < NV)
+        for (int32_t row = sub; row < rows; row += SUBS) v += load_sc1(src + static_cast<size_t>(row) * NV + c);
+#pragma unroll
+    for (int off = kWave / 2; off >= NVP; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;   // valid in lanes < NV
+}
+
+// `v` = this workgroup's sum of component threadIdx.x (threads < NV of wave 0).  Wave 0 only.
+template <int NV>
+__device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws) {
+    const int lane = threadIdx.x;       // wave 0: lane == threadIdx.x
+    const int32_t n_blocks = static_cast<int32_t>(gridDim.x);
+    const int32_t n_groups = (n_blocks + kGroupBlocks - 1) / kGroupBlocks;
+    const int32_t group = static_cast<int32_t>(blockIdx.x) / kGroupBlocks;
+    const int32_t group_size = min(kGroupBlocks, n_blocks - group * kGroupBlocks);
+
+    if (lane < NV) store_sc1(ws.block_rows + static_cast<size_t>(blockIdx.x) * NV + lane, v);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(ws.counters + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != static_cast<uint32_t>(group_size - 1)) return;
+
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const double g = wave_rows_sum<NV>(ws.block_rows + static_cast<size_t>(group) * kGroupBlocks * NV, group_size);
+    if (lane < NV) store_sc1(ws.group_rows + static_cast<size_t>(group) * NV + lane, g);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        __hip_atomic_store(ws.counters + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __hip_atomic_fetch_add(ws.counters + n_groups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != static_cast<uint32_t>(n_groups - 1)) return;
+
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const double total = wave_rows_sum<NV>(ws.group_rows, n_groups);
+    if (lane < NV) ws.out[lane] = total;
+    if (lane == 0) {
+        if (ws.tail >= 0.0) ws.out[NV] = ws.tail;
+        __hip_atomic_store(ws.counters + n_groups, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// One-thread-per-path kernels: fold NV per-thread values over the workgroup (fixed order,
+// LDS-staged across the four waves), then into the grid reduction.
+template <int NV>
+__device__ __forceinline__ void block_then_grid_reduce(const double (&v)[NV], const ReduceWs& ws) {
     __shared__ double stage[kWavesPerBlock][NV];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -113,12 +272,14 @@ __device__ __forceinline__ void block_sum_store(const double (&v)[NV], double* _
         if (lane == 0) stage[wave][i] = s;
     }
     __syncthreads();
+    if (wave != 0) return;
+    double s = 0.0;
     if (threadIdx.x < NV) {
-        double s = stage[0][threadIdx.x];
+        s = stage[0][threadIdx.x];
 #pragma unroll
         for (int w = 1; w < kWavesPerBlock; ++w) s += stage[w][threadIdx.x];
-        dst[threadIdx.x] = s;
     }
+    grid_reduce<NV>(s, ws);
 }
 
 // ------------------------------------------------------------- contracts ----
@@ -145,127 +306,111 @@ struct PathRange {
 
 enum Mode : int { kReduce = 0, kTerminal = 1, kControlVariate = 2 };
 
-// European terminal payoff.  kReduce: partials[block][set][{sum,sumsq}].
-// kTerminal (NSETS == 1): terminal[i] = S_T^+, terminal[count + i] = S_T^- (coalesced,
-// the [pos | neg] layout of gbm_numpy.py:51).  kControlVariate (NSETS == 1):
-// partials[block][{sum_x, sum_s, sum_xx, sum_ss, sum_xs}] with x the UNdiscounted payoff.
+template <int MODE>
+__device__ __forceinline__ void add_sample(double (&acc)[MODE == kControlVariate ? 5 : 2], double x, double st) {
+    if constexpr (MODE == kControlVariate) {
+        acc[0] += x; acc[1] += st; acc[2] += x * x; acc[3] += st * st; acc[4] += x * st;
+    } else {
+        acc[0] += x; acc[1] += x * x;
+    }
+}
+
+// European terminal payoff, one thread per path (= one antithetic pair).
+//   kReduce          out[2s], out[2s+1] = sum x, sum x^2 of contract s (x = UNdiscounted payoff)
+//   kTerminal        terminal[i] = S_T^+, terminal[count + i] = S_T^-  (coalesced [pos | neg], gbm_numpy.py:51)
+//   kControlVariate  out[0..4] = sum x, sum s, sum x^2, sum s^2, sum x*s  (NSETS == 1)
+// A variant in which the four waves of a workgroup split one 64-path tile's steps (4x finer
+// scheduling unit) was built and measured: never faster (121 vs 117.5 us), so it is gone.
 template <int NSETS, bool ANTI, int MODE>
-__global__ __launch_bounds__(kBlock) void european_kernel(PathRange pr, ContractSet<NSETS> cs,
-                                                          double* __restrict__ partials,
-                                                          double* __restrict__ terminal) {
+__global__ __launch_bounds__(kBlock) void european_path_kernel(PathRange pr, ContractSet<NSETS> cs, ReduceWs ws,
+                                                               double* __restrict__ terminal) {
     constexpr int NV = (MODE == kControlVariate) ? 5 : 2 * NSETS;
+    constexpr int NC = (MODE == kControlVariate) ? 5 : 2;
     double acc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = 0.0;
-
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
         const uint64_t g = pr.first + static_cast<uint64_t>(i);
-        const double zsum = path_normal_sum(static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32),
-                                            pr.n_steps, pr.key0, pr.key1);
+        const double zsum = path_normal_sum(static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32), pr.n_steps, pr.key0, pr.key1);
 #pragma unroll
         for (int s = 0; s < NSETS; ++s) {
             const Contract c = cs.c[s];
             const double dz = c.vol * zsum;
-            const double up = exp(c.a + dz);
-            if constexpr (MODE == kTerminal) {
-                terminal[i] = up;
-                if constexpr (ANTI) terminal[pr.count + i] = exp(c.a - dz);
-            } else {
-                const double xu = fmax(c.sign * (up - c.strike), 0.0);
-                if constexpr (MODE == kControlVariate) {
-                    acc[0] += xu; acc[1] += up; acc[2] += xu * xu; acc[3] += up * up; acc[4] += xu * up;
+#pragma unroll
+            for (int leg = 0; leg < (ANTI ? 2 : 1); ++leg) {
+                const double st = exp(leg ? c.a - dz : c.a + dz);
+                if constexpr (MODE == kTerminal) {
+                    terminal[leg * pr.count + i] = st;
                 } else {
-                    acc[2 * s] += xu; acc[2 * s + 1] += xu * xu;
-                }
-                if constexpr (ANTI) {
-                    const double dn = exp(c.a - dz);
-                    const double xd = fmax(c.sign * (dn - c.strike), 0.0);
-                    if constexpr (MODE == kControlVariate) {
-                        acc[0] += xd; acc[1] += dn; acc[2] += xd * xd; acc[3] += dn * dn; acc[4] += xd * dn;
-                    } else {
-                        acc[2 * s] += xd; acc[2 * s + 1] += xd * xd;
-                    }
+                    const double x = fmax(c.sign * (st - c.strike), 0.0);
+                    double (&slot)[NC] = *reinterpret_cast<double (*)[NC]>(&acc[(MODE == kControlVariate) ? 0 : 2 * s]);
+                    add_sample<MODE>(slot, x, st);
                 }
             }
         }
     }
-    if constexpr (MODE != kTerminal) block_sum_store<NV>(acc, partials + static_cast<size_t>(blockIdx.x) * NV);
+    if constexpr (MODE != kTerminal) block_then_grid_reduce<NV>(acc, ws);
 }
 
-// Asian option: running arithmetic sum of S_t (or sum of ln S_t) over t = 1..M
-// kept in registers (exotic_options.py:59-67, 119-122 without the path matrix).
+// Asian option: running arithmetic sum of S_t (or sum of ln S_t) over t = 1..M kept in
+// registers (exotic_options.py:59-67, 119-122 without the (n_paths, n_steps) matrix).
+// The cumulative log-return is fp64; in the arithmetic case each S_t / S_0 = 2^y is one
+// fp32 v_exp_f32 of the fp64 y rounded once (relative error ~1e-7 per term, unbiased, far
+// below the Monte Carlo error) and the running sum is fp64.
 struct AsianContract {
     double log_s0;
-    double drift;     // (r - q - sigma^2/2) dt
-    double vol;       // sigma sqrt(dt)
+    double s0;
+    double drift;      // (r - q - sigma^2/2) dt
+    double vol;        // sigma sqrt(dt)
     double strike;
     double sign;
-    double inv_steps; // 1 / M
+    double inv_steps;  // 1 / M
 };
 
 template <bool ANTI, bool GEOMETRIC>
-__global__ __launch_bounds__(kBlock) void asian_kernel(PathRange pr, AsianContract c,
-                                                       double* __restrict__ partials) {
+__global__ __launch_bounds__(kBlock) void asian_kernel(PathRange pr, AsianContract c, ReduceWs ws) {
+    constexpr double kLog2e = 1.4426950408889634;
     double acc[2] = {0.0, 0.0};
+    // arithmetic: accumulate y = log2(S_t / S_0); geometric: accumulate ln(S_t / S_0)
+    const double unit = GEOMETRIC ? 1.0 : kLog2e;
+    const double drift = c.drift * unit;
+    const double vol = c.vol * kZScale * unit;      // applied to RAW normals
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
         const uint64_t g = pr.first + static_cast<uint64_t>(i);
         const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
-        double cum_u = 0.0, cum_d = 0.0;   // cumsum of log-returns
-        double run_u = 0.0, run_d = 0.0;   // running sum of S_t or of ln S_t
+        double cum_u = 0.0, cum_d = 0.0;   // cumulative log-return (in `unit`s)
+        double run_u = 0.0, run_d = 0.0;   // running sum of S_t / S_0, or of ln(S_t / S_0)
         const int32_t blocks = (pr.n_steps + 3) >> 2;
         for (int32_t b = 0; b < blocks; ++b) {
             float z[4];
-            normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1, z);
+            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1, z);
             const int32_t live = min(4, pr.n_steps - 4 * b);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j < live) {
-                    const double dz = c.vol * static_cast<double>(z[j]);
-                    cum_u += c.drift + dz;
-                    if constexpr (GEOMETRIC) run_u += c.log_s0 + cum_u;
-                    else run_u += exp(c.log_s0 + cum_u);
+                    const double dz = vol * static_cast<double>(z[j]);
+                    cum_u += drift + dz;
+                    if constexpr (GEOMETRIC) run_u += cum_u;
+                    else run_u += static_cast<double>(__builtin_amdgcn_exp2f(static_cast<float>(cum_u)));
                     if constexpr (ANTI) {
-                        cum_d += c.drift - dz;
-                        if constexpr (GEOMETRIC) run_d += c.log_s0 + cum_d;
-                        else run_d += exp(c.log_s0 + cum_d);
+                        cum_d += drift - dz;
+                        if constexpr (GEOMETRIC) run_d += cum_d;
+                        else run_d += static_cast<double>(__builtin_amdgcn_exp2f(static_cast<float>(cum_d)));
                     }
                 }
             }
         }
-        double avg = run_u * c.inv_steps;
-        if constexpr (GEOMETRIC) avg = exp(avg);
-        const double xu = fmax(c.sign * (avg - c.strike), 0.0);
-        acc[0] += xu; acc[1] += xu * xu;
-        if constexpr (ANTI) {
-            double avd = run_d * c.inv_steps;
-            if constexpr (GEOMETRIC) avd = exp(avd);
-            const double xd = fmax(c.sign * (avd - c.strike), 0.0);
-            acc[0] += xd; acc[1] += xd * xd;
+#pragma unroll
+        for (int leg = 0; leg < (ANTI ? 2 : 1); ++leg) {
+            const double mean = (leg ? run_d : run_u) * c.inv_steps;
+            const double avg = GEOMETRIC ? exp(c.log_s0 + mean) : c.s0 * mean;
+            const double x = fmax(c.sign * (avg - c.strike), 0.0);
+            acc[0] += x; acc[1] += x * x;
         }
     }
-    block_sum_store<2>(acc, partials + static_cast<size_t>(blockIdx.x) * 2);
-}
-
-// Second stage: out[v] = sum over blocks of partials[block][v], fixed order
-// (thread t takes blocks t, t+256, ...; then an LDS tree), so equal inputs give
-// equal bits (tests/test_monte_carlo.py:153-158 requires price1 == price2).
-__global__ __launch_bounds__(kBlock) void finalize_kernel(const double* __restrict__ partials, int32_t n_blocks,
-                                                          int32_t nv, double* __restrict__ out) {
-    __shared__ double tree[kBlock];
-    for (int v = 0; v < nv; ++v) {
-        double s = 0.0;
-        for (int32_t b = threadIdx.x; b < n_blocks; b += kBlock) s += partials[static_cast<size_t>(b) * nv + v];
-        tree[threadIdx.x] = s;
-        __syncthreads();
-        for (int half = kBlock / 2; half > 0; half >>= 1) {
-            if (threadIdx.x < half) tree[threadIdx.x] += tree[threadIdx.x + half];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) out[v] = tree[0];
-        __syncthreads();
-    }
+    block_then_grid_reduce<2>(acc, ws);
 }
 
 // ------------------------------------------------------- validation taps ----
@@ -291,9 +436,9 @@ __global__ void normals_kernel(uint64_t first, int64_t n_paths, int32_t n_steps,
         const int32_t b = static_cast<int32_t>(i % blocks);
         const uint64_t g = first + static_cast<uint64_t>(p);
         float z[4];
-        normals4(static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32), static_cast<uint32_t>(b), 0u, k0, k1, z);
+        raw_normals4(static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32), static_cast<uint32_t>(b), 0u, k0, k1, z);
         for (int j = 0; j < 4; ++j)
-            if (4 * b + j < n_steps) out[p * n_steps + 4 * b + j] = z[j];
+            if (4 * b + j < n_steps) out[p * n_steps + 4 * b + j] = kZScaleF * z[j];
     }
 }
 

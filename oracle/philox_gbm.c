@@ -20,7 +20,8 @@
  *
  * Stream contract (include/olmc.h): key = (seed lo, seed hi); counter =
  * (path lo, path hi, step/4, tag); words (x0,x1) -> normals of steps 4b, 4b+1
- * (cos, sin), (x2,x3) -> steps 4b+2, 4b+3; u = fmaf((float)x, 2^-32, 2^-33).
+ * (cos, sin), (x2,x3) -> steps 4b+2, 4b+3; radius u = fmaf((float)x, 2^-32, 2^-33),
+ * angle = (x & 0x7fffff) * 2^-23 turns.
  */
 #include <math.h>
 #include <stdint.h>
@@ -45,49 +46,88 @@ void ol_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
 
 static float unit_open(uint32_t x) { return fmaf((float)x, 0x1p-32f, 0x1p-33f); }
 
-/* Box-Muller evaluated in double on the fp32 uniforms, rounded once to fp32. */
-static void box_muller(uint32_t xa, uint32_t xb, float* zc, float* zs) {
-    const double ua = unit_open(xa), ub = unit_open(xb);
-    const double rad = sqrt(-2.0 * log(ua)), ang = 6.283185307179586476925 * ub;
+#define Z_SCALE 1.1774100225154747 /* sqrt(2 ln 2) */
+
+/* RAW Box-Muller pair z' = sqrt(-log2 u_a) * {cos, sin}(2 pi u_b), evaluated in double on the
+ * device's fp32 inputs and rounded once to fp32 (true normal = sqrt(2 ln 2) * z').
+ * radius: u_a = fmaf(x_a, 2^-32, 2^-33); angle: turn fraction (x_b & 0x7fffff) * 2^-23. */
+static void box_muller_raw(uint32_t xa, uint32_t xb, float* zc, float* zs) {
+    const double ua = unit_open(xa), ub = (double)(xb & 0x007FFFFFu) * 0x1p-23;
+    const double rad = sqrt(-log2(ua)), ang = 6.283185307179586476925 * ub;
     *zc = (float)(rad * cos(ang));
     *zs = (float)(rad * sin(ang));
 }
 
-static void normals4(uint64_t path, uint32_t block, uint64_t seed, float z[4]) {
+static void raw_normals4(uint64_t path, uint32_t block, uint64_t seed, float z[4]) {
     uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), block, 0u};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, w[4];
     ol_philox4x32_10(ctr, key, w);
-    box_muller(w[0], w[1], &z[0], &z[1]);
-    box_muller(w[2], w[3], &z[2], &z[3]);
+    box_muller_raw(w[0], w[1], &z[0], &z[1]);
+    box_muller_raw(w[2], w[3], &z[2], &z[3]);
 }
 
-/* out[p*n_steps + t] */
+/* out[p*n_steps + t]: the normals as the olmc_normals tap reports them (fp32 scale of z'). */
 void ol_normals(uint64_t seed, int64_t path0, int64_t n_paths, int32_t n_steps, float* out) {
     for (int64_t p = 0; p < n_paths; ++p)
         for (int32_t b = 0; 4 * b < n_steps; ++b) {
             float z[4];
-            normals4((uint64_t)(path0 + p), (uint32_t)b, seed, z);
-            for (int j = 0; j < 4 && 4 * b + j < n_steps; ++j) out[p * n_steps + 4 * b + j] = z[j];
+            raw_normals4((uint64_t)(path0 + p), (uint32_t)b, seed, z);
+            for (int j = 0; j < 4 && 4 * b + j < n_steps; ++j) out[p * n_steps + 4 * b + j] = (float)Z_SCALE * z[j];
         }
 }
 
-/* sum_t Z: fp32 inside a block of four, fp64 across blocks (device order). */
-static double path_normal_sum(uint64_t path, int32_t n_steps, uint64_t seed) {
-    double acc = 0.0;
-    float z[4];
-    int32_t full = n_steps >> 2, rem = n_steps & 3;
-    for (int32_t b = 0; b < full; ++b) {
-        normals4(path, (uint32_t)b, seed, z);
-        acc += (double)((z[0] + z[1]) + (z[2] + z[3]));
+/* sum_t Z in the device's order: the Philox blocks are cut into 4 contiguous chunks (chunk w
+ * gets n/4 blocks, the first n%4 one more); inside a chunk fp32 within a Philox block and
+ * across a group of four blocks, fp64 across groups, a trailing partial block on its own;
+ * total = (((c0 + c1) + c2) + c3) * sqrt(2 ln 2). */
+/* sum of a block's four RAW normals in the device's factored form:
+ * rad_a (cos_a + sin_a) + rad_b (cos_b + sin_b), every intermediate rounded to fp32. */
+static float raw_block_sum4(uint64_t path, uint32_t b, uint64_t seed) {
+    uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), b, 0u};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, w[4];
+    ol_philox4x32_10(ctr, key, w);
+    float p[2];
+    for (int h = 0; h < 2; ++h) {
+        const double ua = unit_open(w[2 * h]), ang = 6.283185307179586476925 * ((double)(w[2 * h + 1] & 0x007FFFFFu) * 0x1p-23);
+        const float rad = (float)sqrt(-log2(ua)), c = (float)cos(ang), sn = (float)sin(ang);
+        p[h] = rad * (c + sn);
     }
-    if (rem) {
-        normals4(path, (uint32_t)full, seed, z);
+    return p[0] + p[1];
+}
+
+static double chunk_normal_sum(uint64_t path, int32_t b_begin, int32_t b_end, int32_t n_steps, uint64_t seed) {
+    const int32_t full_end = b_end < (n_steps >> 2) ? b_end : (n_steps >> 2);
+    double acc = 0.0;
+    int32_t b = b_begin, rem = n_steps & 3;
+    for (; b + 4 <= full_end; b += 4) {
+        float s = raw_block_sum4(path, (uint32_t)b, seed);
+        for (int j = 1; j < 4; ++j) s += raw_block_sum4(path, (uint32_t)(b + j), seed);
+        acc += (double)s;
+    }
+    if (b < full_end) {
+        float s = raw_block_sum4(path, (uint32_t)b, seed);
+        for (++b; b < full_end; ++b) s += raw_block_sum4(path, (uint32_t)b, seed);
+        acc += (double)s;
+    }
+    if (rem && b < b_end) {
+        float z[4];
+        raw_normals4(path, (uint32_t)b, seed, z);
         float s = z[0];
         if (rem > 1) s += z[1];
         if (rem > 2) s += z[2];
         acc += (double)s;
     }
     return acc;
+}
+
+static double path_normal_sum(uint64_t path, int32_t n_steps, uint64_t seed) {
+    const int32_t n_blocks = (n_steps + 3) >> 2, q = n_blocks / 4, r = n_blocks % 4;
+    double part[4];
+    for (int w = 0; w < 4; ++w) {
+        const int32_t b0 = w * q + (w < r ? w : r), b1 = b0 + q + (w < r ? 1 : 0);
+        part[w] = chunk_normal_sum(path, b0, b1, n_steps, seed);
+    }
+    return (((part[0] + part[1]) + part[2]) + part[3]) * Z_SCALE;
 }
 
 /* Terminal prices [pos | neg] for global paths path0 .. path0+n-1 (gbm_numpy.py:35-51). */
@@ -130,9 +170,9 @@ void ol_asian_moments(double S, double K, double T, double r, double sigma, doub
         double cum[2] = {0, 0}, run[2] = {0, 0};
         for (int32_t b = 0; 4 * b < n_steps; ++b) {
             float z[4];
-            normals4((uint64_t)(path0 + i), (uint32_t)b, seed, z);
+            raw_normals4((uint64_t)(path0 + i), (uint32_t)b, seed, z);
             for (int j = 0; j < 4 && 4 * b + j < n_steps; ++j) {
-                const double dz = vol * (double)z[j];
+                const double dz = (vol * Z_SCALE) * (double)z[j];
                 cum[0] += drift + dz;
                 cum[1] += drift - dz;
                 for (int leg = 0; leg < 2; ++leg) run[leg] += geometric ? log_s0 + cum[leg] : exp(log_s0 + cum[leg]);

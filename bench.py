@@ -37,6 +37,18 @@ LANE_OPS_PER_PATH_STEP = 32          # algorithmic VALU lane-ops 
 PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 (MI355X_MICROARCH.md: 157.3 TF fp32 = 2 flop/FMA)
 
 
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary
+    (profiles/*_traffic.json; collected with tools/profile_gpu.sh, separate --pmc passes)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return d.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+
+
 def cpu_baseline():
     """Reference-pinned NumPy oracle (oracle/numpy_reference.py) timed on this host: 1 core
     (NumPy's Generator is serial).  Bounded sample: warm-up at 100k x 252, then one full
@@ -143,6 +155,7 @@ def main():
         value = path_steps * K_steps / elapsed
         avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = (hi - lo) * N_STEPS * LANE_OPS_PER_PATH_STEP / avg_kernel_s / 1e12
+        traffic, traffic_src = measured_traffic()
         out = {
             "metric": "MC path-steps/sec (1M paths x 252 steps Euro call); price vs BS |err|/sigma",
             "value": value, "unit": "path-steps/s", "n_gpus": world, "steps": K_steps, "warmup": W,
@@ -154,11 +167,12 @@ def main():
                        "parallelism": f"path-sharded x{world}" + (", 1 RCCL all-reduce of (sum,sumsq,n) per step" if world > 1 else "")},
             "accuracy": {"bs_price": bs, "max_abs_err_over_sigma": worst, "payoffs_per_step": 2 * n_global},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_TLANEOPS, "unit": "Tlane-op/s",
-                         "frac": achieved / PEAK_TLANEOPS, "traffic": None,
-                         "kernel": "european_kernel<1,true,kReduce>", "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "frac": achieved / PEAK_TLANEOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src, "kernel": "european_path_kernel<1,true,kReduce>", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "launches_timed": launches, "lane_ops_per_path_step": LANE_OPS_PER_PATH_STEP,
-                         "note": "VALU-issue bound (not HBM, not MFMA): HBM traffic is 16 B per block partial; "
-                                 "traffic measured with rocprofv3 --pmc is in profiles/ and DESIGN.md"},
+                         "hbm_gbps": (traffic / avg_kernel_s / 1e9) if traffic else None,
+                         "note": "VALU-issue bound (SURVEY 8d: not HBM, not MFMA); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz "
+                                 "(157.3 TF fp32 vector / 2); achieved = 32 lane-ops x path-steps per launch / HIP-event kernel time"},
             "device": info,
         }
         # blocking API at the same size (one host round trip per price() call)

@@ -168,6 +168,23 @@ int olmc_asian(double S, double K, double T, double r, double sigma, double q, i
                int avg_kind, int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
                int antithetic, olmc_stats* out);
 
+/* ---- quasi-Monte Carlo (MCMethod.QMC) --------------------------------------
+ * Replaces simulate_gbm_qmc (src/simulation/gbm_qmc.py:14-46): scrambled-Sobol
+ * points -> clip [1e-10, 1-1e-10] -> inverse normal (fp64) -> sum over dims ->
+ * terminal price; no antithetic mirror, n = n_paths payoffs.  `sv` is the
+ * [dims][bits] scrambled direction matrix and `shift` the [dims] digital shift
+ * of scipy.stats.qmc.Sobol(d=dims, scramble=True, seed) (host memory, uint32,
+ * bits must be 30 = SciPy's default): point k = shift ^ XOR_{b in gray(k)} sv[:, b],
+ * u = x * 2^-bits -- the same uniforms as Sobol.random(n), bit for bit.
+ * dims = min(n_steps, 21201) as in the reference (:30). */
+int olmc_european_qmc(double S, double K, double T, double r, double sigma, double q, int is_call,
+                      int64_t point_offset, int64_t n_paths, int32_t dims,
+                      const uint32_t* sv, const uint32_t* shift, int32_t bits, olmc_stats* out);
+int olmc_european_qmc_terminal(double S, double T, double r, double sigma, double q,
+                               int64_t point_offset, int64_t n_paths, int32_t dims,
+                               const uint32_t* sv, const uint32_t* shift, int32_t bits,
+                               double* out_host /* [n_paths] */);
+
 /* ---- multi-GPU, single process ------------------------------------------
  * n_paths split into n_gpus contiguous global path ranges, one host thread and
  * one stream per device, ONE RCCL all-reduce of {sum, sumsq, n} (3 x fp64)

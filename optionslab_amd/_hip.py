@@ -60,6 +60,8 @@ PROTOTYPES = {
     "olmc_european_greeks_fd": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(_D), C.POINTER(Stats)]),
     "olmc_european_terminal": (_I, [_D] * 5 + [_I64, _I32, _U64T, _I, C.POINTER(_D)]),
     "olmc_european_cv": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(CvMoments)]),
+    "olmc_european_qmc": (_I, _SIX + [_I, _I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, C.POINTER(Stats)]),
+    "olmc_european_qmc_terminal": (_I, [_D] * 5 + [_I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, C.POINTER(_D)]),
     "olmc_asian": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_multi_gpu_european": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(Stats)]),
     "olmc_combine_stats": (_I, [C.POINTER(Stats), _I32, _D, _D, C.POINTER(Stats)]),
@@ -185,6 +187,32 @@ def european_cv(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int,
     out = CvMoments()
     _check(lib().olmc_european_cv(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(n_steps), seed64(seed),
                                   int(antithetic), C.byref(out)))
+    return out
+
+
+def _u32(a: np.ndarray):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def european_qmc(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv: np.ndarray, shift: np.ndarray,
+                 point_offset: int = 0) -> Stats:
+    """sv: (dims, 30) uint32 scrambled direction matrix, shift: (dims,) uint32 (see olmc.h)."""
+    sv, psv = _u32(sv)
+    shift, psh = _u32(shift)
+    out = Stats()
+    _check(lib().olmc_european_qmc(S, K, T, r, sigma, q, int(is_call), int(point_offset), int(n_paths), int(sv.shape[0]),
+                                   psv, psh, int(sv.shape[1]), C.byref(out)))
+    return out
+
+
+def european_qmc_terminal(S, T, r, sigma, q, n_paths: int, sv: np.ndarray, shift: np.ndarray,
+                          point_offset: int = 0) -> np.ndarray:
+    sv, psv = _u32(sv)
+    shift, psh = _u32(shift)
+    out = np.empty(int(n_paths), dtype=np.float64)
+    _check(lib().olmc_european_qmc_terminal(S, T, r, sigma, q, int(point_offset), int(n_paths), int(sv.shape[0]), psv, psh,
+                                            int(sv.shape[1]), out.ctypes.data_as(C.POINTER(C.c_double))))
     return out
 
 

@@ -589,6 +589,82 @@ extern "C" int olmc_asian(double S, double K, double T, double r, double sigma, 
     return OLMC_OK;
 }
 
+// ======================================================================= QMC ====
+namespace {
+int run_qmc(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t point_offset,
+            int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
+            olmc_stats* out, double* terminal_host) {
+    if (!sv || !shift) return fail(OLMC_ERR_ARG, "null pointer");
+    if (bits != kSobolBits) return fail(OLMC_ERR_ARG, "only 30-bit Sobol tables (SciPy's default) are supported");
+    if (dims < 1 || dims > 21201) return fail(OLMC_ERR_ARG, "dims must be in [1, 21201]");
+    int rc = check_paths(point_offset, n_paths, dims);
+    if (rc) return rc;
+    if (point_offset + n_paths > (int64_t(1) << kSobolBits)) return fail(OLMC_ERR_ARG, "at most 2**30 Sobol points");
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const size_t table_words = static_cast<size_t>(dims) * (kSobolBits + 1);
+    const size_t table_bytes = (table_words * sizeof(uint32_t) + 255) / 256 * 256;
+    const size_t term_bytes = terminal_host ? sizeof(double) * static_cast<size_t>(n_paths) : 0;
+    rc = bulk_reserve(c, table_bytes + term_bytes);
+    if (rc) return rc;
+    uint32_t* d_sv = static_cast<uint32_t*>(c->d_bulk);
+    uint32_t* d_shift = d_sv + static_cast<size_t>(dims) * kSobolBits;
+    double* d_term = terminal_host ? reinterpret_cast<double*>(static_cast<char*>(c->d_bulk) + table_bytes) : nullptr;
+    HIP_TRY(hipMemcpyAsync(d_sv, sv, sizeof(uint32_t) * dims * kSobolBits, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_shift, shift, sizeof(uint32_t) * dims, hipMemcpyHostToDevice, c->stream));
+    // gbm_qmc.py:38-44
+    const double dt = T / dims;
+    const double drift = (r - q - 0.5 * sigma * sigma) * dt;
+    Contract ct;
+    ct.vol = sigma * std::sqrt(dt);
+    ct.a = std::log(S) + drift * dims;
+    ct.strike = K;
+    ct.sign = is_call ? 1.0 : -1.0;
+    QmcRange qr;
+    qr.first = static_cast<uint64_t>(point_offset);
+    qr.count = n_paths;
+    qr.dims = dims;
+    const int32_t grid = grid_for(n_paths);
+    ReduceWs ws{};
+    if (!terminal_host) {
+        rc = make_ws(c, grid, 2, c->d_result, -1.0, &ws);
+        if (rc) return rc;
+        hipLaunchKernelGGL((european_qmc_kernel<kReduce>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, nullptr);
+    } else {
+        hipLaunchKernelGGL((european_qmc_kernel<kTerminal>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
+    }
+    {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
+    }
+    if (terminal_host) {
+        HIP_TRY(hipMemcpyAsync(terminal_host, d_term, term_bytes, hipMemcpyDeviceToHost, c->stream));
+        return sync_or_recover(c, c->stream);
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
+    rc = sync_or_recover(c, c->stream);
+    if (rc) return rc;
+    finish_stats(c->h_result[0], c->h_result[1], n_paths, r, T, out);
+    return OLMC_OK;
+}
+}  // namespace
+
+extern "C" int olmc_european_qmc(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                 int64_t point_offset, int64_t n_paths, int32_t dims, const uint32_t* sv,
+                                 const uint32_t* shift, int32_t bits, olmc_stats* out) {
+    if (!out) return fail(OLMC_ERR_ARG, "null pointer");
+    return run_qmc(S, K, T, r, sigma, q, is_call, point_offset, n_paths, dims, sv, shift, bits, out, nullptr);
+}
+
+extern "C" int olmc_european_qmc_terminal(double S, double T, double r, double sigma, double q, int64_t point_offset,
+                                          int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift,
+                                          int32_t bits, double* out_host) {
+    if (!out_host) return fail(OLMC_ERR_ARG, "null pointer");
+    return run_qmc(S, 0.0, T, r, sigma, q, 1, point_offset, n_paths, dims, sv, shift, bits, nullptr, out_host);
+}
+
 // ======================================================== multi-GPU (RCCL) ====
 // librccl is resolved lazily so single-GPU users never load it.
 namespace {

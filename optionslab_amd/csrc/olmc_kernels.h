@@ -413,6 +413,94 @@ __global__ __launch_bounds__(kBlock) void asian_kernel(PathRange pr, AsianContra
     block_then_grid_reduce<2>(acc, ws);
 }
 
+// ------------------------------------------------------------------ QMC ----
+// Scrambled-Sobol terminal prices (src/simulation/gbm_qmc.py:14-46): point k of the sequence is
+//   x_t(k) = shift[t] ^ XOR_{b in gray(k)} sv[t][b],   u = x * 2^-30,
+// with sv / shift the host-built (SciPy LMS + digital shift) direction matrix of dimension t,
+// so the uniforms equal scipy.stats.qmc.Sobol(d, scramble=True, seed).random(n) bit for bit.
+// Then clip to [1e-10, 1-1e-10] (:36), z = Phi^-1(u) in fp64, sum over the dims, exp.  No
+// antithetic mirror (the reference's QMC backend has none).
+constexpr int kSobolBits = 30;      // SciPy's default `bits`
+
+// Inverse normal CDF, Wichura AS241 PPND16 (|rel err| ~1e-16; checked against scipy ndtri
+// to 4.4e-15 abs on [1e-10, 1-1e-10]).  The r > 5 branch is unreachable for clipped inputs
+// (sqrt(-ln 1e-10) = 4.80) but kept for completeness.
+__device__ __forceinline__ double ndtri_as241(double p) {
+    const double q = p - 0.5;
+    if (fabs(q) <= 0.425) {
+        const double r = 0.180625 - q * q;
+        const double num = (((((((2.5090809287301226727e+3 * r + 3.3430575583588128105e+4) * r + 6.7265770927008700853e+4) * r +
+                                4.5921953931549871457e+4) * r + 1.3731693765509461125e+4) * r + 1.9715909503065514427e+3) * r +
+                             1.3314166789178437745e+2) * r + 3.3871328727963666080e0);
+        const double den = (((((((5.2264952788528545610e+3 * r + 2.8729085735721942674e+4) * r + 3.9307895800092710610e+4) * r +
+                                2.1213794301586595867e+4) * r + 5.3941960214247511077e+3) * r + 6.8718700749205790830e+2) * r +
+                             4.2313330701600911252e+1) * r + 1.0);
+        return q * num / den;
+    }
+    double r = sqrt(-log(q < 0.0 ? p : 1.0 - p));
+    double val;
+    if (r <= 5.0) {
+        r -= 1.6;
+        const double num = (((((((7.74545014278341407640e-4 * r + 2.27238449892691845833e-2) * r + 2.41780725177450611770e-1) * r +
+                                1.27045825245236838258e0) * r + 3.64784832476320460504e0) * r + 5.76949722146069140550e0) * r +
+                             4.63033784615654529590e0) * r + 1.42343711074968357734e0);
+        const double den = (((((((1.05075007164441684324e-9 * r + 5.47593808499534494600e-4) * r + 1.51986665636164571966e-2) * r +
+                                1.48103976427480074590e-1) * r + 6.89767334985100004550e-1) * r + 1.67638483018380384940e0) * r +
+                             2.05319162663775882187e0) * r + 1.0);
+        val = num / den;
+    } else {
+        r -= 5.0;
+        const double num = (((((((2.01033439929228813265e-7 * r + 2.71155556874348757815e-5) * r + 1.24266094738807843860e-3) * r +
+                                2.65321895265761230930e-2) * r + 2.96560571828504891230e-1) * r + 1.78482653991729133580e0) * r +
+                             5.46378491116411436990e0) * r + 6.65790464350110377720e0);
+        const double den = (((((((2.04426310338993978564e-15 * r + 1.42151175831644588870e-7) * r + 1.84631831751005468180e-5) * r +
+                                7.86869131145613259100e-4) * r + 1.48753612908506148525e-2) * r + 1.36929880922735805310e-1) * r +
+                             5.99832206555887937690e-1) * r + 1.0);
+        val = num / den;
+    }
+    return q < 0.0 ? -val : val;
+}
+
+struct QmcRange {
+    uint64_t first;    // index of the first Sobol point of this launch
+    int64_t count;
+    int32_t dims;      // effective_steps = min(n_steps, 21201)
+};
+
+// Contract::a = ln S + drift * dims, Contract::vol = sigma sqrt(T / dims) (gbm_qmc.py:38-44).
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contract c, const uint32_t* __restrict__ sv,
+                                                              const uint32_t* __restrict__ shift, ReduceWs ws,
+                                                              double* __restrict__ terminal) {
+    double acc[2] = {0.0, 0.0};
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < qr.count; i += stride) {
+        const uint64_t k = qr.first + static_cast<uint64_t>(i);
+        const uint32_t gray = static_cast<uint32_t>(k ^ (k >> 1));
+        uint32_t mask[kSobolBits];
+#pragma unroll
+        for (int b = 0; b < kSobolBits; ++b) mask[b] = 0u - ((gray >> b) & 1u);
+        double zsum = 0.0;
+        for (int32_t t = 0; t < qr.dims; ++t) {
+            const uint32_t* __restrict__ row = sv + static_cast<size_t>(t) * kSobolBits;
+            uint32_t x = shift[t];
+#pragma unroll
+            for (int b = 0; b < kSobolBits; ++b) x ^= row[b] & mask[b];
+            double u = static_cast<double>(x) * 9.313225746154785e-10;      // 2^-30
+            u = fmin(fmax(u, 1e-10), 1.0 - 1e-10);
+            zsum += ndtri_as241(u);
+        }
+        const double st = exp(c.a + c.vol * zsum);
+        if constexpr (MODE == kTerminal) {
+            terminal[i] = st;
+        } else {
+            const double x = fmax(c.sign * (st - c.strike), 0.0);
+            acc[0] += x; acc[1] += x * x;
+        }
+    }
+    if constexpr (MODE != kTerminal) block_then_grid_reduce<2>(acc, ws);
+}
+
 // ------------------------------------------------------- validation taps ----
 __global__ void philox_words_kernel(uint64_t first, int64_t n_paths, int32_t block0, int32_t n_blocks,
                                     uint32_t tag, uint32_t k0, uint32_t k1, uint32_t* __restrict__ out) {

@@ -19,6 +19,34 @@ import numpy as np
 from . import _hip
 from .exceptions import AccelerationError
 
+SOBOL_MAX_DIM = 21201            # src/simulation/gbm_qmc.py:29-30
+_sobol_cache: "OrderedDict[tuple, tuple]" = OrderedDict()
+
+
+def sobol_tables(n_steps: int, seed: int):
+    """(sv, shift) of scipy.stats.qmc.Sobol(d=min(n_steps, 21201), scramble=True, seed=seed):
+    the scrambled direction matrix and digital shift the device expands into the very same
+    points SciPy's .random(n) returns (src/simulation/gbm_qmc.py:32-33).  Only this small
+    host-side table construction uses SciPy (a dependency of the reference); the points, the
+    inverse normal and the payoff reduction run on the GPU.  Cached: FD Greeks reuse it."""
+    d = min(int(n_steps), SOBOL_MAX_DIM)
+    key = (d, int(seed))
+    hit = _sobol_cache.get(key)
+    if hit is not None:
+        _sobol_cache.move_to_end(key)
+        return hit
+    from scipy.stats.qmc import Sobol
+
+    eng = Sobol(d=d, scramble=True, seed=seed)
+    if eng.bits != 30 or not hasattr(eng, "_sv") or not hasattr(eng, "_shift"):
+        raise AccelerationError("this SciPy's Sobol engine does not expose 30-bit _sv/_shift tables", backend="hip")
+    val = (np.ascontiguousarray(eng._sv, dtype=np.uint32), np.ascontiguousarray(eng._shift, dtype=np.uint32))
+    _sobol_cache[key] = val
+    while len(_sobol_cache) > 8:
+        _sobol_cache.popitem(last=False)
+    return val
+
+
 NUMBA_AVAILABLE = False          # kept for `from ...monte_carlo import NUMBA_AVAILABLE` (monte_carlo.py:189)
 GREEK_KEYS = ("price", "delta", "gamma", "vega", "theta", "rho", "vanna", "charm", "vomma")
 
@@ -26,7 +54,7 @@ GREEK_KEYS = ("price", "delta", "gamma", "vega", "theta", "rho", "vanna", "charm
 class MCMethod(Enum):
     """Backend selector (monte_carlo.py:28-34) plus the new member HIP.  NUMPY,
     NUMBA and HIP all mean "multi-step on the device"; FAST forces a single step
-    (monte_carlo.py:87); QMC has no device implementation yet and raises."""
+    (monte_carlo.py:87); QMC is the device scrambled-Sobol path (no antithetic)."""
 
     NUMPY = "numpy"
     NUMBA = "numba"
@@ -61,8 +89,6 @@ class MonteCarloPricer:
 
     # ------------------------------------------------------------------ helpers
     def _steps(self) -> int:
-        if self.method == MCMethod.QMC:
-            raise AccelerationError("MCMethod.QMC (scrambled Sobol) is not implemented on the device", backend="hip")
         if self.method == MCMethod.FAST:
             return 1
         if self.num_steps < 1:
@@ -72,6 +98,9 @@ class MonteCarloPricer:
     def _simulate(self, S: float, T: float, r: float, sigma: float, q: float, seed: Optional[int] = None) -> np.ndarray:
         """Terminal prices, length 2*num_simulations, [pos | neg] (monte_carlo.py:74-106)."""
         actual_seed = seed if seed is not None else self.seed
+        if self.method == MCMethod.QMC:
+            sv, shift = sobol_tables(self._steps(), actual_seed)
+            return _hip.european_qmc_terminal(S, T, r, sigma, q, self.num_simulations, sv, shift)
         return _hip.european_terminal(S, T, r, sigma, q, self.num_simulations, self._steps(), actual_seed, True)
 
     # -------------------------------------------------------------------- price
@@ -81,8 +110,12 @@ class MonteCarloPricer:
             intrinsic = max(S - K, 0) if option_type == "call" else max(K - S, 0)
             return MCResult(intrinsic, 0.0, 0) if return_error else intrinsic
         actual_seed = seed if seed is not None else self.seed
-        st = _hip.european(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(),
-                           actual_seed, True)
+        if self.method == MCMethod.QMC:
+            sv, shift = sobol_tables(self._steps(), actual_seed)
+            st = _hip.european_qmc(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift)
+        else:
+            st = _hip.european(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(),
+                               actual_seed, True)
         if return_error:
             return MCResult(float(st.price), float(st.std_error), int(st.n))
         return float(st.price)
@@ -92,6 +125,13 @@ class MonteCarloPricer:
                                    seed: Optional[int] = None) -> float:
         """Terminal spot as control, E[S_T] = S e^{(r-q)T} (monte_carlo.py:154-186)."""
         actual_seed = seed if seed is not None else self.seed
+        if self.method == MCMethod.QMC:   # five moments on the host from the device terminal array (N values)
+            st = self._simulate(S, T, r, sigma, q, seed)
+            x = np.maximum(st - K, 0.0) if option_type == "call" else np.maximum(K - st, 0.0)
+            d = np.exp(-r * T) * x
+            cov = np.cov(d, st)
+            beta = cov[0, 1] / cov[1, 1] if cov[1, 1] > 1e-10 else 0.0
+            return float(np.mean(d) - beta * (np.mean(st) - S * np.exp((r - q) * T)))
         m = _hip.european_cv(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(),
                              actual_seed, True)
         return float(m.value)
@@ -109,6 +149,10 @@ class MonteCarloPricer:
         return compute_greeks_unified(self, S, K, T, r, sigma, option_type, q, include_second_order, **kw)
 
     def _fused_greeks(self, S, K, T, r, sigma, option_type, q, include_second_order, seed=None):
+        if self.method == MCMethod.QMC:   # no fused QMC kernel: literal bump-and-reprice (same Sobol points each call)
+            from .greeks import compute_greeks_unified
+            kw = {} if seed is None else {"seed": seed}
+            return compute_greeks_unified(self, S, K, T, r, sigma, option_type, q, include_second_order, fused=False, **kw)
         actual_seed = seed if seed is not None else self.seed
         vals, _ = _hip.european_greeks_fd(S, K, T, r, sigma, q, option_type == "call", self.num_simulations,
                                           self._steps(), actual_seed, include_second_order)

@@ -138,6 +138,16 @@ int olmc_european_batch(const olmc_option* opts, int32_t k,
                         int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
                         int antithetic, olmc_stats* out /* [k] */);
 
+/* n_options INDEPENDENT contracts in one launch (grid.y = contract), each with its own
+ * Philox stream selected by its tag (counter word 3; tags == NULL -> tag j = j) and
+ * its own on-device reduction.  Replaces MonteCarloPricerUni.price_batch /
+ * _simulate_terminal_prices (src/pricing_models/monte_carlo_unified.py:298-343, 562-631),
+ * where option j consumes its own slice of the normals; equal tags give common random
+ * numbers (delta_gamma_batch, :633-689: the S-h / S / S+h copies of option j share tag j). */
+int olmc_european_multi(const olmc_option* opts, const uint32_t* tags, int64_t n_options,
+                        int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
+                        olmc_stats* out /* [n_options] */);
+
 /* Finite-difference Greeks, bumps exactly as unified_greeks.py:274-277, 295-362.
  * out9 = {price, delta, gamma, vega, theta, rho, vanna, charm, vomma}; the last
  * three are written only when second_order != 0.  `evals` (nullable) receives

@@ -10,13 +10,14 @@ from .exceptions import AccelerationError, ConvergenceError, GreeksError, InputV
 from .exotic import AsianOption, price_asian
 from .greeks import ExoticAdapter, PricerProtocol, compute_greeks_unified
 from .monte_carlo import NUMBA_AVAILABLE, MCMethod, MCResult, MonteCarloPricer
+from .monte_carlo_unified import MonteCarloPricerUni
 from .simulation import hip_available, simulate_gbm_hip, simulate_gbm_hip_fast
 from . import sharding  # noqa: E402  (torch is imported lazily inside)
 
 __version__ = "0.1.0"
 
 __all__ = [
-    "MonteCarloPricer", "MCMethod", "MCResult", "NUMBA_AVAILABLE", "compute_greeks_unified", "PricerProtocol",
+    "MonteCarloPricer", "MonteCarloPricerUni", "MCMethod", "MCResult", "NUMBA_AVAILABLE", "compute_greeks_unified", "PricerProtocol",
     "ExoticAdapter", "AsianOption", "price_asian", "black_scholes", "simulate_gbm_hip", "simulate_gbm_hip_fast",
     "hip_available", "MonteCarloError", "InputValidationError", "ConvergenceError", "AccelerationError", "GreeksError",
 ]

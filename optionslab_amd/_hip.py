@@ -57,6 +57,7 @@ PROTOTYPES = {
     "olmc_european_shard": (_I, _SIX + [_I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_european_shard_dev": (_I, _SIX + [_I, _I64, _I64, _I32, _U64T, _I, _P, _P]),
     "olmc_european_batch": (_I, [C.POINTER(Option), _I32, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
+    "olmc_european_multi": (_I, [C.POINTER(Option), C.POINTER(C.c_uint32), _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_european_greeks_fd": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(_D), C.POINTER(Stats)]),
     "olmc_european_terminal": (_I, [_D] * 5 + [_I64, _I32, _U64T, _I, C.POINTER(_D)]),
     "olmc_european_cv": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(CvMoments)]),
@@ -164,6 +165,26 @@ def european_batch(options: Sequence[Tuple[float, float, float, float, float, fl
     out = (Stats * k)()
     _check(lib().olmc_european_batch(arr, k, int(path_offset), int(n_paths), int(n_steps), seed64(seed), int(antithetic), out))
     return list(out)
+
+
+def european_multi(S, K, T, r, sigma, q, is_call, n_paths: int, n_steps: int, seed: int, antithetic: bool = True,
+                   tags=None) -> np.ndarray:
+    """Arrays of contracts -> structured result array with fields of olmc_stats (one launch)."""
+    S, K, T, r, sigma, q = (np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), np.shape(S))) for a in (S, K, T, r, sigma, q))
+    n = S.shape[0]
+    opts = np.zeros(n, dtype=np.dtype([("S", "f8"), ("K", "f8"), ("T", "f8"), ("r", "f8"), ("sigma", "f8"), ("q", "f8"),
+                                       ("is_call", "i4"), ("reserved", "i4")]))
+    for name, arr in zip(("S", "K", "T", "r", "sigma", "q"), (S, K, T, r, sigma, q)):
+        opts[name] = arr
+    opts["is_call"] = np.broadcast_to(np.asarray(is_call, dtype=bool), (n,)).astype(np.int32)
+    out = np.zeros(n, dtype=np.dtype([("sum", "f8"), ("sumsq", "f8"), ("n", "i8"), ("price", "f8"), ("std_error", "f8")]))
+    ptags = None
+    if tags is not None:
+        tags = np.ascontiguousarray(tags, dtype=np.uint32)
+        ptags = tags.ctypes.data_as(C.POINTER(C.c_uint32))
+    _check(lib().olmc_european_multi(opts.ctypes.data_as(C.POINTER(Option)), ptags, n, int(n_paths), int(n_steps), seed64(seed),
+                                     int(antithetic), out.ctypes.data_as(C.POINTER(Stats))))
+    return out
 
 
 def european_greeks_fd(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int, seed: int,

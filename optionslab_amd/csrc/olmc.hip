@@ -58,6 +58,9 @@ struct DeviceCtx {
     double* h_result = nullptr;      // pinned [kMaxNV + 1]
     void* d_bulk = nullptr;          // terminal prices / validation taps
     size_t bulk_bytes = 0;
+    // independent-contract batches (european_multi_kernel)
+    void* d_multi = nullptr;         // [opts | out | rows | counters]
+    size_t multi_bytes = 0;
     std::mutex mu;
     // profiling
     std::vector<EventPair> ev_free, ev_pending;
@@ -339,6 +342,7 @@ extern "C" int olmc_shutdown(void) {
             for (auto& ep : c->ev_pending) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
             for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
             if (c->d_bulk) (void)hipFree(c->d_bulk);
+            if (c->d_multi) (void)hipFree(c->d_multi);
             if (c->d_block_rows) (void)hipFree(c->d_block_rows);
             (void)hipFree(c->d_group_rows);
             (void)hipFree(c->d_counters);
@@ -419,6 +423,61 @@ extern "C" int olmc_combine_stats(const olmc_stats* parts, int32_t n_parts, doub
     }
     if (n < 1) return fail(OLMC_ERR_ARG, "no samples");
     finish_stats(sum, sumsq, n, r, T, out);
+    return OLMC_OK;
+}
+
+// ==================================================== independent contracts ====
+extern "C" int olmc_european_multi(const olmc_option* opts, const uint32_t* tags, int64_t n_options, int64_t n_paths,
+                                   int32_t n_steps, uint64_t seed, int antithetic, olmc_stats* out) {
+    if (!opts || !out) return fail(OLMC_ERR_ARG, "null pointer");
+    if (n_options < 1) return fail(OLMC_ERR_ARG, "n_options must be >= 1");
+    int rc = check_paths(0, n_paths, n_steps);
+    if (rc) return rc;
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const int32_t bpo = static_cast<int32_t>(std::min<int64_t>((n_paths + kBlock - 1) / kBlock, 1024));   // workgroups per contract
+    auto align = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t b_opts = align(sizeof(MultiOption) * n_options), b_out = align(sizeof(double) * 2 * n_options);
+    const size_t b_rows = align(sizeof(double) * 2 * bpo * n_options), b_cnt = align(sizeof(uint32_t) * n_options);
+    const size_t need = b_opts + b_out + b_rows + b_cnt;
+    if (need > c->multi_bytes) {
+        if (c->d_multi) HIP_TRY(hipFree(c->d_multi));
+        c->d_multi = nullptr;
+        c->multi_bytes = 0;
+        HIP_TRY(hipMalloc(&c->d_multi, need));
+        c->multi_bytes = need;
+    }
+    char* base = static_cast<char*>(c->d_multi);
+    MultiOption* d_opts = reinterpret_cast<MultiOption*>(base);
+    double* d_out = reinterpret_cast<double*>(base + b_opts);
+    double* d_rows = reinterpret_cast<double*>(base + b_opts + b_out);
+    uint32_t* d_cnt = reinterpret_cast<uint32_t*>(base + b_opts + b_out + b_rows);
+    std::vector<MultiOption> h(static_cast<size_t>(n_options));
+    for (int64_t j = 0; j < n_options; ++j) {
+        const Contract ct = make_contract(opts[j], n_steps);
+        h[j].a = ct.a; h[j].vol = ct.vol; h[j].strike = ct.strike; h[j].sign = ct.sign;
+        h[j].tag = tags ? tags[j] : static_cast<uint32_t>(j);
+        h[j].pad = 0;
+    }
+    HIP_TRY(hipMemcpyAsync(d_opts, h.data(), sizeof(MultiOption) * n_options, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * n_options, c->stream));   // layout moves with n_options
+    const PathRange pr = make_range(0, n_paths, n_steps, seed);
+    EventPair ep{};
+    if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
+    for (int64_t base_opt = 0; base_opt < n_options; base_opt += 65535) {
+        const unsigned ny = static_cast<unsigned>(std::min<int64_t>(65535, n_options - base_opt));
+        if (antithetic) hipLaunchKernelGGL((european_multi_kernel<true>), dim3(bpo, ny), dim3(kBlock), 0, c->stream, pr, d_opts, base_opt, d_rows, d_cnt, d_out);
+        else hipLaunchKernelGGL((european_multi_kernel<false>), dim3(bpo, ny), dim3(kBlock), 0, c->stream, pr, d_opts, base_opt, d_rows, d_cnt, d_out);
+        HIP_TRY(hipGetLastError());
+    }
+    if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
+    std::vector<double> res(static_cast<size_t>(2 * n_options));
+    HIP_TRY(hipMemcpyAsync(res.data(), d_out, sizeof(double) * 2 * n_options, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int64_t n = n_paths * (antithetic ? 2 : 1);
+    for (int64_t j = 0; j < n_options; ++j) finish_stats(res[2 * j], res[2 * j + 1], n, opts[j].r, opts[j].T, &out[j]);
     return OLMC_OK;
 }
 

@@ -98,10 +98,11 @@ __device__ __forceinline__ void raw_normals4(uint32_t g_lo, uint32_t g_hi, uint3
 // one packed multiply and one add:  rad_a (cos_a + sin_a) + rad_b (cos_b + sin_b).
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float raw_block_sum4(uint32_t g_lo, uint32_t g_hi, uint32_t block, uint32_t k0, uint32_t k1) {
+__device__ __forceinline__ float raw_block_sum4(uint32_t g_lo, uint32_t g_hi, uint32_t block, uint32_t tag,
+                                                uint32_t k0, uint32_t k1) {
     constexpr float kTwoM32 = 2.3283064365386963e-10f;   // 2^-32
     constexpr float kTwoM33 = 1.1641532182693481e-10f;   // 2^-33
-    const Words4 w = philox4x32_10(g_lo, g_hi, block, 0u, k0, k1);
+    const Words4 w = philox4x32_10(g_lo, g_hi, block, tag, k0, k1);
     const float ua = __builtin_fmaf(static_cast<float>(w.x0), kTwoM32, kTwoM33);
     const float ub = __builtin_fmaf(static_cast<float>(w.x2), kTwoM32, kTwoM33);
     const float ta = __uint_as_float((w.x1 & 0x007FFFFFu) | 0x3F800000u);
@@ -128,25 +129,25 @@ __device__ __forceinline__ void chunk_range(int32_t n_blocks, int w, int32_t& b_
 // sum of RAW normals over Philox blocks [b_begin, b_end) of one path; block b covers steps
 // 4b..4b+3 and only steps < n_steps count.  fp32 within a group of kGroup blocks, fp64 across.
 __device__ __forceinline__ double chunk_normal_sum(uint32_t g_lo, uint32_t g_hi, int32_t b_begin, int32_t b_end,
-                                                   int32_t n_steps, uint32_t k0, uint32_t k1) {
+                                                   int32_t n_steps, uint32_t tag, uint32_t k0, uint32_t k1) {
     const int32_t full_end = min(b_end, n_steps >> 2);     // blocks whose four steps all count
     double acc = 0.0;
     int32_t b = b_begin;
     for (; b + kGroup <= full_end; b += kGroup) {
-        float s = raw_block_sum4(g_lo, g_hi, static_cast<uint32_t>(b), k0, k1);
+        float s = raw_block_sum4(g_lo, g_hi, static_cast<uint32_t>(b), tag, k0, k1);
 #pragma unroll
-        for (int j = 1; j < kGroup; ++j) s += raw_block_sum4(g_lo, g_hi, static_cast<uint32_t>(b + j), k0, k1);
+        for (int j = 1; j < kGroup; ++j) s += raw_block_sum4(g_lo, g_hi, static_cast<uint32_t>(b + j), tag, k0, k1);
         acc += static_cast<double>(s);
     }
     if (b < full_end) {
-        float s = raw_block_sum4(g_lo, g_hi, static_cast<uint32_t>(b), k0, k1);
-        for (++b; b < full_end; ++b) s += raw_block_sum4(g_lo, g_hi, static_cast<uint32_t>(b), k0, k1);
+        float s = raw_block_sum4(g_lo, g_hi, static_cast<uint32_t>(b), tag, k0, k1);
+        for (++b; b < full_end; ++b) s += raw_block_sum4(g_lo, g_hi, static_cast<uint32_t>(b), tag, k0, k1);
         acc += static_cast<double>(s);
     }
     const int32_t rem = n_steps & 3;
     if (rem && b < b_end) {                                  // trailing partial block: first `rem` normals
         float z[4];
-        raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, k0, k1, z);
+        raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), tag, k0, k1, z);
         float s = z[0];
         if (rem > 1) s += z[1];
         if (rem > 2) s += z[2];
@@ -156,14 +157,15 @@ __device__ __forceinline__ double chunk_normal_sum(uint32_t g_lo, uint32_t g_hi,
 }
 
 // sum_t Z_t (true normals) of one path, one thread walking all chunks.
-__device__ __forceinline__ double path_normal_sum(uint32_t g_lo, uint32_t g_hi, int32_t n_steps, uint32_t k0, uint32_t k1) {
+__device__ __forceinline__ double path_normal_sum(uint32_t g_lo, uint32_t g_hi, int32_t n_steps, uint32_t k0, uint32_t k1,
+                                                  uint32_t tag = 0u) {
     const int32_t n_blocks = (n_steps + 3) >> 2;
     double part[kChunks];
 #pragma unroll
     for (int w = 0; w < kChunks; ++w) {
         int32_t b0, b1;
         chunk_range(n_blocks, w, b0, b1);
-        part[w] = chunk_normal_sum(g_lo, g_hi, b0, b1, n_steps, k0, k1);
+        part[w] = chunk_normal_sum(g_lo, g_hi, b0, b1, n_steps, tag, k0, k1);
     }
     return (((part[0] + part[1]) + part[2]) + part[3]) * kZScale;
 }
@@ -351,6 +353,59 @@ __global__ __launch_bounds__(kBlock) void european_path_kernel(PathRange pr, Con
         }
     }
     if constexpr (MODE != kTerminal) block_then_grid_reduce<NV>(acc, ws);
+}
+
+// Many INDEPENDENT contracts in one launch (MonteCarloPricerUni.price_batch,
+// src/pricing_models/monte_carlo_unified.py:562-631): blockIdx.y = contract, each contract has
+// its own Philox stream (counter word 3 = its tag) like the reference's per-option slice of Z
+// (:320) / per-option seed (:176), and its own last-arriver reduction: the workgroup that takes
+// the last ticket of contract j sums that contract's rows in index order and writes out[j].
+struct MultiOption {
+    double a, vol, strike, sign;    // as Contract
+    uint32_t tag;                   // stream tag: equal tags => common random numbers
+    uint32_t pad;
+};
+
+template <bool ANTI>
+__global__ __launch_bounds__(kBlock) void european_multi_kernel(PathRange pr, const MultiOption* __restrict__ opts,
+                                                                int64_t opt_base, double* __restrict__ block_rows,
+                                                                uint32_t* __restrict__ counters, double* __restrict__ out) {
+    __shared__ double stage[kWavesPerBlock][2];
+    const int64_t opt = opt_base + blockIdx.y;
+    const MultiOption o = opts[opt];
+    double acc[2] = {0.0, 0.0};
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
+        const uint64_t g = pr.first + static_cast<uint64_t>(i);
+        const double dz = o.vol * path_normal_sum(static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32), pr.n_steps,
+                                                  pr.key0, pr.key1, o.tag);
+#pragma unroll
+        for (int leg = 0; leg < (ANTI ? 2 : 1); ++leg) {
+            const double x = fmax(o.sign * (exp(leg ? o.a - dz : o.a + dz) - o.strike), 0.0);
+            acc[0] += x; acc[1] += x * x;
+        }
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const double s = wave_sum(acc[c]);
+        if (lane == 0) stage[wave][c] = s;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    double v = 0.0;
+    if (lane < 2) v = ((stage[0][lane] + stage[1][lane]) + stage[2][lane]) + stage[3][lane];
+    double* rows = block_rows + static_cast<size_t>(opt) * gridDim.x * 2;
+    if (lane < 2) store_sc1(rows + static_cast<size_t>(blockIdx.x) * 2 + lane, v);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t ticket = 0;
+    if (lane == 0) ticket = __hip_atomic_fetch_add(counters + opt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ticket = __builtin_amdgcn_readfirstlane(ticket);
+    if (ticket != gridDim.x - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const double total = wave_rows_sum<2>(rows, static_cast<int32_t>(gridDim.x));
+    if (lane < 2) out[opt * 2 + lane] = total;
+    if (lane == 0) __hip_atomic_store(counters + opt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Asian option: running arithmetic sum of S_t (or sum of ln S_t) over t = 1..M kept in

@@ -248,3 +248,55 @@ def asian_geometric_closed_form(S, K, T, r, sigma, q=0.0, option_type="call"):
     if option_type == "call":  # :153-156
         return S * np.exp((b - r) * T) * norm.cdf(d1) - K * np.exp(-r * T) * norm.cdf(d2)
     return K * np.exp(-r * T) * norm.cdf(-d2) - S * np.exp((b - r) * T) * norm.cdf(-d1)  # :158-160
+
+
+# --------------------------------------------------------------------------
+# MonteCarloPricerUni, NumPy backend (src/pricing_models/monte_carlo_unified.py:298-343, 451-689)
+# --------------------------------------------------------------------------
+class OracleUni:
+    def __init__(self, num_simulations=100_000, num_steps=100, seed=None):
+        if num_simulations <= 0 or num_steps <= 0:  # :277-280
+            raise ValueError("num_simulations and num_steps must be positive integers")
+        self.num_simulations, self.num_steps = num_simulations, num_steps
+        self.seed = seed if seed is not None else np.random.default_rng().integers(0, 2**31)
+        self.rng = np.random.default_rng(seed)  # :287
+
+    def terminal(self, S, T, r, sigma, q, seed=None):
+        """:298-343 -- Z has shape (n_options, sims, steps): option j consumes slice j of ONE stream."""
+        gen = np.random.default_rng(seed if seed is not None else self.seed)
+        n = len(S)
+        dt = T / self.num_steps
+        drift = (r - q - 0.5 * sigma**2)[:, None] * dt[:, None]
+        vol = sigma[:, None] * np.sqrt(dt[:, None])
+        Z = gen.standard_normal((n, self.num_simulations, self.num_steps))
+        log_S = np.log(S)[:, None, None]
+        up = log_S + np.cumsum(drift[:, None, :] + vol[:, None, :] * Z, axis=2)
+        dn = log_S + np.cumsum(drift[:, None, :] - vol[:, None, :] * Z, axis=2)
+        return np.concatenate([np.exp(up[:, :, -1]), np.exp(dn[:, :, -1])], axis=1)
+
+    def price(self, S, K, T, r, sigma, option_type, q=0.0, seed=None):  # :451-511
+        st = self.terminal(np.array([S]), np.array([T]), np.array([r]), np.array([sigma]), np.array([q]), seed)[0]
+        x = np.maximum(st - K, 0.0) if option_type == "call" else np.maximum(K - st, 0.0)
+        return float(np.exp(-r * T) * np.mean(x))
+
+    def delta_gamma(self, S, K, T, r, sigma, option_type, q=0.0, h=1e-4, seed=None):  # :513-560
+        if seed is None:
+            seed = int(self.rng.integers(0, 2**31))
+        up = self.price(S + h, K, T, r, sigma, option_type, q, seed=seed)
+        mid = self.price(S, K, T, r, sigma, option_type, q, seed=seed)
+        dn = self.price(S - h, K, T, r, sigma, option_type, q, seed=seed)
+        return (up - dn) / (2 * h), (up - 2 * mid + dn) / (h**2)
+
+    def price_batch(self, S, K, T, r, sigma, option_type, q=0.0):  # :562-631
+        S, K, T, r, sigma = (np.asarray(a, dtype=np.float64) for a in (S, K, T, r, sigma))
+        q = np.full_like(S, q) if isinstance(q, (int, float)) else np.asarray(q, dtype=np.float64)
+        st = self.terminal(S, T, r, sigma, q)
+        x = np.maximum(st - K[:, None], 0.0) if option_type == "call" else np.maximum(K[:, None] - st, 0.0)
+        return np.exp(-r * T) * np.mean(x, axis=1)
+
+    def delta_gamma_batch(self, S, K, T, r, sigma, option_type, q=0.0, h=1e-4):  # :633-689
+        S = np.asarray(S, dtype=np.float64)
+        dn = self.price_batch(S - h, K, T, r, sigma, option_type, q)
+        mid = self.price_batch(S, K, T, r, sigma, option_type, q)
+        up = self.price_batch(S + h, K, T, r, sigma, option_type, q)
+        return (up - dn) / (2 * h), (up - 2 * mid + dn) / (h**2)

@@ -31,8 +31,9 @@ def load_reference():
     from src.pricing_models.black_scholes import black_scholes
     from src.pricing_models.exotic_options import AsianOption, price_asian
     from src.pricing_models.monte_carlo import MCMethod, MonteCarloPricer
+    from src.pricing_models.monte_carlo_unified import MonteCarloPricerUni
 
-    return dict(MonteCarloPricer=MonteCarloPricer, MCMethod=MCMethod, black_scholes=black_scholes,
+    return dict(MonteCarloPricerUni=MonteCarloPricerUni, MonteCarloPricer=MonteCarloPricer, MCMethod=MCMethod, black_scholes=black_scholes,
                 AsianOption=AsianOption, price_asian=price_asian,
                 compute_greeks_unified=compute_greeks_unified, ExoticAdapter=ExoticAdapter)
 
@@ -144,6 +145,27 @@ def main():
     ad = ref["ExoticAdapter"](A(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, seed=42), n_paths=20000, n_steps=64, avg_type="arithmetic")
     g = cgu(ad, 100.0, 100.0, 1.0, 0.05, 0.2, "call", 0.0, include_second_order=False)
     doc["asian_greeks"] = dict(n_paths=20000, n_steps=64, seed=42, values={k: float(x) for k, x in g.items()})
+
+    # -- MonteCarloPricerUni, NumPy backend (monte_carlo_unified.py:298-343, 451-689) ----
+    Uni = ref["MonteCarloPricerUni"]
+    batch = dict(S=[100.0, 110.0, 90.0, 100.0, 100.0], K=[100.0, 100.0, 100.0, 95.0, 105.0], T=[1.0, 1.0, 1.0, 0.5, 0.5],
+                 r=[0.05] * 5, sigma=[0.2, 0.2, 0.2, 0.3, 0.15], q=[0.0, 0.0, 0.0, 0.02, 0.01])   # tests/test_monte_carlo.py:75-87
+    u = Uni(num_simulations=10000, num_steps=50, seed=42, use_numba=False, use_gpu=False)
+    arr = {k: np.array(v) for k, v in batch.items()}
+    doc["uni"] = dict(
+        ctor=[10000, 50, 42], batch=batch,
+        price_call=u.price(100, 100, 1.0, 0.05, 0.2, "call"), price_put=u.price(100, 100, 1.0, 0.05, 0.2, "put"),
+        price_seed7=u.price(100, 100, 1.0, 0.05, 0.2, "call", q=0.01, seed=7),
+        delta_gamma_seed5=list(u.delta_gamma(100, 100, 1.0, 0.05, 0.2, "call", seed=5)),
+        delta_gamma_h1_seed5=list(u.delta_gamma(100, 100, 1.0, 0.05, 0.2, "put", q=0.01, h=1.0, seed=5)),
+        price_batch_call=[float(x) for x in u.price_batch(arr["S"], arr["K"], arr["T"], arr["r"], arr["sigma"], "call", arr["q"])],
+        price_batch_put_scalar_q=[float(x) for x in u.price_batch(arr["S"], arr["K"], arr["T"], arr["r"], arr["sigma"], "put", 0.01)],
+        delta_gamma_batch_h1=[[float(x) for x in a] for a in u.delta_gamma_batch(arr["S"], arr["K"], arr["T"], arr["r"], arr["sigma"], "call", arr["q"], h=1.0)],
+        delta_gamma_batch=[[float(x) for x in a] for a in u.delta_gamma_batch(arr["S"], arr["K"], arr["T"], arr["r"], arr["sigma"], "call", arr["q"])],
+    )
+    # unseeded delta_gamma draws its seed from pricer.rng (:549-550): record the first draw
+    u2 = Uni(num_simulations=2000, num_steps=10, seed=11, use_numba=False, use_gpu=False)
+    doc["uni"]["delta_gamma_unseeded_first"] = list(u2.delta_gamma(100, 100, 1.0, 0.05, 0.2, "call", h=1.0))
 
     with open(OUT, "w") as f:
         json.dump(doc, f, indent=1)

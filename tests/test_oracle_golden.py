@@ -96,3 +96,23 @@ def test_asian_greeks_via_adapter(golden):
     g = orc.fd_greeks(price, 100.0, 100.0, 1.0, 0.05, 0.2, "call", 0.0, include_second_order=False)
     for k, x in c["values"].items():
         assert float(g[k]) == x, k
+
+
+def test_unified_pricer(golden):
+    g = golden["uni"]
+    N, M, seed = g["ctor"]
+    u = orc.OracleUni(N, M, seed)
+    b = {k: np.array(v) for k, v in g["batch"].items()}
+    assert u.price(100, 100, 1.0, 0.05, 0.2, "call") == g["price_call"]
+    assert u.price(100, 100, 1.0, 0.05, 0.2, "put") == g["price_put"]
+    assert u.price(100, 100, 1.0, 0.05, 0.2, "call", q=0.01, seed=7) == g["price_seed7"]
+    assert list(u.delta_gamma(100, 100, 1.0, 0.05, 0.2, "call", seed=5)) == g["delta_gamma_seed5"]
+    assert list(u.delta_gamma(100, 100, 1.0, 0.05, 0.2, "put", q=0.01, h=1.0, seed=5)) == g["delta_gamma_h1_seed5"]
+    assert [float(x) for x in u.price_batch(b["S"], b["K"], b["T"], b["r"], b["sigma"], "call", b["q"])] == g["price_batch_call"]
+    assert [float(x) for x in u.price_batch(b["S"], b["K"], b["T"], b["r"], b["sigma"], "put", 0.01)] == g["price_batch_put_scalar_q"]
+    got = u.delta_gamma_batch(b["S"], b["K"], b["T"], b["r"], b["sigma"], "call", b["q"], h=1.0)
+    assert [[float(x) for x in a] for a in got] == g["delta_gamma_batch_h1"]
+    got = u.delta_gamma_batch(b["S"], b["K"], b["T"], b["r"], b["sigma"], "call", b["q"])
+    assert [[float(x) for x in a] for a in got] == g["delta_gamma_batch"]
+    u2 = orc.OracleUni(2000, 10, 11)
+    assert list(u2.delta_gamma(100, 100, 1.0, 0.05, 0.2, "call", h=1.0)) == g["delta_gamma_unseeded_first"]

@@ -178,6 +178,20 @@ int olmc_asian(double S, double K, double T, double r, double sigma, double q, i
                int avg_kind, int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
                int antithetic, olmc_stats* out);
 
+/* ---- barrier and lookback (running extrema of the path, t = 0 included) ------
+ * Replace BarrierOption.price (src/pricing_models/exotic_options.py:174-224) and
+ * LookbackOption.price (:359-401) on ExoticOptionBase._generate_paths (:40-67): the
+ * running max / min of ln S_t live in registers, no path matrix.  barrier_kind:
+ * OLMC_BARRIER_*; fixed_strike: 0 = floating (call S_T - S_min, put S_max - S_T),
+ * 1 = fixed (call max(S_max - K, 0), put max(K - S_min, 0)). */
+enum { OLMC_BARRIER_UP_OUT = 0, OLMC_BARRIER_UP_IN = 1, OLMC_BARRIER_DOWN_OUT = 2, OLMC_BARRIER_DOWN_IN = 3 };
+int olmc_barrier(double S, double K, double T, double r, double sigma, double q, int is_call,
+                 double barrier, int barrier_kind, int64_t path_offset, int64_t n_local,
+                 int32_t n_steps, uint64_t seed, int antithetic, olmc_stats* out);
+int olmc_lookback(double S, double K, double T, double r, double sigma, double q, int is_call,
+                  int fixed_strike, int64_t path_offset, int64_t n_local, int32_t n_steps,
+                  uint64_t seed, int antithetic, olmc_stats* out);
+
 /* ---- quasi-Monte Carlo (MCMethod.QMC) --------------------------------------
  * Replaces simulate_gbm_qmc (src/simulation/gbm_qmc.py:14-46): scrambled-Sobol
  * points -> clip [1e-10, 1-1e-10] -> inverse normal (fp64) -> sum over dims ->

@@ -7,7 +7,7 @@ a device) is missing -- there is no CPU fallback.
 """
 from .black_scholes import black_scholes
 from .exceptions import AccelerationError, ConvergenceError, GreeksError, InputValidationError, MonteCarloError
-from .exotic import AsianOption, price_asian
+from .exotic import AsianOption, BarrierOption, LookbackOption, price_asian, price_barrier
 from .greeks import ExoticAdapter, PricerProtocol, compute_greeks_unified
 from .monte_carlo import NUMBA_AVAILABLE, MCMethod, MCResult, MonteCarloPricer
 from .monte_carlo_unified import MonteCarloPricerUni
@@ -18,6 +18,6 @@ __version__ = "0.1.0"
 
 __all__ = [
     "MonteCarloPricer", "MonteCarloPricerUni", "MCMethod", "MCResult", "NUMBA_AVAILABLE", "compute_greeks_unified", "PricerProtocol",
-    "ExoticAdapter", "AsianOption", "price_asian", "black_scholes", "simulate_gbm_hip", "simulate_gbm_hip_fast",
+    "ExoticAdapter", "AsianOption", "BarrierOption", "LookbackOption", "price_asian", "price_barrier", "black_scholes", "simulate_gbm_hip", "simulate_gbm_hip_fast",
     "hip_available", "MonteCarloError", "InputValidationError", "ConvergenceError", "AccelerationError", "GreeksError",
 ]

@@ -64,6 +64,8 @@ PROTOTYPES = {
     "olmc_european_qmc": (_I, _SIX + [_I, _I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, C.POINTER(Stats)]),
     "olmc_european_qmc_terminal": (_I, [_D] * 5 + [_I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, C.POINTER(_D)]),
     "olmc_asian": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
+    "olmc_barrier": (_I, _SIX + [_I, _D, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
+    "olmc_lookback": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_multi_gpu_european": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(Stats)]),
     "olmc_combine_stats": (_I, [C.POINTER(Stats), _I32, _D, _D, C.POINTER(Stats)]),
     "olmc_philox_words": (_I, [_U64T, _I64, _I64, _I32, _I32, C.c_uint32, C.POINTER(C.c_uint32)]),
@@ -242,6 +244,25 @@ def asian(S, K, T, r, sigma, q, is_call: bool, geometric: bool, n_paths: int, n_
     out = Stats()
     _check(lib().olmc_asian(S, K, T, r, sigma, q, int(is_call), AVG_GEOMETRIC if geometric else AVG_ARITHMETIC,
                             int(path_offset), int(n_paths), int(n_steps), seed64(seed), int(antithetic), C.byref(out)))
+    return out
+
+
+BARRIER_KINDS = {"up-and-out": 0, "up-and-in": 1, "down-and-out": 2, "down-and-in": 3}
+
+
+def barrier(S, K, T, r, sigma, q, is_call: bool, level: float, kind: int, n_paths: int, n_steps: int, seed: int,
+            antithetic: bool = False, path_offset: int = 0) -> Stats:
+    out = Stats()
+    _check(lib().olmc_barrier(S, K, T, r, sigma, q, int(is_call), float(level), int(kind), int(path_offset), int(n_paths),
+                              int(n_steps), seed64(seed), int(antithetic), C.byref(out)))
+    return out
+
+
+def lookback(S, K, T, r, sigma, q, is_call: bool, fixed_strike: bool, n_paths: int, n_steps: int, seed: int,
+             antithetic: bool = False, path_offset: int = 0) -> Stats:
+    out = Stats()
+    _check(lib().olmc_lookback(S, K, T, r, sigma, q, int(is_call), int(fixed_strike), int(path_offset), int(n_paths),
+                               int(n_steps), seed64(seed), int(antithetic), C.byref(out)))
     return out
 
 

@@ -648,6 +648,64 @@ extern "C" int olmc_asian(double S, double K, double T, double r, double sigma, 
     return OLMC_OK;
 }
 
+// ========================================================== barrier / lookback ====
+namespace {
+int run_extrema(double S, double K, double T, double r, double sigma, double q, int is_call, int payoff, double barrier,
+                int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic, olmc_stats* out) {
+    if (!out) return fail(OLMC_ERR_ARG, "null pointer");
+    int rc = check_paths(path_offset, n_local, n_steps);
+    if (rc) return rc;
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
+    const int32_t grid = grid_for(n_local);
+    ExtremaContract ec;
+    const double dt = T / n_steps;                               // exotic_options.py:54-56
+    ec.s0 = S;
+    ec.log_barrier_rel = payoff <= kBarrierDownIn ? std::log(barrier / S) : 0.0;
+    ec.drift = (r - q - 0.5 * sigma * sigma) * dt;
+    ec.vol = sigma * std::sqrt(dt);
+    ec.strike = K;
+    ec.sign = is_call ? 1.0 : -1.0;
+    ec.payoff = payoff;
+    ec.pad = 0;
+    ReduceWs ws;
+    rc = make_ws(c, grid, 2, c->d_result, -1.0, &ws);
+    if (rc) return rc;
+    EventPair ep{};
+    if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
+    if (antithetic) hipLaunchKernelGGL((extrema_kernel<true>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ec, ws);
+    else hipLaunchKernelGGL((extrema_kernel<false>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ec, ws);
+    {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
+    }
+    if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
+    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
+    rc = sync_or_recover(c, c->stream);
+    if (rc) return rc;
+    finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r, T, out);
+    return OLMC_OK;
+}
+}  // namespace
+
+extern "C" int olmc_barrier(double S, double K, double T, double r, double sigma, double q, int is_call, double barrier,
+                            int barrier_kind, int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
+                            int antithetic, olmc_stats* out) {
+    if (!(barrier > 0.0)) return fail(OLMC_ERR_ARG, "Barrier must be positive");
+    if (barrier_kind < OLMC_BARRIER_UP_OUT || barrier_kind > OLMC_BARRIER_DOWN_IN) return fail(OLMC_ERR_ARG, "bad barrier_kind");
+    return run_extrema(S, K, T, r, sigma, q, is_call, barrier_kind, barrier, path_offset, n_local, n_steps, seed, antithetic, out);
+}
+
+extern "C" int olmc_lookback(double S, double K, double T, double r, double sigma, double q, int is_call, int fixed_strike,
+                             int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic,
+                             olmc_stats* out) {
+    return run_extrema(S, K, T, r, sigma, q, is_call, fixed_strike ? kLookbackFixed : kLookbackFloating, 0.0, path_offset,
+                       n_local, n_steps, seed, antithetic, out);
+}
+
 // ======================================================================= QMC ====
 namespace {
 int run_qmc(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t point_offset,

@@ -468,6 +468,79 @@ __global__ __launch_bounds__(kBlock) void asian_kernel(PathRange pr, AsianContra
     block_then_grid_reduce<2>(acc, ws);
 }
 
+// Barrier and lookback options: both depend on the path only through its terminal value and
+// its running extrema, and exp is monotone, so the step loop tracks max / min of the cumulative
+// LOG-return (t = 0 included, as the reference's paths[:, 0] = S is: exotic_options.py:64-67,
+// 200-204, 379-381) in fp64 -- three fp64 ops per leg per step, no per-step exp.
+//   barrier  (exotic_options.py:174-224): crossed = max >= ln(B/S) (up) | min <= ln(B/S) (down);
+//            knock-out pays if !crossed, knock-in if crossed; payoff max(+-(S_T - K), 0).
+//   lookback (exotic_options.py:359-401):  floating call S_T - S_min, floating put S_max - S_T,
+//            fixed call max(S_max - K, 0), fixed put max(K - S_min, 0).
+enum ExtremaPayoff : int {
+    kBarrierUpOut = 0, kBarrierUpIn = 1, kBarrierDownOut = 2, kBarrierDownIn = 3,
+    kLookbackFloating = 4, kLookbackFixed = 5
+};
+
+struct ExtremaContract {
+    double s0, log_barrier_rel;   // ln(B / S0)
+    double drift, vol;            // per step: (r - q - sigma^2/2) dt, sigma sqrt(dt)
+    double strike, sign;
+    int32_t payoff;               // ExtremaPayoff
+    int32_t pad;
+};
+
+__device__ __forceinline__ double extrema_payoff(const ExtremaContract& c, double cum, double mx, double mn) {
+    const double st = c.s0 * exp(cum);
+    if (c.payoff <= kBarrierDownIn) {
+        const bool up = c.payoff <= kBarrierUpIn;
+        const bool crossed = up ? (mx >= c.log_barrier_rel) : (mn <= c.log_barrier_rel);
+        const bool knock_out = (c.payoff == kBarrierUpOut) || (c.payoff == kBarrierDownOut);
+        const bool active = knock_out ? !crossed : crossed;
+        return active ? fmax(c.sign * (st - c.strike), 0.0) : 0.0;
+    }
+    if (c.payoff == kLookbackFloating) return c.sign > 0.0 ? st - c.s0 * exp(mn) : c.s0 * exp(mx) - st;
+    return c.sign > 0.0 ? fmax(c.s0 * exp(mx) - c.strike, 0.0) : fmax(c.strike - c.s0 * exp(mn), 0.0);
+}
+
+template <bool ANTI>
+__global__ __launch_bounds__(kBlock) void extrema_kernel(PathRange pr, ExtremaContract c, ReduceWs ws) {
+    double acc[2] = {0.0, 0.0};
+    const double vol = c.vol * kZScale;             // applied to RAW normals
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
+        const uint64_t g = pr.first + static_cast<uint64_t>(i);
+        const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
+        double cum_u = 0.0, mx_u = 0.0, mn_u = 0.0, cum_d = 0.0, mx_d = 0.0, mn_d = 0.0;   // t = 0: ln(S_0/S_0) = 0
+        const int32_t blocks = (pr.n_steps + 3) >> 2;
+        for (int32_t b = 0; b < blocks; ++b) {
+            float z[4];
+            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1, z);
+            const int32_t live = min(4, pr.n_steps - 4 * b);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < live) {
+                    const double dz = vol * static_cast<double>(z[j]);
+                    cum_u += c.drift + dz;
+                    mx_u = fmax(mx_u, cum_u);
+                    mn_u = fmin(mn_u, cum_u);
+                    if constexpr (ANTI) {
+                        cum_d += c.drift - dz;
+                        mx_d = fmax(mx_d, cum_d);
+                        mn_d = fmin(mn_d, cum_d);
+                    }
+                }
+            }
+        }
+        const double xu = extrema_payoff(c, cum_u, mx_u, mn_u);
+        acc[0] += xu; acc[1] += xu * xu;
+        if constexpr (ANTI) {
+            const double xd = extrema_payoff(c, cum_d, mx_d, mn_d);
+            acc[0] += xd; acc[1] += xd * xd;
+        }
+    }
+    block_then_grid_reduce<2>(acc, ws);
+}
+
 // ------------------------------------------------------------------ QMC ----
 // Scrambled-Sobol terminal prices (src/simulation/gbm_qmc.py:14-46): point k of the sequence is
 //   x_t(k) = shift[t] ^ XOR_{b in gray(k)} sv[t][b],   u = x * 2^-30,

@@ -1,4 +1,4 @@
-"""AsianOption on the device step loop (reference: ExoticOptionBase._generate_paths
+"""AsianOption / BarrierOption / LookbackOption on the device step loop (reference: ExoticOptionBase._generate_paths
 + AsianOption, src/pricing_models/exotic_options.py:28-160, price_asian :558-572).
 
 Same dataclass fields and ``price(n_paths, n_steps, avg_type, option_type)``
@@ -52,6 +52,63 @@ class AsianOption:
         if option_type == "call":
             return self.S * grow * _ncdf(d1) - self.K * disc * _ncdf(d2)
         return self.K * disc * _ncdf(-d2) - self.S * grow * _ncdf(-d1)
+
+
+@dataclass
+class BarrierOption:
+    """exotic_options.py:163-224: knock-in / knock-out on discrete monitoring dates t = 0..M."""
+
+    S: float
+    K: float
+    T: float
+    r: float
+    sigma: float
+    q: float = 0.0
+    seed: Optional[int] = None
+    barrier: float = 0.0
+
+    def price(self, n_paths: int = 100000, n_steps: int = 252,
+              barrier_type: Literal["up-and-out", "up-and-in", "down-and-out", "down-and-in"] = "up-and-out",
+              option_type: Literal["call", "put"] = "call", antithetic: bool = False, return_error: bool = False):
+        if self.barrier <= 0:                       # :195-196
+            raise ValueError("Barrier must be positive")
+        if n_paths < 1 or n_steps < 1:
+            raise ValueError("n_paths and n_steps must be >= 1")
+        # the reference dispatches on startswith("up") / endswith("out") (:201-212)
+        kind = (0 if barrier_type.startswith("up") else 2) + (0 if barrier_type.endswith("out") else 1)
+        seed = self.seed if self.seed is not None else int(np.random.default_rng().integers(0, 2**31))
+        st = _hip.barrier(self.S, self.K, self.T, self.r, self.sigma, self.q, option_type == "call", self.barrier, kind,
+                          n_paths, n_steps, seed, antithetic)
+        return (np.float64(st.price), float(st.std_error)) if return_error else np.float64(st.price)
+
+
+@dataclass
+class LookbackOption:
+    """exotic_options.py:347-401: floating / fixed strike on the discrete path extrema (t = 0 included)."""
+
+    S: float
+    K: float
+    T: float
+    r: float
+    sigma: float
+    q: float = 0.0
+    seed: Optional[int] = None
+
+    def price(self, n_paths: int = 100000, n_steps: int = 252, lookback_type: Literal["floating", "fixed"] = "floating",
+              option_type: Literal["call", "put"] = "call", antithetic: bool = False, return_error: bool = False):
+        if n_paths < 1 or n_steps < 1:
+            raise ValueError("n_paths and n_steps must be >= 1")
+        seed = self.seed if self.seed is not None else int(np.random.default_rng().integers(0, 2**31))
+        st = _hip.lookback(self.S, self.K, self.T, self.r, self.sigma, self.q, option_type == "call",
+                           lookback_type != "floating", n_paths, n_steps, seed, antithetic)
+        return (np.float64(st.price), float(st.std_error)) if return_error else np.float64(st.price)
+
+
+def price_barrier(S: float, K: float, T: float, r: float, sigma: float, barrier: float, barrier_type: str = "up-and-out",
+                  option_type: str = "call", n_paths: int = 100000, seed: int = None) -> float:
+    """exotic_options.py:575-590"""
+    return BarrierOption(S=S, K=K, T=T, r=r, sigma=sigma, barrier=barrier, seed=seed).price(
+        n_paths=n_paths, barrier_type=barrier_type, option_type=option_type)
 
 
 def price_asian(S: float, K: float, T: float, r: float, sigma: float, avg_type: str = "arithmetic",

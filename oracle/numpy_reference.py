@@ -239,6 +239,31 @@ def asian_price(S, K, T, r, sigma, q=0.0, seed=None, n_paths=100000, n_steps=252
     return np.exp(-r * T) * np.mean(x)  # :131  (np.float64)
 
 
+def barrier_price(S, K, T, r, sigma, barrier, q=0.0, seed=None, n_paths=100000, n_steps=252,
+                  barrier_type="up-and-out", option_type="call"):
+    """exotic_options.py:174-224 -- monitoring includes t = 0 (paths[:, 0] = S)."""
+    if barrier <= 0:  # :195-196
+        raise ValueError("Barrier must be positive")
+    paths = asian_paths(S, T, r, sigma, q, n_paths, n_steps, seed)
+    crossed = np.any(paths >= barrier, axis=1) if barrier_type.startswith("up") else np.any(paths <= barrier, axis=1)
+    active = ~crossed if barrier_type.endswith("out") else crossed  # :207-212
+    st = paths[:, -1]
+    x = np.maximum(st - K, 0) if option_type == "call" else np.maximum(K - st, 0)
+    return np.exp(-r * T) * np.mean(x * active)  # :221-223
+
+
+def lookback_price(S, K, T, r, sigma, q=0.0, seed=None, n_paths=100000, n_steps=252, lookback_type="floating",
+                   option_type="call"):
+    """exotic_options.py:359-401"""
+    paths = asian_paths(S, T, r, sigma, q, n_paths, n_steps, seed)
+    st, hi, lo = paths[:, -1], np.max(paths, axis=1), np.min(paths, axis=1)
+    if lookback_type == "floating":
+        x = st - lo if option_type == "call" else hi - st
+    else:
+        x = np.maximum(hi - K, 0) if option_type == "call" else np.maximum(K - lo, 0)
+    return np.exp(-r * T) * np.mean(x)
+
+
 def asian_geometric_closed_form(S, K, T, r, sigma, q=0.0, option_type="call"):
     """exotic_options.py:133-160 (continuous-monitoring lognormal approximation)."""
     v = sigma / np.sqrt(3)  # :145

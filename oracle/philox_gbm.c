@@ -187,3 +187,45 @@ void ol_asian_moments(double S, double K, double T, double r, double sigma, doub
     }
     moments[0] = (double)m0; moments[1] = (double)m1;
 }
+
+/* Barrier / lookback: running max / min of the cumulative log-return, t = 0 included
+ * (exotic_options.py:174-224, 359-401).  payoff: 0 up-out, 1 up-in, 2 down-out, 3 down-in,
+ * 4 lookback floating, 5 lookback fixed.  moments[0..1] = sum x, sum x^2. */
+void ol_extrema_moments(double S, double K, double T, double r, double sigma, double q, int is_call, int payoff,
+                        double barrier, int64_t path0, int64_t n, int32_t n_steps, uint64_t seed, int antithetic,
+                        double moments[2]) {
+    const double dt = T / n_steps, drift = (r - q - 0.5 * sigma * sigma) * dt, vol = sigma * sqrt(dt) * Z_SCALE;
+    const double lb = payoff <= 3 ? log(barrier / S) : 0.0, sign = is_call ? 1.0 : -1.0;
+    long double m0 = 0, m1 = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double cum[2] = {0, 0}, mx[2] = {0, 0}, mn[2] = {0, 0};
+        for (int32_t b = 0; 4 * b < n_steps; ++b) {
+            float z[4];
+            raw_normals4((uint64_t)(path0 + i), (uint32_t)b, seed, z);
+            for (int j = 0; j < 4 && 4 * b + j < n_steps; ++j) {
+                const double dz = vol * (double)z[j];
+                cum[0] += drift + dz;
+                cum[1] += drift - dz;
+                for (int leg = 0; leg < 2; ++leg) {
+                    if (cum[leg] > mx[leg]) mx[leg] = cum[leg];
+                    if (cum[leg] < mn[leg]) mn[leg] = cum[leg];
+                }
+            }
+        }
+        for (int leg = 0; leg < (antithetic ? 2 : 1); ++leg) {
+            const double st = S * exp(cum[leg]);
+            double x;
+            if (payoff <= 3) {
+                const int crossed = payoff <= 1 ? (mx[leg] >= lb) : (mn[leg] <= lb);
+                const int active = (payoff == 0 || payoff == 2) ? !crossed : crossed;
+                x = active ? fmax(sign * (st - K), 0.0) : 0.0;
+            } else if (payoff == 4) {
+                x = is_call ? st - S * exp(mn[leg]) : S * exp(mx[leg]) - st;
+            } else {
+                x = is_call ? fmax(S * exp(mx[leg]) - K, 0.0) : fmax(K - S * exp(mn[leg]), 0.0);
+            }
+            m0 += x; m1 += x * x;
+        }
+    }
+    moments[0] = (double)m0; moments[1] = (double)m1;
+}

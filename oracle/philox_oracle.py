@@ -81,6 +81,15 @@ def asian_moments(S, K, T, r, sigma, q, is_call, geometric, n_paths, n_steps, se
     return m[0], m[1], n_paths * (2 if antithetic else 1)
 
 
+def extrema_moments(S, K, T, r, sigma, q, is_call, payoff, barrier, n_paths, n_steps, seed, antithetic=False, path0=0):
+    """payoff: 0 up-out, 1 up-in, 2 down-out, 3 down-in, 4 lookback floating, 5 lookback fixed."""
+    m = (C.c_double * 2)()
+    _load().ol_extrema_moments(C.c_double(S), C.c_double(K), C.c_double(T), C.c_double(r), C.c_double(sigma), C.c_double(q),
+                               C.c_int(int(is_call)), C.c_int(int(payoff)), C.c_double(barrier), C.c_int64(path0),
+                               C.c_int64(n_paths), C.c_int32(n_steps), C.c_uint64(int(seed) & _U64), C.c_int(int(antithetic)), m)
+    return m[0], m[1], n_paths * (2 if antithetic else 1)
+
+
 def price_and_error(sum_x, sum_xx, n, r, T):
     """monte_carlo.py:145-150 on the moments."""
     disc, mean = math.exp(-r * T), sum_x / n

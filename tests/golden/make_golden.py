@@ -29,11 +29,12 @@ def load_reference():
     sys.path.insert(0, REF)
     from src.greeks.unified_greeks import ExoticAdapter, compute_greeks_unified
     from src.pricing_models.black_scholes import black_scholes
-    from src.pricing_models.exotic_options import AsianOption, price_asian
+    from src.pricing_models.exotic_options import AsianOption, BarrierOption, LookbackOption, price_asian, price_barrier
     from src.pricing_models.monte_carlo import MCMethod, MonteCarloPricer
     from src.pricing_models.monte_carlo_unified import MonteCarloPricerUni
 
-    return dict(MonteCarloPricerUni=MonteCarloPricerUni, MonteCarloPricer=MonteCarloPricer, MCMethod=MCMethod, black_scholes=black_scholes,
+    return dict(MonteCarloPricerUni=MonteCarloPricerUni, BarrierOption=BarrierOption, LookbackOption=LookbackOption,
+                price_barrier=price_barrier, MonteCarloPricer=MonteCarloPricer, MCMethod=MCMethod, black_scholes=black_scholes,
                 AsianOption=AsianOption, price_asian=price_asian,
                 compute_greeks_unified=compute_greeks_unified, ExoticAdapter=ExoticAdapter)
 
@@ -145,6 +146,24 @@ def main():
     ad = ref["ExoticAdapter"](A(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, seed=42), n_paths=20000, n_steps=64, avg_type="arithmetic")
     g = cgu(ad, 100.0, 100.0, 1.0, 0.05, 0.2, "call", 0.0, include_second_order=False)
     doc["asian_greeks"] = dict(n_paths=20000, n_steps=64, seed=42, values={k: float(x) for k, x in g.items()})
+
+    # -- barrier / lookback (exotic_options.py:163-224, 347-401) -------------------------
+    doc["barrier"], doc["lookback"] = [], []
+    B, L = ref["BarrierOption"], ref["LookbackOption"]
+    for level, kind, typ, n, m, q in [(120.0, "up-and-out", "call", 100000, 252, 0.0), (120.0, "up-and-in", "call", 100000, 252, 0.0),
+                                      (80.0, "down-and-out", "put", 100000, 252, 0.0), (80.0, "down-and-in", "put", 100000, 252, 0.0),
+                                      (130.0, "up-and-out", "call", 50000, 252, 0.0), (90.0, "down-and-out", "call", 20000, 64, 0.02),
+                                      (110.0, "up-and-in", "put", 20000, 64, 0.02), (100.0, "up-and-out", "call", 1000, 16, 0.0)]:
+        o = B(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, q=q, barrier=level, seed=42)
+        doc["barrier"].append(dict(params=[100.0, 100.0, 1.0, 0.05, 0.2, q], barrier=level, barrier_type=kind, option_type=typ,
+                                   n_paths=n, n_steps=m, seed=42, price=float(o.price(n, m, kind, typ))))
+    for kind, typ, n, m, q in [("floating", "call", 100000, 252, 0.0), ("floating", "put", 100000, 252, 0.0),
+                               ("fixed", "call", 100000, 252, 0.0), ("fixed", "put", 100000, 252, 0.0), ("floating", "call", 20000, 50, 0.02)]:
+        o = L(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, q=q, seed=42)
+        doc["lookback"].append(dict(params=[100.0, 100.0, 1.0, 0.05, 0.2, q], lookback_type=kind, option_type=typ, n_paths=n,
+                                    n_steps=m, seed=42, price=float(o.price(n, m, kind, typ))))
+    doc["price_barrier_helper"] = dict(args=[100.0, 100.0, 1.0, 0.05, 0.2, 120.0, "up-and-out", "call", 20000, 42],
+                                       value=float(ref["price_barrier"](100.0, 100.0, 1.0, 0.05, 0.2, 120.0, "up-and-out", "call", 20000, 42)))
 
     # -- MonteCarloPricerUni, NumPy backend (monte_carlo_unified.py:298-343, 451-689) ----
     Uni = ref["MonteCarloPricerUni"]

@@ -116,3 +116,19 @@ def test_unified_pricer(golden):
     assert [[float(x) for x in a] for a in got] == g["delta_gamma_batch"]
     u2 = orc.OracleUni(2000, 10, 11)
     assert list(u2.delta_gamma(100, 100, 1.0, 0.05, 0.2, "call", h=1.0)) == g["delta_gamma_unseeded_first"]
+
+
+def test_barrier_and_lookback(golden):
+    for c in golden["barrier"]:
+        S, K, T, r, v, q = c["params"]
+        got = orc.barrier_price(S, K, T, r, v, c["barrier"], q, c["seed"], c["n_paths"], c["n_steps"], c["barrier_type"], c["option_type"])
+        assert float(got) == c["price"], c
+    for c in golden["lookback"]:
+        S, K, T, r, v, q = c["params"]
+        got = orc.lookback_price(S, K, T, r, v, q, c["seed"], c["n_paths"], c["n_steps"], c["lookback_type"], c["option_type"])
+        assert float(got) == c["price"], c
+    h = golden["price_barrier_helper"]
+    S, K, T, r, v, level, kind, typ, n, seed = h["args"]
+    assert float(orc.barrier_price(S, K, T, r, v, level, 0.0, seed, n, 252, kind, typ)) == h["value"]
+    with pytest.raises(ValueError, match="positive"):
+        orc.barrier_price(100, 100, 1.0, 0.05, 0.2, 0.0)

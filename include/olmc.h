@@ -51,7 +51,7 @@ enum {
     OLMC_ERR_RCCL = 4     /* RCCL failure in the multi-GPU entry points                            */
 };
 
-enum { OLMC_STREAM_GBM = 0 };                    /* counter word 3 (stream_tag)          */
+enum { OLMC_STREAM_GBM = 0, OLMC_STREAM_HESTON = 1 };   /* counter word 3 (stream_tag); batches use tag = contract index */
 enum { OLMC_AVG_ARITHMETIC = 0, OLMC_AVG_GEOMETRIC = 1 };
 #define OLMC_MAX_BATCH 16                        /* parameter sets per fused launch      */
 
@@ -191,6 +191,15 @@ int olmc_barrier(double S, double K, double T, double r, double sigma, double q,
 int olmc_lookback(double S, double K, double T, double r, double sigma, double q, int is_call,
                   int fixed_strike, int64_t path_offset, int64_t n_local, int32_t n_steps,
                   uint64_t seed, int antithetic, olmc_stats* out);
+
+/* ---- Heston stochastic volatility, full-truncation Euler ----------------------
+ * Replaces HestonPricer.price_monte_carlo (src/pricing_models/heston.py:184-255): two
+ * normals per step, (ln S, v) in fp64 registers, Philox stream tag 1.  The reference
+ * has no antithetic mirror here (antithetic = 0 reproduces its n = n_paths samples). */
+int olmc_heston(double S, double K, double T, double r, double q, int is_call,
+                double kappa, double theta, double sigma_v, double rho, double v0,
+                int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
+                int antithetic, olmc_stats* out);
 
 /* ---- quasi-Monte Carlo (MCMethod.QMC) --------------------------------------
  * Replaces simulate_gbm_qmc (src/simulation/gbm_qmc.py:14-46): scrambled-Sobol

@@ -9,6 +9,7 @@ from .black_scholes import black_scholes
 from .exceptions import AccelerationError, ConvergenceError, GreeksError, InputValidationError, MonteCarloError
 from .exotic import AsianOption, BarrierOption, LookbackOption, price_asian, price_barrier
 from .greeks import ExoticAdapter, PricerProtocol, compute_greeks_unified
+from .heston import HestonAdapter, HestonPricer
 from .monte_carlo import NUMBA_AVAILABLE, MCMethod, MCResult, MonteCarloPricer
 from .monte_carlo_unified import MonteCarloPricerUni
 from .simulation import hip_available, simulate_gbm_hip, simulate_gbm_hip_fast
@@ -18,6 +19,6 @@ __version__ = "0.1.0"
 
 __all__ = [
     "MonteCarloPricer", "MonteCarloPricerUni", "MCMethod", "MCResult", "NUMBA_AVAILABLE", "compute_greeks_unified", "PricerProtocol",
-    "ExoticAdapter", "AsianOption", "BarrierOption", "LookbackOption", "price_asian", "price_barrier", "black_scholes", "simulate_gbm_hip", "simulate_gbm_hip_fast",
+    "ExoticAdapter", "HestonPricer", "HestonAdapter", "AsianOption", "BarrierOption", "LookbackOption", "price_asian", "price_barrier", "black_scholes", "simulate_gbm_hip", "simulate_gbm_hip_fast",
     "hip_available", "MonteCarloError", "InputValidationError", "ConvergenceError", "AccelerationError", "GreeksError",
 ]

@@ -66,6 +66,7 @@ PROTOTYPES = {
     "olmc_asian": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_barrier": (_I, _SIX + [_I, _D, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_lookback": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
+    "olmc_heston": (_I, [_D] * 5 + [_I] + [_D] * 5 + [_I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_multi_gpu_european": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(Stats)]),
     "olmc_combine_stats": (_I, [C.POINTER(Stats), _I32, _D, _D, C.POINTER(Stats)]),
     "olmc_philox_words": (_I, [_U64T, _I64, _I64, _I32, _I32, C.c_uint32, C.POINTER(C.c_uint32)]),
@@ -263,6 +264,14 @@ def lookback(S, K, T, r, sigma, q, is_call: bool, fixed_strike: bool, n_paths: i
     out = Stats()
     _check(lib().olmc_lookback(S, K, T, r, sigma, q, int(is_call), int(fixed_strike), int(path_offset), int(n_paths),
                                int(n_steps), seed64(seed), int(antithetic), C.byref(out)))
+    return out
+
+
+def heston(S, K, T, r, q, is_call: bool, kappa, theta, sigma_v, rho, v0, n_paths: int, n_steps: int, seed: int,
+           antithetic: bool = False, path_offset: int = 0) -> Stats:
+    out = Stats()
+    _check(lib().olmc_heston(S, K, T, r, q, int(is_call), kappa, theta, sigma_v, rho, v0, int(path_offset), int(n_paths),
+                             int(n_steps), seed64(seed), int(antithetic), C.byref(out)))
     return out
 
 

@@ -706,6 +706,53 @@ extern "C" int olmc_lookback(double S, double K, double T, double r, double sigm
                        n_local, n_steps, seed, antithetic, out);
 }
 
+// ===================================================================== Heston ====
+extern "C" int olmc_heston(double S, double K, double T, double r, double q, int is_call, double kappa, double theta,
+                           double sigma_v, double rho, double v0, int64_t path_offset, int64_t n_local, int32_t n_steps,
+                           uint64_t seed, int antithetic, olmc_stats* out) {
+    if (!out) return fail(OLMC_ERR_ARG, "null pointer");
+    if (!(rho >= -1.0 && rho <= 1.0)) return fail(OLMC_ERR_ARG, "rho must be in [-1, 1]");
+    int rc = check_paths(path_offset, n_local, n_steps);
+    if (rc) return rc;
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
+    const int32_t grid = grid_for(n_local);
+    HestonContract hc;
+    const double dt = T / n_steps;                     // heston.py:218-219
+    hc.log_s0 = std::log(S);
+    hc.v0 = v0;
+    hc.mu_dt = (r - q) * dt;
+    hc.dt = dt;
+    hc.sqrt_dt = std::sqrt(dt);
+    hc.kappa_dt = kappa * dt;
+    hc.theta = theta;
+    hc.sigma_v = sigma_v;
+    hc.rho = rho;
+    hc.rho_c = std::sqrt(1 - rho * rho);               // :228
+    hc.strike = K;
+    hc.sign = is_call ? 1.0 : -1.0;
+    ReduceWs ws;
+    rc = make_ws(c, grid, 2, c->d_result, -1.0, &ws);
+    if (rc) return rc;
+    EventPair ep{};
+    if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
+    if (antithetic) hipLaunchKernelGGL((heston_kernel<true>), dim3(grid), dim3(kBlock), 0, c->stream, pr, hc, ws);
+    else hipLaunchKernelGGL((heston_kernel<false>), dim3(grid), dim3(kBlock), 0, c->stream, pr, hc, ws);
+    {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
+    }
+    if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
+    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
+    rc = sync_or_recover(c, c->stream);
+    if (rc) return rc;
+    finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r, T, out);
+    return OLMC_OK;
+}
+
 // ======================================================================= QMC ====
 namespace {
 int run_qmc(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t point_offset,

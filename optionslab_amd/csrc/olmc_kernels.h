@@ -541,6 +541,60 @@ __global__ __launch_bounds__(kBlock) void extrema_kernel(PathRange pr, ExtremaCo
     block_then_grid_reduce<2>(acc, ws);
 }
 
+// Heston full-truncation Euler (src/pricing_models/heston.py:184-255): per step two normals
+// (Z1, and Z2 = rho Z1 + sqrt(1 - rho^2) Z2'), state (ln S, v) in fp64 registers:
+//   v+ = max(v, 0);  ln S += (r - q - v+/2) dt + sqrt(v+ dt) Z1;
+//   v  += kappa (theta - v+) dt + sigma_v sqrt(v+ dt) Z2;  v = max(v, 0).
+// One Philox block feeds two steps: (z0, z1) -> step 2b, (z2, z3) -> step 2b+1, stream tag 1.
+constexpr uint32_t kTagHeston = 1u;
+
+struct HestonContract {
+    double log_s0, v0;
+    double mu_dt;          // (r - q) dt
+    double dt, sqrt_dt;
+    double kappa_dt, theta, sigma_v;
+    double rho, rho_c;     // rho, sqrt(1 - rho^2)
+    double strike, sign;
+};
+
+template <bool ANTI>
+__global__ __launch_bounds__(kBlock) void heston_kernel(PathRange pr, HestonContract c, ReduceWs ws) {
+    double acc[2] = {0.0, 0.0};
+    const double zs = kZScale * c.sqrt_dt;          // RAW normal -> sqrt(dt) * Z
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
+        const uint64_t g = pr.first + static_cast<uint64_t>(i);
+        const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
+        double ls[2] = {c.log_s0, c.log_s0}, v[2] = {c.v0, c.v0};
+        const int32_t blocks = (pr.n_steps + 1) >> 1;
+        for (int32_t b = 0; b < blocks; ++b) {
+            float z[4];
+            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), kTagHeston, pr.key0, pr.key1, z);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (2 * b + h < pr.n_steps) {
+                    const double w1 = zs * static_cast<double>(z[2 * h]);
+                    const double w2 = c.rho * w1 + c.rho_c * (zs * static_cast<double>(z[2 * h + 1]));
+#pragma unroll
+                    for (int leg = 0; leg < (ANTI ? 2 : 1); ++leg) {
+                        const double sgn = leg ? -1.0 : 1.0;
+                        const double vp = fmax(v[leg], 0.0);
+                        const double sv = sqrt(vp);
+                        ls[leg] += (c.mu_dt - 0.5 * vp * c.dt) + sv * (sgn * w1);
+                        v[leg] = fmax(v[leg] + c.kappa_dt * (c.theta - vp) + c.sigma_v * sv * (sgn * w2), 0.0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int leg = 0; leg < (ANTI ? 2 : 1); ++leg) {
+            const double x = fmax(c.sign * (exp(ls[leg]) - c.strike), 0.0);
+            acc[0] += x; acc[1] += x * x;
+        }
+    }
+    block_then_grid_reduce<2>(acc, ws);
+}
+
 // ------------------------------------------------------------------ QMC ----
 // Scrambled-Sobol terminal prices (src/simulation/gbm_qmc.py:14-46): point k of the sequence is
 //   x_t(k) = shift[t] ^ XOR_{b in gray(k)} sv[t][b],   u = x * 2^-30,

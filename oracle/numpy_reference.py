@@ -325,3 +325,63 @@ class OracleUni:
         mid = self.price_batch(S, K, T, r, sigma, option_type, q)
         up = self.price_batch(S + h, K, T, r, sigma, option_type, q)
         return (up - dn) / (2 * h), (up - 2 * mid + dn) / (h**2)
+
+
+# --------------------------------------------------------------------------
+# Heston (src/pricing_models/heston.py:80-255)
+# --------------------------------------------------------------------------
+def heston_cf(u, S, K, T, r, q, kappa, theta, sigma_v, rho, v0):
+    """:80-129 Gatheral formulation."""
+    x = np.log(S / K) + (r - q) * T
+    alpha = -0.5 * u * (u + 1j)
+    beta = kappa - rho * sigma_v * 1j * u
+    gamma = 0.5 * sigma_v**2
+    d = np.sqrt(beta**2 - 4 * alpha * gamma)
+    r_plus = (beta + d) / (sigma_v**2)
+    r_minus = (beta - d) / (sigma_v**2)
+    g = r_minus / r_plus
+    exp_dT = np.exp(-d * T)
+    C_ = kappa * (r_minus * T - (2 / sigma_v**2) * np.log((1 - g * exp_dT) / (1 - g)))
+    D_ = r_minus * (1 - exp_dT) / (1 - g * exp_dT)
+    return np.exp(C_ * theta + D_ * v0 + 1j * u * x)
+
+
+def heston_price_european(S, K, T, r, q, option_type, kappa, theta, sigma_v, rho, v0):
+    """:131-182 Lewis formula, quad on [0, 100]."""
+    from scipy.integrate import quad
+
+    if T <= 0:
+        return max(S - K, 0) if option_type == "call" else max(K - S, 0)
+    F = S * np.exp((r - q) * T)
+
+    def integrand(u):
+        cf = heston_cf(u - 0.5j, S, K, T, r, q, kappa, theta, sigma_v, rho, v0)
+        return np.real(np.exp(-1j * u * np.log(K / F)) * cf / (u**2 + 0.25))
+
+    integral, _ = quad(integrand, 0, 100, limit=100)
+    call = S * np.exp(-q * T) - (np.sqrt(K * F) / np.pi) * np.exp(-r * T) * integral
+    if option_type == "call":
+        return max(call, 0.0)
+    return max(call - S * np.exp(-q * T) + K * np.exp(-r * T), 0.0)
+
+
+def heston_price_mc(S, K, T, r, q, option_type, kappa, theta, sigma_v, rho, v0, n_paths=100000, n_steps=252, seed=None):
+    """:184-255 full-truncation Euler, legacy global RandomState, no antithetic."""
+    if seed is not None:
+        np.random.seed(seed)
+    dt = T / n_steps
+    sqrt_dt = np.sqrt(dt)
+    log_S = np.full(n_paths, np.log(S))
+    v = np.full(n_paths, v0)
+    rho_sqrt = np.sqrt(1 - rho**2)
+    for _ in range(n_steps):
+        Z1 = np.random.standard_normal(n_paths)
+        Z2 = rho * Z1 + rho_sqrt * np.random.standard_normal(n_paths)
+        v_pos = np.maximum(v, 0)
+        sqrt_v = np.sqrt(v_pos)
+        log_S += (r - q - 0.5 * v_pos) * dt + sqrt_v * sqrt_dt * Z1
+        v += kappa * (theta - v_pos) * dt + sigma_v * sqrt_v * sqrt_dt * Z2
+        v = np.maximum(v, 0)
+    st = np.exp(log_S)
+    x = np.maximum(st - K, 0) if option_type == "call" else np.maximum(K - st, 0)
+    return np.exp(-r * T) * np.mean(x)

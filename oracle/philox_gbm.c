@@ -229,3 +229,37 @@ void ol_extrema_moments(double S, double K, double T, double r, double sigma, do
     }
     moments[0] = (double)m0; moments[1] = (double)m1;
 }
+
+/* Heston full-truncation Euler (heston.py:184-255), stream tag 1, two steps per Philox block. */
+void ol_heston_moments(double S, double K, double T, double r, double q, int is_call, double kappa, double theta,
+                       double sigma_v, double rho, double v0, int64_t path0, int64_t n, int32_t n_steps, uint64_t seed,
+                       int antithetic, double moments[2]) {
+    const double dt = T / n_steps, sqrt_dt = sqrt(dt), rho_c = sqrt(1 - rho * rho), sign = is_call ? 1.0 : -1.0;
+    const double zs = Z_SCALE * sqrt_dt;
+    long double m0 = 0, m1 = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double ls[2] = {log(S), log(S)}, v[2] = {v0, v0};
+        for (int32_t b = 0; 2 * b < n_steps; ++b) {
+            uint64_t path = (uint64_t)(path0 + i);
+            uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), (uint32_t)b, 1u};
+            uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, w[4];
+            float z[4];
+            ol_philox4x32_10(ctr, key, w);
+            box_muller_raw(w[0], w[1], &z[0], &z[1]);
+            box_muller_raw(w[2], w[3], &z[2], &z[3]);
+            for (int h = 0; h < 2 && 2 * b + h < n_steps; ++h) {
+                const double w1 = zs * (double)z[2 * h], w2 = rho * w1 + rho_c * (zs * (double)z[2 * h + 1]);
+                for (int leg = 0; leg < 2; ++leg) {
+                    const double sg = leg ? -1.0 : 1.0, vp = fmax(v[leg], 0.0), sv = sqrt(vp);
+                    ls[leg] += ((r - q) * dt - 0.5 * vp * dt) + sv * (sg * w1);
+                    v[leg] = fmax(v[leg] + kappa * dt * (theta - vp) + sigma_v * sv * (sg * w2), 0.0);
+                }
+            }
+        }
+        for (int leg = 0; leg < (antithetic ? 2 : 1); ++leg) {
+            const double x = fmax(sign * (exp(ls[leg]) - K), 0.0);
+            m0 += x; m1 += x * x;
+        }
+    }
+    moments[0] = (double)m0; moments[1] = (double)m1;
+}

@@ -90,6 +90,15 @@ def extrema_moments(S, K, T, r, sigma, q, is_call, payoff, barrier, n_paths, n_s
     return m[0], m[1], n_paths * (2 if antithetic else 1)
 
 
+def heston_moments(S, K, T, r, q, is_call, kappa, theta, sigma_v, rho, v0, n_paths, n_steps, seed, antithetic=False, path0=0):
+    m = (C.c_double * 2)()
+    _load().ol_heston_moments(C.c_double(S), C.c_double(K), C.c_double(T), C.c_double(r), C.c_double(q), C.c_int(int(is_call)),
+                              C.c_double(kappa), C.c_double(theta), C.c_double(sigma_v), C.c_double(rho), C.c_double(v0),
+                              C.c_int64(path0), C.c_int64(n_paths), C.c_int32(n_steps), C.c_uint64(int(seed) & _U64),
+                              C.c_int(int(antithetic)), m)
+    return m[0], m[1], n_paths * (2 if antithetic else 1)
+
+
 def price_and_error(sum_x, sum_xx, n, r, T):
     """monte_carlo.py:145-150 on the moments."""
     disc, mean = math.exp(-r * T), sum_x / n

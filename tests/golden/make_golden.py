@@ -30,10 +30,11 @@ def load_reference():
     from src.greeks.unified_greeks import ExoticAdapter, compute_greeks_unified
     from src.pricing_models.black_scholes import black_scholes
     from src.pricing_models.exotic_options import AsianOption, BarrierOption, LookbackOption, price_asian, price_barrier
+    from src.pricing_models.heston import HestonPricer
     from src.pricing_models.monte_carlo import MCMethod, MonteCarloPricer
     from src.pricing_models.monte_carlo_unified import MonteCarloPricerUni
 
-    return dict(MonteCarloPricerUni=MonteCarloPricerUni, BarrierOption=BarrierOption, LookbackOption=LookbackOption,
+    return dict(HestonPricer=HestonPricer, MonteCarloPricerUni=MonteCarloPricerUni, BarrierOption=BarrierOption, LookbackOption=LookbackOption,
                 price_barrier=price_barrier, MonteCarloPricer=MonteCarloPricer, MCMethod=MCMethod, black_scholes=black_scholes,
                 AsianOption=AsianOption, price_asian=price_asian,
                 compute_greeks_unified=compute_greeks_unified, ExoticAdapter=ExoticAdapter)
@@ -164,6 +165,21 @@ def main():
                                     n_steps=m, seed=42, price=float(o.price(n, m, kind, typ))))
     doc["price_barrier_helper"] = dict(args=[100.0, 100.0, 1.0, 0.05, 0.2, 120.0, "up-and-out", "call", 20000, 42],
                                        value=float(ref["price_barrier"](100.0, 100.0, 1.0, 0.05, 0.2, 120.0, "up-and-out", "call", 20000, 42)))
+
+    # -- Heston (heston.py:131-255) ---------------------------------------------------------
+    import warnings
+    doc["heston"] = []
+    for (kappa, theta, sv, rho, v0), (S, K, T, r, q), typ, n, m in [
+            ((2.0, 0.04, 0.3, -0.7, 0.04), (100.0, 100.0, 1.0, 0.05, 0.0), "call", 100000, 252),
+            ((2.0, 0.04, 0.3, -0.7, 0.04), (100.0, 100.0, 1.0, 0.05, 0.0), "put", 100000, 252),
+            ((1.5, 0.06, 0.5, -0.5, 0.03), (100.0, 110.0, 0.5, 0.03, 0.01), "call", 50000, 100),
+            ((3.0, 0.02, 0.8, 0.3, 0.05), (100.0, 90.0, 2.0, 0.02, 0.0), "put", 50000, 101)]:      # Feller violated: v hits 0
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            hp = ref["HestonPricer"](kappa=kappa, theta=theta, sigma_v=sv, rho=rho, v0=v0)
+        doc["heston"].append(dict(model=[kappa, theta, sv, rho, v0], args=[S, K, T, r, q], option_type=typ, n_paths=n, n_steps=m, seed=42,
+                                  mc=float(hp.price_monte_carlo(S, K, T, r, q, typ, n, m, 42)),
+                                  semi_analytic=float(hp.price_european(S, K, T, r, q, typ))))
 
     # -- MonteCarloPricerUni, NumPy backend (monte_carlo_unified.py:298-343, 451-689) ----
     Uni = ref["MonteCarloPricerUni"]

@@ -92,3 +92,50 @@ def test_greeks_through_exotic_adapter():
     assert g2["price"] > 0 and g2["vega"] > 0
     # floating lookback is homogeneous of degree 1 in S: delta = price / S
     assert g2["delta"] == pytest.approx(g2["price"] / 100.0, rel=1e-6)
+
+
+# ------------------------------------------------------------------ Heston
+H = dict(kappa=2.0, theta=0.04, sigma_v=0.3, rho=-0.7, v0=0.04)
+
+
+@pytest.mark.parametrize("call,anti,N,M,model", [
+    (True, False, 20000, 64, (2.0, 0.04, 0.3, -0.7, 0.04)), (False, True, 5001, 13, (1.5, 0.06, 0.5, -0.5, 0.03)),
+    (False, False, 4000, 101, (3.0, 0.02, 0.8, 0.3, 0.05)),      # odd step count; Feller violated: v is truncated at 0
+])
+def test_heston_matches_same_stream_checker(call, anti, N, M, model):
+    st = _hip.heston(100.0, 95.0, 1.5, 0.03, 0.01, call, *model, N, M, 21, anti)
+    sx, sxx, n = po.heston_moments(100.0, 95.0, 1.5, 0.03, 0.01, call, *model, N, M, 21, anti)
+    assert st.n == n
+    assert st.sum == pytest.approx(sx, rel=REL) and st.sumsq == pytest.approx(sxx, rel=4 * REL)
+
+
+def test_heston_against_reference_golden(golden):
+    import warnings
+    for c in golden["heston"]:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            hp = ol.HestonPricer(*c["model"])
+        S, K, T, r, q = c["args"]
+        price, se = hp.price_monte_carlo(S, K, T, r, q, c["option_type"], c["n_paths"], c["n_steps"], c["seed"], return_error=True)
+        assert isinstance(price, np.float64)
+        assert abs(price - c["mc"]) <= 3 * math.sqrt(2) * se, c
+        # the reference's semi-analytic formula is mirrored bit-for-bit-ish (it is NOT an accuracy anchor: it
+        # disagrees with the reference's own Monte Carlo by 13-80 %)
+        assert hp.price_european(S, K, T, r, q, c["option_type"]) == pytest.approx(c["semi_analytic"], rel=1e-12)
+
+
+def test_heston_limits_and_parity():
+    S, K, T, r, q = 100.0, 100.0, 1.0, 0.05, 0.02
+    hp = ol.HestonPricer(kappa=2.0, theta=0.04, sigma_v=1e-6, rho=0.0, v0=0.04)      # no vol-of-vol: Black-Scholes, sigma = 0.2
+    p, se = hp.price_monte_carlo(S, K, T, r, q, "call", 400_000, 64, 3, return_error=True)
+    assert abs(p - ol.black_scholes(S, K, T, r, 0.2, "call", q)) <= 3.5 * se
+    h2 = ol.HestonPricer(**H)
+    c, se_c = h2.price_monte_carlo(S, K, T, r, q, "call", 400_000, 128, 9, return_error=True)
+    pt, se_p = h2.price_monte_carlo(S, K, T, r, q, "put", 400_000, 128, 9, return_error=True)
+    assert abs((c - pt) - (S * math.exp(-q * T) - K * math.exp(-r * T))) <= 3.5 * math.hypot(se_c, se_p)
+    assert h2.price_monte_carlo(S, K, T, r, q, "call", 1000, 16, 5) == h2.price_monte_carlo(S, K, T, r, q, "call", 1000, 16, 5)
+    for bad in (dict(kappa=0), dict(theta=-1), dict(sigma_v=0), dict(rho=1.5), dict(v0=0)):
+        with pytest.raises(ValueError):
+            ol.HestonPricer(**{**H, **bad})
+    g = ol.compute_greeks_unified(ol.HestonAdapter(h2), 100.0, 100.0, 1.0, 0.05, 0.2, "call", include_second_order=False)
+    assert set(g) == {"price", "delta", "gamma", "vega", "theta", "rho"} and h2.v0 == 0.04

@@ -132,3 +132,11 @@ def test_barrier_and_lookback(golden):
     assert float(orc.barrier_price(S, K, T, r, v, level, 0.0, seed, n, 252, kind, typ)) == h["value"]
     with pytest.raises(ValueError, match="positive"):
         orc.barrier_price(100, 100, 1.0, 0.05, 0.2, 0.0)
+
+
+def test_heston(golden):
+    for c in golden["heston"]:
+        S, K, T, r, q = c["args"]
+        mc = orc.heston_price_mc(S, K, T, r, q, c["option_type"], *c["model"], c["n_paths"], c["n_steps"], c["seed"])
+        assert float(mc) == c["mc"], c
+        assert float(orc.heston_price_european(S, K, T, r, q, c["option_type"], *c["model"])) == c["semi_analytic"], c

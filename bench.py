@@ -5,12 +5,14 @@ per GPU (BASELINE.json configs[1]), antithetic on, on-device reduction.
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one complete pricing of the contract over this rank's block of
-1,000,000 global paths x 252 steps: path kernel -> on-device reduction -> (N > 1:
-one all-reduce of the 24-byte (sum, sumsq, n) triple over RCCL/xGMI) -> the triple
-lands in a per-step device slot.  Steps are enqueued back to back on the stream
-(pricing requests in flight); the timed region ends with a full synchronise and
-includes the D2H copy of all K results, each of which is then checked (every
-step's price must be within 3 sigma of Black-Scholes).  Inputs are scalars, so
+1,000,000 global paths x 252 steps: ONE path kernel with fused on-device reduction ->
+(N > 1: one all-reduce of the 24-byte (sum, sumsq, n) triple over RCCL/xGMI) -> the
+triple lands in a per-step device slot.  The K steps are independent pricing requests;
+they are dealt round-robin to `--streams` HIP streams so the ~15 us tail of one launch
+hides under the head of the next.  The timed region ends with a full synchronise and
+includes the D2H copy of all K results, each of which is then checked (every step's
+price within 4.5 sigma of Black-Scholes).  The same K steps are then repeated on ONE
+stream with HIP events around each kernel (`serial`, and the roofline attribution).  Inputs are scalars, so
 nothing but the results crosses PCIe.  The JSON line also carries `sync_call`:
 the same workload through the blocking MonteCarloPricer.price() API, one host
 round trip per call.
@@ -70,8 +72,9 @@ def cpu_baseline():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--streams", type=int, default=8, help="HIP streams the K pricings are spread over (>= 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -97,48 +100,62 @@ def main():
     n_global = PATHS_PER_GPU * world
     lo, hi = sharding.shard_bounds(n_global, rank, world)
     S, K, T, r, sigma, q = (WORK[k] for k in ("S", "K", "T", "r", "sigma", "q"))
-    stream = torch.cuda.Stream()          # one explicit stream: kernels, collectives' dependencies and D2H are ordered on it
-    torch.cuda.set_stream(stream)
+    # The K pricings are independent requests: they are dealt round-robin to `--streams` HIP streams, so
+    # the ~15 us tail of one launch (its last lone workgroup + the reduction chain) hides under the head
+    # of the next.  The library rotates event-guarded reduction workspaces, so launches never share state.
+    main_stream = torch.cuda.Stream()
+    torch.cuda.set_stream(main_stream)
+    streams = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
     K_steps, W = args.steps, args.warmup
     slots = torch.zeros((max(K_steps, W, 1), 3), dtype=torch.float64, device="cuda")
-
-    def enqueue(k, seed):
-        _hip.european_shard_dev(S, K, T, r, sigma, q, True, lo, hi - lo, N_STEPS, seed, True,
-                                slots[k].data_ptr(), stream.cuda_stream)
-        if world > 1:
-            return dist.all_reduce(slots[k], op=dist.ReduceOp.SUM, async_op=True)
-        return None
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up (untimed)
-    pend = [enqueue(k, SEED + 1000 + k) for k in range(W)]
-    for w in pend:
-        if w is not None:
-            w.wait()
-    fence()
+    def run_pass(n_streams, steps, seed0, events):
+        """Enqueue `steps` pricings round-robin over the first n_streams streams; returns (seconds, triples)."""
+        use = streams[:n_streams]
 
-    _hip.profile_enable(True)
-    _hip.profile_reset()
-    fence()
-    t0 = time.perf_counter()
-    pend = [enqueue(k, SEED + k) for k in range(K_steps)]
-    for w in pend:
-        if w is not None:
-            w.wait()
-    results = slots[:K_steps].cpu()          # D2H of the K triples, inside the timed region
-    fence()
-    elapsed = time.perf_counter() - t0
+        def enq(k):
+            st = use[k % n_streams]
+            with torch.cuda.stream(st):
+                _hip.european_shard_dev(S, K, T, r, sigma, q, True, lo, hi - lo, N_STEPS, seed0 + k, True,
+                                        slots[k].data_ptr(), st.cuda_stream)
+                if world > 1:
+                    return dist.all_reduce(slots[k], op=dist.ReduceOp.SUM, async_op=True)
+            return None
+
+        _hip.profile_enable(events)
+        _hip.profile_reset()
+        fence()
+        t0 = time.perf_counter()
+        pend = [enq(k) for k in range(steps)]
+        for w in pend:
+            if w is not None:
+                w.wait()
+        for st in use:
+            main_stream.wait_stream(st)
+        res = slots[:steps].cpu()            # D2H of the triples, inside the timed region
+        fence()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item()), res
+
+    run_pass(len(streams), W, SEED + 1000, False)                 # warm-up (untimed)
+    elapsed, results = run_pass(len(streams), K_steps, SEED, False)          # THE timed K steps -> `value`
+    # same K steps on ONE stream with HIP events around every path kernel: launches do not overlap here, so
+    # an event pair measures the kernel's own duration -> roofline attribution (and the `serial` figures)
+    serial_elapsed, serial_results = run_pass(1, K_steps, SEED, True)
     launches, kernel_ms = _hip.kernel_time()
     _hip.profile_enable(False)
-
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    if world == 1:
+        assert torch.equal(results, serial_results), "overlapped and serial passes must give identical bits"
+    else:   # the collective's summation order is RCCL's
+        assert torch.allclose(results, serial_results, rtol=1e-13, atol=0)
 
     # every step's result must be a valid price
     bs = ol.black_scholes(S, K, T, r, sigma, "call", q)
@@ -164,13 +181,18 @@ def main():
             "config": {"workload": "European call S0=100 K=100 sigma=0.2 r=0.05 T=1, 1,000,000 paths x 252 steps per GPU, "
                                    "antithetic on (2M payoffs per GPU), Philox4x32-10 + Box-Muller in registers, on-device reduction",
                        "paths_per_gpu": PATHS_PER_GPU, "n_steps": N_STEPS, "global_paths": n_global,
+                       "streams": len(streams),
                        "parallelism": f"path-sharded x{world}" + (", 1 RCCL all-reduce of (sum,sumsq,n) per step" if world > 1 else "")},
+            "serial": {"value": path_steps * K_steps / serial_elapsed, "ms_per_step": serial_elapsed / K_steps * 1e3, "streams": 1,
+                       "what": "the same K pricings back to back on one stream (no overlap between launches)"},
             "accuracy": {"bs_price": bs, "max_abs_err_over_sigma": worst, "payoffs_per_step": 2 * n_global},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_TLANEOPS, "unit": "Tlane-op/s",
                          "frac": achieved / PEAK_TLANEOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src, "kernel": "european_path_kernel<1,true,kReduce>", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "launches_timed": launches, "lane_ops_per_path_step": LANE_OPS_PER_PATH_STEP,
                          "hbm_gbps": (traffic / avg_kernel_s / 1e9) if traffic else None,
+                         "measured_on": "the single-stream pass of this run (see `serial`): with overlapping launches an event "
+                                        "pair would time co-resident kernels, not one kernel",
                          "note": "VALU-issue bound (SURVEY 8d: not HBM, not MFMA); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz "
                                  "(157.3 TF fp32 vector / 2); achieved = 32 lane-ops x path-steps per launch / HIP-event kernel time"},
             "device": info,

@@ -123,8 +123,10 @@ int olmc_european_shard(double S, double K, double T, double r, double sigma, do
  * the caller, e.g. a torch tensor handed to an RCCL all-reduce) on `hip_stream`
  * (a hipStream_t used as given; NULL = the HIP null stream, which is torch's
  * default stream) and does not synchronise: later work on that stream is
- * ordered after it.  Calls sharing one device serialise on the library's
- * per-device scratch, so use ONE stream per device for these calls. */
+ * ordered after it.  Calls on DIFFERENT streams may overlap on the device: the
+ * library rotates event-guarded reduction workspaces, so they never share rows
+ * or counters (a launch waits, on its own stream, for the previous user of its
+ * workspace). */
 int olmc_european_shard_dev(double S, double K, double T, double r, double sigma, double q, int is_call,
                             int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
                             int antithetic, double* d_triple, void* hip_stream);

@@ -50,10 +50,20 @@ struct DeviceCtx {
     int device = -1;
     int cus = 0;
     hipStream_t stream = nullptr;
-    double* d_block_rows = nullptr;  // [block_rows_cap] doubles, grown on demand (grid x NV)
-    size_t block_rows_cap = 0;
-    double* d_group_rows = nullptr;  // [kMaxGroups][kMaxNV]
-    uint32_t* d_counters = nullptr;  // [kMaxGroups + 1], zero between launches (self-resetting)
+    // Reduction workspaces.  Launches rotate over kSlots of them, each guarded by an event, so
+    // independent pricings enqueued on DIFFERENT streams may overlap on the device (the tail of
+    // one launch hides under the head of the next) without sharing rows or counters.
+    struct WsSlot {
+        double* block_rows = nullptr;  // [cap] doubles, grown on demand (grid x NV)
+        size_t cap = 0;
+        double* group_rows = nullptr;  // [kMaxGroups][kMaxNV]
+        uint32_t* counters = nullptr;  // [kMaxGroups + 1], zero between launches (self-resetting)
+        hipEvent_t done = nullptr;     // recorded after the slot's latest launch
+        bool used = false;
+    };
+    static constexpr int kSlots = 4;
+    WsSlot slots[kSlots];
+    int next_slot = 0, cur_slot = 0;
     double* d_result = nullptr;      // [kMaxNV + 1]
     double* h_result = nullptr;      // pinned [kMaxNV + 1]
     void* d_bulk = nullptr;          // terminal prices / validation taps
@@ -87,9 +97,12 @@ int ctx_create(int device, DeviceCtx** out) {
     c->device = device;
     c->cus = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipMalloc(&c->d_group_rows, sizeof(double) * kMaxNV * kMaxGroups));
-    HIP_TRY(hipMalloc(&c->d_counters, sizeof(uint32_t) * (kMaxGroups + 1)));
-    HIP_TRY(hipMemset(c->d_counters, 0, sizeof(uint32_t) * (kMaxGroups + 1)));
+    for (auto& sl : c->slots) {
+        HIP_TRY(hipMalloc(&sl.group_rows, sizeof(double) * kMaxNV * kMaxGroups));
+        HIP_TRY(hipMalloc(&sl.counters, sizeof(uint32_t) * (kMaxGroups + 1)));
+        HIP_TRY(hipMemset(sl.counters, 0, sizeof(uint32_t) * (kMaxGroups + 1)));
+        HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
     HIP_TRY(hipMalloc(&c->d_result, sizeof(double) * (kMaxNV + 1)));
     HIP_TRY(hipHostMalloc(&c->h_result, sizeof(double) * (kMaxNV + 1), hipHostMallocDefault));
     *out = c;
@@ -133,19 +146,24 @@ int32_t grid_for(int64_t n_paths) {
 }
 
 // Workspace of the fused grid reduction for a launch of `grid` workgroups x nv values.
-int make_ws(DeviceCtx* c, int32_t grid, int nv, double* d_out, double tail, ReduceWs* ws) {
+int make_ws(DeviceCtx* c, hipStream_t stream, int32_t grid, int nv, double* d_out, double tail, ReduceWs* ws) {
+    DeviceCtx::WsSlot& sl = c->slots[c->next_slot];
+    c->cur_slot = c->next_slot;
+    c->next_slot = (c->next_slot + 1) % DeviceCtx::kSlots;
     const size_t need = static_cast<size_t>(grid) * nv;
-    if (need > c->block_rows_cap) {
-        if (c->d_block_rows) HIP_TRY(hipFree(c->d_block_rows));
-        c->d_block_rows = nullptr;
-        c->block_rows_cap = 0;
+    if (need > sl.cap) {
+        if (sl.used) HIP_TRY(hipEventSynchronize(sl.done));
+        if (sl.block_rows) HIP_TRY(hipFree(sl.block_rows));
+        sl.block_rows = nullptr;
+        sl.cap = 0;
         const size_t cap = std::max<size_t>(need, size_t(1) << 16);
-        HIP_TRY(hipMalloc(&c->d_block_rows, sizeof(double) * cap));
-        c->block_rows_cap = cap;
+        HIP_TRY(hipMalloc(&sl.block_rows, sizeof(double) * cap));
+        sl.cap = cap;
     }
-    ws->block_rows = c->d_block_rows;
-    ws->group_rows = c->d_group_rows;
-    ws->counters = c->d_counters;
+    if (sl.used) HIP_TRY(hipStreamWaitEvent(stream, sl.done, 0));   // previous user of this slot, whatever its stream
+    ws->block_rows = sl.block_rows;
+    ws->group_rows = sl.group_rows;
+    ws->counters = sl.counters;
     ws->out = d_out;
     ws->tail = tail;
     return OLMC_OK;
@@ -155,7 +173,17 @@ int make_ws(DeviceCtx* c, int32_t grid, int nv, double* d_out, double tail, Redu
 void ws_recover(DeviceCtx* c) {
     (void)hipDeviceSynchronize();
     (void)hipGetLastError();
-    (void)hipMemset(c->d_counters, 0, sizeof(uint32_t) * (kMaxGroups + 1));
+    for (auto& sl : c->slots) (void)hipMemset(sl.counters, 0, sizeof(uint32_t) * (kMaxGroups + 1));
+}
+
+// Call right after launching a kernel that uses the workspace handed out by make_ws.
+int after_launch(DeviceCtx* c, hipStream_t stream) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
+    DeviceCtx::WsSlot& sl = c->slots[c->cur_slot];
+    HIP_TRY(hipEventRecord(sl.done, stream));
+    sl.used = true;
+    return OLMC_OK;
 }
 
 // ---- profiling brackets ---------------------------------------------------
@@ -251,7 +279,7 @@ int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32
     const bool anti = antithetic != 0;
     const int nsets = k == 1 ? 1 : (k <= 8 ? 8 : 16);
     ReduceWs ws;
-    int rc = make_ws(c, grid, 2 * nsets, d_out, tail, &ws);
+    int rc = make_ws(c, s, grid, 2 * nsets, d_out, tail, &ws);
     if (rc) return rc;
     EventPair ep{};
     if (g_profile) { rc = prof_begin(c, s, &ep); if (rc) return rc; }
@@ -268,8 +296,8 @@ int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32
         for (int i = 0; i < 16; ++i) cs.c[i] = make_contract(opts[i < k ? i : 0], n_steps);
         launch_european<16, kReduce>(anti, grid, s, pr, cs, ws, nullptr);
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
+    rc = after_launch(c, s);
+    if (rc) return rc;
     if (g_profile) { rc = prof_end(c, s, ep); if (rc) return rc; }
     return OLMC_OK;
 }
@@ -343,9 +371,12 @@ extern "C" int olmc_shutdown(void) {
             for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
             if (c->d_bulk) (void)hipFree(c->d_bulk);
             if (c->d_multi) (void)hipFree(c->d_multi);
-            if (c->d_block_rows) (void)hipFree(c->d_block_rows);
-            (void)hipFree(c->d_group_rows);
-            (void)hipFree(c->d_counters);
+            for (auto& sl : c->slots) {
+                if (sl.block_rows) (void)hipFree(sl.block_rows);
+                (void)hipFree(sl.group_rows);
+                (void)hipFree(sl.counters);
+                (void)hipEventDestroy(sl.done);
+            }
             (void)hipFree(c->d_result);
             (void)hipHostFree(c->h_result);
             (void)hipStreamDestroy(c->stream);
@@ -573,13 +604,11 @@ extern "C" int olmc_european_cv(double S, double K, double T, double r, double s
     ContractSet<1> cs;
     cs.c[0] = make_contract(make_option(S, K, T, r, sigma, q, is_call), n_steps);
     ReduceWs ws;
-    rc = make_ws(c, grid, 5, c->d_result, -1.0, &ws);
+    rc = make_ws(c, c->stream, grid, 5, c->d_result, -1.0, &ws);
     if (rc) return rc;
     launch_european<1, kControlVariate>(antithetic != 0, grid, c->stream, pr, cs, ws, nullptr);
-    {
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
-    }
+    rc = after_launch(c, c->stream);
+    if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
@@ -627,7 +656,7 @@ extern "C" int olmc_asian(double S, double K, double T, double r, double sigma, 
     ac.sign = is_call ? 1.0 : -1.0;
     ac.inv_steps = 1.0 / n_steps;
     ReduceWs ws;
-    rc = make_ws(c, grid, 2, c->d_result, -1.0, &ws);
+    rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
     if (rc) return rc;
     EventPair ep{};
     if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
@@ -636,10 +665,8 @@ extern "C" int olmc_asian(double S, double K, double T, double r, double sigma, 
     else if (anti) hipLaunchKernelGGL((asian_kernel<true, false>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, ws);
     else if (geo) hipLaunchKernelGGL((asian_kernel<false, true>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, ws);
     else hipLaunchKernelGGL((asian_kernel<false, false>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, ws);
-    {
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
-    }
+    rc = after_launch(c, c->stream);
+    if (rc) return rc;
     if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
     HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
     rc = sync_or_recover(c, c->stream);
@@ -672,16 +699,14 @@ int run_extrema(double S, double K, double T, double r, double sigma, double q, 
     ec.payoff = payoff;
     ec.pad = 0;
     ReduceWs ws;
-    rc = make_ws(c, grid, 2, c->d_result, -1.0, &ws);
+    rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
     if (rc) return rc;
     EventPair ep{};
     if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
     if (antithetic) hipLaunchKernelGGL((extrema_kernel<true>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ec, ws);
     else hipLaunchKernelGGL((extrema_kernel<false>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ec, ws);
-    {
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
-    }
+    rc = after_launch(c, c->stream);
+    if (rc) return rc;
     if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
     HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
     rc = sync_or_recover(c, c->stream);
@@ -735,16 +760,14 @@ extern "C" int olmc_heston(double S, double K, double T, double r, double q, int
     hc.strike = K;
     hc.sign = is_call ? 1.0 : -1.0;
     ReduceWs ws;
-    rc = make_ws(c, grid, 2, c->d_result, -1.0, &ws);
+    rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
     if (rc) return rc;
     EventPair ep{};
     if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
     if (antithetic) hipLaunchKernelGGL((heston_kernel<true>), dim3(grid), dim3(kBlock), 0, c->stream, pr, hc, ws);
     else hipLaunchKernelGGL((heston_kernel<false>), dim3(grid), dim3(kBlock), 0, c->stream, pr, hc, ws);
-    {
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
-    }
+    rc = after_launch(c, c->stream);
+    if (rc) return rc;
     if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
     HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
     rc = sync_or_recover(c, c->stream);
@@ -793,16 +816,14 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
     const int32_t grid = grid_for(n_paths);
     ReduceWs ws{};
     if (!terminal_host) {
-        rc = make_ws(c, grid, 2, c->d_result, -1.0, &ws);
+        rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
         if (rc) return rc;
         hipLaunchKernelGGL((european_qmc_kernel<kReduce>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, nullptr);
     } else {
         hipLaunchKernelGGL((european_qmc_kernel<kTerminal>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
     }
-    {
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
-    }
+    rc = after_launch(c, c->stream);
+    if (rc) return rc;
     if (terminal_host) {
         HIP_TRY(hipMemcpyAsync(terminal_host, d_term, term_bytes, hipMemcpyDeviceToHost, c->stream));
         return sync_or_recover(c, c->stream);

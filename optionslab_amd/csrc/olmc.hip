@@ -64,8 +64,8 @@ struct DeviceCtx {
     static constexpr int kSlots = 4;
     WsSlot slots[kSlots];
     int next_slot = 0, cur_slot = 0;
-    double* d_result = nullptr;      // [kMaxNV + 1]
-    double* h_result = nullptr;      // pinned [kMaxNV + 1]
+    double* h_result = nullptr;      // pinned + mapped [kMaxNV + 1]: the last workgroup writes the sums straight to the host
+    double* d_result = nullptr;      // device alias of h_result (zero-copy: no D2H copy node, only a stream sync)
     void* d_bulk = nullptr;          // terminal prices / validation taps
     size_t bulk_bytes = 0;
     // independent-contract batches (european_multi_kernel)
@@ -103,8 +103,8 @@ int ctx_create(int device, DeviceCtx** out) {
         HIP_TRY(hipMemset(sl.counters, 0, sizeof(uint32_t) * (kMaxGroups + 1)));
         HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
-    HIP_TRY(hipMalloc(&c->d_result, sizeof(double) * (kMaxNV + 1)));
-    HIP_TRY(hipHostMalloc(&c->h_result, sizeof(double) * (kMaxNV + 1), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&c->h_result, sizeof(double) * (kMaxNV + 1), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_result), c->h_result, 0));
     *out = c;
     return OLMC_OK;
 }
@@ -320,7 +320,6 @@ int run_batch(const olmc_option* opts, int32_t k, int64_t path_offset, int64_t n
     std::lock_guard<std::mutex> lock(c->mu);
     rc = run_batch_device(c, c->stream, opts, k, path_offset, n_local, n_steps, seed, antithetic, c->d_result, -1.0);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 2 * k, hipMemcpyDeviceToHost, c->stream));
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     const int64_t n = n_local * (antithetic ? 2 : 1);
@@ -377,7 +376,6 @@ extern "C" int olmc_shutdown(void) {
                 (void)hipFree(sl.counters);
                 (void)hipEventDestroy(sl.done);
             }
-            (void)hipFree(c->d_result);
             (void)hipHostFree(c->h_result);
             (void)hipStreamDestroy(c->stream);
         }
@@ -609,7 +607,6 @@ extern "C" int olmc_european_cv(double S, double K, double T, double r, double s
     launch_european<1, kControlVariate>(antithetic != 0, grid, c->stream, pr, cs, ws, nullptr);
     rc = after_launch(c, c->stream);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 5, hipMemcpyDeviceToHost, c->stream));
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     // device moments are of the UNdiscounted payoff x; d = disc * x (monte_carlo.py:175)
@@ -668,7 +665,6 @@ extern "C" int olmc_asian(double S, double K, double T, double r, double sigma, 
     rc = after_launch(c, c->stream);
     if (rc) return rc;
     if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
-    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r, T, out);
@@ -708,7 +704,6 @@ int run_extrema(double S, double K, double T, double r, double sigma, double q, 
     rc = after_launch(c, c->stream);
     if (rc) return rc;
     if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
-    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r, T, out);
@@ -769,7 +764,6 @@ extern "C" int olmc_heston(double S, double K, double T, double r, double q, int
     rc = after_launch(c, c->stream);
     if (rc) return rc;
     if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
-    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r, T, out);
@@ -828,7 +822,6 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
         HIP_TRY(hipMemcpyAsync(terminal_host, d_term, term_bytes, hipMemcpyDeviceToHost, c->stream));
         return sync_or_recover(c, c->stream);
     }
-    HIP_TRY(hipMemcpyAsync(c->h_result, c->d_result, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     finish_stats(c->h_result[0], c->h_result[1], n_paths, r, T, out);

@@ -352,3 +352,32 @@ def test_asian_greeks_through_exotic_adapter(golden):
     assert g["delta"] == pytest.approx(want["delta"], abs=0.02)
     assert g["vega"] == pytest.approx(want["vega"], rel=0.05)
     assert g["rho"] == pytest.approx(want["rho"], rel=0.05)
+
+
+# ------------------------------------------------------------------ re-entrancy (Streamlit sessions are threads)
+def test_concurrent_calls_from_threads_are_serialised_correctly():
+    import threading
+    p = ol.MonteCarloPricer(50_000, 16, 7)
+    want = {k: p.price(100.0 + k, 100.0, 1.0, 0.05, 0.2, "call", seed=k) for k in range(8)}
+    wantg = p.greeks(*ATM, "call", include_second_order=False)
+    got, errs = {}, []
+
+    def work(k):
+        try:
+            for _ in range(20):
+                got[k] = p.price(100.0 + k, 100.0, 1.0, 0.05, 0.2, "call", seed=k)
+                assert p.greeks(*ATM, "call", include_second_order=False) == wantg
+                assert ol.AsianOption(*ATM, seed=k).price(2000, 8) > 0
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs and got == want
+
+
+def test_shutdown_and_reinitialise():
+    a = ol.MonteCarloPricer(10_000, 8, 3).price(*ATM, "put")
+    _hip.shutdown()
+    assert ol.MonteCarloPricer(10_000, 8, 3).price(*ATM, "put") == a

@@ -92,8 +92,13 @@ def main():
     from optionslab_amd import _hip, sharding
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # OLMC_BENCH_FORCE_DIST=1 exercises the process-group + all-reduce code path with a single rank
+    use_dist = world > 1 or os.environ.get("OLMC_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     info = _hip.device_info()
 
@@ -110,7 +115,7 @@ def main():
     slots = torch.zeros((max(K_steps, W, 1), 3), dtype=torch.float64, device="cuda")
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -123,7 +128,7 @@ def main():
             with torch.cuda.stream(st):
                 _hip.european_shard_dev(S, K, T, r, sigma, q, True, lo, hi - lo, N_STEPS, seed0 + k, True,
                                         slots[k].data_ptr(), st.cuda_stream)
-                if world > 1:
+                if use_dist:
                     return dist.all_reduce(slots[k], op=dist.ReduceOp.SUM, async_op=True)
             return None
 
@@ -141,7 +146,7 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        if world > 1:
+        if use_dist:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item()), res
 
@@ -213,7 +218,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline()
                 out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

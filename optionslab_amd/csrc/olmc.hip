@@ -246,6 +246,18 @@ void finish_stats(double sum, double sumsq, int64_t n, double r, double T, olmc_
     out->std_error = disc * std::sqrt(var) / std::sqrt(static_cast<double>(n));
 }
 
+// The reference validates nothing at call time (tests/test_monte_carlo.py:143-151 skip it): a negative
+// spot or a NaN input makes np.log / the arithmetic produce NaN, np.maximum PROPAGATES it, and the price
+// is NaN.  Device fmax() would swallow the NaN (payoff 0), so such inputs are answered on the host.
+bool poisoned(double S, double K, double T, double r, double sigma, double q) {
+    return std::isnan(S + K + T + r + sigma + q) || S < 0.0;
+}
+
+void nan_stats(int64_t n, olmc_stats* out) {
+    const double nan = std::nan("");
+    out->sum = nan; out->sumsq = nan; out->n = n; out->price = nan; out->std_error = nan;
+}
+
 int check_paths(int64_t path_offset, int64_t n_local, int32_t n_steps) {
     if (n_local < 1) return fail(OLMC_ERR_ARG, "n_paths must be >= 1");
     if (n_steps < 1) return fail(OLMC_ERR_ARG, "n_steps must be >= 1");
@@ -323,8 +335,10 @@ int run_batch(const olmc_option* opts, int32_t k, int64_t path_offset, int64_t n
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     const int64_t n = n_local * (antithetic ? 2 : 1);
-    for (int i = 0; i < k; ++i)
-        finish_stats(c->h_result[2 * i], c->h_result[2 * i + 1], n, opts[i].r, opts[i].T, &out[i]);
+    for (int i = 0; i < k; ++i) {
+        if (poisoned(opts[i].S, opts[i].K, opts[i].T, opts[i].r, opts[i].sigma, opts[i].q)) nan_stats(n, &out[i]);
+        else finish_stats(c->h_result[2 * i], c->h_result[2 * i + 1], n, opts[i].r, opts[i].T, &out[i]);
+    }
     return OLMC_OK;
 }
 
@@ -506,7 +520,10 @@ extern "C" int olmc_european_multi(const olmc_option* opts, const uint32_t* tags
     HIP_TRY(hipMemcpyAsync(res.data(), d_out, sizeof(double) * 2 * n_options, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const int64_t n = n_paths * (antithetic ? 2 : 1);
-    for (int64_t j = 0; j < n_options; ++j) finish_stats(res[2 * j], res[2 * j + 1], n, opts[j].r, opts[j].T, &out[j]);
+    for (int64_t j = 0; j < n_options; ++j) {
+        if (poisoned(opts[j].S, opts[j].K, opts[j].T, opts[j].r, opts[j].sigma, opts[j].q)) nan_stats(n, &out[j]);
+        else finish_stats(res[2 * j], res[2 * j + 1], n, opts[j].r, opts[j].T, &out[j]);
+    }
     return OLMC_OK;
 }
 
@@ -626,6 +643,7 @@ extern "C" int olmc_european_cv(double S, double K, double T, double r, double s
     const double beta = (n > 1.0 && var_s > 1e-10) ? cov_ds / var_s : 0.0;        // :182
     const double forward = S * std::exp((r - q) * T);                              // :179
     out->value = mean_d - beta * (mean_s - forward);                               // :184
+    if (poisoned(S, K, T, r, sigma, q)) out->value = std::nan("");
     return OLMC_OK;
 }
 
@@ -668,6 +686,7 @@ extern "C" int olmc_asian(double S, double K, double T, double r, double sigma, 
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r, T, out);
+    if (poisoned(S, K, T, r, sigma, q)) nan_stats(out->n, out);
     return OLMC_OK;
 }
 
@@ -707,6 +726,7 @@ int run_extrema(double S, double K, double T, double r, double sigma, double q, 
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r, T, out);
+    if (poisoned(S, K, T, r, sigma, q) || std::isnan(barrier)) nan_stats(out->n, out);
     return OLMC_OK;
 }
 }  // namespace
@@ -767,6 +787,7 @@ extern "C" int olmc_heston(double S, double K, double T, double r, double q, int
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r, T, out);
+    if (poisoned(S, K, T, r, 0.0, q) || std::isnan(kappa + theta + sigma_v + rho + v0)) nan_stats(out->n, out);
     return OLMC_OK;
 }
 
@@ -825,6 +846,7 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     finish_stats(c->h_result[0], c->h_result[1], n_paths, r, T, out);
+    if (poisoned(S, K, T, r, sigma, q)) nan_stats(n_paths, out);
     return OLMC_OK;
 }
 }  // namespace

@@ -381,3 +381,52 @@ def test_shutdown_and_reinitialise():
     a = ol.MonteCarloPricer(10_000, 8, 3).price(*ATM, "put")
     _hip.shutdown()
     assert ol.MonteCarloPricer(10_000, 8, 3).price(*ATM, "put") == a
+
+
+# ------------------------------------------------------------------ unvalidated inputs behave like the reference
+def test_invalid_inputs_propagate_nan_like_numpy():
+    """monte_carlo.py validates nothing at call time: S < 0 -> np.log -> nan -> np.maximum propagates -> nan price."""
+    p = ol.MonteCarloPricer(1000, 4, 1)
+    assert math.isnan(p.price(-100.0, 100.0, 1.0, 0.05, 0.2, "call"))
+    res = p.price(100.0, float("nan"), 1.0, 0.05, 0.2, "put", return_error=True)
+    assert math.isnan(res.price) and math.isnan(res.std_error) and res.n_paths == 2000
+    assert np.isnan(p._simulate(-1.0, 1.0, 0.05, 0.2, 0.0)).all()
+    # S = 0 is not NaN in NumPy either: ln 0 = -inf, S_T = 0 -> call 0, put K e^{-rT}
+    assert p.price(0.0, 100.0, 1.0, 0.05, 0.2, "call") == 0.0
+    assert p.price(0.0, 100.0, 1.0, 0.05, 0.2, "put") == pytest.approx(100.0 * math.exp(-0.05), rel=1e-12)
+    # sigma < 0 only flips the antithetic legs
+    assert p.price(*ATM[:4], -0.2, "call") == pytest.approx(p.price(*ATM, "call"), rel=1e-12)
+    assert math.isnan(ol.AsianOption(-1.0, 100.0, 1.0, 0.05, 0.2, seed=1).price(100, 4))
+    with pytest.raises(ol.GreeksError):       # NaN greeks are still returned by the reference; a GreeksError only on exceptions
+        ol.compute_greeks_unified(ol.MonteCarloPricer(100, 0, 1), *ATM)
+
+
+# ------------------------------------------------------------------ RNG stream quality at scale
+def test_normal_stream_quality_large_sample():
+    from scipy import stats
+    z = _hip.normals(2024, 0, 40_000, 252).astype(np.float64)          # 10.08M normals
+    flat = z.ravel()
+    n = flat.size
+    m = [np.mean(flat ** k) for k in range(1, 9)]
+    want = [0, 1, 0, 3, 0, 15, 0, 105]
+    sd = [1, math.sqrt(2), math.sqrt(15), math.sqrt(96), math.sqrt(945), math.sqrt(10170), math.sqrt(135135), math.sqrt(2016000)]
+    for k in range(8):
+        assert abs(m[k] - want[k]) < 5 * sd[k] / math.sqrt(n), (k + 1, m[k])
+    assert stats.kstest(flat[:2_000_000], "norm").pvalue > 1e-4
+    # the sum over steps is what the European payoff consumes: N(0, 252)
+    rows = z.sum(axis=1)
+    assert abs(rows.mean()) < 5 * math.sqrt(252 / 40_000) and abs(rows.var() / 252 - 1) < 5 * math.sqrt(2 / 40_000)
+    assert stats.kstest(rows / math.sqrt(252), "norm").pvalue > 1e-4
+    # serial structure: lag-1..4 autocorrelation along steps, and across neighbouring paths
+    for lag in (1, 2, 3, 4):
+        c = np.mean(z[:, lag:] * z[:, :-lag])
+        assert abs(c) < 5 / math.sqrt(z[:, lag:].size), (lag, c)
+    assert abs(np.mean(z[1:] * z[:-1])) < 5 / math.sqrt(z[1:].size)
+    # cos/sin legs of one Box-Muller pair are independent: chi-square on a 16x16 grid of their CDF values
+    u0, u1 = stats.norm.cdf(z[:, 0::4].ravel()), stats.norm.cdf(z[:, 1::4].ravel())
+    h, _, _ = np.histogram2d(u0, u1, bins=16, range=[[0, 1], [0, 1]])
+    chi2 = ((h - u0.size / 256) ** 2 / (u0.size / 256)).sum()
+    assert stats.chi2.sf(chi2, 255) > 1e-4, chi2
+    # tail: P(|z| > 4) = 6.33e-5
+    tail = np.mean(np.abs(flat) > 4.0)
+    assert abs(tail - 6.334e-5) < 5 * math.sqrt(6.334e-5 / n)

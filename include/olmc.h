@@ -194,6 +194,20 @@ int olmc_lookback(double S, double K, double T, double r, double sigma, double q
                   int fixed_strike, int64_t path_offset, int64_t n_local, int32_t n_steps,
                   uint64_t seed, int antithetic, olmc_stats* out);
 
+/* ---- structured products on the step loop ----------------------------------------
+ * olmc_autocallable replaces AutocallableOption.price (src/pricing_models/exotic_options.py:404-491):
+ * barriers are relative to spot; out->price = mean of the per-path DISCOUNTED payoffs (the reference
+ * discounts each redemption at its own date), fraction of notional.
+ * olmc_cliquet replaces CliquetOption.price (:494-554): n_periods resets of n_steps // n_periods steps. */
+int olmc_autocallable(double S, double T, double r, double sigma, double q, double autocall_barrier,
+                      double coupon_barrier, double coupon_rate, double ki_barrier,
+                      int32_t observation_freq, int64_t path_offset, int64_t n_local,
+                      int32_t n_steps, uint64_t seed, int antithetic, olmc_stats* out);
+int olmc_cliquet(double S, double T, double r, double sigma, double q, double local_cap,
+                 double local_floor, double global_cap, double global_floor, int32_t n_periods,
+                 int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
+                 int antithetic, olmc_stats* out);
+
 /* ---- Heston stochastic volatility, full-truncation Euler ----------------------
  * Replaces HestonPricer.price_monte_carlo (src/pricing_models/heston.py:184-255): two
  * normals per step, (ln S, v) in fp64 registers, Philox stream tag 1.  The reference

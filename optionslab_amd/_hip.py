@@ -66,6 +66,8 @@ PROTOTYPES = {
     "olmc_asian": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_barrier": (_I, _SIX + [_I, _D, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_lookback": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
+    "olmc_autocallable": (_I, [_D] * 9 + [_I32, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
+    "olmc_cliquet": (_I, [_D] * 9 + [_I32, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_heston": (_I, [_D] * 5 + [_I] + [_D] * 5 + [_I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_multi_gpu_european": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(Stats)]),
     "olmc_combine_stats": (_I, [C.POINTER(Stats), _I32, _D, _D, C.POINTER(Stats)]),
@@ -264,6 +266,23 @@ def lookback(S, K, T, r, sigma, q, is_call: bool, fixed_strike: bool, n_paths: i
     out = Stats()
     _check(lib().olmc_lookback(S, K, T, r, sigma, q, int(is_call), int(fixed_strike), int(path_offset), int(n_paths),
                                int(n_steps), seed64(seed), int(antithetic), C.byref(out)))
+    return out
+
+
+def autocallable(S, T, r, sigma, q, autocall_barrier, coupon_barrier, coupon_rate, ki_barrier, observation_freq: int,
+                 n_paths: int, n_steps: int, seed: int, antithetic: bool = False, path_offset: int = 0) -> Stats:
+    out = Stats()
+    _check(lib().olmc_autocallable(S, T, r, sigma, q, autocall_barrier, coupon_barrier, coupon_rate, ki_barrier,
+                                   int(observation_freq), int(path_offset), int(n_paths), int(n_steps), seed64(seed),
+                                   int(antithetic), C.byref(out)))
+    return out
+
+
+def cliquet(S, T, r, sigma, q, local_cap, local_floor, global_cap, global_floor, n_periods: int, n_paths: int, n_steps: int,
+            seed: int, antithetic: bool = False, path_offset: int = 0) -> Stats:
+    out = Stats()
+    _check(lib().olmc_cliquet(S, T, r, sigma, q, local_cap, local_floor, global_cap, global_floor, int(n_periods),
+                              int(path_offset), int(n_paths), int(n_steps), seed64(seed), int(antithetic), C.byref(out)))
     return out
 
 

@@ -746,6 +746,84 @@ extern "C" int olmc_lookback(double S, double K, double T, double r, double sigm
                        n_local, n_steps, seed, antithetic, out);
 }
 
+// ======================================================= autocallable / cliquet ====
+namespace {
+template <typename Launch>
+int run_structured(int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic, double r_for_discount,
+                   double T, bool poisoned_inputs, olmc_stats* out, Launch launch) {
+    if (!out) return fail(OLMC_ERR_ARG, "null pointer");
+    int rc = check_paths(path_offset, n_local, n_steps);
+    if (rc) return rc;
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
+    const int32_t grid = grid_for(n_local);
+    ReduceWs ws;
+    rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
+    if (rc) return rc;
+    EventPair ep{};
+    if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
+    launch(grid, c->stream, pr, ws);
+    rc = after_launch(c, c->stream);
+    if (rc) return rc;
+    if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
+    rc = sync_or_recover(c, c->stream);
+    if (rc) return rc;
+    finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r_for_discount, T, out);
+    if (poisoned_inputs) nan_stats(out->n, out);
+    return OLMC_OK;
+}
+}  // namespace
+
+extern "C" int olmc_autocallable(double S, double T, double r, double sigma, double q, double autocall_barrier,
+                                 double coupon_barrier, double coupon_rate, double ki_barrier, int32_t observation_freq,
+                                 int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic,
+                                 olmc_stats* out) {
+    if (observation_freq < 1) return fail(OLMC_ERR_ARG, "observation_freq must be >= 1");
+    if (n_steps >= 1 && n_steps / observation_freq < 1) return fail(OLMC_ERR_ARG, "no observation date: observation_freq > n_steps");
+    AutocallContract ac;
+    const double dt = T / n_steps;
+    ac.drift = (r - q - 0.5 * sigma * sigma) * dt;
+    ac.vol = sigma * std::sqrt(dt);
+    ac.log_autocall = std::log(autocall_barrier);
+    ac.log_coupon = std::log(coupon_barrier);
+    ac.log_ki = std::log(ki_barrier);
+    ac.coupon_rate = coupon_rate;
+    ac.T = T;
+    ac.r_dt = r * dt;
+    ac.obs_freq = observation_freq;
+    ac.n_obs = n_steps / observation_freq;                      // len(range(f, M + 1, f))
+    const bool bad = poisoned(S, 1.0, T, r, sigma, q) || std::isnan(autocall_barrier + coupon_barrier + coupon_rate + ki_barrier);
+    // payoffs are already discounted path by path (exotic_options.py:463, 489): no outer discount
+    return run_structured(path_offset, n_local, n_steps, seed, antithetic, 0.0, T, bad, out,
+                          [&](int32_t grid, hipStream_t st, const PathRange& pr, const ReduceWs& ws) {
+                              if (antithetic) hipLaunchKernelGGL((autocall_kernel<true>), dim3(grid), dim3(kBlock), 0, st, pr, ac, ws);
+                              else hipLaunchKernelGGL((autocall_kernel<false>), dim3(grid), dim3(kBlock), 0, st, pr, ac, ws);
+                          });
+}
+
+extern "C" int olmc_cliquet(double S, double T, double r, double sigma, double q, double local_cap, double local_floor,
+                            double global_cap, double global_floor, int32_t n_periods, int64_t path_offset,
+                            int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic, olmc_stats* out) {
+    if (n_periods < 1 || (n_steps >= 1 && n_steps / n_periods < 1)) return fail(OLMC_ERR_ARG, "n_periods must be in [1, n_steps]");
+    CliquetContract cc;
+    const double dt = T / n_steps;
+    cc.s0 = S;
+    cc.drift = (r - q - 0.5 * sigma * sigma) * dt;
+    cc.vol = sigma * std::sqrt(dt);
+    cc.local_cap = local_cap; cc.local_floor = local_floor; cc.global_cap = global_cap; cc.global_floor = global_floor;
+    cc.steps_per_period = n_steps / n_periods;                  // exotic_options.py:532
+    cc.n_periods = n_periods;
+    const bool bad = poisoned(S, 1.0, T, r, sigma, q) || std::isnan(local_cap + local_floor + global_cap + global_floor);
+    return run_structured(path_offset, n_local, n_steps, seed, antithetic, r, T, bad, out,
+                          [&](int32_t grid, hipStream_t st, const PathRange& pr, const ReduceWs& ws) {
+                              if (antithetic) hipLaunchKernelGGL((cliquet_kernel<true>), dim3(grid), dim3(kBlock), 0, st, pr, cc, ws);
+                              else hipLaunchKernelGGL((cliquet_kernel<false>), dim3(grid), dim3(kBlock), 0, st, pr, cc, ws);
+                          });
+}
+
 // ===================================================================== Heston ====
 extern "C" int olmc_heston(double S, double K, double T, double r, double q, int is_call, double kappa, double theta,
                            double sigma_v, double rho, double v0, int64_t path_offset, int64_t n_local, int32_t n_steps,

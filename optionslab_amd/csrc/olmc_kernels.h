@@ -541,6 +541,122 @@ __global__ __launch_bounds__(kBlock) void extrema_kernel(PathRange pr, ExtremaCo
     block_then_grid_reduce<2>(acc, ws);
 }
 
+// Structured products on the step loop, observation dates counted down in a scalar register.
+//   autocallable (exotic_options.py:404-491): on every observation date t = f, 2f, ... <= M an
+//     unredeemed path with S_t/S_0 >= autocall_barrier redeems (1 + c (i+1)/n_obs T) e^{-r t dt};
+//     at maturity the rest get 1 (+ c T if S_T/S_0 >= coupon_barrier), or S_T/S_0 if the path ever
+//     touched ki_barrier (min over ALL steps, t = 0 included) and ends below 1; x e^{-rT}.
+//     Barriers are compared in log space; the payoff already carries its discount.
+//   cliquet (exotic_options.py:494-554): sum over n_periods of clip(S_end/S_start - 1, floor, cap),
+//     clipped globally, payoff max(total, 0) * S_0; periods are M // n_periods steps long.
+struct AutocallContract {
+    double drift, vol;                     // per step
+    double log_autocall, log_coupon, log_ki;
+    double coupon_rate, T, r_dt;           // r * dt
+    int32_t obs_freq, n_obs;
+};
+
+template <bool ANTI>
+__global__ __launch_bounds__(kBlock) void autocall_kernel(PathRange pr, AutocallContract c, ReduceWs ws) {
+    double acc[2] = {0.0, 0.0};
+    const double vol = c.vol * kZScale;
+    constexpr int LEGS = ANTI ? 2 : 1;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
+        const uint64_t g = pr.first + static_cast<uint64_t>(i);
+        const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
+        double cum[2] = {0.0, 0.0}, mn[2] = {0.0, 0.0}, pay[2] = {0.0, 0.0};
+        bool redeemed[2] = {false, false};
+        int32_t until_obs = c.obs_freq, obs_index = 0;
+        const int32_t blocks = (pr.n_steps + 3) >> 2;
+        for (int32_t b = 0; b < blocks; ++b) {
+            float z[4];
+            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1, z);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int32_t t = 4 * b + j + 1;                 // step just completed (1-based time index)
+                if (t <= pr.n_steps) {
+                    const double dz = vol * static_cast<double>(z[j]);
+                    const bool observe = (--until_obs == 0);
+                    if (observe) { until_obs = c.obs_freq; ++obs_index; }
+#pragma unroll
+                    for (int leg = 0; leg < LEGS; ++leg) {
+                        cum[leg] += c.drift + (leg ? -dz : dz);
+                        mn[leg] = fmin(mn[leg], cum[leg]);
+                        if (observe && !redeemed[leg] && cum[leg] >= c.log_autocall) {
+                            redeemed[leg] = true;
+                            const double coupon = c.coupon_rate * (static_cast<double>(obs_index) / c.n_obs) * c.T;
+                            pay[leg] = (1.0 + coupon) * exp(-c.r_dt * t);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int leg = 0; leg < LEGS; ++leg) {
+            double x = pay[leg];
+            if (!redeemed[leg]) {
+                double fin = 1.0;
+                if (cum[leg] >= c.log_coupon) fin += c.coupon_rate * c.T;
+                if (mn[leg] <= c.log_ki && cum[leg] < 0.0) fin = exp(cum[leg]);
+                x = fin * exp(-c.r_dt * pr.n_steps);
+            }
+            acc[0] += x; acc[1] += x * x;
+        }
+    }
+    block_then_grid_reduce<2>(acc, ws);
+}
+
+struct CliquetContract {
+    double s0, drift, vol;
+    double local_cap, local_floor, global_cap, global_floor;
+    int32_t steps_per_period, n_periods;
+};
+
+template <bool ANTI>
+__global__ __launch_bounds__(kBlock) void cliquet_kernel(PathRange pr, CliquetContract c, ReduceWs ws) {
+    double acc[2] = {0.0, 0.0};
+    const double vol = c.vol * kZScale;
+    constexpr int LEGS = ANTI ? 2 : 1;
+    const int32_t used_steps = c.steps_per_period * c.n_periods;      // trailing steps never enter a period
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
+        const uint64_t g = pr.first + static_cast<uint64_t>(i);
+        const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
+        double cum[2] = {0.0, 0.0}, start[2] = {0.0, 0.0}, total[2] = {0.0, 0.0};
+        int32_t until_reset = c.steps_per_period;
+        const int32_t blocks = (used_steps + 3) >> 2;
+        for (int32_t b = 0; b < blocks; ++b) {
+            float z[4];
+            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1, z);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (4 * b + j < used_steps) {
+                    const double dz = vol * static_cast<double>(z[j]);
+                    const bool reset = (--until_reset == 0);
+                    if (reset) until_reset = c.steps_per_period;
+#pragma unroll
+                    for (int leg = 0; leg < LEGS; ++leg) {
+                        cum[leg] += c.drift + (leg ? -dz : dz);
+                        if (reset) {
+                            const double local = exp(cum[leg] - start[leg]) - 1.0;      // (S_end - S_start) / S_start
+                            total[leg] += fmin(fmax(local, c.local_floor), c.local_cap);
+                            start[leg] = cum[leg];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int leg = 0; leg < LEGS; ++leg) {
+            const double clipped = fmin(fmax(total[leg], c.global_floor), c.global_cap);
+            const double x = fmax(clipped, 0.0) * c.s0;
+            acc[0] += x; acc[1] += x * x;
+        }
+    }
+    block_then_grid_reduce<2>(acc, ws);
+}
+
 // Heston full-truncation Euler (src/pricing_models/heston.py:184-255): per step two normals
 // (Z1, and Z2 = rho Z1 + sqrt(1 - rho^2) Z2'), state (ln S, v) in fp64 registers:
 //   v+ = max(v, 0);  ln S += (r - q - v+/2) dt + sqrt(v+ dt) Z1;

@@ -104,6 +104,58 @@ class LookbackOption:
         return (np.float64(st.price), float(st.std_error)) if return_error else np.float64(st.price)
 
 
+@dataclass
+class AutocallableOption:
+    """exotic_options.py:404-491 (snowball note; barriers relative to spot; result = fraction of notional)."""
+
+    S: float
+    K: float
+    T: float
+    r: float
+    sigma: float
+    q: float = 0.0
+    seed: Optional[int] = None
+    autocall_barrier: float = 1.0
+    coupon_barrier: float = 0.8
+    coupon_rate: float = 0.10
+    ki_barrier: float = 0.6
+
+    def price(self, n_paths: int = 100000, n_steps: int = 252, observation_freq: int = 21, antithetic: bool = False,
+              return_error: bool = False, **kwargs):
+        if n_paths < 1 or n_steps < 1:
+            raise ValueError("n_paths and n_steps must be >= 1")
+        seed = self.seed if self.seed is not None else int(np.random.default_rng().integers(0, 2**31))
+        st = _hip.autocallable(self.S, self.T, self.r, self.sigma, self.q, self.autocall_barrier, self.coupon_barrier,
+                               self.coupon_rate, self.ki_barrier, observation_freq, n_paths, n_steps, seed, antithetic)
+        return (np.float64(st.price), float(st.std_error)) if return_error else np.float64(st.price)
+
+
+@dataclass
+class CliquetOption:
+    """exotic_options.py:494-554 (ratchet: sum of locally capped/floored period returns, globally clipped)."""
+
+    S: float
+    K: float
+    T: float
+    r: float
+    sigma: float
+    q: float = 0.0
+    seed: Optional[int] = None
+    local_cap: float = 0.05
+    local_floor: float = -0.05
+    global_cap: float = 0.30
+    global_floor: float = 0.0
+
+    def price(self, n_paths: int = 100000, n_steps: int = 252, n_periods: int = 12, antithetic: bool = False,
+              return_error: bool = False, **kwargs):
+        if n_paths < 1 or n_steps < 1:
+            raise ValueError("n_paths and n_steps must be >= 1")
+        seed = self.seed if self.seed is not None else int(np.random.default_rng().integers(0, 2**31))
+        st = _hip.cliquet(self.S, self.T, self.r, self.sigma, self.q, self.local_cap, self.local_floor, self.global_cap,
+                          self.global_floor, n_periods, n_paths, n_steps, seed, antithetic)
+        return (np.float64(st.price), float(st.std_error)) if return_error else np.float64(st.price)
+
+
 def price_barrier(S: float, K: float, T: float, r: float, sigma: float, barrier: float, barrier_type: str = "up-and-out",
                   option_type: str = "call", n_paths: int = 100000, seed: int = None) -> float:
     """exotic_options.py:575-590"""

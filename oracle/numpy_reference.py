@@ -264,6 +264,43 @@ def lookback_price(S, K, T, r, sigma, q=0.0, seed=None, n_paths=100000, n_steps=
     return np.exp(-r * T) * np.mean(x)
 
 
+def autocallable_price(S, T, r, sigma, q=0.0, seed=None, n_paths=100000, n_steps=252, observation_freq=21,
+                       autocall_barrier=1.0, coupon_barrier=0.8, coupon_rate=0.10, ki_barrier=0.6):
+    """exotic_options.py:404-491"""
+    paths = asian_paths(S, T, r, sigma, q, n_paths, n_steps, seed)
+    dt = T / n_steps
+    obs = list(range(observation_freq, n_steps + 1, observation_freq))
+    pay = np.zeros(n_paths)
+    redeemed = np.zeros(n_paths, dtype=bool)
+    knocked_in = np.min(paths / S, axis=1) <= ki_barrier  # :445-446
+    for i, t in enumerate(obs):  # :448-463
+        active = ~redeemed
+        hit = np.where(active)[0][paths[active, t] / S >= autocall_barrier]
+        pay[hit] = (1 + coupon_rate * ((i + 1) / len(obs)) * T) * np.exp(-r * t * dt)
+        redeemed[hit] = True
+    still = ~redeemed
+    rel = paths[still, -1] / S
+    fin = np.ones(np.sum(still))
+    fin[rel >= coupon_barrier] += coupon_rate * T  # :477-478
+    loss = knocked_in[still] & (rel < 1.0)  # :481-483
+    fin[loss] = rel[loss]
+    pay[still] = fin * np.exp(-r * T)
+    return np.mean(pay)
+
+
+def cliquet_price(S, T, r, sigma, q=0.0, seed=None, n_paths=100000, n_steps=252, n_periods=12, local_cap=0.05,
+                  local_floor=-0.05, global_cap=0.30, global_floor=0.0):
+    """exotic_options.py:494-554"""
+    paths = asian_paths(S, T, r, sigma, q, n_paths, n_steps, seed)
+    spp = n_steps // n_periods
+    total = np.zeros(n_paths)
+    for p_ in range(n_periods):
+        a, b = paths[:, p_ * spp], paths[:, (p_ + 1) * spp]
+        total += np.clip((b - a) / a, local_floor, local_cap)
+    total = np.clip(total, global_floor, global_cap)
+    return np.exp(-r * T) * np.mean(np.maximum(total, 0) * S)
+
+
 def asian_geometric_closed_form(S, K, T, r, sigma, q=0.0, option_type="call"):
     """exotic_options.py:133-160 (continuous-monitoring lognormal approximation)."""
     v = sigma / np.sqrt(3)  # :145

@@ -263,3 +263,79 @@ void ol_heston_moments(double S, double K, double T, double r, double q, int is_
     }
     moments[0] = (double)m0; moments[1] = (double)m1;
 }
+
+/* Autocallable (exotic_options.py:404-491): moments of the per-path DISCOUNTED payoff. */
+void ol_autocall_moments(double S, double T, double r, double sigma, double q, double autocall_b, double coupon_b,
+                         double coupon_rate, double ki_b, int32_t freq, int64_t path0, int64_t n, int32_t n_steps,
+                         uint64_t seed, int antithetic, double moments[2]) {
+    (void)S;
+    const double dt = T / n_steps, drift = (r - q - 0.5 * sigma * sigma) * dt, vol = sigma * sqrt(dt) * Z_SCALE;
+    const int32_t n_obs = n_steps / freq;
+    long double m0 = 0, m1 = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double cum[2] = {0, 0}, mn[2] = {0, 0}, pay[2] = {0, 0};
+        int red[2] = {0, 0};
+        for (int32_t b = 0; 4 * b < n_steps; ++b) {
+            float z[4];
+            raw_normals4((uint64_t)(path0 + i), (uint32_t)b, seed, z);
+            for (int j = 0; j < 4 && 4 * b + j < n_steps; ++j) {
+                const int32_t t = 4 * b + j + 1;
+                const double dz = vol * (double)z[j];
+                for (int leg = 0; leg < 2; ++leg) {
+                    cum[leg] += drift + (leg ? -dz : dz);
+                    if (cum[leg] < mn[leg]) mn[leg] = cum[leg];
+                    if (t % freq == 0 && !red[leg] && cum[leg] >= log(autocall_b)) {
+                        red[leg] = 1;
+                        pay[leg] = (1.0 + coupon_rate * ((double)(t / freq) / n_obs) * T) * exp(-(r * dt) * t);
+                    }
+                }
+            }
+        }
+        for (int leg = 0; leg < (antithetic ? 2 : 1); ++leg) {
+            double x = pay[leg];
+            if (!red[leg]) {
+                double fin = 1.0;
+                if (cum[leg] >= log(coupon_b)) fin += coupon_rate * T;
+                if (mn[leg] <= log(ki_b) && cum[leg] < 0.0) fin = exp(cum[leg]);
+                x = fin * exp(-(r * dt) * n_steps);
+            }
+            m0 += x; m1 += x * x;
+        }
+    }
+    moments[0] = (double)m0; moments[1] = (double)m1;
+}
+
+/* Cliquet (exotic_options.py:494-554): moments of the UNdiscounted payoff. */
+void ol_cliquet_moments(double S, double T, double r, double sigma, double q, double lcap, double lfloor, double gcap,
+                        double gfloor, int32_t n_periods, int64_t path0, int64_t n, int32_t n_steps, uint64_t seed,
+                        int antithetic, double moments[2]) {
+    const double dt = T / n_steps, drift = (r - q - 0.5 * sigma * sigma) * dt, vol = sigma * sqrt(dt) * Z_SCALE;
+    const int32_t spp = n_steps / n_periods, used = spp * n_periods;
+    long double m0 = 0, m1 = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        double cum[2] = {0, 0}, start[2] = {0, 0}, total[2] = {0, 0};
+        for (int32_t b = 0; 4 * b < used; ++b) {
+            float z[4];
+            raw_normals4((uint64_t)(path0 + i), (uint32_t)b, seed, z);
+            for (int j = 0; j < 4 && 4 * b + j < used; ++j) {
+                const int32_t t = 4 * b + j + 1;
+                const double dz = vol * (double)z[j];
+                for (int leg = 0; leg < 2; ++leg) {
+                    cum[leg] += drift + (leg ? -dz : dz);
+                    if (t % spp == 0) {
+                        double local = exp(cum[leg] - start[leg]) - 1.0;
+                        local = local < lfloor ? lfloor : (local > lcap ? lcap : local);
+                        total[leg] += local;
+                        start[leg] = cum[leg];
+                    }
+                }
+            }
+        }
+        for (int leg = 0; leg < (antithetic ? 2 : 1); ++leg) {
+            double tot = total[leg] < gfloor ? gfloor : (total[leg] > gcap ? gcap : total[leg]);
+            const double x = (tot > 0 ? tot : 0.0) * S;
+            m0 += x; m1 += x * x;
+        }
+    }
+    moments[0] = (double)m0; moments[1] = (double)m1;
+}

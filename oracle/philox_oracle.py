@@ -99,6 +99,22 @@ def heston_moments(S, K, T, r, q, is_call, kappa, theta, sigma_v, rho, v0, n_pat
     return m[0], m[1], n_paths * (2 if antithetic else 1)
 
 
+def autocall_moments(S, T, r, sigma, q, autocall_b, coupon_b, coupon_rate, ki_b, freq, n_paths, n_steps, seed, antithetic=False, path0=0):
+    m = (C.c_double * 2)()
+    _load().ol_autocall_moments(*(C.c_double(x) for x in (S, T, r, sigma, q, autocall_b, coupon_b, coupon_rate, ki_b)), C.c_int32(freq),
+                                C.c_int64(path0), C.c_int64(n_paths), C.c_int32(n_steps), C.c_uint64(int(seed) & _U64),
+                                C.c_int(int(antithetic)), m)
+    return m[0], m[1], n_paths * (2 if antithetic else 1)
+
+
+def cliquet_moments(S, T, r, sigma, q, lcap, lfloor, gcap, gfloor, n_periods, n_paths, n_steps, seed, antithetic=False, path0=0):
+    m = (C.c_double * 2)()
+    _load().ol_cliquet_moments(*(C.c_double(x) for x in (S, T, r, sigma, q, lcap, lfloor, gcap, gfloor)), C.c_int32(n_periods),
+                               C.c_int64(path0), C.c_int64(n_paths), C.c_int32(n_steps), C.c_uint64(int(seed) & _U64),
+                               C.c_int(int(antithetic)), m)
+    return m[0], m[1], n_paths * (2 if antithetic else 1)
+
+
 def price_and_error(sum_x, sum_xx, n, r, T):
     """monte_carlo.py:145-150 on the moments."""
     disc, mean = math.exp(-r * T), sum_x / n

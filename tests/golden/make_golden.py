@@ -29,12 +29,14 @@ def load_reference():
     sys.path.insert(0, REF)
     from src.greeks.unified_greeks import ExoticAdapter, compute_greeks_unified
     from src.pricing_models.black_scholes import black_scholes
-    from src.pricing_models.exotic_options import AsianOption, BarrierOption, LookbackOption, price_asian, price_barrier
+    from src.pricing_models.exotic_options import (AsianOption, AutocallableOption, BarrierOption, CliquetOption,
+                                                    LookbackOption, price_asian, price_barrier)
     from src.pricing_models.heston import HestonPricer
     from src.pricing_models.monte_carlo import MCMethod, MonteCarloPricer
     from src.pricing_models.monte_carlo_unified import MonteCarloPricerUni
 
-    return dict(HestonPricer=HestonPricer, MonteCarloPricerUni=MonteCarloPricerUni, BarrierOption=BarrierOption, LookbackOption=LookbackOption,
+    return dict(HestonPricer=HestonPricer, MonteCarloPricerUni=MonteCarloPricerUni, BarrierOption=BarrierOption, LookbackOption=LookbackOption, AutocallableOption=AutocallableOption,
+                CliquetOption=CliquetOption,
                 price_barrier=price_barrier, MonteCarloPricer=MonteCarloPricer, MCMethod=MCMethod, black_scholes=black_scholes,
                 AsianOption=AsianOption, price_asian=price_asian,
                 compute_greeks_unified=compute_greeks_unified, ExoticAdapter=ExoticAdapter)
@@ -165,6 +167,17 @@ def main():
                                     n_steps=m, seed=42, price=float(o.price(n, m, kind, typ))))
     doc["price_barrier_helper"] = dict(args=[100.0, 100.0, 1.0, 0.05, 0.2, 120.0, "up-and-out", "call", 20000, 42],
                                        value=float(ref["price_barrier"](100.0, 100.0, 1.0, 0.05, 0.2, 120.0, "up-and-out", "call", 20000, 42)))
+
+    # -- autocallable / cliquet (exotic_options.py:404-554) -----------------------------------
+    doc["autocallable"], doc["cliquet"] = [], []
+    for kw, n, m, f in [(dict(), 100000, 252, 21), (dict(autocall_barrier=1.05, coupon_barrier=0.7, coupon_rate=0.08, ki_barrier=0.65), 50000, 252, 63),
+                        (dict(q=0.02), 20000, 100, 30), (dict(ki_barrier=0.9), 20000, 50, 7)]:
+        o = ref["AutocallableOption"](S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, seed=42, **kw)
+        doc["autocallable"].append(dict(kwargs=kw, n_paths=n, n_steps=m, observation_freq=f, seed=42, price=float(o.price(n, m, f))))
+    for kw, n, m, p_ in [(dict(), 100000, 252, 12), (dict(local_cap=0.03, local_floor=-0.02, global_cap=0.2, global_floor=0.02), 50000, 252, 4),
+                         (dict(q=0.01), 20000, 100, 7)]:
+        o = ref["CliquetOption"](S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, seed=42, **kw)
+        doc["cliquet"].append(dict(kwargs=kw, n_paths=n, n_steps=m, n_periods=p_, seed=42, price=float(o.price(n, m, p_))))
 
     # -- Heston (heston.py:131-255) ---------------------------------------------------------
     import warnings

@@ -139,3 +139,47 @@ def test_heston_limits_and_parity():
             ol.HestonPricer(**{**H, **bad})
     g = ol.compute_greeks_unified(ol.HestonAdapter(h2), 100.0, 100.0, 1.0, 0.05, 0.2, "call", include_second_order=False)
     assert set(g) == {"price", "delta", "gamma", "vega", "theta", "rho"} and h2.v0 == 0.04
+
+
+# ------------------------------------------------------------------ autocallable / cliquet
+AC = dict(autocall_barrier=1.0, coupon_barrier=0.8, coupon_rate=0.10, ki_barrier=0.6)
+
+
+@pytest.mark.parametrize("anti,N,M,freq,kw", [(False, 20000, 252, 21, {}), (True, 5001, 100, 30, dict(autocall_barrier=1.05, ki_barrier=0.9)),
+                                              (False, 3000, 50, 7, dict(coupon_barrier=0.95, coupon_rate=0.2)), (False, 2000, 13, 13, {})])
+def test_autocallable_matches_same_stream_checker(anti, N, M, freq, kw):
+    k = {**AC, **kw}
+    st = _hip.autocallable(100.0, 1.0, 0.05, 0.2, 0.01, k["autocall_barrier"], k["coupon_barrier"], k["coupon_rate"], k["ki_barrier"], freq, N, M, 5, anti)
+    sx, sxx, n = po.autocall_moments(100.0, 1.0, 0.05, 0.2, 0.01, k["autocall_barrier"], k["coupon_barrier"], k["coupon_rate"], k["ki_barrier"], freq, N, M, 5, anti)
+    assert st.n == n
+    assert st.sum == pytest.approx(sx, rel=REL) and st.sumsq == pytest.approx(sxx, rel=4 * REL)
+    assert st.price == pytest.approx(sx / n, rel=REL)            # payoffs carry their own discount: no outer factor
+
+
+@pytest.mark.parametrize("anti,N,M,periods,kw", [(False, 20000, 252, 12, {}), (True, 5001, 100, 7, dict(local_cap=0.03, local_floor=-0.02, global_cap=0.2, global_floor=0.02)),
+                                                 (False, 3000, 50, 50, {}), (False, 2000, 10, 3, {})])
+def test_cliquet_matches_same_stream_checker(anti, N, M, periods, kw):
+    k = {**dict(local_cap=0.05, local_floor=-0.05, global_cap=0.30, global_floor=0.0), **kw}
+    st = _hip.cliquet(100.0, 1.0, 0.05, 0.2, 0.01, k["local_cap"], k["local_floor"], k["global_cap"], k["global_floor"], periods, N, M, 5, anti)
+    sx, sxx, n = po.cliquet_moments(100.0, 1.0, 0.05, 0.2, 0.01, k["local_cap"], k["local_floor"], k["global_cap"], k["global_floor"], periods, N, M, 5, anti)
+    assert st.n == n
+    assert st.sum == pytest.approx(sx, rel=REL) and st.sumsq == pytest.approx(sxx, rel=4 * REL)
+
+
+def test_autocallable_and_cliquet_against_reference_golden(golden):
+    for c in golden["autocallable"]:
+        o = ol.AutocallableOption(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, seed=c["seed"], **c["kwargs"])
+        price, se = o.price(c["n_paths"], c["n_steps"], c["observation_freq"], return_error=True)
+        assert isinstance(price, np.float64) and 0.5 < price < 1.2
+        assert abs(price - c["price"]) <= 3 * math.sqrt(2) * se, c
+    for c in golden["cliquet"]:
+        o = ol.CliquetOption(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, seed=c["seed"], **c["kwargs"])
+        price, se = o.price(c["n_paths"], c["n_steps"], c["n_periods"], return_error=True)
+        assert abs(price - c["price"]) <= 3 * math.sqrt(2) * se, c
+    with pytest.raises(ol.AccelerationError):
+        _hip.autocallable(100.0, 1.0, 0.05, 0.2, 0.0, 1.0, 0.8, 0.1, 0.6, 300, 100, 252, 1)     # no observation date
+    with pytest.raises(ol.AccelerationError):
+        _hip.cliquet(100.0, 1.0, 0.05, 0.2, 0.0, 0.05, -0.05, 0.3, 0.0, 300, 100, 252, 1)
+    # bounds: a cliquet pays between global_floor and global_cap of spot, discounted
+    p = ol.CliquetOption(100.0, 100.0, 1.0, 0.05, 0.2, seed=1).price(20000)
+    assert 0.0 <= p <= 30.0 * math.exp(-0.05)

@@ -140,3 +140,16 @@ def test_heston(golden):
         mc = orc.heston_price_mc(S, K, T, r, q, c["option_type"], *c["model"], c["n_paths"], c["n_steps"], c["seed"])
         assert float(mc) == c["mc"], c
         assert float(orc.heston_price_european(S, K, T, r, q, c["option_type"], *c["model"])) == c["semi_analytic"], c
+
+
+def test_autocallable_and_cliquet(golden):
+    for c in golden["autocallable"]:
+        kw = dict(c["kwargs"])
+        q = kw.pop("q", 0.0)
+        got = orc.autocallable_price(100.0, 1.0, 0.05, 0.2, q, c["seed"], c["n_paths"], c["n_steps"], c["observation_freq"], **kw)
+        assert float(got) == c["price"], c
+    for c in golden["cliquet"]:
+        kw = dict(c["kwargs"])
+        q = kw.pop("q", 0.0)
+        got = orc.cliquet_price(100.0, 1.0, 0.05, 0.2, q, c["seed"], c["n_paths"], c["n_steps"], c["n_periods"], **kw)
+        assert float(got) == c["price"], c

@@ -208,6 +208,17 @@ int olmc_cliquet(double S, double T, double r, double sigma, double q, double lo
                  int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
                  int antithetic, olmc_stats* out);
 
+/* ---- American option, Longstaff-Schwartz LSM --------------------------------------
+ * Replaces AmericanOption.price (src/pricing_models/exotic_options.py:227-305): stores the path
+ * matrix in HBM (time-major), one launch per exercise date doing {exercise decision of the later
+ * date, one-step discount, regression moments of this date} with the fused deterministic
+ * reduction, and the small normal-equation solve on the host in between.  Polynomial basis in
+ * S/K of degree poly_degree in [1, 4] (the reference's default is 3).  out->price = mean of the
+ * time-0 cash flows; single device. */
+int olmc_american_lsm(double S, double K, double T, double r, double sigma, double q, int is_call,
+                      int64_t n_paths, int32_t n_steps, int32_t poly_degree, uint64_t seed,
+                      olmc_stats* out);
+
 /* ---- Heston stochastic volatility, full-truncation Euler ----------------------
  * Replaces HestonPricer.price_monte_carlo (src/pricing_models/heston.py:184-255): two
  * normals per step, (ln S, v) in fp64 registers, Philox stream tag 1.  The reference

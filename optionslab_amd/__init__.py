@@ -7,7 +7,7 @@ a device) is missing -- there is no CPU fallback.
 """
 from .black_scholes import black_scholes
 from .exceptions import AccelerationError, ConvergenceError, GreeksError, InputValidationError, MonteCarloError
-from .exotic import AsianOption, AutocallableOption, BarrierOption, CliquetOption, LookbackOption, price_asian, price_barrier
+from .exotic import AmericanOption, price_american, AsianOption, AutocallableOption, BarrierOption, CliquetOption, LookbackOption, price_asian, price_barrier
 from .greeks import ExoticAdapter, PricerProtocol, compute_greeks_unified
 from .heston import HestonAdapter, HestonPricer
 from .monte_carlo import NUMBA_AVAILABLE, MCMethod, MCResult, MonteCarloPricer
@@ -19,6 +19,6 @@ __version__ = "0.1.0"
 
 __all__ = [
     "MonteCarloPricer", "MonteCarloPricerUni", "MCMethod", "MCResult", "NUMBA_AVAILABLE", "compute_greeks_unified", "PricerProtocol",
-    "ExoticAdapter", "HestonPricer", "HestonAdapter", "AsianOption", "BarrierOption", "LookbackOption", "AutocallableOption", "CliquetOption", "price_asian", "price_barrier", "black_scholes", "simulate_gbm_hip", "simulate_gbm_hip_fast",
+    "ExoticAdapter", "HestonPricer", "HestonAdapter", "AsianOption", "BarrierOption", "LookbackOption", "AmericanOption", "price_american", "AutocallableOption", "CliquetOption", "price_asian", "price_barrier", "black_scholes", "simulate_gbm_hip", "simulate_gbm_hip_fast",
     "hip_available", "MonteCarloError", "InputValidationError", "ConvergenceError", "AccelerationError", "GreeksError",
 ]

@@ -68,6 +68,7 @@ PROTOTYPES = {
     "olmc_lookback": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_autocallable": (_I, [_D] * 9 + [_I32, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_cliquet": (_I, [_D] * 9 + [_I32, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
+    "olmc_american_lsm": (_I, _SIX + [_I, _I64, _I32, _I32, _U64T, C.POINTER(Stats)]),
     "olmc_heston": (_I, [_D] * 5 + [_I] + [_D] * 5 + [_I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_multi_gpu_european": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(Stats)]),
     "olmc_combine_stats": (_I, [C.POINTER(Stats), _I32, _D, _D, C.POINTER(Stats)]),
@@ -283,6 +284,13 @@ def cliquet(S, T, r, sigma, q, local_cap, local_floor, global_cap, global_floor,
     out = Stats()
     _check(lib().olmc_cliquet(S, T, r, sigma, q, local_cap, local_floor, global_cap, global_floor, int(n_periods),
                               int(path_offset), int(n_paths), int(n_steps), seed64(seed), int(antithetic), C.byref(out)))
+    return out
+
+
+def american_lsm(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int, poly_degree: int, seed: int) -> Stats:
+    out = Stats()
+    _check(lib().olmc_american_lsm(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(n_steps), int(poly_degree),
+                                   seed64(seed), C.byref(out)))
     return out
 
 

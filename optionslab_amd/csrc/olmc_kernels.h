@@ -657,6 +657,112 @@ __global__ __launch_bounds__(kBlock) void cliquet_kernel(PathRange pr, CliquetCo
     block_then_grid_reduce<2>(acc, ws);
 }
 
+// American option, Longstaff-Schwartz least-squares Monte Carlo (exotic_options.py:227-305).
+// The only path here that must STORE paths: time-major paths[t][i] (t = 0..M) so that a time
+// slice is one coalesced stream; n_paths * (M+1) * 8 bytes (20 MB at the reference's defaults).
+// Backward induction is one launch per exercise date t = M-1 .. 1:
+//   1. finish date t+1: if its regression was valid, in-the-money paths whose intrinsic value
+//      beats the fitted continuation value exercise (cash flow := intrinsic);
+//   2. discount the cash flow one step;
+//   3. accumulate, over paths in the money at t, the normal-equation moments of the polynomial
+//      regression of cash flow on x = S_t / K:  sum x^m (m = 0..2d), sum x^k cf (k = 0..d), count
+//      -- through the fused deterministic grid reduction.
+// The (d+1)x(d+1) solve happens on the host between launches (the sums land in mapped memory).
+// The basis is the reference's raw powers X^k re-scaled by the strike (same polynomial space,
+// well-conditioned moments); its lstsq(rcond=None) is replaced by the normal equations.
+constexpr int kLsmMaxDegree = 4;
+constexpr int kLsmNV = 16;          // 2d+1 + d+1 + 1 <= 15 sums, padded
+
+struct LsmContract {
+    double log_s0, drift, vol;      // per step
+    double strike, inv_strike, sign;
+    double discount;                // exp(-r dt)
+    int32_t degree;
+    int32_t n_steps;
+};
+
+template <int DUMMY = 0>
+__global__ __launch_bounds__(kBlock) void lsm_paths_kernel(PathRange pr, LsmContract c, double* __restrict__ paths) {
+    const double vol = c.vol * kZScale;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
+        const uint64_t g = pr.first + static_cast<uint64_t>(i);
+        const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
+        double cum = 0.0;
+        paths[i] = exp(c.log_s0);
+        const int32_t blocks = (pr.n_steps + 3) >> 2;
+        for (int32_t b = 0; b < blocks; ++b) {
+            float z[4];
+            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1, z);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int32_t t = 4 * b + j + 1;
+                if (t <= pr.n_steps) {
+                    cum += c.drift + vol * static_cast<double>(z[j]);
+                    paths[static_cast<size_t>(t) * pr.count + i] = exp(c.log_s0 + cum);
+                }
+            }
+        }
+    }
+}
+
+struct LsmCoeffs {
+    double beta[kLsmMaxDegree + 1];
+    int32_t valid;                  // regression at the date being finished was fitted
+    int32_t pad;
+};
+
+__device__ __forceinline__ double lsm_intrinsic(const LsmContract& c, double s) { return fmax(c.sign * (s - c.strike), 0.0); }
+
+// t_fit: the date whose moments are accumulated (>= 1); the date finished first is t_fit + 1
+// (skipped when t_fit + 1 == M: the terminal payoff needs no regression).  init != 0: cash flow
+// starts as the terminal intrinsic value.
+__global__ __launch_bounds__(kBlock) void lsm_step_kernel(int64_t n, LsmContract c, LsmCoeffs prev, int32_t t_fit, int32_t init,
+                                                          const double* __restrict__ paths, double* __restrict__ cash,
+                                                          ReduceWs ws) {
+    double acc[kLsmNV];
+#pragma unroll
+    for (int k = 0; k < kLsmNV; ++k) acc[k] = 0.0;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
+        double cf;
+        if (init) {
+            cf = lsm_intrinsic(c, paths[static_cast<size_t>(c.n_steps) * n + i]);
+        } else {
+            cf = cash[i];
+            const double s1 = paths[static_cast<size_t>(t_fit + 1) * n + i];
+            const double iv = lsm_intrinsic(c, s1);
+            if (prev.valid && iv > 0.0) {
+                const double x = s1 * c.inv_strike;
+                double cont = prev.beta[kLsmMaxDegree];
+#pragma unroll
+                for (int k = kLsmMaxDegree - 1; k >= 0; --k) cont = cont * x + prev.beta[k];
+                if (iv > cont) cf = iv;
+            }
+        }
+        cf *= c.discount;
+        cash[i] = cf;
+        if (t_fit >= 1) {
+            const double s0 = paths[static_cast<size_t>(t_fit) * n + i];
+            if (lsm_intrinsic(c, s0) > 0.0) {
+                const double x = s0 * c.inv_strike;
+                double p = 1.0;
+#pragma unroll
+                for (int m = 0; m <= 2 * kLsmMaxDegree; ++m) {
+                    if (m <= 2 * c.degree) acc[m] += p;
+                    if (m <= c.degree) acc[2 * kLsmMaxDegree + 1 + m] += p * cf;
+                    p *= x;
+                }
+                acc[kLsmNV - 2] += 1.0;       // in-the-money count
+            }
+        } else {
+            acc[0] += cf;                     // final launch (t_fit == 0): moments of the time-0 cash flow
+            acc[1] += cf * cf;
+        }
+    }
+    block_then_grid_reduce<kLsmNV>(acc, ws);
+}
+
 // Heston full-truncation Euler (src/pricing_models/heston.py:184-255): per step two normals
 // (Z1, and Z2 = rho Z1 + sqrt(1 - rho^2) Z2'), state (ln S, v) in fp64 registers:
 //   v+ = max(v, 0);  ln S += (r - q - v+/2) dt + sqrt(v+ dt) Z1;

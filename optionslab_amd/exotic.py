@@ -105,6 +105,35 @@ class LookbackOption:
 
 
 @dataclass
+class AmericanOption:
+    """exotic_options.py:227-305: Longstaff-Schwartz least-squares Monte Carlo on stored device paths.
+    (`early_exercise_boundary`, a percentile plot helper of the reference, is not provided.)"""
+
+    S: float
+    K: float
+    T: float
+    r: float
+    sigma: float
+    q: float = 0.0
+    seed: Optional[int] = None
+
+    def price(self, n_paths: int = 50000, n_steps: int = 50, option_type: Literal["call", "put"] = "put",
+              poly_degree: int = 3, return_error: bool = False):
+        if n_paths < 1 or n_steps < 1:
+            raise ValueError("n_paths and n_steps must be >= 1")
+        seed = self.seed if self.seed is not None else int(np.random.default_rng().integers(0, 2**31))
+        st = _hip.american_lsm(self.S, self.K, self.T, self.r, self.sigma, self.q, option_type == "call", n_paths, n_steps,
+                               poly_degree, seed)
+        return (np.float64(st.price), float(st.std_error)) if return_error else np.float64(st.price)
+
+
+def price_american(S: float, K: float, T: float, r: float, sigma: float, option_type: str = "put", n_paths: int = 50000,
+                   seed: int = None) -> float:
+    """exotic_options.py:593-606"""
+    return AmericanOption(S=S, K=K, T=T, r=r, sigma=sigma, seed=seed).price(n_paths=n_paths, option_type=option_type)
+
+
+@dataclass
 class AutocallableOption:
     """exotic_options.py:404-491 (snowball note; barriers relative to spot; result = fraction of notional)."""
 

@@ -264,6 +264,27 @@ def lookback_price(S, K, T, r, sigma, q=0.0, seed=None, n_paths=100000, n_steps=
     return np.exp(-r * T) * np.mean(x)
 
 
+def american_price(S, K, T, r, sigma, q=0.0, seed=None, n_paths=50000, n_steps=50, option_type="put", poly_degree=3):
+    """exotic_options.py:237-305 Longstaff-Schwartz."""
+    paths = asian_paths(S, T, r, sigma, q, n_paths, n_steps, seed)
+    dt = T / n_steps
+    discount = np.exp(-r * dt)
+    intrinsic = np.maximum(paths - K, 0) if option_type == "call" else np.maximum(K - paths, 0)
+    cf = intrinsic[:, -1].copy()
+    for t in range(n_steps - 1, 0, -1):  # :273-300
+        cf = cf * discount
+        itm = intrinsic[:, t] > 0
+        if np.sum(itm) > poly_degree + 1:
+            X, Y = paths[itm, t], cf[itm]
+            Xp = np.column_stack([X**i for i in range(poly_degree + 1)])
+            coeffs = np.linalg.lstsq(Xp, Y, rcond=None)[0]
+            cont = Xp @ coeffs
+            ex = intrinsic[itm, t] > cont
+            idx = np.where(itm)[0][ex]
+            cf[idx] = intrinsic[idx, t]
+    return np.mean(cf * discount)
+
+
 def autocallable_price(S, T, r, sigma, q=0.0, seed=None, n_paths=100000, n_steps=252, observation_freq=21,
                        autocall_barrier=1.0, coupon_barrier=0.8, coupon_rate=0.10, ki_barrier=0.6):
     """exotic_options.py:404-491"""

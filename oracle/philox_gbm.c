@@ -339,3 +339,89 @@ void ol_cliquet_moments(double S, double T, double r, double sigma, double q, do
     }
     moments[0] = (double)m0; moments[1] = (double)m1;
 }
+
+/* American LSM (exotic_options.py:237-305) on the device's paths; regression in x = S/K by the
+ * normal equations (long double Gaussian elimination with partial pivoting), degree <= 4.
+ * moments[0..1] = sum, sum of squares of the time-0 cash flows. */
+static int lsm_solve(const long double* mom, const long double* rhs, int degree, double* beta) {
+    int n = degree + 1;
+    long double a[5][6];
+    for (int k = 0; k < n; ++k) {
+        for (int l = 0; l < n; ++l) a[k][l] = mom[k + l];
+        a[k][n] = rhs[k];
+    }
+    for (int col = 0; col < n; ++col) {
+        int piv = col;
+        for (int row = col + 1; row < n; ++row)
+            if (fabsl(a[row][col]) > fabsl(a[piv][col])) piv = row;
+        if (!(fabsl(a[piv][col]) > 1e-280L)) return 0;
+        for (int l = 0; l <= n; ++l) { long double tmp = a[piv][l]; a[piv][l] = a[col][l]; a[col][l] = tmp; }
+        for (int row = col + 1; row < n; ++row) {
+            long double f = a[row][col] / a[col][col];
+            for (int l = col; l <= n; ++l) a[row][l] -= f * a[col][l];
+        }
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        long double v = a[k][n];
+        for (int l = k + 1; l < n; ++l) v -= a[k][l] * beta[l];
+        beta[k] = (double)(v / a[k][k]);
+    }
+    return 1;
+}
+
+int ol_american_lsm(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t n, int32_t n_steps,
+                    int32_t degree, uint64_t seed, double moments[2]) {
+    const double dt = T / n_steps, drift = (r - q - 0.5 * sigma * sigma) * dt, vol = sigma * sqrt(dt) * Z_SCALE;
+    const double sign = is_call ? 1.0 : -1.0, disc = exp(-r * dt);
+    double* paths = (double*)malloc(sizeof(double) * (size_t)n * (n_steps + 1));
+    double* cf = (double*)malloc(sizeof(double) * (size_t)n);
+    if (!paths || !cf) { free(paths); free(cf); return 1; }
+    for (int64_t i = 0; i < n; ++i) {
+        double cum = 0.0;
+        paths[i] = exp(log(S));
+        for (int32_t b = 0; 4 * b < n_steps; ++b) {
+            float z[4];
+            raw_normals4((uint64_t)i, (uint32_t)b, seed, z);
+            for (int j = 0; j < 4 && 4 * b + j < n_steps; ++j) {
+                cum += drift + vol * (double)z[j];
+                paths[(size_t)(4 * b + j + 1) * n + i] = exp(log(S) + cum);
+            }
+        }
+    }
+    for (int64_t i = 0; i < n; ++i) cf[i] = fmax(sign * (paths[(size_t)n_steps * n + i] - K), 0.0);
+    for (int32_t t = n_steps - 1; t >= 1; --t) {
+        long double mom[9] = {0}, rhs[5] = {0};
+        int64_t count = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            cf[i] *= disc;
+            const double s = paths[(size_t)t * n + i];
+            if (fmax(sign * (s - K), 0.0) > 0.0) {
+                const double x = s / K;
+                double p = 1.0;
+                for (int m = 0; m <= 2 * degree; ++m) {
+                    mom[m] += p;
+                    if (m <= degree) rhs[m] += p * cf[i];
+                    p *= x;
+                }
+                ++count;
+            }
+        }
+        double beta[5] = {0, 0, 0, 0, 0};
+        if (count > degree + 1 && lsm_solve(mom, rhs, degree, beta)) {
+            for (int64_t i = 0; i < n; ++i) {
+                const double s = paths[(size_t)t * n + i], iv = fmax(sign * (s - K), 0.0);
+                if (iv > 0.0) {
+                    const double x = s / K;
+                    double cont = beta[4];
+                    for (int k = 3; k >= 0; --k) cont = cont * x + beta[k];
+                    if (iv > cont) cf[i] = iv;
+                }
+            }
+        }
+    }
+    long double m0 = 0, m1 = 0;
+    for (int64_t i = 0; i < n; ++i) { const double x = cf[i] * disc; m0 += x; m1 += x * x; }
+    moments[0] = (double)m0; moments[1] = (double)m1;
+    free(paths); free(cf);
+    return 0;
+}

@@ -115,6 +115,16 @@ def cliquet_moments(S, T, r, sigma, q, lcap, lfloor, gcap, gfloor, n_periods, n_
     return m[0], m[1], n_paths * (2 if antithetic else 1)
 
 
+def american_lsm(S, K, T, r, sigma, q, is_call, n_paths, n_steps, degree, seed):
+    """-> (sum, sumsq, n) of the time-0 cash flows (already discounted)."""
+    m = (C.c_double * 2)()
+    rc = _load().ol_american_lsm(C.c_double(S), C.c_double(K), C.c_double(T), C.c_double(r), C.c_double(sigma), C.c_double(q),
+                                 C.c_int(int(is_call)), C.c_int64(n_paths), C.c_int32(n_steps), C.c_int32(degree),
+                                 C.c_uint64(int(seed) & _U64), m)
+    assert rc == 0
+    return m[0], m[1], n_paths
+
+
 def price_and_error(sum_x, sum_xx, n, r, T):
     """monte_carlo.py:145-150 on the moments."""
     disc, mean = math.exp(-r * T), sum_x / n

@@ -29,14 +29,14 @@ def load_reference():
     sys.path.insert(0, REF)
     from src.greeks.unified_greeks import ExoticAdapter, compute_greeks_unified
     from src.pricing_models.black_scholes import black_scholes
-    from src.pricing_models.exotic_options import (AsianOption, AutocallableOption, BarrierOption, CliquetOption,
+    from src.pricing_models.exotic_options import (AmericanOption, AsianOption, AutocallableOption, BarrierOption, CliquetOption,
                                                     LookbackOption, price_asian, price_barrier)
     from src.pricing_models.heston import HestonPricer
     from src.pricing_models.monte_carlo import MCMethod, MonteCarloPricer
     from src.pricing_models.monte_carlo_unified import MonteCarloPricerUni
 
     return dict(HestonPricer=HestonPricer, MonteCarloPricerUni=MonteCarloPricerUni, BarrierOption=BarrierOption, LookbackOption=LookbackOption, AutocallableOption=AutocallableOption,
-                CliquetOption=CliquetOption,
+                CliquetOption=CliquetOption, AmericanOption=AmericanOption,
                 price_barrier=price_barrier, MonteCarloPricer=MonteCarloPricer, MCMethod=MCMethod, black_scholes=black_scholes,
                 AsianOption=AsianOption, price_asian=price_asian,
                 compute_greeks_unified=compute_greeks_unified, ExoticAdapter=ExoticAdapter)
@@ -178,6 +178,15 @@ def main():
                          (dict(q=0.01), 20000, 100, 7)]:
         o = ref["CliquetOption"](S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, seed=42, **kw)
         doc["cliquet"].append(dict(kwargs=kw, n_paths=n, n_steps=m, n_periods=p_, seed=42, price=float(o.price(n, m, p_))))
+
+    # -- American LSM (exotic_options.py:227-305) -----------------------------------------------
+    doc["american"] = []
+    for (S, K, T, r, v, q), typ, n, m, deg in [((100.0, 100.0, 1.0, 0.05, 0.2, 0.0), "put", 50000, 50, 3), ((100.0, 100.0, 1.0, 0.05, 0.2, 0.0), "call", 50000, 50, 3),
+                                               ((90.0, 100.0, 0.5, 0.03, 0.3, 0.0), "put", 20000, 25, 2), ((100.0, 100.0, 1.0, 0.05, 0.2, 0.08), "call", 20000, 40, 3),
+                                               ((100.0, 100.0, 1.0, 0.05, 0.2, 0.0), "put", 5000, 1, 3)]:
+        o = ref["AmericanOption"](S=S, K=K, T=T, r=r, sigma=v, q=q, seed=42)
+        doc["american"].append(dict(params=[S, K, T, r, v, q], option_type=typ, n_paths=n, n_steps=m, poly_degree=deg, seed=42,
+                                    price=float(o.price(n, m, typ, deg))))
 
     # -- Heston (heston.py:131-255) ---------------------------------------------------------
     import warnings

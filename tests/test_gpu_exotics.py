@@ -183,3 +183,36 @@ def test_autocallable_and_cliquet_against_reference_golden(golden):
     # bounds: a cliquet pays between global_floor and global_cap of spot, discounted
     p = ol.CliquetOption(100.0, 100.0, 1.0, 0.05, 0.2, seed=1).price(20000)
     assert 0.0 <= p <= 30.0 * math.exp(-0.05)
+
+
+# ------------------------------------------------------------------ American (Longstaff-Schwartz)
+@pytest.mark.parametrize("S,K,T,r,v,q,call,N,M,deg", [
+    (100.0, 100.0, 1.0, 0.05, 0.2, 0.0, False, 50000, 50, 3), (90.0, 100.0, 0.5, 0.03, 0.3, 0.0, False, 20000, 25, 2),
+    (100.0, 100.0, 1.0, 0.05, 0.2, 0.08, True, 20000, 40, 3), (100.0, 100.0, 1.0, 0.05, 0.2, 0.0, False, 5000, 1, 3),
+    (100.0, 95.0, 1.0, 0.05, 0.25, 0.0, False, 7001, 13, 4), (100.0, 100.0, 1.0, 0.05, 0.2, 0.0, False, 3000, 2, 1),
+])
+def test_american_matches_same_stream_checker(S, K, T, r, v, q, call, N, M, deg):
+    """Same paths, same regression algebra: exercise decisions agree path by path, so the sums agree to rounding."""
+    st = _hip.american_lsm(S, K, T, r, v, q, call, N, M, deg, 42)
+    sx, sxx, n = po.american_lsm(S, K, T, r, v, q, call, N, M, deg, 42)
+    assert st.n == n
+    assert st.sum == pytest.approx(sx, rel=1e-7) and st.sumsq == pytest.approx(sxx, rel=1e-7)
+    assert st.price == pytest.approx(sx / n, rel=1e-7)
+
+
+def test_american_against_reference_golden_and_bounds(golden):
+    for c in golden["american"]:
+        S, K, T, r, v, q = c["params"]
+        o = ol.AmericanOption(S=S, K=K, T=T, r=r, sigma=v, q=q, seed=c["seed"])
+        price, se = o.price(c["n_paths"], c["n_steps"], c["option_type"], c["poly_degree"], return_error=True)
+        assert isinstance(price, np.float64)
+        assert abs(price - c["price"]) <= 3 * math.sqrt(2) * se, c
+    put = ol.AmericanOption(*P, seed=3).price(100_000, 50, "put")
+    assert put > ol.black_scholes(*P, "put") + 0.2                                   # early-exercise premium
+    assert put >= 0 and put < 100.0
+    call, se = ol.AmericanOption(*P, seed=3).price(100_000, 50, "call", return_error=True)
+    assert abs(call - ol.black_scholes(*P, "call")) <= 4 * se + 0.15                 # no dividends: never exercised early (LSM is biased low)
+    assert ol.price_american(100.0, 100.0, 1.0, 0.05, 0.2, "put", 20000, 7) == ol.AmericanOption(*P, seed=7).price(20000, 50, "put")
+    with pytest.raises(ol.AccelerationError):
+        _hip.american_lsm(*P, 0.0, False, 1000, 10, 7, 1)
+    assert math.isnan(ol.AmericanOption(-1.0, 100.0, 1.0, 0.05, 0.2, seed=1).price(100, 4))

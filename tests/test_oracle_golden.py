@@ -153,3 +153,10 @@ def test_autocallable_and_cliquet(golden):
         q = kw.pop("q", 0.0)
         got = orc.cliquet_price(100.0, 1.0, 0.05, 0.2, q, c["seed"], c["n_paths"], c["n_steps"], c["n_periods"], **kw)
         assert float(got) == c["price"], c
+
+
+def test_american_lsm(golden):
+    for c in golden["american"]:
+        S, K, T, r, v, q = c["params"]
+        got = orc.american_price(S, K, T, r, v, q, c["seed"], c["n_paths"], c["n_steps"], c["option_type"], c["poly_degree"])
+        assert float(got) == c["price"], c

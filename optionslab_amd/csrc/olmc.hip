@@ -790,11 +790,12 @@ extern "C" int olmc_autocallable(double S, double T, double r, double sigma, dou
     ac.log_autocall = std::log(autocall_barrier);
     ac.log_coupon = std::log(coupon_barrier);
     ac.log_ki = std::log(ki_barrier);
-    ac.coupon_rate = coupon_rate;
-    ac.T = T;
-    ac.r_dt = r * dt;
     ac.obs_freq = observation_freq;
     ac.n_obs = n_steps / observation_freq;                      // len(range(f, M + 1, f))
+    ac.coupon_unit = coupon_rate * T / ac.n_obs;                // coupon_rate * ((i+1)/n_obs) * T, accrued per observation (:459-460)
+    ac.final_coupon = coupon_rate * T;
+    ac.obs_df = std::exp(-r * dt * observation_freq);           // exp(-r t dt) at t = k f, built up by products (:461)
+    ac.final_df = std::exp(-r * T);
     const bool bad = poisoned(S, 1.0, T, r, sigma, q) || std::isnan(autocall_barrier + coupon_barrier + coupon_rate + ki_barrier);
     // payoffs are already discounted path by path (exotic_options.py:463, 489): no outer discount
     return run_structured(path_offset, n_local, n_steps, seed, antithetic, 0.0, T, bad, out,

@@ -552,7 +552,9 @@ __global__ __launch_bounds__(kBlock) void extrema_kernel(PathRange pr, ExtremaCo
 struct AutocallContract {
     double drift, vol;                     // per step
     double log_autocall, log_coupon, log_ki;
-    double coupon_rate, T, r_dt;           // r * dt
+    double coupon_unit;                    // coupon_rate * T / n_obs: coupon accrued per observation
+    double final_coupon;                   // coupon_rate * T
+    double obs_df, final_df;               // exp(-r dt obs_freq), exp(-r T)
     int32_t obs_freq, n_obs;
 };
 
@@ -567,27 +569,32 @@ __global__ __launch_bounds__(kBlock) void autocall_kernel(PathRange pr, Autocall
         const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
         double cum[2] = {0.0, 0.0}, mn[2] = {0.0, 0.0}, pay[2] = {0.0, 0.0};
         bool redeemed[2] = {false, false};
-        int32_t until_obs = c.obs_freq, obs_index = 0;
+        // wave-uniform running values of the redemption amount (1 + coupon_k) * exp(-r t_k): no exp, no division in the loop
+        int32_t until_obs = c.obs_freq;
+        double coupon = 0.0, df = 1.0;
         const int32_t blocks = (pr.n_steps + 3) >> 2;
         for (int32_t b = 0; b < blocks; ++b) {
             float z[4];
             raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1, z);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int32_t t = 4 * b + j + 1;                 // step just completed (1-based time index)
-                if (t <= pr.n_steps) {
+                if (4 * b + j < pr.n_steps) {
                     const double dz = vol * static_cast<double>(z[j]);
                     const bool observe = (--until_obs == 0);
-                    if (observe) { until_obs = c.obs_freq; ++obs_index; }
+                    double redemption = 0.0;
+                    if (observe) {
+                        until_obs = c.obs_freq;
+                        coupon += c.coupon_unit;
+                        df *= c.obs_df;
+                        redemption = (1.0 + coupon) * df;
+                    }
 #pragma unroll
                     for (int leg = 0; leg < LEGS; ++leg) {
                         cum[leg] += c.drift + (leg ? -dz : dz);
                         mn[leg] = fmin(mn[leg], cum[leg]);
-                        if (observe && !redeemed[leg] && cum[leg] >= c.log_autocall) {
-                            redeemed[leg] = true;
-                            const double coupon = c.coupon_rate * (static_cast<double>(obs_index) / c.n_obs) * c.T;
-                            pay[leg] = (1.0 + coupon) * exp(-c.r_dt * t);
-                        }
+                        const bool call_now = observe && !redeemed[leg] && cum[leg] >= c.log_autocall;
+                        pay[leg] = call_now ? redemption : pay[leg];
+                        redeemed[leg] = redeemed[leg] || call_now;
                     }
                 }
             }
@@ -597,9 +604,9 @@ __global__ __launch_bounds__(kBlock) void autocall_kernel(PathRange pr, Autocall
             double x = pay[leg];
             if (!redeemed[leg]) {
                 double fin = 1.0;
-                if (cum[leg] >= c.log_coupon) fin += c.coupon_rate * c.T;
+                if (cum[leg] >= c.log_coupon) fin += c.final_coupon;
                 if (mn[leg] <= c.log_ki && cum[leg] < 0.0) fin = exp(cum[leg]);
-                x = fin * exp(-c.r_dt * pr.n_steps);
+                x = fin * c.final_df;
             }
             acc[0] += x; acc[1] += x * x;
         }

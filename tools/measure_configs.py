@@ -73,6 +73,32 @@ def main():
            lambda: a.price(N, MA, "arithmetic", "call", antithetic=True, return_error=True), lambda r: dict(price=float(r[0]), std_error=r[1]), reps=10)
     report("geometric Asian call 1M x 1024", N * MA,
            lambda: a.price(N, MA, "geometric", "call", return_error=True), lambda r: dict(price=float(r[0]), std_error=r[1], closed_form=a.price_geometric_closed_form("call")), reps=10)
+    report("QMC (scrambled Sobol, 2^17 points x 64 dims)", 2**17 * 64, lambda: ol.MonteCarloPricer(2**17, 64, 42, ol.MCMethod.QMC).price(*ATM, "call", return_error=True),
+           lambda r: dict(price=r.price, std_error=r.std_error), reps=10)
+    uni = ol.MonteCarloPricerUni(100_000, 100, 42)
+    rng = __import__("numpy").random.default_rng(0)
+    nb = 256
+    Sb, Kb = rng.uniform(80, 120, nb), rng.uniform(80, 120, nb)
+    Tb, rb, vb = rng.uniform(0.25, 2, nb), rng.uniform(0, 0.08, nb), rng.uniform(0.1, 0.5, nb)
+    report("MonteCarloPricerUni.price_batch: 256 contracts x 100k x 100 (one launch)", nb * 100_000 * 100,
+           lambda: uni.price_batch(Sb, Kb, Tb, rb, vb, "call", 0.01), lambda a: dict(mean_price=float(a.mean())), reps=5)
+    report("MonteCarloPricerUni.delta_gamma (3 contracts CRN, one launch) 100k x 100", 100_000 * 100,
+           lambda: uni.delta_gamma(*ATM, "call", h=1.0, seed=5), lambda dg: dict(delta=dg[0], gamma=dg[1]))
+    report("barrier up-and-out call 1M x 252", N * M, lambda: ol.BarrierOption(*ATM, barrier=120.0, seed=42).price(N, M, "up-and-out", "call", return_error=True),
+           lambda r: dict(price=float(r[0]), std_error=r[1]), reps=10)
+    report("lookback floating call 1M x 252", N * M, lambda: ol.LookbackOption(*ATM, seed=42).price(N, M, "floating", "call", return_error=True),
+           lambda r: dict(price=float(r[0]), std_error=r[1]), reps=10)
+    report("autocallable 1M x 252, monthly observation", N * M, lambda: ol.AutocallableOption(*ATM, seed=42).price(N, M, 21, return_error=True),
+           lambda r: dict(price=float(r[0]), std_error=r[1]), reps=10)
+    report("cliquet 1M x 252, 12 periods", N * M, lambda: ol.CliquetOption(*ATM, seed=42).price(N, M, 12, return_error=True),
+           lambda r: dict(price=float(r[0]), std_error=r[1]), reps=10)
+    hes = ol.HestonPricer(2.0, 0.04, 0.3, -0.7, 0.04)
+    report("Heston full-truncation Euler 1M x 252", N * M, lambda: hes.price_monte_carlo(100.0, 100.0, 1.0, 0.05, 0.0, "call", N, M, 42, return_error=True),
+           lambda r: dict(price=float(r[0]), std_error=r[1]), reps=10)
+    report("American put LSM 50k x 50 (reference defaults), degree 3", 50_000 * 50, lambda: ol.AmericanOption(*ATM, seed=42).price(50_000, 50, "put", 3, return_error=True),
+           lambda r: dict(price=float(r[0]), std_error=r[1]), reps=10)
+    report("American put LSM 1M x 50, degree 3", N * 50, lambda: ol.AmericanOption(*ATM, seed=42).price(N, 50, "put", 3, return_error=True),
+           lambda r: dict(price=float(r[0]), std_error=r[1]), reps=5)
     p8 = ol.MonteCarloPricer(8_000_000, M, 42)
     report("C5 per-GPU shard: european call 8M x 252", 8_000_000 * M, lambda: p8.price(*ATM, "call", return_error=True),
            lambda r: dict(price=r.price, std_error=r.std_error, z_vs_bs=(r.price - BS) / r.std_error), reps=10)

@@ -14,8 +14,9 @@ def short(name):
 
 def main(root):
     print(f"# rocprofv3 summary of {root}")
-    for f in glob.glob(os.path.join(root, "stats", "*", "*_kernel_stats.csv")):
-        print("\n## kernel-trace --stats")
+    for sub, title in (("stats", "bench.py --streams 1 (launches back to back, no overlap)"), ("stats_default", "bench.py default (8 streams; the serial pass is included, so durations mix overlapped and serial launches)")):
+      for f in glob.glob(os.path.join(root, sub, "*", "*_kernel_stats.csv")):
+        print(f"\n## kernel-trace --stats: {title}")
         for row in csv.DictReader(open(f)):
             print(f"{short(row['Name']):70s} calls {row['Calls']:>5s}  avg_ns {float(row['AverageNs']):>12.1f}  min {row['MinNs']:>8s}  max {row['MaxNs']:>8s}  {row['Percentage']}%")
     for p in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):

@@ -99,8 +99,8 @@ int ctx_create(int device, DeviceCtx** out) {
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& sl : c->slots) {
         HIP_TRY(hipMalloc(&sl.group_rows, sizeof(double) * kMaxNV * kMaxGroups));
-        HIP_TRY(hipMalloc(&sl.counters, sizeof(uint32_t) * (kMaxGroups + 1)));
-        HIP_TRY(hipMemset(sl.counters, 0, sizeof(uint32_t) * (kMaxGroups + 1)));
+        HIP_TRY(hipMalloc(&sl.counters, sizeof(uint32_t) * (kMaxGroups + 1) * kCounterStride));
+        HIP_TRY(hipMemset(sl.counters, 0, sizeof(uint32_t) * (kMaxGroups + 1) * kCounterStride));
         HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
     HIP_TRY(hipHostMalloc(&c->h_result, sizeof(double) * (kMaxNV + 1), hipHostMallocMapped));
@@ -173,7 +173,7 @@ int make_ws(DeviceCtx* c, hipStream_t stream, int32_t grid, int nv, double* d_ou
 void ws_recover(DeviceCtx* c) {
     (void)hipDeviceSynchronize();
     (void)hipGetLastError();
-    for (auto& sl : c->slots) (void)hipMemset(sl.counters, 0, sizeof(uint32_t) * (kMaxGroups + 1));
+    for (auto& sl : c->slots) (void)hipMemset(sl.counters, 0, sizeof(uint32_t) * (kMaxGroups + 1) * kCounterStride);
 }
 
 // Call right after launching a kernel that uses the workspace handed out by make_ws.
@@ -483,7 +483,7 @@ extern "C" int olmc_european_multi(const olmc_option* opts, const uint32_t* tags
     const int32_t bpo = static_cast<int32_t>(std::min<int64_t>((n_paths + kBlock - 1) / kBlock, 1024));   // workgroups per contract
     auto align = [](size_t b) { return (b + 255) / 256 * 256; };
     const size_t b_opts = align(sizeof(MultiOption) * n_options), b_out = align(sizeof(double) * 2 * n_options);
-    const size_t b_rows = align(sizeof(double) * 2 * bpo * n_options), b_cnt = align(sizeof(uint32_t) * n_options);
+    const size_t b_rows = align(sizeof(double) * 2 * bpo * n_options), b_cnt = align(sizeof(uint32_t) * n_options * kMultiCounterStride);
     const size_t need = b_opts + b_out + b_rows + b_cnt;
     if (need > c->multi_bytes) {
         if (c->d_multi) HIP_TRY(hipFree(c->d_multi));
@@ -505,7 +505,7 @@ extern "C" int olmc_european_multi(const olmc_option* opts, const uint32_t* tags
         h[j].pad = 0;
     }
     HIP_TRY(hipMemcpyAsync(d_opts, h.data(), sizeof(MultiOption) * n_options, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * n_options, c->stream));   // layout moves with n_options
+    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * n_options * kMultiCounterStride, c->stream));   // layout moves with n_options
     const PathRange pr = make_range(0, n_paths, n_steps, seed);
     EventPair ep{};
     if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }

@@ -192,11 +192,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 // sc1 payload + drained vmcnt before the agent-scope add on the producer, agent acquire
 // fence after the returned add on the consumer.  Only wave 0 of a workgroup takes part.
 constexpr int kGroupBlocks = 256;
+constexpr int kCounterStride = 64;     // uint32 words between ticket counters: one 256-B granule each.  Packed
+                                       // into one line, 3,907 tickets serialised at ~88 atomics/us (a 44 us floor
+                                       // under every 1M-path launch, whatever its step count)
 
 struct ReduceWs {
     double* block_rows;     // [gridDim.x][NV]
     double* group_rows;     // [n_groups][NV]
-    uint32_t* counters;     // [n_groups + 1], last = top counter
+    uint32_t* counters;     // [(n_groups + 1) * kCounterStride], one counter per stride, last = top counter
     double* out;            // [NV] (+1 when tail >= 0)
     double tail;            // if >= 0, written to out[NV] (the sample count of the triple)
 };
@@ -237,7 +240,7 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws) {
     if (lane < NV) store_sc1(ws.block_rows + static_cast<size_t>(blockIdx.x) * NV + lane, v);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t ticket = 0;
-    if (lane == 0) ticket = __hip_atomic_fetch_add(ws.counters + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) ticket = __hip_atomic_fetch_add(ws.counters + static_cast<size_t>(group) * kCounterStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     if (ticket != static_cast<uint32_t>(group_size - 1)) return;
 
@@ -246,8 +249,8 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws) {
     if (lane < NV) store_sc1(ws.group_rows + static_cast<size_t>(group) * NV + lane, g);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {
-        __hip_atomic_store(ws.counters + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ticket = __hip_atomic_fetch_add(ws.counters + n_groups, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ws.counters + static_cast<size_t>(group) * kCounterStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __hip_atomic_fetch_add(ws.counters + static_cast<size_t>(n_groups) * kCounterStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     if (ticket != static_cast<uint32_t>(n_groups - 1)) return;
@@ -257,7 +260,7 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws) {
     if (lane < NV) ws.out[lane] = total;
     if (lane == 0) {
         if (ws.tail >= 0.0) ws.out[NV] = ws.tail;
-        __hip_atomic_store(ws.counters + n_groups, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ws.counters + static_cast<size_t>(n_groups) * kCounterStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -360,6 +363,8 @@ __global__ __launch_bounds__(kBlock) void european_path_kernel(PathRange pr, Con
 // its own Philox stream (counter word 3 = its tag) like the reference's per-option slice of Z
 // (:320) / per-option seed (:176), and its own last-arriver reduction: the workgroup that takes
 // the last ticket of contract j sums that contract's rows in index order and writes out[j].
+constexpr int kMultiCounterStride = 32;   // uint32 words between per-contract ticket counters (128 B)
+
 struct MultiOption {
     double a, vol, strike, sign;    // as Contract
     uint32_t tag;                   // stream tag: equal tags => common random numbers
@@ -399,13 +404,13 @@ __global__ __launch_bounds__(kBlock) void european_multi_kernel(PathRange pr, co
     if (lane < 2) store_sc1(rows + static_cast<size_t>(blockIdx.x) * 2 + lane, v);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t ticket = 0;
-    if (lane == 0) ticket = __hip_atomic_fetch_add(counters + opt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) ticket = __hip_atomic_fetch_add(counters + static_cast<size_t>(opt) * kMultiCounterStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     if (ticket != gridDim.x - 1) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const double total = wave_rows_sum<2>(rows, static_cast<int32_t>(gridDim.x));
     if (lane < 2) out[opt * 2 + lane] = total;
-    if (lane == 0) __hip_atomic_store(counters + opt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(counters + static_cast<size_t>(opt) * kMultiCounterStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Asian option: running arithmetic sum of S_t (or sum of ln S_t) over t = 1..M kept in

@@ -246,6 +246,14 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws) {
 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     const double g = wave_rows_sum<NV>(ws.block_rows + static_cast<size_t>(group) * kGroupBlocks * NV, group_size);
+    if (n_groups == 1) {            // <= 65,536 paths (the interactive sizes): the only group IS the total, skip level 2
+        if (lane < NV) ws.out[lane] = g;
+        if (lane == 0) {
+            if (ws.tail >= 0.0) ws.out[NV] = ws.tail;
+            __hip_atomic_store(ws.counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
     if (lane < NV) store_sc1(ws.group_rows + static_cast<size_t>(group) * NV + lane, g);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) {

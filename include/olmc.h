@@ -212,7 +212,8 @@ int olmc_cliquet(double S, double T, double r, double sigma, double q, double lo
  * Replaces AmericanOption.price (src/pricing_models/exotic_options.py:227-305): stores the path
  * matrix in HBM (time-major), one launch per exercise date doing {exercise decision of the later
  * date, one-step discount, regression moments of this date} with the fused deterministic
- * reduction, and the small normal-equation solve on the host in between.  Polynomial basis in
+ * reduction; the launch's last workgroup solves the small normal equations and leaves the
+ * coefficients in device memory for the next launch (no host round trip per date).  Polynomial basis in
  * S/K of degree poly_degree in [1, 4] (the reference's default is 3).  out->price = mean of the
  * time-0 cash flows; single device. */
 int olmc_american_lsm(double S, double K, double T, double r, double sigma, double q, int is_call,

@@ -826,45 +826,13 @@ extern "C" int olmc_cliquet(double S, double T, double r, double sigma, double q
 }
 
 // ================================================================ American (LSM) ====
-namespace {
-// Solve the (d+1)x(d+1) normal equations  sum_l M[k+l] beta_l = R[k]  (Gaussian elimination with
-// partial pivoting, long double).  Returns false when the system is numerically singular.
-bool lsm_solve(const double* moments, const double* rhs, int degree, double* beta) {
-    const int n = degree + 1;
-    long double a[kLsmMaxDegree + 1][kLsmMaxDegree + 2];
-    for (int k = 0; k < n; ++k) {
-        for (int l = 0; l < n; ++l) a[k][l] = moments[k + l];
-        a[k][n] = rhs[k];
-    }
-    for (int col = 0; col < n; ++col) {
-        int piv = col;
-        for (int row = col + 1; row < n; ++row)
-            if (fabsl(a[row][col]) > fabsl(a[piv][col])) piv = row;
-        if (!(fabsl(a[piv][col]) > 1e-280L)) return false;
-        if (piv != col)
-            for (int l = 0; l <= n; ++l) std::swap(a[piv][l], a[col][l]);
-        for (int row = col + 1; row < n; ++row) {
-            const long double f = a[row][col] / a[col][col];
-            for (int l = col; l <= n; ++l) a[row][l] -= f * a[col][l];
-        }
-    }
-    for (int k = n - 1; k >= 0; --k) {
-        long double v = a[k][n];
-        for (int l = k + 1; l < n; ++l) v -= a[k][l] * beta[l];
-        beta[k] = static_cast<double>(v / a[k][k]);
-    }
-    for (int k = n; k <= kLsmMaxDegree; ++k) beta[k] = 0.0;
-    return true;
-}
-}  // namespace
-
 extern "C" int olmc_american_lsm(double S, double K, double T, double r, double sigma, double q, int is_call,
                                  int64_t n_paths, int32_t n_steps, int32_t poly_degree, uint64_t seed, olmc_stats* out) {
     if (!out) return fail(OLMC_ERR_ARG, "null pointer");
     if (poly_degree < 1 || poly_degree > kLsmMaxDegree) return fail(OLMC_ERR_ARG, "poly_degree must be in [1, 4]");
     int rc = check_paths(0, n_paths, n_steps);
     if (rc) return rc;
-    const double path_bytes = 8.0 * static_cast<double>(n_paths) * (n_steps + 2.0);
+    const double path_bytes = 8.0 * static_cast<double>(n_paths) * (n_steps + 2.0) + 256.0;
     if (path_bytes > 64e9) return fail(OLMC_ERR_ARG, "path matrix would exceed 64 GB: lower n_paths or n_steps");
     DeviceCtx* c = nullptr;
     rc = ctx_get(&c);
@@ -874,6 +842,7 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
     if (rc) return rc;
     double* d_paths = static_cast<double*>(c->d_bulk);                                  // [n_steps + 1][n_paths]
     double* d_cash = d_paths + static_cast<size_t>(n_steps + 1) * n_paths;              // [n_paths]
+    LsmCoeffs* d_coef = reinterpret_cast<LsmCoeffs*>(d_cash + n_paths);                  // fit handed from launch to launch
     LsmContract lc;
     const double dt = T / n_steps;                      // exotic_options.py:54-56, 260-261
     lc.log_s0 = std::log(S);
@@ -886,30 +855,27 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
     lc.degree = poly_degree;
     lc.n_steps = n_steps;
     const PathRange pr = make_range(0, n_paths, n_steps, seed);
-    const int32_t grid = grid_for(n_paths);
+    const int32_t path_grid = grid_for(n_paths);
+    // the per-date launches do ~30 flops per path and then reduce 16 sums per wave: few, fat workgroups
+    const int32_t grid = std::min<int32_t>(path_grid, 2 * c->cus);
     EventPair ep{};
     if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
-    hipLaunchKernelGGL((lsm_paths_kernel<0>), dim3(grid), dim3(kBlock), 0, c->stream, pr, lc, d_paths);
+    hipLaunchKernelGGL((lsm_paths_kernel<0>), dim3(path_grid), dim3(kBlock), 0, c->stream, pr, lc, d_paths);
     HIP_TRY(hipGetLastError());
-    LsmCoeffs coef{};
-    coef.valid = 0;
+    // every launch reads the fit of the later date from d_coef and (its last workgroup) writes its own fit there:
+    // stream order is the only synchronisation, the host waits once at the end
     int32_t init = 1;
     for (int32_t t_fit = n_steps - 1; t_fit >= 0; --t_fit) {
         ReduceWs ws;
         rc = make_ws(c, c->stream, grid, kLsmNV, c->d_result, -1.0, &ws);
         if (rc) return rc;
-        hipLaunchKernelGGL(lsm_step_kernel, dim3(grid), dim3(kBlock), 0, c->stream, n_paths, lc, coef, t_fit, init, d_paths, d_cash, ws);
+        hipLaunchKernelGGL(lsm_step_kernel, dim3(grid), dim3(kBlock), 0, c->stream, n_paths, lc, d_coef, t_fit, init, d_paths, d_cash, ws);
         rc = after_launch(c, c->stream);
         if (rc) return rc;
-        rc = sync_or_recover(c, c->stream);
-        if (rc) return rc;
         init = 0;
-        if (t_fit >= 1) {                               // fit the continuation value at date t_fit (:279-290)
-            const double* h = c->h_result;
-            coef.valid = 0;
-            if (h[kLsmNV - 2] > poly_degree + 1) coef.valid = lsm_solve(h, h + 2 * kLsmMaxDegree + 1, poly_degree, coef.beta) ? 1 : 0;
-        }
     }
+    rc = sync_or_recover(c, c->stream);
+    if (rc) return rc;
     if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
     // the time-0 cash flows are already discounted step by step (:302-304): no outer factor
     finish_stats(c->h_result[0], c->h_result[1], n_paths, 0.0, T, out);

@@ -221,16 +221,33 @@ __device__ __forceinline__ double wave_rows_sum(const double* src, int32_t rows)
     const int lane = threadIdx.x & (kWave - 1);
     const int c = lane % NVP, sub = lane / NVP;
     double v = 0.0;
-    if (c < NV)
-        for (int32_t row = sub; row < rows; row += SUBS) v += load_sc1(src + static_cast<size_t>(row) * NV + c);
+    if (c < NV) {
+        constexpr int kBatch = 8;      // loads issued back to back, then added in row order: the chain is latency-bound
+        for (int32_t row = sub; row < rows; row += SUBS * kBatch) {
+            double t[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int32_t rj = row + j * SUBS;
+                t[j] = rj < rows ? load_sc1(src + static_cast<size_t>(rj) * NV + c) : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) v += t[j];
+        }
+    }
 #pragma unroll
     for (int off = kWave / 2; off >= NVP; off >>= 1) v += __shfl_down(v, off, kWave);
     return v;   // valid in lanes < NV
 }
 
 // `v` = this workgroup's sum of component threadIdx.x (threads < NV of wave 0).  Wave 0 only.
-template <int NV>
-__device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws) {
+// `done(total)` runs in the ONE wave that holds the grid totals (lane c < NV has component c),
+// right after out[] is written: device-side post-processing without another launch.
+struct NoEpilogue {
+    __device__ __forceinline__ void operator()(double) const {}
+};
+
+template <int NV, typename Epilogue = NoEpilogue>
+__device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws, Epilogue done = Epilogue()) {
     const int lane = threadIdx.x;       // wave 0: lane == threadIdx.x
     const int32_t n_blocks = static_cast<int32_t>(gridDim.x);
     const int32_t n_groups = (n_blocks + kGroupBlocks - 1) / kGroupBlocks;
@@ -252,6 +269,7 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws) {
             if (ws.tail >= 0.0) ws.out[NV] = ws.tail;
             __hip_atomic_store(ws.counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        done(g);
         return;
     }
     if (lane < NV) store_sc1(ws.group_rows + static_cast<size_t>(group) * NV + lane, g);
@@ -270,12 +288,13 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws) {
         if (ws.tail >= 0.0) ws.out[NV] = ws.tail;
         __hip_atomic_store(ws.counters + static_cast<size_t>(n_groups) * kCounterStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    done(total);
 }
 
 // One-thread-per-path kernels: fold NV per-thread values over the workgroup (fixed order,
 // LDS-staged across the four waves), then into the grid reduction.
-template <int NV>
-__device__ __forceinline__ void block_then_grid_reduce(const double (&v)[NV], const ReduceWs& ws) {
+template <int NV, typename Epilogue = NoEpilogue>
+__device__ __forceinline__ void block_then_grid_reduce(const double (&v)[NV], const ReduceWs& ws, Epilogue done = Epilogue()) {
     __shared__ double stage[kWavesPerBlock][NV];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
@@ -292,7 +311,7 @@ __device__ __forceinline__ void block_then_grid_reduce(const double (&v)[NV], co
 #pragma unroll
         for (int w = 1; w < kWavesPerBlock; ++w) s += stage[w][threadIdx.x];
     }
-    grid_reduce<NV>(s, ws);
+    grid_reduce<NV, Epilogue>(s, ws, done);
 }
 
 // ------------------------------------------------------------- contracts ----
@@ -734,15 +753,89 @@ struct LsmCoeffs {
 
 __device__ __forceinline__ double lsm_intrinsic(const LsmContract& c, double s) { return fmax(c.sign * (s - c.strike), 0.0); }
 
+// Runs in the wave that holds the grid totals of one exercise date: lane m < 2d+1 has sum x^m,
+// lane 9+k has sum x^k cf, lane 14 the in-the-money count.  Lane 0 gathers them, solves the
+// (d+1)x(d+1) normal equations (Gaussian elimination, partial pivoting, fp64 -- the moments of
+// x = S/K in (0, ~2) are benign) and publishes the coefficients for the NEXT launch, which is
+// ordered behind this one on the stream: no host round trip per exercise date.
+struct LsmFit {
+    LsmCoeffs* coef;
+    int32_t degree;
+    __device__ __forceinline__ void operator()(double total) const {
+        double sums[kLsmNV];
+#pragma unroll
+        for (int k = 0; k < kLsmNV; ++k) sums[k] = __shfl(total, k, kWave);
+        if (threadIdx.x != 0) return;
+        const int n = degree + 1;
+        double a[kLsmMaxDegree + 1][kLsmMaxDegree + 2];
+#pragma unroll
+        for (int k = 0; k <= kLsmMaxDegree; ++k) {
+#pragma unroll
+            for (int l = 0; l <= kLsmMaxDegree; ++l) a[k][l] = sums[k + l];
+            a[k][kLsmMaxDegree + 1] = sums[2 * kLsmMaxDegree + 1 + k];
+        }
+        bool ok = sums[kLsmNV - 2] > static_cast<double>(degree + 1);       // np.sum(itm) > poly_degree + 1 (:279)
+        // unknowns beyond `degree` are pinned to 0 by turning their rows/columns into the identity
+#pragma unroll
+        for (int k = 0; k <= kLsmMaxDegree; ++k)
+            if (k >= n) {
+#pragma unroll
+                for (int l = 0; l <= kLsmMaxDegree + 1; ++l) a[k][l] = 0.0;
+#pragma unroll
+                for (int l = 0; l <= kLsmMaxDegree; ++l) a[l][k] = 0.0;
+                a[k][k] = 1.0;
+            }
+#pragma unroll
+        for (int col = 0; col <= kLsmMaxDegree; ++col) {
+            int piv = col;
+#pragma unroll
+            for (int row = 0; row <= kLsmMaxDegree; ++row)
+                if (row > col && fabs(a[row][col]) > fabs(a[piv][col])) piv = row;
+#pragma unroll
+            for (int row = 0; row <= kLsmMaxDegree; ++row)            // swap rows piv <-> col without dynamic indexing
+                if (row > col && row == piv) {
+#pragma unroll
+                    for (int l = 0; l <= kLsmMaxDegree + 1; ++l) { const double tmp = a[row][l]; a[row][l] = a[col][l]; a[col][l] = tmp; }
+                }
+            if (!(fabs(a[col][col]) > 1e-280)) ok = false;
+            const double inv = 1.0 / a[col][col];
+#pragma unroll
+            for (int row = 0; row <= kLsmMaxDegree; ++row)
+                if (row > col) {
+                    const double f = a[row][col] * inv;
+#pragma unroll
+                    for (int l = 0; l <= kLsmMaxDegree + 1; ++l)
+                        if (l >= col) a[row][l] -= f * a[col][l];
+                }
+        }
+        double beta[kLsmMaxDegree + 1];
+#pragma unroll
+        for (int k = kLsmMaxDegree; k >= 0; --k) {
+            double v = a[k][kLsmMaxDegree + 1];
+#pragma unroll
+            for (int l = 0; l <= kLsmMaxDegree; ++l)
+                if (l > k) v -= a[k][l] * beta[l];
+            beta[k] = v / a[k][k];
+        }
+#pragma unroll
+        for (int k = 0; k <= kLsmMaxDegree; ++k) coef->beta[k] = ok ? beta[k] : 0.0;
+        coef->valid = ok ? 1 : 0;
+    }
+};
+
 // t_fit: the date whose moments are accumulated (>= 1); the date finished first is t_fit + 1
 // (skipped when t_fit + 1 == M: the terminal payoff needs no regression).  init != 0: cash flow
-// starts as the terminal intrinsic value.
-__global__ __launch_bounds__(kBlock) void lsm_step_kernel(int64_t n, LsmContract c, LsmCoeffs prev, int32_t t_fit, int32_t init,
-                                                          const double* __restrict__ paths, double* __restrict__ cash,
-                                                          ReduceWs ws) {
+// starts as the terminal intrinsic value.  `coef` is read at entry (fit of date t_fit + 1, written
+// by the previous launch) and overwritten at the very end by this launch's fit.
+__global__ __launch_bounds__(kBlock) void lsm_step_kernel(int64_t n, LsmContract c, LsmCoeffs* __restrict__ coef, int32_t t_fit,
+                                                          int32_t init, const double* __restrict__ paths,
+                                                          double* __restrict__ cash, ReduceWs ws) {
     double acc[kLsmNV];
 #pragma unroll
     for (int k = 0; k < kLsmNV; ++k) acc[k] = 0.0;
+    LsmCoeffs prev;
+    prev.valid = 0;
+    if (!init) prev = *coef;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
         double cf;
@@ -780,7 +873,8 @@ __global__ __launch_bounds__(kBlock) void lsm_step_kernel(int64_t n, LsmContract
             acc[1] += cf * cf;
         }
     }
-    block_then_grid_reduce<kLsmNV>(acc, ws);
+    if (t_fit >= 1) block_then_grid_reduce<kLsmNV>(acc, ws, LsmFit{coef, c.degree});
+    else block_then_grid_reduce<kLsmNV>(acc, ws);
 }
 
 // Heston full-truncation Euler (src/pricing_models/heston.py:184-255): per step two normals

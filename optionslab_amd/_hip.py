@@ -8,7 +8,9 @@ for exactly this, src/exceptions/montecarlo_exceptions.py:105-131).
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 import threading
 from typing import List, Optional, Sequence, Tuple
 
@@ -85,11 +87,35 @@ _lib: Optional[C.CDLL] = None
 _initialised = False
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, unversioned soname).  If
+    libolmc initialises the system runtime first, a later `import torch` in the same process brings up a
+    SECOND runtime and reports "no GPUs found"; with torch's copy loaded globally first, libolmc's HIP symbols
+    bind to it (global scope wins) and the process has one runtime whichever is imported first -- needed
+    because torch streams / device buffers are handed to olmc_european_shard_dev.  torch itself is NOT
+    imported here.  OLMC_SYSTEM_HIP=1 opts out."""
+    if "torch" in sys.modules or os.environ.get("OLMC_SYSTEM_HIP") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library() -> C.CDLL:
     """dlopen libolmc.so and bind every prototype (no device is touched)."""
     global _lib
     with _lock:
         if _lib is None:
+            _share_hip_runtime_with_torch()
             if not os.path.exists(LIBRARY_PATH):
                 raise AccelerationError(
                     f"{LIBRARY_PATH} is not built (run `python -m optionslab_amd.build`); there is no CPU fallback",

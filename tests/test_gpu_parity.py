@@ -430,3 +430,29 @@ def test_normal_stream_quality_large_sample():
     # tail: P(|z| > 4) = 6.33e-5
     tail = np.mean(np.abs(flat) > 4.0)
     assert abs(tail - 6.334e-5) < 5 * math.sqrt(6.334e-5 / n)
+
+
+# ------------------------------------------------------------------ one-process-per-GPU entry (torch = plumbing)
+def test_sharded_price_through_process_group_single_rank():
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        price, se, n = ol.sharding.price_european_sharded(*ATM, "call", 0.0, 300_000, 21, 11)
+        whole = _hip.european(*ATM, 0.0, True, 300_000, 21, 11)
+        assert (price, n) == (whole.price, whole.n) and se == pytest.approx(whole.std_error, rel=1e-12)
+        # on a non-default torch stream too: the kernel is ordered on the stream it is given
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            buf = torch.empty(3, dtype=torch.float64, device="cuda")
+            p2, _, _ = ol.sharding.price_european_sharded(*ATM, "call", 0.0, 300_000, 21, 11, device_buffer=buf)
+        assert p2 == price
+    finally:
+        dist.destroy_process_group()

@@ -80,19 +80,18 @@ void ol_normals(uint64_t seed, int64_t path0, int64_t n_paths, int32_t n_steps, 
  * gets n/4 blocks, the first n%4 one more); inside a chunk fp32 within a Philox block and
  * across a group of four blocks, fp64 across groups, a trailing partial block on its own;
  * total = (((c0 + c1) + c2) + c3) * sqrt(2 ln 2). */
-/* sum of a block's four RAW normals in the device's factored form:
- * rad_a (cos_a + sin_a) + rad_b (cos_b + sin_b), every intermediate rounded to fp32. */
-static float raw_block_sum4(uint64_t path, uint32_t b, uint64_t seed) {
+/* acc + a block's four RAW normals in the device's factored form:
+ * fmaf(rad_b, cos_b + sin_b, fmaf(rad_a, cos_a + sin_a, acc)), every intermediate rounded to fp32. */
+static float raw_block_accumulate(float acc, uint64_t path, uint32_t b, uint64_t seed) {
     uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), b, 0u};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, w[4];
     ol_philox4x32_10(ctr, key, w);
-    float p[2];
     for (int h = 0; h < 2; ++h) {
         const double ua = unit_open(w[2 * h]), ang = 6.283185307179586476925 * ((double)(w[2 * h + 1] & 0x007FFFFFu) * 0x1p-23);
         const float rad = (float)sqrt(-log2(ua)), c = (float)cos(ang), sn = (float)sin(ang);
-        p[h] = rad * (c + sn);
+        acc = fmaf(rad, c + sn, acc);
     }
-    return p[0] + p[1];
+    return acc;
 }
 
 static double chunk_normal_sum(uint64_t path, int32_t b_begin, int32_t b_end, int32_t n_steps, uint64_t seed) {
@@ -100,13 +99,13 @@ static double chunk_normal_sum(uint64_t path, int32_t b_begin, int32_t b_end, in
     double acc = 0.0;
     int32_t b = b_begin, rem = n_steps & 3;
     for (; b + 4 <= full_end; b += 4) {
-        float s = raw_block_sum4(path, (uint32_t)b, seed);
-        for (int j = 1; j < 4; ++j) s += raw_block_sum4(path, (uint32_t)(b + j), seed);
+        float s = 0.0f;
+        for (int j = 0; j < 4; ++j) s = raw_block_accumulate(s, path, (uint32_t)(b + j), seed);
         acc += (double)s;
     }
     if (b < full_end) {
-        float s = raw_block_sum4(path, (uint32_t)b, seed);
-        for (++b; b < full_end; ++b) s += raw_block_sum4(path, (uint32_t)b, seed);
+        float s = 0.0f;
+        for (; b < full_end; ++b) s = raw_block_accumulate(s, path, (uint32_t)b, seed);
         acc += (double)s;
     }
     if (rem && b < b_end) {

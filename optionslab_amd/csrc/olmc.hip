@@ -57,7 +57,7 @@ struct DeviceCtx {
         double* block_rows = nullptr;  // [cap] doubles, grown on demand (grid x NV)
         size_t cap = 0;
         double* group_rows = nullptr;  // [kMaxGroups][kMaxNV]
-        uint32_t* counters = nullptr;  // [kMaxGroups + 1], zero between launches (self-resetting)
+        uint32_t* counters = nullptr;  // [(kMaxGroups + 1) * kCounterStride], zero between launches (self-resetting)
         hipEvent_t done = nullptr;     // recorded after the slot's latest launch
         bool used = false;
     };
@@ -83,6 +83,37 @@ DeviceCtx* g_ctx[kMaxDevices] = {};
 int g_default_device = -1;
 bool g_profile = false;
 
+int ctx_allocate(DeviceCtx* c) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& sl : c->slots) {
+        HIP_TRY(hipMalloc(&sl.group_rows, sizeof(double) * kMaxNV * kMaxGroups));
+        HIP_TRY(hipMalloc(&sl.counters, sizeof(uint32_t) * (kMaxGroups + 1) * kCounterStride));
+        HIP_TRY(hipMemset(sl.counters, 0, sizeof(uint32_t) * (kMaxGroups + 1) * kCounterStride));
+        HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    }
+    HIP_TRY(hipHostMalloc(&c->h_result, sizeof(double) * (kMaxNV + 1), hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_result), c->h_result, 0));
+    return OLMC_OK;
+}
+
+// Frees whatever a context owns (tolerates partially built contexts) and deletes it.
+void ctx_release(DeviceCtx* c) {
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& ep : c->ev_pending) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
+    for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
+    if (c->d_bulk) (void)hipFree(c->d_bulk);
+    if (c->d_multi) (void)hipFree(c->d_multi);
+    for (auto& sl : c->slots) {
+        if (sl.block_rows) (void)hipFree(sl.block_rows);
+        if (sl.group_rows) (void)hipFree(sl.group_rows);
+        if (sl.counters) (void)hipFree(sl.counters);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (c->h_result) (void)hipHostFree(c->h_result);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
 int ctx_create(int device, DeviceCtx** out) {
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -96,15 +127,11 @@ int ctx_create(int device, DeviceCtx** out) {
     DeviceCtx* c = new DeviceCtx();
     c->device = device;
     c->cus = prop.multiProcessorCount;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    for (auto& sl : c->slots) {
-        HIP_TRY(hipMalloc(&sl.group_rows, sizeof(double) * kMaxNV * kMaxGroups));
-        HIP_TRY(hipMalloc(&sl.counters, sizeof(uint32_t) * (kMaxGroups + 1) * kCounterStride));
-        HIP_TRY(hipMemset(sl.counters, 0, sizeof(uint32_t) * (kMaxGroups + 1) * kCounterStride));
-        HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    const int rc = ctx_allocate(c);
+    if (rc) {                       // do not leak a half-built context
+        ctx_release(c);
+        return rc;
     }
-    HIP_TRY(hipHostMalloc(&c->h_result, sizeof(double) * (kMaxNV + 1), hipHostMallocMapped));
-    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_result), c->h_result, 0));
     *out = c;
     return OLMC_OK;
 }
@@ -378,22 +405,8 @@ extern "C" int olmc_shutdown(void) {
     for (int d = 0; d < kMaxDevices; ++d) {
         DeviceCtx* c = g_ctx[d];
         if (!c) continue;
-        if (hipSetDevice(d) == hipSuccess) {
-            (void)hipStreamSynchronize(c->stream);
-            for (auto& ep : c->ev_pending) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
-            for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
-            if (c->d_bulk) (void)hipFree(c->d_bulk);
-            if (c->d_multi) (void)hipFree(c->d_multi);
-            for (auto& sl : c->slots) {
-                if (sl.block_rows) (void)hipFree(sl.block_rows);
-                (void)hipFree(sl.group_rows);
-                (void)hipFree(sl.counters);
-                (void)hipEventDestroy(sl.done);
-            }
-            (void)hipHostFree(c->h_result);
-            (void)hipStreamDestroy(c->stream);
-        }
-        delete c;
+        if (hipSetDevice(d) == hipSuccess) ctx_release(c);
+        else delete c;
         g_ctx[d] = nullptr;
     }
     g_default_device = -1;

@@ -456,3 +456,23 @@ def test_sharded_price_through_process_group_single_rank():
         assert p2 == price
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ large sizes (size-independent properties)
+def test_large_path_count_grid_stride_and_long_paths():
+    S, K, T, r, v = ATM
+    # 2^28 paths: beyond 2^18 workgroups the kernel grid-strides; se ~ 6e-4, so this is a sharp accuracy check
+    st = _hip.european(S, K, T, r, v, 0.0, True, 1 << 28, 8, 5)
+    assert st.n == 1 << 29
+    assert abs(st.price - BS_CALL) <= 3.5 * st.std_error and st.std_error < 1e-3
+    halves = [_hip.european(S, K, T, r, v, 0.0, True, 1 << 27, 8, 5, True, path_offset=k << 27) for k in range(2)]
+    comb = _hip.combine_stats([(h.sum, h.sumsq, h.n) for h in halves], r, T)
+    assert comb.price == pytest.approx(st.price, rel=1e-12)
+    # very long paths: 100,000 steps (25,000 Philox blocks per path)
+    lp = _hip.european(S, K, T, r, v, 0.0, False, 20_000, 100_000, 3)
+    assert abs(lp.price - ol.black_scholes(S, K, T, r, v, "put")) <= 3.5 * lp.std_error
+    # the fused 14-contract Greeks at the 64M-path scale of config 5 on one GPU stay within tight bands of Black-Scholes
+    g = ol.MonteCarloPricer(16_000_000, 16, 9).greeks(*ATM, "call", include_second_order=False)
+    ex = orc.bs_greeks(*ATM, "call")
+    assert g["delta"] == pytest.approx(ex["delta"], abs=2e-4) and g["vega"] == pytest.approx(ex["vega"], rel=2e-3)
+    assert g["rho"] == pytest.approx(ex["rho"], rel=2e-3) and g["gamma"] == pytest.approx(ex["gamma"], abs=2e-4)

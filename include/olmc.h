@@ -26,9 +26,8 @@
  *     u_b = (x_b & 0x7fffff) * 2^-23     (turn fraction, 23 bits),
  *     z_even = rad * cos(2 pi u_b),  z_odd = rad * sin(2 pi u_b),
  *   pair (x0,x1) -> steps 4b,4b+1; pair (x2,x3) -> steps 4b+2,4b+3.
- *   sum_t Z of a path is formed as 4 chunk sums of contiguous Philox blocks
- *   (fp32 within 16 normals, fp64 across), added in chunk order -- the same bits
- *   whichever kernel form or grid shape computes it.
+ *   sum_t Z of a path is accumulated in fp32 within 16 normals (4 Philox blocks)
+ *   and in fp64 across those groups -- the same bits whatever the grid shape.
  *   Normals are fp32; every quantity that depends on S, K, T, r, sigma, q is
  *   fp64 (finite-difference Greeks under common random numbers stay smooth).
  */

@@ -114,60 +114,37 @@ __device__ __forceinline__ float raw_block_accumulate(float acc, uint32_t g_lo, 
     return __builtin_fmaf(rad_b, sum_b, __builtin_fmaf(rad_a, sum_a, acc));
 }
 
-// The Philox blocks of a path are cut into kChunks contiguous chunks (chunk w gets
-// n/4 blocks, the first n%4 chunks one more) and sum_t z' = ((c0 + c1) + c2) + c3: four
-// independent fp64 accumulation chains per thread.
-constexpr int kChunks = 4;
-constexpr int kGroup = 4;   // blocks summed in fp32 (16 normals) before one fp64 add (measured: 2 is 2 % slower, 8 no faster)
+// sum_t Z_t (true normals) of one path.  Block b covers steps 4b..4b+3; fp32 within a group of
+// kGroup blocks (16 normals, interleaved by hipcc for ILP), fp64 across groups; a trailing
+// partial block contributes its first n_steps % 4 normals.
+constexpr int kGroup = 4;   // measured: 2 is 2 % slower, 8 no faster
 
-__device__ __forceinline__ void chunk_range(int32_t n_blocks, int w, int32_t& b_begin, int32_t& b_end) {
-    const int32_t q = n_blocks / kChunks, r = n_blocks % kChunks;
-    b_begin = w * q + min(w, r);
-    b_end = b_begin + q + (w < r ? 1 : 0);
-}
-
-// sum of RAW normals over Philox blocks [b_begin, b_end) of one path; block b covers steps
-// 4b..4b+3 and only steps < n_steps count.  fp32 within a group of kGroup blocks, fp64 across.
-__device__ __forceinline__ double chunk_normal_sum(uint32_t g_lo, uint32_t g_hi, int32_t b_begin, int32_t b_end,
-                                                   int32_t n_steps, uint32_t tag, uint32_t k0, uint32_t k1) {
-    const int32_t full_end = min(b_end, n_steps >> 2);     // blocks whose four steps all count
+__device__ __forceinline__ double path_normal_sum(uint32_t g_lo, uint32_t g_hi, int32_t n_steps, uint32_t k0, uint32_t k1,
+                                                  uint32_t tag = 0u) {
+    const int32_t full = n_steps >> 2;         // blocks whose four steps all count
     double acc = 0.0;
-    int32_t b = b_begin;
-    for (; b + kGroup <= full_end; b += kGroup) {
+    int32_t b = 0;
+    for (; b + kGroup <= full; b += kGroup) {
         float s = 0.0f;
 #pragma unroll
         for (int j = 0; j < kGroup; ++j) s = raw_block_accumulate(s, g_lo, g_hi, static_cast<uint32_t>(b + j), tag, k0, k1);
         acc += static_cast<double>(s);
     }
-    if (b < full_end) {
+    if (b < full) {
         float s = 0.0f;
-        for (; b < full_end; ++b) s = raw_block_accumulate(s, g_lo, g_hi, static_cast<uint32_t>(b), tag, k0, k1);
+        for (; b < full; ++b) s = raw_block_accumulate(s, g_lo, g_hi, static_cast<uint32_t>(b), tag, k0, k1);
         acc += static_cast<double>(s);
     }
     const int32_t rem = n_steps & 3;
-    if (rem && b < b_end) {                                  // trailing partial block: first `rem` normals
+    if (rem) {
         float z[4];
-        raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), tag, k0, k1, z);
+        raw_normals4(g_lo, g_hi, static_cast<uint32_t>(full), tag, k0, k1, z);
         float s = z[0];
         if (rem > 1) s += z[1];
         if (rem > 2) s += z[2];
         acc += static_cast<double>(s);
     }
-    return acc;
-}
-
-// sum_t Z_t (true normals) of one path, one thread walking all chunks.
-__device__ __forceinline__ double path_normal_sum(uint32_t g_lo, uint32_t g_hi, int32_t n_steps, uint32_t k0, uint32_t k1,
-                                                  uint32_t tag = 0u) {
-    const int32_t n_blocks = (n_steps + 3) >> 2;
-    double part[kChunks];
-#pragma unroll
-    for (int w = 0; w < kChunks; ++w) {
-        int32_t b0, b1;
-        chunk_range(n_blocks, w, b0, b1);
-        part[w] = chunk_normal_sum(g_lo, g_hi, b0, b1, n_steps, tag, k0, k1);
-    }
-    return (((part[0] + part[1]) + part[2]) + part[3]) * kZScale;
+    return acc * kZScale;
 }
 
 // ------------------------------------------------------------ reductions ----

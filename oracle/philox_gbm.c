@@ -76,10 +76,8 @@ void ol_normals(uint64_t seed, int64_t path0, int64_t n_paths, int32_t n_steps, 
         }
 }
 
-/* sum_t Z in the device's order: the Philox blocks are cut into 4 contiguous chunks (chunk w
- * gets n/4 blocks, the first n%4 one more); inside a chunk fp32 within a Philox block and
- * across a group of four blocks, fp64 across groups, a trailing partial block on its own;
- * total = (((c0 + c1) + c2) + c3) * sqrt(2 ln 2). */
+/* sum_t Z in the device's order: fp32 within a Philox block and across a group of four blocks
+ * (fma chain), fp64 across groups, a trailing partial block on its own; total * sqrt(2 ln 2). */
 /* acc + a block's four RAW normals in the device's factored form:
  * fmaf(rad_b, cos_b + sin_b, fmaf(rad_a, cos_a + sin_a, acc)), every intermediate rounded to fp32. */
 static float raw_block_accumulate(float acc, uint64_t path, uint32_t b, uint64_t seed) {
@@ -94,39 +92,29 @@ static float raw_block_accumulate(float acc, uint64_t path, uint32_t b, uint64_t
     return acc;
 }
 
-static double chunk_normal_sum(uint64_t path, int32_t b_begin, int32_t b_end, int32_t n_steps, uint64_t seed) {
-    const int32_t full_end = b_end < (n_steps >> 2) ? b_end : (n_steps >> 2);
+static double path_normal_sum(uint64_t path, int32_t n_steps, uint64_t seed) {
+    const int32_t full = n_steps >> 2, rem = n_steps & 3;
     double acc = 0.0;
-    int32_t b = b_begin, rem = n_steps & 3;
-    for (; b + 4 <= full_end; b += 4) {
+    int32_t b = 0;
+    for (; b + 4 <= full; b += 4) {
         float s = 0.0f;
         for (int j = 0; j < 4; ++j) s = raw_block_accumulate(s, path, (uint32_t)(b + j), seed);
         acc += (double)s;
     }
-    if (b < full_end) {
+    if (b < full) {
         float s = 0.0f;
-        for (; b < full_end; ++b) s = raw_block_accumulate(s, path, (uint32_t)b, seed);
+        for (; b < full; ++b) s = raw_block_accumulate(s, path, (uint32_t)b, seed);
         acc += (double)s;
     }
-    if (rem && b < b_end) {
+    if (rem) {
         float z[4];
-        raw_normals4(path, (uint32_t)b, seed, z);
+        raw_normals4(path, (uint32_t)full, seed, z);
         float s = z[0];
         if (rem > 1) s += z[1];
         if (rem > 2) s += z[2];
         acc += (double)s;
     }
-    return acc;
-}
-
-static double path_normal_sum(uint64_t path, int32_t n_steps, uint64_t seed) {
-    const int32_t n_blocks = (n_steps + 3) >> 2, q = n_blocks / 4, r = n_blocks % 4;
-    double part[4];
-    for (int w = 0; w < 4; ++w) {
-        const int32_t b0 = w * q + (w < r ? w : r), b1 = b0 + q + (w < r ? 1 : 0);
-        part[w] = chunk_normal_sum(path, b0, b1, n_steps, seed);
-    }
-    return (((part[0] + part[1]) + part[2]) + part[3]) * Z_SCALE;
+    return acc * Z_SCALE;
 }
 
 /* Terminal prices [pos | neg] for global paths path0 .. path0+n-1 (gbm_numpy.py:35-51). */

@@ -22,3 +22,11 @@ __all__ = [
     "ExoticAdapter", "HestonPricer", "HestonAdapter", "AsianOption", "BarrierOption", "LookbackOption", "AmericanOption", "price_american", "AutocallableOption", "CliquetOption", "price_asian", "price_barrier", "black_scholes", "simulate_gbm_hip", "simulate_gbm_hip_fast",
     "hip_available", "MonteCarloError", "InputValidationError", "ConvergenceError", "AccelerationError", "GreeksError",
 ]
+
+
+def __getattr__(name):
+    """`HIP_AVAILABLE`: availability flag in the style of the reference's NUMBA_AVAILABLE / GPU_AVAILABLE
+    (src/pricing_models/__init__.py:52-59), evaluated on first access because it touches the device."""
+    if name == "HIP_AVAILABLE":
+        return hip_available()
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

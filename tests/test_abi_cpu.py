@@ -92,4 +92,4 @@ def test_compute_fails_loudly_without_a_gpu():
         ol.AsianOption(100, 100, 1.0, 0.05, 0.2, seed=1).price(100, 8)
     with pytest.raises(AccelerationError):
         ol.simulate_gbm_hip(100, 1.0, 0.05, 0.2, 0.0, 100, 4, 1)
-    assert ol.hip_available() is False
+    assert ol.hip_available() is False and ol.HIP_AVAILABLE is False

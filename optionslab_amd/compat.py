@@ -1,0 +1,97 @@
+"""Import-path compatibility: make the reference's own import statements resolve to this engine.
+
+    import optionslab_amd.compat as compat
+    compat.install()
+    from src.pricing_models.monte_carlo import MonteCarloPricer, MCMethod      # the HIP pricer
+    from src.greeks.unified_greeks import compute_greeks_unified
+
+`install()` registers the modules of the hot path under the reference's names
+(src/pricing_models/monte_carlo.py, src/simulation, src/greeks/unified_greeks.py, ...), so the
+Streamlit page (streamlit_app/pages/1_MonteCarlo_Basic.py:139-160) and tests/test_monte_carlo.py
+run unchanged.  When the real OptionsLab `src` package is importable only the hot-path submodules
+are overridden; everything else of OptionsLab stays the reference's.  `uninstall()` restores.
+"""
+from __future__ import annotations
+
+import importlib
+import sys
+import types
+
+from .black_scholes import black_scholes as _black_scholes
+from . import exceptions as _exc
+from . import exotic as _exotic
+from . import greeks as _greeks
+from . import heston as _heston
+from . import monte_carlo as _mc
+from . import monte_carlo_unified as _uni
+from . import simulation as _sim
+
+_installed: dict = {}
+
+
+def _module(name: str, **attrs) -> types.ModuleType:
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__optionslab_amd__ = True
+    return m
+
+
+def _targets() -> dict:
+    sim = _module("src.simulation", simulate_gbm_hip=_sim.simulate_gbm_hip, simulate_gbm_hip_fast=_sim.simulate_gbm_hip_fast,
+                  # the reference's backend names resolve to the device backend (same contract, src/simulation/__init__.py:5-6)
+                  simulate_gbm_numpy=_sim.simulate_gbm_hip, simulate_gbm_numpy_fast=_sim.simulate_gbm_hip_fast,
+                  NUMBA_AVAILABLE=False)
+    return {
+        "src.pricing_models.monte_carlo": _module("src.pricing_models.monte_carlo", MonteCarloPricer=_mc.MonteCarloPricer,
+                                                  MCMethod=_mc.MCMethod, MCResult=_mc.MCResult, NUMBA_AVAILABLE=False),
+        "src.pricing_models.monte_carlo_unified": _module("src.pricing_models.monte_carlo_unified", MonteCarloPricerUni=_uni.MonteCarloPricerUni,
+                                                          InputValidationError=_uni.InputValidationError, MonteCarloError=_uni.MonteCarloError,
+                                                          NUMBA_AVAILABLE=False, GPU_AVAILABLE=True),
+        "src.pricing_models.black_scholes": _module("src.pricing_models.black_scholes", black_scholes=_black_scholes),
+        "src.pricing_models.exotic_options": _module("src.pricing_models.exotic_options", AsianOption=_exotic.AsianOption,
+                                                     BarrierOption=_exotic.BarrierOption, LookbackOption=_exotic.LookbackOption,
+                                                     AmericanOption=_exotic.AmericanOption, AutocallableOption=_exotic.AutocallableOption,
+                                                     CliquetOption=_exotic.CliquetOption, price_asian=_exotic.price_asian,
+                                                     price_barrier=_exotic.price_barrier, price_american=_exotic.price_american),
+        "src.pricing_models.heston": _module("src.pricing_models.heston", HestonPricer=_heston.HestonPricer),
+        "src.simulation": sim,
+        "src.greeks.unified_greeks": _module("src.greeks.unified_greeks", compute_greeks_unified=_greeks.compute_greeks_unified,
+                                             PricerProtocol=_greeks.PricerProtocol, ExoticAdapter=_greeks.ExoticAdapter,
+                                             HestonAdapter=_heston.HestonAdapter),
+        "src.exceptions.montecarlo_exceptions": _module("src.exceptions.montecarlo_exceptions", MonteCarloError=_exc.MonteCarloError,
+                                                        InputValidationError=_exc.InputValidationError, ConvergenceError=_exc.ConvergenceError,
+                                                        AccelerationError=_exc.AccelerationError),
+        "src.exceptions.greek_exceptions": _module("src.exceptions.greek_exceptions", GreeksError=_exc.GreeksError),
+    }
+
+
+def install() -> None:
+    """Idempotent.  Parents (`src`, `src.pricing_models`, ...) are created as empty packages only if the
+    real ones cannot be imported."""
+    if _installed:
+        return
+    for name, mod in _targets().items():
+        parts = name.split(".")
+        for depth in range(1, len(parts)):
+            parent = ".".join(parts[:depth])
+            if parent not in sys.modules:
+                try:
+                    importlib.import_module(parent)
+                except Exception:       # the reference's package __init__ pulls optional deps (numba, streamlit): treat as absent
+                    pkg = types.ModuleType(parent)
+                    pkg.__path__ = []
+                    pkg.__optionslab_amd__ = True
+                    sys.modules[parent] = pkg
+                    _installed[parent] = None
+        _installed[name] = sys.modules.get(name)
+        sys.modules[name] = mod
+        setattr(sys.modules[".".join(parts[:-1])], parts[-1], mod)
+
+
+def uninstall() -> None:
+    for name, previous in reversed(list(_installed.items())):
+        if previous is None:
+            sys.modules.pop(name, None)
+        else:
+            sys.modules[name] = previous
+    _installed.clear()

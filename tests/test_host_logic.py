@@ -153,3 +153,36 @@ def test_importing_the_package_loads_neither_torch_nor_the_library():
             "assert 'torch' not in sys.modules; assert h._lib is None; print('ok')")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
     assert out.stdout.strip() == "ok", out.stderr
+
+
+def test_compat_install_makes_reference_import_paths_resolve_here():
+    import importlib
+    import sys
+
+    from optionslab_amd import compat
+
+    saved = {k: v for k, v in sys.modules.items() if k == "src" or k.startswith("src.")}
+    for k in saved:
+        del sys.modules[k]
+    try:
+        compat.install()
+        compat.install()                                      # idempotent
+        mc = importlib.import_module("src.pricing_models.monte_carlo")
+        from src.greeks.unified_greeks import compute_greeks_unified          # noqa: F401  (the reference's import lines)
+        from src.pricing_models.black_scholes import black_scholes
+        from src.pricing_models.monte_carlo import NUMBA_AVAILABLE, MCMethod, MonteCarloPricer
+        from src.pricing_models.monte_carlo_unified import InputValidationError as UniErr
+        from src.pricing_models.monte_carlo_unified import MonteCarloPricerUni
+        from src.simulation import simulate_gbm_numpy
+        assert MonteCarloPricer is ol.MonteCarloPricer and MCMethod is ol.MCMethod and NUMBA_AVAILABLE is False
+        assert mc.MonteCarloPricer(num_simulations=10, num_steps=5, seed=1).price(120, 100, 0.0, 0.05, 0.2, "call") == 20
+        assert black_scholes(100, 100, 1.0, 0.05, 0.2) == ol.black_scholes(100, 100, 1.0, 0.05, 0.2)
+        assert simulate_gbm_numpy is ol.simulate_gbm_hip
+        with pytest.raises(UniErr):
+            MonteCarloPricerUni(num_simulations=0)
+    finally:
+        compat.uninstall()
+        for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    assert "src.pricing_models.monte_carlo" not in sys.modules or not getattr(sys.modules["src.pricing_models.monte_carlo"], "__optionslab_amd__", False)

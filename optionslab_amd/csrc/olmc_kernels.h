@@ -454,12 +454,12 @@ __global__ __launch_bounds__(kBlock) void asian_kernel(PathRange pr, AsianContra
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j < live) {
-                    const double dz = vol * static_cast<double>(z[j]);
-                    cum_u += drift + dz;
+                    const double zj = static_cast<double>(z[j]);
+                    cum_u += __builtin_fma(vol, zj, drift);          // one fma + one add per leg and step
                     if constexpr (GEOMETRIC) run_u += cum_u;
                     else run_u += static_cast<double>(__builtin_amdgcn_exp2f(static_cast<float>(cum_u)));
                     if constexpr (ANTI) {
-                        cum_d += drift - dz;
+                        cum_d += __builtin_fma(-vol, zj, drift);
                         if constexpr (GEOMETRIC) run_d += cum_d;
                         else run_d += static_cast<double>(__builtin_amdgcn_exp2f(static_cast<float>(cum_d)));
                     }
@@ -528,12 +528,12 @@ __global__ __launch_bounds__(kBlock) void extrema_kernel(PathRange pr, ExtremaCo
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j < live) {
-                    const double dz = vol * static_cast<double>(z[j]);
-                    cum_u += c.drift + dz;
+                    const double zj = static_cast<double>(z[j]);
+                    cum_u += __builtin_fma(vol, zj, c.drift);
                     mx_u = fmax(mx_u, cum_u);
                     mn_u = fmin(mn_u, cum_u);
                     if constexpr (ANTI) {
-                        cum_d += c.drift - dz;
+                        cum_d += __builtin_fma(-vol, zj, c.drift);
                         mx_d = fmax(mx_d, cum_d);
                         mn_d = fmin(mn_d, cum_d);
                     }
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(kBlock) void autocall_kernel(PathRange pr, Autocall
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (4 * b + j < pr.n_steps) {
-                    const double dz = vol * static_cast<double>(z[j]);
+                    const double zj = static_cast<double>(z[j]);
                     const bool observe = (--until_obs == 0);
                     double redemption = 0.0;
                     if (observe) {
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(kBlock) void autocall_kernel(PathRange pr, Autocall
                     }
 #pragma unroll
                     for (int leg = 0; leg < LEGS; ++leg) {
-                        cum[leg] += c.drift + (leg ? -dz : dz);
+                        cum[leg] += __builtin_fma(leg ? -vol : vol, zj, c.drift);
                         mn[leg] = fmin(mn[leg], cum[leg]);
                         const bool call_now = observe && !redeemed[leg] && cum[leg] >= c.log_autocall;
                         pay[leg] = call_now ? redemption : pay[leg];
@@ -648,12 +648,12 @@ __global__ __launch_bounds__(kBlock) void cliquet_kernel(PathRange pr, CliquetCo
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (4 * b + j < used_steps) {
-                    const double dz = vol * static_cast<double>(z[j]);
+                    const double zj = static_cast<double>(z[j]);
                     const bool reset = (--until_reset == 0);
                     if (reset) until_reset = c.steps_per_period;
 #pragma unroll
                     for (int leg = 0; leg < LEGS; ++leg) {
-                        cum[leg] += c.drift + (leg ? -dz : dz);
+                        cum[leg] += __builtin_fma(leg ? -vol : vol, zj, c.drift);
                         if (reset) {
                             const double local = exp(cum[leg] - start[leg]) - 1.0;      // (S_end - S_start) / S_start
                             total[leg] += fmin(fmax(local, c.local_floor), c.local_cap);
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(kBlock) void lsm_paths_kernel(PathRange pr, LsmCont
             for (int j = 0; j < 4; ++j) {
                 const int32_t t = 4 * b + j + 1;
                 if (t <= pr.n_steps) {
-                    cum += c.drift + vol * static_cast<double>(z[j]);
+                    cum += __builtin_fma(vol, static_cast<double>(z[j]), c.drift);
                     paths[static_cast<size_t>(t) * pr.count + i] = exp(c.log_s0 + cum);
                 }
             }

@@ -432,6 +432,29 @@ struct AsianContract {
     double inv_steps;  // 1 / M
 };
 
+// One Philox block = four monitoring dates of one path.  LIVE < 4 only for the trailing block.
+template <bool ANTI, bool GEOMETRIC, int LIVE>
+__device__ __forceinline__ void asian_block(const float (&z)[4], double drift, double vol, double& cum_u, double& cum_d,
+                                            double& run_u, double& run_d) {
+    float e_u = 0.0f, e_d = 0.0f;          // arithmetic: the block's four 2^y terms are summed in fp32 (each ~1)
+#pragma unroll
+    for (int j = 0; j < LIVE; ++j) {
+        const double zj = static_cast<double>(z[j]);
+        cum_u += __builtin_fma(vol, zj, drift);
+        if constexpr (GEOMETRIC) run_u += cum_u;
+        else e_u += __builtin_amdgcn_exp2f(static_cast<float>(cum_u));
+        if constexpr (ANTI) {
+            cum_d += __builtin_fma(-vol, zj, drift);
+            if constexpr (GEOMETRIC) run_d += cum_d;
+            else e_d += __builtin_amdgcn_exp2f(static_cast<float>(cum_d));
+        }
+    }
+    if constexpr (!GEOMETRIC) {
+        run_u += static_cast<double>(e_u);
+        if constexpr (ANTI) run_d += static_cast<double>(e_d);
+    }
+}
+
 template <bool ANTI, bool GEOMETRIC>
 __global__ __launch_bounds__(kBlock) void asian_kernel(PathRange pr, AsianContract c, ReduceWs ws) {
     constexpr double kLog2e = 1.4426950408889634;
@@ -440,31 +463,23 @@ __global__ __launch_bounds__(kBlock) void asian_kernel(PathRange pr, AsianContra
     const double unit = GEOMETRIC ? 1.0 : kLog2e;
     const double drift = c.drift * unit;
     const double vol = c.vol * kZScale * unit;      // applied to RAW normals
+    const int32_t full = pr.n_steps >> 2, rem = pr.n_steps & 3;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
         const uint64_t g = pr.first + static_cast<uint64_t>(i);
         const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
         double cum_u = 0.0, cum_d = 0.0;   // cumulative log-return (in `unit`s)
         double run_u = 0.0, run_d = 0.0;   // running sum of S_t / S_0, or of ln(S_t / S_0)
-        const int32_t blocks = (pr.n_steps + 3) >> 2;
-        for (int32_t b = 0; b < blocks; ++b) {
-            float z[4];
+        float z[4];
+        for (int32_t b = 0; b < full; ++b) {           // branch-free body: the four dates schedule together
             raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1, z);
-            const int32_t live = min(4, pr.n_steps - 4 * b);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j < live) {
-                    const double zj = static_cast<double>(z[j]);
-                    cum_u += __builtin_fma(vol, zj, drift);          // one fma + one add per leg and step
-                    if constexpr (GEOMETRIC) run_u += cum_u;
-                    else run_u += static_cast<double>(__builtin_amdgcn_exp2f(static_cast<float>(cum_u)));
-                    if constexpr (ANTI) {
-                        cum_d += __builtin_fma(-vol, zj, drift);
-                        if constexpr (GEOMETRIC) run_d += cum_d;
-                        else run_d += static_cast<double>(__builtin_amdgcn_exp2f(static_cast<float>(cum_d)));
-                    }
-                }
-            }
+            asian_block<ANTI, GEOMETRIC, 4>(z, drift, vol, cum_u, cum_d, run_u, run_d);
+        }
+        if (rem) {
+            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(full), 0u, pr.key0, pr.key1, z);
+            if (rem == 1) asian_block<ANTI, GEOMETRIC, 1>(z, drift, vol, cum_u, cum_d, run_u, run_d);
+            else if (rem == 2) asian_block<ANTI, GEOMETRIC, 2>(z, drift, vol, cum_u, cum_d, run_u, run_d);
+            else asian_block<ANTI, GEOMETRIC, 3>(z, drift, vol, cum_u, cum_d, run_u, run_d);
         }
 #pragma unroll
         for (int leg = 0; leg < (ANTI ? 2 : 1); ++leg) {
@@ -511,34 +526,43 @@ __device__ __forceinline__ double extrema_payoff(const ExtremaContract& c, doubl
     return c.sign > 0.0 ? fmax(c.s0 * exp(mx) - c.strike, 0.0) : fmax(c.strike - c.s0 * exp(mn), 0.0);
 }
 
+template <bool ANTI, int LIVE>
+__device__ __forceinline__ void extrema_block(const float (&z)[4], double drift, double vol, double& cum_u, double& mx_u,
+                                              double& mn_u, double& cum_d, double& mx_d, double& mn_d) {
+#pragma unroll
+    for (int j = 0; j < LIVE; ++j) {
+        const double zj = static_cast<double>(z[j]);
+        cum_u += __builtin_fma(vol, zj, drift);
+        mx_u = fmax(mx_u, cum_u);
+        mn_u = fmin(mn_u, cum_u);
+        if constexpr (ANTI) {
+            cum_d += __builtin_fma(-vol, zj, drift);
+            mx_d = fmax(mx_d, cum_d);
+            mn_d = fmin(mn_d, cum_d);
+        }
+    }
+}
+
 template <bool ANTI>
 __global__ __launch_bounds__(kBlock) void extrema_kernel(PathRange pr, ExtremaContract c, ReduceWs ws) {
     double acc[2] = {0.0, 0.0};
     const double vol = c.vol * kZScale;             // applied to RAW normals
+    const int32_t full = pr.n_steps >> 2, rem = pr.n_steps & 3;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
         const uint64_t g = pr.first + static_cast<uint64_t>(i);
         const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
         double cum_u = 0.0, mx_u = 0.0, mn_u = 0.0, cum_d = 0.0, mx_d = 0.0, mn_d = 0.0;   // t = 0: ln(S_0/S_0) = 0
-        const int32_t blocks = (pr.n_steps + 3) >> 2;
-        for (int32_t b = 0; b < blocks; ++b) {
-            float z[4];
+        float z[4];
+        for (int32_t b = 0; b < full; ++b) {           // branch-free body
             raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1, z);
-            const int32_t live = min(4, pr.n_steps - 4 * b);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j < live) {
-                    const double zj = static_cast<double>(z[j]);
-                    cum_u += __builtin_fma(vol, zj, c.drift);
-                    mx_u = fmax(mx_u, cum_u);
-                    mn_u = fmin(mn_u, cum_u);
-                    if constexpr (ANTI) {
-                        cum_d += __builtin_fma(-vol, zj, c.drift);
-                        mx_d = fmax(mx_d, cum_d);
-                        mn_d = fmin(mn_d, cum_d);
-                    }
-                }
-            }
+            extrema_block<ANTI, 4>(z, c.drift, vol, cum_u, mx_u, mn_u, cum_d, mx_d, mn_d);
+        }
+        if (rem) {
+            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(full), 0u, pr.key0, pr.key1, z);
+            if (rem == 1) extrema_block<ANTI, 1>(z, c.drift, vol, cum_u, mx_u, mn_u, cum_d, mx_d, mn_d);
+            else if (rem == 2) extrema_block<ANTI, 2>(z, c.drift, vol, cum_u, mx_u, mn_u, cum_d, mx_d, mn_d);
+            else extrema_block<ANTI, 3>(z, c.drift, vol, cum_u, mx_u, mn_u, cum_d, mx_d, mn_d);
         }
         const double xu = extrema_payoff(c, cum_u, mx_u, mn_u);
         acc[0] += xu; acc[1] += xu * xu;

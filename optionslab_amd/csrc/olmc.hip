@@ -258,7 +258,36 @@ Contract make_contract(const olmc_option& o, int32_t n_steps) {
     c.vol = vol;
     c.strike = o.K;
     c.sign = o.is_call ? 1.0 : -1.0;
+    c.scale = 0.0;
     return c;
+}
+
+// Orders k contracts so that those with bit-identical vol are contiguous, the first of each group being its
+// base (scale 0) and the others carrying scale = exp(a - a_base); fills `set` (padded to nsets with scale-1
+// copies of the last contract) and pos[i] = slot of contract i.
+template <int NSETS>
+void group_contracts(const olmc_option* opts, int32_t k, int32_t n_steps, ContractSet<NSETS>* set, int* pos) {
+    Contract all[OLMC_MAX_BATCH];
+    bool placed[OLMC_MAX_BATCH] = {};
+    for (int i = 0; i < k; ++i) all[i] = make_contract(opts[i], n_steps);
+    int slot = 0;
+    for (int i = 0; i < k; ++i) {
+        if (placed[i]) continue;
+        set->c[slot] = all[i];                       // base of a new group
+        pos[i] = slot++;
+        placed[i] = true;
+        for (int j = i + 1; j < k; ++j)
+            if (!placed[j] && std::memcmp(&all[j].vol, &all[i].vol, sizeof(double)) == 0 && std::isfinite(all[j].a - all[i].a)) {
+                set->c[slot] = all[j];
+                set->c[slot].scale = std::exp(all[j].a - all[i].a);
+                pos[j] = slot++;
+                placed[j] = true;
+            }
+    }
+    for (; slot < NSETS; ++slot) {                   // padding: cheap non-base copies
+        set->c[slot] = set->c[slot - 1];
+        set->c[slot].scale = 1.0;
+    }
 }
 
 void finish_stats(double sum, double sumsq, int64_t n, double r, double T, olmc_stats* out) {
@@ -305,14 +334,21 @@ PathRange make_range(int64_t path_offset, int64_t n_local, int32_t n_steps, uint
 template <int NSETS, int MODE>
 void launch_european(bool anti, int32_t grid, hipStream_t s, const PathRange& pr, const ContractSet<NSETS>& cs,
                      const ReduceWs& ws, double* terminal) {
-    if (anti) hipLaunchKernelGGL((european_path_kernel<NSETS, true, MODE>), dim3(grid), dim3(kBlock), 0, s, pr, cs, ws, terminal);
-    else hipLaunchKernelGGL((european_path_kernel<NSETS, false, MODE>), dim3(grid), dim3(kBlock), 0, s, pr, cs, ws, terminal);
+    const bool strided = static_cast<int64_t>(grid) * kBlock < pr.count;      // the grid does not cover every path
+    if (strided) {
+        if (anti) hipLaunchKernelGGL((european_path_kernel<NSETS, true, MODE, true>), dim3(grid), dim3(kBlock), 0, s, pr, cs, ws, terminal);
+        else hipLaunchKernelGGL((european_path_kernel<NSETS, false, MODE, true>), dim3(grid), dim3(kBlock), 0, s, pr, cs, ws, terminal);
+    } else {
+        if (anti) hipLaunchKernelGGL((european_path_kernel<NSETS, true, MODE, false>), dim3(grid), dim3(kBlock), 0, s, pr, cs, ws, terminal);
+        else hipLaunchKernelGGL((european_path_kernel<NSETS, false, MODE, false>), dim3(grid), dim3(kBlock), 0, s, pr, cs, ws, terminal);
+    }
 }
 
 // ONE launch on stream `s` for k contracts: leaves {sum, sumsq} x k in d_out[0 .. 2k)
 // (padded to the kernel's NSETS) and, when tail >= 0, `tail` in d_out[2 * nsets].
 int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32_t k, int64_t path_offset,
-                     int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic, double* d_out, double tail) {
+                     int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic, double* d_out, double tail,
+                     int* pos /* [k]: slot of contract i in d_out, may be NULL when k == 1 */) {
     const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
     const int32_t grid = grid_for(n_local);
     const bool anti = antithetic != 0;
@@ -325,14 +361,15 @@ int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32
     if (nsets == 1) {
         ContractSet<1> cs;
         cs.c[0] = make_contract(opts[0], n_steps);
+        if (pos) pos[0] = 0;
         launch_european<1, kReduce>(anti, grid, s, pr, cs, ws, nullptr);
     } else if (nsets == 8) {
         ContractSet<8> cs;
-        for (int i = 0; i < 8; ++i) cs.c[i] = make_contract(opts[i < k ? i : 0], n_steps);
+        group_contracts<8>(opts, k, n_steps, &cs, pos);
         launch_european<8, kReduce>(anti, grid, s, pr, cs, ws, nullptr);
     } else {
         ContractSet<16> cs;
-        for (int i = 0; i < 16; ++i) cs.c[i] = make_contract(opts[i < k ? i : 0], n_steps);
+        group_contracts<16>(opts, k, n_steps, &cs, pos);
         launch_european<16, kReduce>(anti, grid, s, pr, cs, ws, nullptr);
     }
     rc = after_launch(c, s);
@@ -357,14 +394,15 @@ int run_batch(const olmc_option* opts, int32_t k, int64_t path_offset, int64_t n
     rc = ctx_get(&c);
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(c->mu);
-    rc = run_batch_device(c, c->stream, opts, k, path_offset, n_local, n_steps, seed, antithetic, c->d_result, -1.0);
+    int pos[OLMC_MAX_BATCH];
+    rc = run_batch_device(c, c->stream, opts, k, path_offset, n_local, n_steps, seed, antithetic, c->d_result, -1.0, pos);
     if (rc) return rc;
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     const int64_t n = n_local * (antithetic ? 2 : 1);
     for (int i = 0; i < k; ++i) {
         if (poisoned(opts[i].S, opts[i].K, opts[i].T, opts[i].r, opts[i].sigma, opts[i].q)) nan_stats(n, &out[i]);
-        else finish_stats(c->h_result[2 * i], c->h_result[2 * i + 1], n, opts[i].r, opts[i].T, &out[i]);
+        else finish_stats(c->h_result[2 * pos[i]], c->h_result[2 * pos[i] + 1], n, opts[i].r, opts[i].T, &out[i]);
     }
     return OLMC_OK;
 }
@@ -460,7 +498,7 @@ extern "C" int olmc_european_shard_dev(double S, double K, double T, double r, d
     const olmc_option o = make_option(S, K, T, r, sigma, q, is_call);
     const double n = static_cast<double>(n_local * (antithetic ? 2 : 1));
     // the path kernel's last workgroup writes {sum, sumsq, n} straight into the caller's buffer
-    return run_batch_device(c, s, &o, 1, path_offset, n_local, n_steps, seed, antithetic, d_triple, n);
+    return run_batch_device(c, s, &o, 1, path_offset, n_local, n_steps, seed, antithetic, d_triple, n, nullptr);
 }
 
 extern "C" int olmc_european_batch(const olmc_option* opts, int32_t k, int64_t path_offset, int64_t n_local,
@@ -974,6 +1012,7 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
     ct.a = std::log(S) + drift * dims;
     ct.strike = K;
     ct.sign = is_call ? 1.0 : -1.0;
+    ct.scale = 0.0;
     QmcRange qr;
     qr.first = static_cast<uint64_t>(point_offset);
     qr.count = n_paths;

@@ -270,23 +270,56 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws, Epilog
 
 // One-thread-per-path kernels: fold NV per-thread values over the workgroup (fixed order,
 // LDS-staged across the four waves), then into the grid reduction.
+// Wave-wide sums of P (a power of two) per-lane values in P-1 + (6 - log2 P) shuffle-adds instead of
+// 6 P: at every halving step a lane trades half of its values with the lane `off` away and keeps the
+// sums of the other half, so after log2 P steps each lane holds ONE value's sum over a lane subset;
+// the remaining steps finish that single value.  On return v[0] of every lane holds the total of value
+// index  lane >> (6 - log2 P).  Fixed exchange pattern => deterministic.
+template <int P, int OFF = kWave / 2>
+__device__ __forceinline__ void wave_transpose_reduce(double (&v)[P]) {
+    if constexpr (P > 1) {
+        constexpr int H = P / 2;
+        const bool upper = (threadIdx.x & OFF) != 0;
+        double kept[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const double send = upper ? v[k] : v[k + H];
+            const double mine = upper ? v[k + H] : v[k];
+            kept[k] = mine + __shfl_xor(send, OFF, kWave);
+        }
+        wave_transpose_reduce<H, OFF / 2>(kept);
+        v[0] = kept[0];
+    } else if constexpr (OFF >= 1) {
+        double one[1] = {v[0] + __shfl_xor(v[0], OFF, kWave)};
+        wave_transpose_reduce<1, OFF / 2>(one);
+        v[0] = one[0];
+    }
+}
+
+constexpr int pow2_ceil(int n) { return n <= 1 ? 1 : 2 * pow2_ceil((n + 1) / 2); }
+constexpr int log2_of(int p) { return p <= 1 ? 0 : 1 + log2_of(p / 2); }
+
+// One-thread-per-path kernels: fold NV per-thread values over the workgroup (fixed order,
+// LDS-staged across the four waves), then into the grid reduction.
 template <int NV, typename Epilogue = NoEpilogue>
 __device__ __forceinline__ void block_then_grid_reduce(const double (&v)[NV], const ReduceWs& ws, Epilogue done = Epilogue()) {
-    __shared__ double stage[kWavesPerBlock][NV];
+    constexpr int P = pow2_ceil(NV);
+    constexpr int SHIFT = 6 - log2_of(P);           // lanes sharing one value after the transpose-reduce: 2^SHIFT
+    __shared__ double stage[kWavesPerBlock][P];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
+    double w[P];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const double s = wave_sum(v[i]);
-        if (lane == 0) stage[wave][i] = s;
-    }
+    for (int i = 0; i < P; ++i) w[i] = i < NV ? v[i] : 0.0;
+    wave_transpose_reduce<P>(w);
+    if ((lane & ((1 << SHIFT) - 1)) == 0) stage[wave][lane >> SHIFT] = w[0];
     __syncthreads();
     if (wave != 0) return;
     double s = 0.0;
     if (threadIdx.x < NV) {
         s = stage[0][threadIdx.x];
 #pragma unroll
-        for (int w = 1; w < kWavesPerBlock; ++w) s += stage[w][threadIdx.x];
+        for (int k = 1; k < kWavesPerBlock; ++k) s += stage[k][threadIdx.x];
     }
     grid_reduce<NV, Epilogue>(s, ws, done);
 }
@@ -299,6 +332,9 @@ struct Contract {
     double vol;      // sigma * sqrt(dt)
     double strike;
     double sign;     // +1 call, -1 put : payoff = max(sign * (S_T - K), 0)
+    double scale;    // 0: evaluates its own exp(a +- vol z).  > 0: shares vol with the nearest base contract
+                     // before it in the set and S_T = scale * S_T(base), scale = exp(a - a_base): the S- and
+                     // r-bumped contracts of a Greeks batch cost a multiply instead of two fp64 exps
 };
 
 template <int NSETS>
@@ -330,31 +366,48 @@ __device__ __forceinline__ void add_sample(double (&acc)[MODE == kControlVariate
 //   kControlVariate  out[0..4] = sum x, sum s, sum x^2, sum s^2, sum x*s  (NSETS == 1)
 // A variant in which the four waves of a workgroup split one 64-path tile's steps (4x finer
 // scheduling unit) was built and measured: never faster (121 vs 117.5 us), so it is gone.
-template <int NSETS, bool ANTI, int MODE>
+// STRIDED = false: the grid covers every path (one per thread), so the accumulators are born AFTER
+// the step loop and do not occupy registers during it -- with 8 / 16 contracts (16 / 32 fp64 sums)
+// that is the difference between 5 and 7-8 waves per SIMD in the loop that matters.
+template <int NSETS, bool ANTI, int MODE, bool STRIDED>
 __global__ __launch_bounds__(kBlock) void european_path_kernel(PathRange pr, ContractSet<NSETS> cs, ReduceWs ws,
                                                                double* __restrict__ terminal) {
     constexpr int NV = (MODE == kControlVariate) ? 5 : 2 * NSETS;
     constexpr int NC = (MODE == kControlVariate) ? 5 : 2;
     double acc[NV];
+    if constexpr (STRIDED) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+        for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+    }
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; STRIDED ? i < pr.count : i == static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+         i += stride) {
+        const bool live = i < pr.count;                 // always true when STRIDED
         const uint64_t g = pr.first + static_cast<uint64_t>(i);
         const double zsum = path_normal_sum(static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32), pr.n_steps, pr.key0, pr.key1);
+        if constexpr (!STRIDED) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+        }
+        double base_st[2] = {0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < NSETS; ++s) {
             const Contract c = cs.c[s];
-            const double dz = c.vol * zsum;
+            const bool is_base = NSETS == 1 || c.scale == 0.0;          // wave-uniform
+            if (is_base) {
+                const double dz = c.vol * zsum;
+                base_st[0] = exp(c.a + dz);
+                if constexpr (ANTI) base_st[1] = exp(c.a - dz);
+            }
 #pragma unroll
             for (int leg = 0; leg < (ANTI ? 2 : 1); ++leg) {
-                const double st = exp(leg ? c.a - dz : c.a + dz);
+                const double st = is_base ? base_st[leg] : c.scale * base_st[leg];
                 if constexpr (MODE == kTerminal) {
-                    terminal[leg * pr.count + i] = st;
+                    if (live) terminal[leg * pr.count + i] = st;
                 } else {
                     const double x = fmax(c.sign * (st - c.strike), 0.0);
                     double (&slot)[NC] = *reinterpret_cast<double (*)[NC]>(&acc[(MODE == kControlVariate) ? 0 : 2 * s]);
-                    add_sample<MODE>(slot, x, st);
+                    add_sample<MODE>(slot, live ? x : 0.0, live ? st : 0.0);
                 }
             }
         }

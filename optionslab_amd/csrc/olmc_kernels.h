@@ -27,24 +27,18 @@ struct Words4 {
     uint32_t x0, x1, x2, x3;
 };
 
-// Philox4x32-10 (Salmon et al., SC'11).  The key is wave-uniform; each round is two
-// 32x32->64 multiplies (v_mad_u64_u32: hi and lo from one instruction) and two 3-input XORs.
-// (Pinning the round keys in VGPRs to avoid SGPR-source XORs was measured: no gain --
-// in this mix every non-transcendental VALU instruction costs ~4 cycles of SIMD issue.)
-// a ^ b ^ c in ONE instruction: gfx950's v_bitop3_b32 with truth table 0x96.  hipcc does not
-// form it from `a ^ b ^ c` on its own (it emits two v_xor_b32), and the XORs are the largest
-// instruction class of a Philox call, so this removes ~18 of ~80 instructions per 4 normals.
-#ifndef OLMC_USE_BITOP3
-#define OLMC_USE_BITOP3 1
-#endif
+// a ^ b ^ c in ONE instruction: gfx950's v_bitop3_b32 with truth table 0x96.  hipcc does not form it
+// from `a ^ b ^ c` on its own (it emits two v_xor_b32), and XORs were the largest instruction class of
+// a Philox call: 38 -> 19 per call, kernel 146 -> 117.5 us (A/B on one device, identical prices).
 __device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
-#if OLMC_USE_BITOP3
     return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
-#else
-    return a ^ b ^ c;
-#endif
 }
 
+// Philox4x32-10 (Salmon et al., SC'11).  The key is wave-uniform; each round is two 32x32->64
+// multiplies (v_mad_u64_u32: hi and lo from one instruction, ~4.4 cycles, not quarter rate) and two
+// 3-input XORs.  Round 1 and half of round 2 are loop-invariant or wave-uniform in the step loop and are
+// hoisted by hipcc.  (Pinning the round keys in VGPRs to avoid SGPR-source XORs was measured: no gain --
+// in this mix every non-transcendental VALU instruction costs ~4 cycles of SIMD issue.)
 __device__ __forceinline__ Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                 uint32_t k0, uint32_t k1) {
 #pragma unroll

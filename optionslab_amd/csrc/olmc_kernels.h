@@ -262,8 +262,6 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws, Epilog
     done(total);
 }
 
-// One-thread-per-path kernels: fold NV per-thread values over the workgroup (fixed order,
-// LDS-staged across the four waves), then into the grid reduction.
 // Wave-wide sums of P (a power of two) per-lane values in P-1 + (6 - log2 P) shuffle-adds instead of
 // 6 P: at every halving step a lane trades half of its values with the lane `off` away and keeps the
 // sums of the other half, so after log2 P steps each lane holds ONE value's sum over a lane subset;

@@ -50,7 +50,7 @@ enum {
     OLMC_ERR_RCCL = 4     /* RCCL failure in the multi-GPU entry points                            */
 };
 
-enum { OLMC_STREAM_GBM = 0, OLMC_STREAM_HESTON = 1 };   /* counter word 3 (stream_tag); batches use tag = contract index */
+enum { OLMC_STREAM_GBM = 0, OLMC_STREAM_HESTON = 1, OLMC_STREAM_JUMP = 2, OLMC_STREAM_KOU = 3 };   /* counter word 3 (stream_tag); batches use tag = contract index */
 enum { OLMC_AVG_ARITHMETIC = 0, OLMC_AVG_GEOMETRIC = 1 };
 #define OLMC_MAX_BATCH 16                        /* parameter sets per fused launch      */
 
@@ -227,6 +227,17 @@ int olmc_heston(double S, double K, double T, double r, double q, int is_call,
                 double kappa, double theta, double sigma_v, double rho, double v0,
                 int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
                 int antithetic, olmc_stats* out);
+
+/* ---- jump diffusion ----------------------------------------------------------------
+ * Replaces MertonJumpDiffusion.price_monte_carlo (src/pricing_models/jump_diffusion.py:160-225)
+ * and KouJumpDiffusion.price_monte_carlo (:325-372): per step a diffusion normal, a
+ * Poisson(lambda dt) jump count and the jump sum, compensated drift.  model = OLMC_JUMP_MERTON:
+ * (a1, a2) = (mu_j, sigma_j);  OLMC_JUMP_KOU: (a1, a2, a3) = (p, eta1, eta2).  No antithetic. */
+enum { OLMC_JUMP_MERTON = 0, OLMC_JUMP_KOU = 1 };
+int olmc_jump_diffusion(double S, double K, double T, double r, double sigma, double q, int is_call,
+                        int model, double lambda_j, double a1, double a2, double a3,
+                        int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
+                        olmc_stats* out);
 
 /* ---- quasi-Monte Carlo (MCMethod.QMC) --------------------------------------
  * Replaces simulate_gbm_qmc (src/simulation/gbm_qmc.py:14-46): scrambled-Sobol

@@ -10,6 +10,7 @@ from .exceptions import AccelerationError, ConvergenceError, GreeksError, InputV
 from .exotic import AmericanOption, price_american, AsianOption, AutocallableOption, BarrierOption, CliquetOption, LookbackOption, price_asian, price_barrier
 from .greeks import ExoticAdapter, PricerProtocol, compute_greeks_unified
 from .heston import HestonAdapter, HestonPricer
+from .jump_diffusion import KouJumpDiffusion, MertonJumpDiffusion
 from .monte_carlo import NUMBA_AVAILABLE, MCMethod, MCResult, MonteCarloPricer
 from .monte_carlo_unified import MonteCarloPricerUni
 from .simulation import hip_available, simulate_gbm_hip, simulate_gbm_hip_fast
@@ -19,7 +20,7 @@ __version__ = "0.1.0"
 
 __all__ = [
     "MonteCarloPricer", "MonteCarloPricerUni", "MCMethod", "MCResult", "NUMBA_AVAILABLE", "compute_greeks_unified", "PricerProtocol",
-    "ExoticAdapter", "HestonPricer", "HestonAdapter", "AsianOption", "BarrierOption", "LookbackOption", "AmericanOption", "price_american", "AutocallableOption", "CliquetOption", "price_asian", "price_barrier", "black_scholes", "simulate_gbm_hip", "simulate_gbm_hip_fast",
+    "ExoticAdapter", "HestonPricer", "HestonAdapter", "MertonJumpDiffusion", "KouJumpDiffusion", "AsianOption", "BarrierOption", "LookbackOption", "AmericanOption", "price_american", "AutocallableOption", "CliquetOption", "price_asian", "price_barrier", "black_scholes", "simulate_gbm_hip", "simulate_gbm_hip_fast",
     "hip_available", "MonteCarloError", "InputValidationError", "ConvergenceError", "AccelerationError", "GreeksError",
 ]
 

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "olmc_autocallable": (_I, [_D] * 9 + [_I32, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_cliquet": (_I, [_D] * 9 + [_I32, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_american_lsm": (_I, _SIX + [_I, _I64, _I32, _I32, _U64T, C.POINTER(Stats)]),
+    "olmc_jump_diffusion": (_I, _SIX + [_I, _I, _D, _D, _D, _D, _I64, _I64, _I32, _U64T, C.POINTER(Stats)]),
     "olmc_heston": (_I, [_D] * 5 + [_I] + [_D] * 5 + [_I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_multi_gpu_european": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(Stats)]),
     "olmc_combine_stats": (_I, [C.POINTER(Stats), _I32, _D, _D, C.POINTER(Stats)]),
@@ -317,6 +318,15 @@ def american_lsm(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int
     out = Stats()
     _check(lib().olmc_american_lsm(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(n_steps), int(poly_degree),
                                    seed64(seed), C.byref(out)))
+    return out
+
+
+def jump_diffusion(S, K, T, r, sigma, q, is_call: bool, kou: bool, lambda_j, a1, a2, a3, n_paths: int, n_steps: int, seed: int,
+                   path_offset: int = 0) -> Stats:
+    """Merton: (a1, a2) = (mu_j, sigma_j), a3 ignored; Kou: (a1, a2, a3) = (p, eta1, eta2)."""
+    out = Stats()
+    _check(lib().olmc_jump_diffusion(S, K, T, r, sigma, q, int(is_call), int(kou), lambda_j, a1, a2, a3, int(path_offset),
+                                     int(n_paths), int(n_steps), seed64(seed), C.byref(out)))
     return out
 
 

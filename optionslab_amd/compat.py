@@ -22,6 +22,7 @@ from . import exceptions as _exc
 from . import exotic as _exotic
 from . import greeks as _greeks
 from . import heston as _heston
+from . import jump_diffusion as _jump
 from . import monte_carlo as _mc
 from . import monte_carlo_unified as _uni
 from . import simulation as _sim
@@ -54,6 +55,8 @@ def _targets() -> dict:
                                                      CliquetOption=_exotic.CliquetOption, price_asian=_exotic.price_asian,
                                                      price_barrier=_exotic.price_barrier, price_american=_exotic.price_american),
         "src.pricing_models.heston": _module("src.pricing_models.heston", HestonPricer=_heston.HestonPricer),
+        "src.pricing_models.jump_diffusion": _module("src.pricing_models.jump_diffusion", MertonJumpDiffusion=_jump.MertonJumpDiffusion,
+                                                     KouJumpDiffusion=_jump.KouJumpDiffusion),
         "src.simulation": sim,
         "src.greeks.unified_greeks": _module("src.greeks.unified_greeks", compute_greeks_unified=_greeks.compute_greeks_unified,
                                              PricerProtocol=_greeks.PricerProtocol, ExoticAdapter=_greeks.ExoticAdapter,

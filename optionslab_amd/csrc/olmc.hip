@@ -979,6 +979,40 @@ extern "C" int olmc_heston(double S, double K, double T, double r, double q, int
     return OLMC_OK;
 }
 
+// ============================================================== jump diffusion ====
+extern "C" int olmc_jump_diffusion(double S, double K, double T, double r, double sigma, double q, int is_call, int model,
+                                   double lambda_j, double a1, double a2, double a3, int64_t path_offset, int64_t n_local,
+                                   int32_t n_steps, uint64_t seed, olmc_stats* out) {
+    if (model != OLMC_JUMP_MERTON && model != OLMC_JUMP_KOU) return fail(OLMC_ERR_ARG, "bad jump model");
+    if (!(lambda_j >= 0.0)) return fail(OLMC_ERR_ARG, "lambda_j must be non-negative");
+    JumpContract jc;
+    const double dt = T / n_steps;
+    double kappa;                                            // E[e^Y - 1]
+    if (model == OLMC_JUMP_MERTON) {
+        jc.mu_j = a1; jc.sigma_j = a2;
+        jc.kou_p = 0.0; jc.inv_eta1 = 0.0; jc.inv_eta2 = 0.0;
+        kappa = std::exp(a1 + 0.5 * a2 * a2) - 1;            // jump_diffusion.py:64-67
+    } else {
+        jc.mu_j = 0.0; jc.sigma_j = 0.0;
+        jc.kou_p = a1; jc.inv_eta1 = 1.0 / a2; jc.inv_eta2 = 1.0 / a3;
+        kappa = a1 * a2 / (a2 - 1) + (1 - a1) * a3 / (a3 + 1) - 1;   // :293-299
+    }
+    jc.kou = model == OLMC_JUMP_KOU;
+    jc.pad = 0;
+    jc.log_s0 = std::log(S);
+    jc.drift = (r - q - lambda_j * kappa - 0.5 * sigma * sigma) * dt;   // :207 / :346 compensated drift
+    jc.vol = sigma * std::sqrt(dt);
+    jc.strike = K;
+    jc.sign = is_call ? 1.0 : -1.0;
+    jc.lam_dt = lambda_j * dt;
+    jc.p0 = std::exp(-jc.lam_dt);
+    const bool bad = poisoned(S, K, T, r, sigma, q) || std::isnan(lambda_j + a1 + a2 + a3);
+    return run_structured(path_offset, n_local, n_steps, seed, 0, r, T, bad, out,
+                          [&](int32_t grid, hipStream_t st, const PathRange& pr, const ReduceWs& ws) {
+                              hipLaunchKernelGGL(jump_kernel, dim3(grid), dim3(kBlock), 0, st, pr, jc, ws);
+                          });
+}
+
 // ======================================================================= QMC ====
 namespace {
 int run_qmc(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t point_offset,

@@ -977,6 +977,67 @@ __global__ __launch_bounds__(kBlock) void heston_kernel(PathRange pr, HestonCont
     block_then_grid_reduce<2>(acc, ws);
 }
 
+// Jump diffusion (src/pricing_models/jump_diffusion.py:160-225 Merton, :325-372 Kou): per step one
+// diffusion normal, a Poisson(lambda dt) number of jumps, and the jump sum added to ln S.
+// One Philox block PER STEP (stream tag 2): (x0, x1) -> Box-Muller pair {diffusion normal, jump normal},
+// x2 -> the Poisson uniform (inversion).  Merton: n jumps ~ N(n mu_j, n sigma_j^2), drawn exactly as
+// n mu_j + sigma_j sqrt(n) z (the sum of n iid normals).  Kou: each jump is +Exp(eta1) with probability p,
+// else -Exp(eta2); jump j takes its two uniforms from block (path, step, tag 3 + j/2), words 2(j%2), 2(j%2)+1
+// -- drawn only by the lanes that jump (lambda dt ~ 1e-3: rare, divergent, cheap).
+constexpr uint32_t kTagJump = 2u, kTagKou = 3u;
+
+struct JumpContract {
+    double log_s0, drift, vol;      // drift = (r - q - lambda kappa - sigma^2/2) dt, vol = sigma sqrt(dt)
+    double strike, sign;
+    double p0, lam_dt;              // exp(-lambda dt), lambda dt
+    double mu_j, sigma_j;           // Merton
+    double kou_p, inv_eta1, inv_eta2;
+    int32_t kou;                    // 0 Merton, 1 Kou
+    int32_t pad;
+};
+
+__device__ __forceinline__ double unit_open64(uint32_t x) { return (static_cast<double>(x) + 0.5) * 2.3283064365386963e-10; }
+
+__global__ __launch_bounds__(kBlock) void jump_kernel(PathRange pr, JumpContract c, ReduceWs ws) {
+    double acc[2] = {0.0, 0.0};
+    const double vol = c.vol * kZScale;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
+        const uint64_t g = pr.first + static_cast<uint64_t>(i);
+        const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
+        double ls = c.log_s0;
+        for (int32_t t = 0; t < pr.n_steps; ++t) {
+            const Words4 w = philox4x32_10(g_lo, g_hi, static_cast<uint32_t>(t), kTagJump, pr.key0, pr.key1);
+            float z_diff, z_jump;
+            box_muller_raw(w.x0, w.x1, z_diff, z_jump);
+            ls += __builtin_fma(vol, static_cast<double>(z_diff), c.drift);
+            const double u = unit_open64(w.x2);
+            if (u >= c.p0) {                                   // at least one jump
+                int32_t n = 1;
+                double pk = c.p0 * c.lam_dt, cdf = c.p0 + pk;
+                while (u >= cdf && n < 64) {
+                    ++n;
+                    pk *= c.lam_dt / n;
+                    cdf += pk;
+                }
+                if (!c.kou) {
+                    ls += n * c.mu_j + c.sigma_j * sqrt(static_cast<double>(n)) * (kZScale * static_cast<double>(z_jump));
+                } else {
+                    for (int32_t j = 0; j < n; ++j) {
+                        const Words4 k = philox4x32_10(g_lo, g_hi, static_cast<uint32_t>(t), kTagKou + static_cast<uint32_t>(j >> 1),
+                                                       pr.key0, pr.key1);
+                        const double ud = unit_open64((j & 1) ? k.x2 : k.x0), um = unit_open64((j & 1) ? k.x3 : k.x1);
+                        ls += ud < c.kou_p ? -log(um) * c.inv_eta1 : log(um) * c.inv_eta2;
+                    }
+                }
+            }
+        }
+        const double x = fmax(c.sign * (exp(ls) - c.strike), 0.0);
+        acc[0] += x; acc[1] += x * x;
+    }
+    block_then_grid_reduce<2>(acc, ws);
+}
+
 // ------------------------------------------------------------------ QMC ----
 // Scrambled-Sobol terminal prices (src/simulation/gbm_qmc.py:14-46): point k of the sequence is
 //   x_t(k) = shift[t] ^ XOR_{b in gray(k)} sv[t][b],   u = x * 2^-30,

@@ -443,3 +443,90 @@ def heston_price_mc(S, K, T, r, q, option_type, kappa, theta, sigma_v, rho, v0, 
     st = np.exp(log_S)
     x = np.maximum(st - K, 0) if option_type == "call" else np.maximum(K - st, 0)
     return np.exp(-r * T) * np.mean(x)
+
+
+# --------------------------------------------------------------------------
+# Jump diffusion (src/pricing_models/jump_diffusion.py)
+# --------------------------------------------------------------------------
+def merton_kappa(mu_j, sigma_j):  # :61-67
+    return np.exp(mu_j + 0.5 * sigma_j**2) - 1
+
+
+def _merton_bs(S, K, T, r, sigma, option_type, q):  # :134-158
+    if sigma <= 0 or T <= 0:
+        if option_type == "call":
+            return max(S * np.exp(-q * T) - K * np.exp(-r * T), 0)
+        return max(K * np.exp(-r * T) - S * np.exp(-q * T), 0)
+    d1 = (np.log(S / K) + (r - q + 0.5 * sigma**2) * T) / (sigma * np.sqrt(T))
+    d2 = d1 - sigma * np.sqrt(T)
+    if option_type == "call":
+        return S * np.exp(-q * T) * norm.cdf(d1) - K * np.exp(-r * T) * norm.cdf(d2)
+    return K * np.exp(-r * T) * norm.cdf(-d2) - S * np.exp(-q * T) * norm.cdf(-d1)
+
+
+def merton_series(S, K, T, r, sigma, lambda_j, mu_j, sigma_j, option_type="call", q=0.0, n_terms=50):  # :69-132
+    from scipy.special import factorial
+
+    if T <= 0:
+        return max(S - K, 0) if option_type == "call" else max(K - S, 0)
+    kappa = merton_kappa(mu_j, sigma_j)
+    lam_p = lambda_j * (1 + kappa)
+    price = 0.0
+    for n in range(n_terms):
+        w = np.exp(-lam_p * T) * (lam_p * T) ** n / factorial(n)
+        sigma_n = np.sqrt(sigma**2 + n * sigma_j**2 / T)
+        r_n = r - lambda_j * kappa + n * np.log(1 + kappa) / T
+        price += w * _merton_bs(S, K, T, r_n, sigma_n, option_type, q)
+        if w < 1e-12:
+            break
+    return price
+
+
+def merton_mc(S, K, T, r, sigma, lambda_j, mu_j, sigma_j, option_type="call", q=0.0, n_paths=100000, n_steps=252, seed=None):
+    """:160-225 (legacy global RandomState; per-path Python loop for the jumps)."""
+    if seed is not None:
+        np.random.seed(seed)
+    dt = T / n_steps
+    kappa = merton_kappa(mu_j, sigma_j)
+    drift = (r - q - lambda_j * kappa - 0.5 * sigma**2) * dt
+    vol = sigma * np.sqrt(dt)
+    log_S = np.full(n_paths, np.log(S))
+    for _ in range(n_steps):
+        log_S += drift + vol * np.random.standard_normal(n_paths)
+        n_jumps = np.random.poisson(lambda_j * dt, n_paths)
+        for i in np.nonzero(n_jumps)[0]:  # same draws in the same order as the reference's `for i in range(n_paths)`
+            log_S[i] += np.sum(np.random.normal(mu_j, sigma_j, n_jumps[i]))
+    st = np.exp(log_S)
+    x = np.maximum(st - K, 0) if option_type == "call" else np.maximum(K - st, 0)
+    return np.exp(-r * T) * np.mean(x)
+
+
+def kou_kappa(p, eta1, eta2):  # :293-299
+    return p * eta1 / (eta1 - 1) + (1 - p) * eta2 / (eta2 + 1) - 1
+
+
+def kou_mc(S, K, T, r, sigma, lambda_j, p, eta1, eta2, option_type="call", q=0.0, n_paths=100000, n_steps=252, seed=None):
+    """:325-372"""
+    if seed is not None:
+        np.random.seed(seed)
+    dt = T / n_steps
+    drift = (r - q - lambda_j * kou_kappa(p, eta1, eta2) - 0.5 * sigma**2) * dt
+    vol = sigma * np.sqrt(dt)
+    log_S = np.full(n_paths, np.log(S))
+    for _ in range(n_steps):
+        log_S += drift + vol * np.random.standard_normal(n_paths)
+        n_jumps = np.random.poisson(lambda_j * dt, n_paths)
+        total = np.sum(n_jumps)
+        if total > 0:
+            jumps = np.zeros(total)  # simulate_jump, :301-316
+            u = np.random.uniform(0, 1, total)
+            up = u < p
+            jumps[up] = np.random.exponential(1 / eta1, np.sum(up))
+            jumps[~up] = -np.random.exponential(1 / eta2, np.sum(~up))
+            idx = 0
+            for i in np.nonzero(n_jumps)[0]:
+                log_S[i] += np.sum(jumps[idx: idx + n_jumps[i]])
+                idx += n_jumps[i]
+    st = np.exp(log_S)
+    x = np.maximum(st - K, 0) if option_type == "call" else np.maximum(K - st, 0)
+    return np.exp(-r * T) * np.mean(x)

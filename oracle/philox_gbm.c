@@ -412,3 +412,47 @@ int ol_american_lsm(double S, double K, double T, double r, double sigma, double
     free(paths); free(cf);
     return 0;
 }
+
+/* Jump diffusion (jump_diffusion.py:160-225, 325-372): one Philox block per step, tag 2; Kou jumps from tag 3 + j/2. */
+static double unit_open64(uint32_t x) { return ((double)x + 0.5) * 0x1p-32; }
+
+void ol_jump_moments(double S, double K, double T, double r, double sigma, double q, int is_call, int kou, double lambda_j,
+                     double a1, double a2, double a3, int64_t path0, int64_t n, int32_t n_steps, uint64_t seed,
+                     double moments[2]) {
+    const double dt = T / n_steps, sign = is_call ? 1.0 : -1.0;
+    const double kappa = kou ? a1 * a2 / (a2 - 1) + (1 - a1) * a3 / (a3 + 1) - 1 : exp(a1 + 0.5 * a2 * a2) - 1;
+    const double drift = (r - q - lambda_j * kappa - 0.5 * sigma * sigma) * dt, vol = sigma * sqrt(dt) * Z_SCALE;
+    const double lam_dt = lambda_j * dt, p0 = exp(-lam_dt);
+    long double m0 = 0, m1 = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint64_t path = (uint64_t)(path0 + i);
+        double ls = log(S);
+        for (int32_t t = 0; t < n_steps; ++t) {
+            uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), (uint32_t)t, 2u};
+            uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, w[4];
+            float zd, zj;
+            ol_philox4x32_10(ctr, key, w);
+            box_muller_raw(w[0], w[1], &zd, &zj);
+            ls += vol * (double)zd + drift;
+            const double u = unit_open64(w[2]);
+            if (u >= p0) {
+                int nj = 1;
+                double pk = p0 * lam_dt, cdf = p0 + pk;
+                while (u >= cdf && nj < 64) { ++nj; pk *= lam_dt / nj; cdf += pk; }
+                if (!kou) {
+                    ls += nj * a1 + a2 * sqrt((double)nj) * (Z_SCALE * (double)zj);
+                } else {
+                    for (int j = 0; j < nj; ++j) {
+                        uint32_t c2[4] = {(uint32_t)path, (uint32_t)(path >> 32), (uint32_t)t, 3u + (uint32_t)(j >> 1)}, k[4];
+                        ol_philox4x32_10(c2, key, k);
+                        const double ud = unit_open64((j & 1) ? k[2] : k[0]), um = unit_open64((j & 1) ? k[3] : k[1]);
+                        ls += ud < a1 ? -log(um) / a2 : log(um) / a3;
+                    }
+                }
+            }
+        }
+        const double x = fmax(sign * (exp(ls) - K), 0.0);
+        m0 += x; m1 += x * x;
+    }
+    moments[0] = (double)m0; moments[1] = (double)m1;
+}

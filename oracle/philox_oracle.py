@@ -125,6 +125,14 @@ def american_lsm(S, K, T, r, sigma, q, is_call, n_paths, n_steps, degree, seed):
     return m[0], m[1], n_paths
 
 
+def jump_moments(S, K, T, r, sigma, q, is_call, kou, lambda_j, a1, a2, a3, n_paths, n_steps, seed, path0=0):
+    m = (C.c_double * 2)()
+    _load().ol_jump_moments(C.c_double(S), C.c_double(K), C.c_double(T), C.c_double(r), C.c_double(sigma), C.c_double(q),
+                            C.c_int(int(is_call)), C.c_int(int(kou)), C.c_double(lambda_j), C.c_double(a1), C.c_double(a2),
+                            C.c_double(a3), C.c_int64(path0), C.c_int64(n_paths), C.c_int32(n_steps), C.c_uint64(int(seed) & _U64), m)
+    return m[0], m[1], n_paths
+
+
 def price_and_error(sum_x, sum_xx, n, r, T):
     """monte_carlo.py:145-150 on the moments."""
     disc, mean = math.exp(-r * T), sum_x / n

@@ -32,10 +32,11 @@ def load_reference():
     from src.pricing_models.exotic_options import (AmericanOption, AsianOption, AutocallableOption, BarrierOption, CliquetOption,
                                                     LookbackOption, price_asian, price_barrier)
     from src.pricing_models.heston import HestonPricer
+    from src.pricing_models.jump_diffusion import KouJumpDiffusion, MertonJumpDiffusion
     from src.pricing_models.monte_carlo import MCMethod, MonteCarloPricer
     from src.pricing_models.monte_carlo_unified import MonteCarloPricerUni
 
-    return dict(HestonPricer=HestonPricer, MonteCarloPricerUni=MonteCarloPricerUni, BarrierOption=BarrierOption, LookbackOption=LookbackOption, AutocallableOption=AutocallableOption,
+    return dict(MertonJumpDiffusion=MertonJumpDiffusion, KouJumpDiffusion=KouJumpDiffusion, HestonPricer=HestonPricer, MonteCarloPricerUni=MonteCarloPricerUni, BarrierOption=BarrierOption, LookbackOption=LookbackOption, AutocallableOption=AutocallableOption,
                 CliquetOption=CliquetOption, AmericanOption=AmericanOption,
                 price_barrier=price_barrier, MonteCarloPricer=MonteCarloPricer, MCMethod=MCMethod, black_scholes=black_scholes,
                 AsianOption=AsianOption, price_asian=price_asian,
@@ -202,6 +203,21 @@ def main():
         doc["heston"].append(dict(model=[kappa, theta, sv, rho, v0], args=[S, K, T, r, q], option_type=typ, n_paths=n, n_steps=m, seed=42,
                                   mc=float(hp.price_monte_carlo(S, K, T, r, q, typ, n, m, 42)),
                                   semi_analytic=float(hp.price_european(S, K, T, r, q, typ))))
+
+    # -- jump diffusion (jump_diffusion.py) -----------------------------------------------------
+    doc["merton"], doc["kou"] = [], []
+    for (lam, mu, sj), (S, K, T, r, v, q), typ, n, m in [((0.5, -0.1, 0.2), (100.0, 100.0, 1.0, 0.05, 0.2, 0.0), "call", 40000, 50),
+                                                         ((2.0, 0.05, 0.1), (100.0, 105.0, 0.5, 0.03, 0.15, 0.01), "put", 40000, 25),
+                                                         ((0.0, -0.1, 0.2), (100.0, 100.0, 1.0, 0.05, 0.2, 0.0), "call", 20000, 10)]:
+        jd = ref["MertonJumpDiffusion"](lambda_j=lam, mu_j=mu, sigma_j=sj)
+        doc["merton"].append(dict(model=[lam, mu, sj], args=[S, K, T, r, v, q], option_type=typ, n_paths=n, n_steps=m, seed=42,
+                                  kappa=float(jd.kappa), series=float(jd.price(S, K, T, r, v, typ, q)),
+                                  mc=float(jd.price_monte_carlo(S, K, T, r, v, typ, q, n, m, 42))))
+    for (lam, p_, e1, e2), (S, K, T, r, v, q), typ, n, m in [((1.0, 0.4, 10.0, 5.0), (100.0, 100.0, 1.0, 0.05, 0.2, 0.0), "call", 40000, 50),
+                                                            ((3.0, 0.6, 25.0, 20.0), (100.0, 95.0, 0.5, 0.03, 0.15, 0.01), "put", 40000, 25)]:
+        kj = ref["KouJumpDiffusion"](lambda_j=lam, p=p_, eta1=e1, eta2=e2)
+        doc["kou"].append(dict(model=[lam, p_, e1, e2], args=[S, K, T, r, v, q], option_type=typ, n_paths=n, n_steps=m, seed=42,
+                               kappa=float(kj.kappa), mc=float(kj.price_monte_carlo(S, K, T, r, v, typ, q, n, m, 42))))
 
     # -- MonteCarloPricerUni, NumPy backend (monte_carlo_unified.py:298-343, 451-689) ----
     Uni = ref["MonteCarloPricerUni"]

@@ -216,3 +216,45 @@ def test_american_against_reference_golden_and_bounds(golden):
     with pytest.raises(ol.AccelerationError):
         _hip.american_lsm(*P, 0.0, False, 1000, 10, 7, 1)
     assert math.isnan(ol.AmericanOption(-1.0, 100.0, 1.0, 0.05, 0.2, seed=1).price(100, 4))
+
+
+# ------------------------------------------------------------------ jump diffusion (Merton, Kou)
+@pytest.mark.parametrize("kou,lam,a1,a2,a3,call,N,M", [
+    (False, 0.5, -0.1, 0.2, 0.0, True, 20000, 50), (False, 40.0, 0.02, 0.1, 0.0, False, 5001, 13),      # lambda dt = 3: multi-jump steps
+    (True, 1.0, 0.4, 10.0, 5.0, True, 20000, 50), (True, 60.0, 0.6, 25.0, 20.0, False, 3000, 7),         # up to ~20 jumps per step
+    (False, 0.0, -0.1, 0.2, 0.0, True, 4000, 10),
+])
+def test_jump_diffusion_matches_same_stream_checker(kou, lam, a1, a2, a3, call, N, M):
+    st = _hip.jump_diffusion(100.0, 100.0, 1.0, 0.05, 0.2, 0.01, call, kou, lam, a1, a2, a3, N, M, 17)
+    sx, sxx, n = po.jump_moments(100.0, 100.0, 1.0, 0.05, 0.2, 0.01, call, kou, lam, a1, a2, a3, N, M, 17)
+    assert st.n == n
+    assert st.sum == pytest.approx(sx, rel=REL) and st.sumsq == pytest.approx(sxx, rel=4 * REL)
+
+
+def test_jump_diffusion_against_reference_golden_and_series(golden):
+    for c in golden["merton"]:
+        S, K, T, r, v, q = c["args"]
+        jd = ol.MertonJumpDiffusion(*c["model"])
+        assert jd.kappa == pytest.approx(c["kappa"], rel=1e-14)
+        assert jd.price(S, K, T, r, v, c["option_type"], q) == pytest.approx(c["series"], rel=1e-12)
+        price, se = jd.price_monte_carlo(S, K, T, r, v, c["option_type"], q, c["n_paths"], c["n_steps"], c["seed"], return_error=True)
+        assert isinstance(price, np.float64)
+        assert abs(price - c["mc"]) <= 3 * math.sqrt(2) * se, c
+        big, se_big = jd.price_monte_carlo(S, K, T, r, v, c["option_type"], q, 1_000_000, c["n_steps"], 3, return_error=True)
+        assert abs(big - c["series"]) <= 3.5 * se_big, c                        # the MC converges to Merton's series
+    for c in golden["kou"]:
+        S, K, T, r, v, q = c["args"]
+        kj = ol.KouJumpDiffusion(*c["model"])
+        assert kj.kappa == pytest.approx(c["kappa"], rel=1e-14)
+        price, se = kj.price_monte_carlo(S, K, T, r, v, c["option_type"], q, c["n_paths"], c["n_steps"], c["seed"], return_error=True)
+        assert abs(price - c["mc"]) <= 3 * math.sqrt(2) * se, c
+    # martingale check for Kou: E[S_T] = S e^{(r-q)T}  <=>  call(K -> 0) = S e^{-qT}
+    kj = ol.KouJumpDiffusion(3.0, 0.4, 10.0, 5.0)
+    deep, se = kj.price_monte_carlo(100.0, 1e-9, 1.0, 0.05, 0.2, "call", 0.02, 1_000_000, 32, 5, return_error=True)
+    assert abs(deep - 100.0 * math.exp(-0.02)) <= 3.5 * se
+    for bad in (dict(lambda_j=-1, mu_j=0, sigma_j=0.1), dict(lambda_j=1, mu_j=0, sigma_j=-0.1)):
+        with pytest.raises(ValueError):
+            ol.MertonJumpDiffusion(**bad)
+    for bad in ((1, 1.5, 10, 5), (1, 0.5, 1.0, 5), (1, 0.5, 10, 0)):
+        with pytest.raises(ValueError):
+            ol.KouJumpDiffusion(*bad)

@@ -160,3 +160,17 @@ def test_american_lsm(golden):
         S, K, T, r, v, q = c["params"]
         got = orc.american_price(S, K, T, r, v, q, c["seed"], c["n_paths"], c["n_steps"], c["option_type"], c["poly_degree"])
         assert float(got) == c["price"], c
+
+
+def test_jump_diffusion(golden):
+    for c in golden["merton"]:
+        S, K, T, r, v, q = c["args"]
+        lam, mu, sj = c["model"]
+        assert float(orc.merton_kappa(mu, sj)) == c["kappa"]
+        assert float(orc.merton_series(S, K, T, r, v, lam, mu, sj, c["option_type"], q)) == c["series"]
+        assert float(orc.merton_mc(S, K, T, r, v, lam, mu, sj, c["option_type"], q, c["n_paths"], c["n_steps"], c["seed"])) == c["mc"]
+    for c in golden["kou"]:
+        S, K, T, r, v, q = c["args"]
+        lam, p_, e1, e2 = c["model"]
+        assert float(orc.kou_kappa(p_, e1, e2)) == c["kappa"]
+        assert float(orc.kou_mc(S, K, T, r, v, lam, p_, e1, e2, c["option_type"], q, c["n_paths"], c["n_steps"], c["seed"])) == c["mc"]

@@ -23,6 +23,7 @@ MAIN = textwrap.dedent(r"""
     void ol_autocall_moments(double, double, double, double, double, double, double, double, double, int32_t, int64_t, int64_t, int32_t, uint64_t, int, double*);
     void ol_cliquet_moments(double, double, double, double, double, double, double, double, double, int32_t, int64_t, int64_t, int32_t, uint64_t, int, double*);
     int ol_american_lsm(double, double, double, double, double, double, int, int64_t, int32_t, int32_t, uint64_t, double*);
+    void ol_jump_moments(double, double, double, double, double, double, int, int, double, double, double, double, int64_t, int64_t, int32_t, uint64_t, double*);
     int main(void) {
         uint32_t c[4] = {1, 2, 3, 4}, k[2] = {5, 6}, w[4];
         ol_philox4x32_10(c, k, w);
@@ -42,6 +43,8 @@ MAIN = textwrap.dedent(r"""
             ol_heston_moments(100, 100, 1, .05, 0, 1, 2, .04, .3, -.7, .04, 0, 9, steps, 3, 1, m); acc += m[0];
             ol_autocall_moments(100, 1, .05, .2, 0, 1.0, .8, .1, .6, 1 + steps / 3, 0, 9, steps, 4, 1, m); acc += m[0];
             ol_cliquet_moments(100, 1, .05, .2, 0, .05, -.05, .3, 0, 1 + steps / 4, 0, 9, steps, 5, 1, m); acc += m[0];
+            ol_jump_moments(100, 100, 1, .05, .2, 0, 1, 0, 30.0, -.1, .2, 0, 0, 50, steps, 7, m); acc += m[0];
+            ol_jump_moments(100, 100, 1, .05, .2, 0, 0, 1, 40.0, .4, 10, 5, 0, 50, steps, 7, m); acc += m[0];
             if (ol_american_lsm(100, 100, 1, .05, .2, 0, 0, 200, steps, 1 + steps % 4, 6, m)) return 2;
             acc += m[0];
         }

@@ -476,3 +476,20 @@ def test_large_path_count_grid_stride_and_long_paths():
     ex = orc.bs_greeks(*ATM, "call")
     assert g["delta"] == pytest.approx(ex["delta"], abs=2e-4) and g["vega"] == pytest.approx(ex["vega"], rel=2e-3)
     assert g["rho"] == pytest.approx(ex["rho"], rel=2e-3) and g["gamma"] == pytest.approx(ex["gamma"], abs=2e-4)
+
+
+def test_monte_carlo_error_shrinks_like_one_over_sqrt_n():
+    """The harness of src/pricing_models/validation.py:202-239 applied to the device pricer: the spread of
+    independent estimates must fall like 1/sqrt(N) and bracket Black-Scholes."""
+    stds, means = [], []
+    for N in (10_000, 40_000, 160_000, 640_000):
+        prices = [ol.MonteCarloPricer(N, 16, seed).price(*ATM, "call") for seed in range(100, 148)]
+        stds.append(float(np.std(prices)))
+        means.append(float(np.mean(prices)))
+    for a, b in zip(stds, stds[1:]):
+        assert 1.45 < a / b < 2.75, stds                      # expected 2.0; 48 trials => ~10 % noise on each std
+    for m, s in zip(means, stds):
+        assert abs(m - BS_CALL) <= 4 * s / math.sqrt(48)
+    # the reported (naive, reference-formula) std_error overstates the true spread of the antithetic estimator
+    rep = ol.MonteCarloPricer(640_000, 16, 1).price(*ATM, "call", return_error=True).std_error
+    assert 0.4 * rep < stds[-1] < 1.05 * rep

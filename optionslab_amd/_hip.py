@@ -76,6 +76,7 @@ PROTOTYPES = {
     "olmc_multi_gpu_european": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(Stats)]),
     "olmc_combine_stats": (_I, [C.POINTER(Stats), _I32, _D, _D, C.POINTER(Stats)]),
     "olmc_philox_words": (_I, [_U64T, _I64, _I64, _I32, _I32, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "olmc_normal_moments": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(_D)]),
     "olmc_normals": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(C.c_float)]),
     "olmc_profile_enable": (_I, [_I]),
     "olmc_tune": (_I, [_I, _I]),
@@ -374,6 +375,13 @@ TUNE_GRID_CAP = 2
 
 def tune(knob: int, value: int) -> None:
     _check(load_library().olmc_tune(int(knob), int(value)))
+
+
+def normal_moments(seed: int, n_paths: int, n_steps: int, path_offset: int = 0):
+    """(sum z, sum z^2, sum z^3, sum z^4) over n_paths * n_steps normals of the device stream."""
+    out = (C.c_double * 4)()
+    _check(lib().olmc_normal_moments(seed64(seed), int(path_offset), int(n_paths), int(n_steps), out))
+    return tuple(out)
 
 
 def profile_enable(on: bool) -> None:

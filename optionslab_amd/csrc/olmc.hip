@@ -41,6 +41,7 @@ constexpr int kMaxDevices = 16;
 constexpr int kMaxNV = 2 * OLMC_MAX_BATCH;       // values per workgroup row
 constexpr int32_t kMaxGrid = 1 << 18;            // workgroups per launch; larger jobs grid-stride
 constexpr int32_t kMaxGroups = kMaxGrid / kGroupBlocks + 1;
+static_assert(kMaxGroups * kMaxNV == kGroupRowsCapacity, "device-side guard must match the group_rows allocation");
 
 struct EventPair {
     hipEvent_t start, stop;
@@ -193,6 +194,7 @@ int make_ws(DeviceCtx* c, hipStream_t stream, int32_t grid, int nv, double* d_ou
     ws->counters = sl.counters;
     ws->out = d_out;
     ws->tail = tail;
+    ws->row_capacity = sl.cap;
     return OLMC_OK;
 }
 
@@ -801,7 +803,7 @@ extern "C" int olmc_lookback(double S, double K, double T, double r, double sigm
 namespace {
 template <typename Launch>
 int run_structured(int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic, double r_for_discount,
-                   double T, bool poisoned_inputs, olmc_stats* out, Launch launch) {
+                   double T, bool poisoned_inputs, olmc_stats* out, Launch launch, int nv = 2) {
     if (!out) return fail(OLMC_ERR_ARG, "null pointer");
     int rc = check_paths(path_offset, n_local, n_steps);
     if (rc) return rc;
@@ -812,7 +814,7 @@ int run_structured(int64_t path_offset, int64_t n_local, int32_t n_steps, uint64
     const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
     const int32_t grid = grid_for(n_local);
     ReduceWs ws;
-    rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
+    rc = make_ws(c, c->stream, grid, nv, c->d_result, -1.0, &ws);
     if (rc) return rc;
     EventPair ep{};
     if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
@@ -1209,6 +1211,21 @@ extern "C" int olmc_philox_words(uint64_t seed, int64_t path_offset, int64_t n_p
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_host, c->d_bulk, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return OLMC_OK;
+}
+
+extern "C" int olmc_normal_moments(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps, double* out4) {
+    if (!out4) return fail(OLMC_ERR_ARG, "null pointer");
+    olmc_stats dummy;
+    int rc = run_structured(path_offset, n_paths, n_steps, seed, 0, 0.0, 1.0, false, &dummy,
+                            [&](int32_t grid, hipStream_t st, const PathRange& pr, const ReduceWs& ws) {
+                                hipLaunchKernelGGL(normal_moments_kernel, dim3(grid), dim3(kBlock), 0, st, pr, ws);
+                            }, 4);
+    if (rc) return rc;
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    for (int m = 0; m < 4; ++m) out4[m] = c->h_result[m];     // still there: the next launch has not happened (same thread)
     return OLMC_OK;
 }
 

@@ -163,6 +163,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 // sc1 payload + drained vmcnt before the agent-scope add on the producer, agent acquire
 // fence after the returned add on the consumer.  Only wave 0 of a workgroup takes part.
 constexpr int kGroupBlocks = 256;
+constexpr int kGroupRowsCapacity = ((1 << 18) / kGroupBlocks + 1) * 32;    // doubles behind group_rows (host: kMaxGroups * kMaxNV)
 constexpr int kCounterStride = 64;     // uint32 words between ticket counters: one 256-B granule each.  Packed
                                        // into one line, 3,907 tickets serialised at ~88 atomics/us (a 44 us floor
                                        // under every 1M-path launch, whatever its step count)
@@ -173,6 +174,8 @@ struct ReduceWs {
     uint32_t* counters;     // [(n_groups + 1) * kCounterStride], one counter per stride, last = top counter
     double* out;            // [NV] (+1 when tail >= 0)
     double tail;            // if >= 0, written to out[NV] (the sample count of the triple)
+    uint64_t row_capacity;  // doubles allocated behind block_rows: a launch whose gridDim.x * NV exceeds it
+                            // refuses to store (out[] = NaN) instead of writing out of bounds
 };
 
 __device__ __forceinline__ void store_sc1(double* p, double v) {
@@ -225,6 +228,10 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws, Epilog
     const int32_t group = static_cast<int32_t>(blockIdx.x) / kGroupBlocks;
     const int32_t group_size = min(kGroupBlocks, n_blocks - group * kGroupBlocks);
 
+    if (static_cast<uint64_t>(n_blocks) * NV > ws.row_capacity || n_groups * NV > kGroupRowsCapacity) {   // host/kernel NV mismatch
+        if (blockIdx.x == 0 && lane < NV) ws.out[lane] = __builtin_nan("");
+        return;
+    }
     if (lane < NV) store_sc1(ws.block_rows + static_cast<size_t>(blockIdx.x) * NV + lane, v);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t ticket = 0;
@@ -1124,6 +1131,30 @@ __global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contr
         }
     }
     if constexpr (MODE != kTerminal) block_then_grid_reduce<2>(acc, ws);
+}
+
+// Power sums of the normal stream (validation tap): out[m-1] = sum over paths and steps of z^m, m = 1..4,
+// z = kZScale * z' in fp64.  At 2^36 normals the second moment is resolved to 5e-6: a bias hunt.
+__global__ __launch_bounds__(kBlock) void normal_moments_kernel(PathRange pr, ReduceWs ws) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int32_t blocks = (pr.n_steps + 3) >> 2;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
+        const uint64_t g = pr.first + static_cast<uint64_t>(i);
+        double m1 = 0.0, m2 = 0.0, m3 = 0.0, m4 = 0.0;
+        for (int32_t b = 0; b < blocks; ++b) {
+            float z[4];
+            raw_normals4(static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32), static_cast<uint32_t>(b), 0u, pr.key0, pr.key1, z);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * b + j < pr.n_steps) {
+                    const double x = kZScale * static_cast<double>(z[j]), x2 = x * x;
+                    m1 += x; m2 += x2; m3 += x2 * x; m4 += x2 * x2;
+                }
+        }
+        acc[0] += m1; acc[1] += m2; acc[2] += m3; acc[3] += m4;
+    }
+    block_then_grid_reduce<4>(acc, ws);
 }
 
 // ------------------------------------------------------- validation taps ----

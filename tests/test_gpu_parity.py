@@ -493,3 +493,13 @@ def test_monte_carlo_error_shrinks_like_one_over_sqrt_n():
     # the reported (naive, reference-formula) std_error overstates the true spread of the antithetic estimator
     rep = ol.MonteCarloPricer(640_000, 16, 1).price(*ATM, "call", return_error=True).std_error
     assert 0.4 * rep < stds[-1] < 1.05 * rep
+
+
+def test_normal_moments_tap_agrees_with_the_normals_tap():
+    z = _hip.normals(5, 100, 3000, 7).astype(np.float64)
+    s1, s2, s3, s4 = _hip.normal_moments(5, 3000, 7, path_offset=100)
+    assert s1 == pytest.approx(z.sum(), rel=1e-5, abs=1e-3) and s2 == pytest.approx((z**2).sum(), rel=1e-6)
+    assert s3 == pytest.approx((z**3).sum(), rel=1e-5, abs=1e-2) and s4 == pytest.approx((z**4).sum(), rel=1e-6)
+    big = _hip.normal_moments(9, 1 << 22, 64)              # 2.7e8 normals: variance to 9e-5
+    n = (1 << 22) * 64
+    assert abs(big[0] / n) < 5 / math.sqrt(n) and abs(big[1] / n - 1) < 5 * math.sqrt(2 / n) and abs(big[3] / n - 3) < 5 * math.sqrt(96 / n)

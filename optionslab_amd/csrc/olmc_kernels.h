@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contr
             const uint32_t* __restrict__ row = sv + static_cast<size_t>(t) * kSobolBits;
             uint32_t x = shift[t];
 #pragma unroll
-            for (int b = 0; b < kSobolBits; ++b) x ^= row[b] & mask[b];
+            for (int b = 0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);   // x ^ (row & mask), one v_bitop3_b32
             double u = static_cast<double>(x) * 9.313225746154785e-10;      // 2^-30
             u = fmin(fmax(u, 1e-10), 1.0 - 1e-10);
             zsum += ndtri_as241(u);

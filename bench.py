@@ -196,6 +196,7 @@ def main():
                          "traffic_source": traffic_src, "kernel": "european_path_kernel<1,true,kReduce>", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "launches_timed": launches, "lane_ops_per_path_step": LANE_OPS_PER_PATH_STEP,
                          "hbm_gbps": (traffic / avg_kernel_s / 1e9) if traffic else None,
+                         "hbm_frac_of_8TBps": (traffic / avg_kernel_s / 8e12) if traffic else None,
                          "measured_on": "the single-stream pass of this run (see `serial`): with overlapping launches an event "
                                         "pair would time co-resident kernels, not one kernel",
                          "note": "VALU-issue bound (SURVEY 8d: not HBM, not MFMA); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz "

@@ -165,6 +165,12 @@ int olmc_european_terminal(double S, double T, double r, double sigma, double q,
                            int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
                            double* out_host);
 
+/* Full GBM paths to caller-owned HOST memory, TIME-MAJOR: out_host[t * n_paths + i] = S_t of path i,
+ * t = 0 .. n_steps (t = 0 is the spot).  Replaces simulate_gbm_paths (src/simulation/gbm_numpy.py:86-118),
+ * which returns the transpose, shape (n_paths, n_steps + 1); no antithetic mirror there either. */
+int olmc_gbm_paths(double S, double T, double r, double sigma, double q, int64_t n_paths,
+                   int32_t n_steps, uint64_t seed, double* out_host);
+
 /* Control-variate estimator, five moments reduced on device
  * (MonteCarloPricer.price_with_control_variate, monte_carlo.py:154-186). */
 int olmc_european_cv(double S, double K, double T, double r, double sigma, double q, int is_call,

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "olmc_european_multi": (_I, [C.POINTER(Option), C.POINTER(C.c_uint32), _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_european_greeks_fd": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(_D), C.POINTER(Stats)]),
     "olmc_european_terminal": (_I, [_D] * 5 + [_I64, _I32, _U64T, _I, C.POINTER(_D)]),
+    "olmc_gbm_paths": (_I, [_D] * 5 + [_I64, _I32, _U64T, C.POINTER(_D)]),
     "olmc_european_cv": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(CvMoments)]),
     "olmc_european_qmc": (_I, _SIX + [_I, _I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, C.POINTER(Stats)]),
     "olmc_european_qmc_terminal": (_I, [_D] * 5 + [_I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, C.POINTER(_D)]),
@@ -234,6 +235,13 @@ def european_terminal(S, T, r, sigma, q, n_paths: int, n_steps: int, seed: int, 
     out = np.empty(int(n_paths) * (2 if antithetic else 1), dtype=np.float64)
     _check(lib().olmc_european_terminal(S, T, r, sigma, q, int(n_paths), int(n_steps), seed64(seed), int(antithetic),
                                         out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def gbm_paths(S, T, r, sigma, q, n_paths: int, n_steps: int, seed: int) -> np.ndarray:
+    """Time-major (n_steps + 1, n_paths) array of prices, row 0 = spot."""
+    out = np.empty((int(n_steps) + 1, int(n_paths)), dtype=np.float64)
+    _check(lib().olmc_gbm_paths(S, T, r, sigma, q, int(n_paths), int(n_steps), seed64(seed), out.ctypes.data_as(C.POINTER(C.c_double))))
     return out
 
 

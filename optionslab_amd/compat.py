@@ -41,6 +41,7 @@ def _targets() -> dict:
     sim = _module("src.simulation", simulate_gbm_hip=_sim.simulate_gbm_hip, simulate_gbm_hip_fast=_sim.simulate_gbm_hip_fast,
                   # the reference's backend names resolve to the device backend (same contract, src/simulation/__init__.py:5-6)
                   simulate_gbm_numpy=_sim.simulate_gbm_hip, simulate_gbm_numpy_fast=_sim.simulate_gbm_hip_fast,
+                  simulate_gbm_paths=_sim.simulate_gbm_paths_hip, simulate_gbm_paths_hip=_sim.simulate_gbm_paths_hip,
                   NUMBA_AVAILABLE=False)
     return {
         "src.pricing_models.monte_carlo": _module("src.pricing_models.monte_carlo", MonteCarloPricer=_mc.MonteCarloPricer,

@@ -878,6 +878,35 @@ extern "C" int olmc_cliquet(double S, double T, double r, double sigma, double q
                           });
 }
 
+// ================================================================== full paths ====
+extern "C" int olmc_gbm_paths(double S, double T, double r, double sigma, double q, int64_t n_paths, int32_t n_steps,
+                              uint64_t seed, double* out_host) {
+    if (!out_host) return fail(OLMC_ERR_ARG, "null pointer");
+    int rc = check_paths(0, n_paths, n_steps);
+    if (rc) return rc;
+    const double bytes = 8.0 * static_cast<double>(n_paths) * (n_steps + 1.0);
+    if (bytes > 64e9) return fail(OLMC_ERR_ARG, "path matrix would exceed 64 GB");
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    rc = bulk_reserve(c, static_cast<size_t>(bytes));
+    if (rc) return rc;
+    LsmContract lc{};
+    const double dt = T / n_steps;                      // gbm_numpy.py:106-108
+    lc.log_s0 = std::log(S);
+    lc.s_first = S;
+    lc.drift = (r - q - 0.5 * sigma * sigma) * dt;
+    lc.vol = sigma * std::sqrt(dt);
+    lc.n_steps = n_steps;
+    const PathRange pr = make_range(0, n_paths, n_steps, seed);
+    hipLaunchKernelGGL((lsm_paths_kernel<0>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, lc, static_cast<double*>(c->d_bulk));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_host, c->d_bulk, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OLMC_OK;
+}
+
 // ================================================================ American (LSM) ====
 extern "C" int olmc_american_lsm(double S, double K, double T, double r, double sigma, double q, int is_call,
                                  int64_t n_paths, int32_t n_steps, int32_t poly_degree, uint64_t seed, olmc_stats* out) {
@@ -899,6 +928,7 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
     LsmContract lc;
     const double dt = T / n_steps;                      // exotic_options.py:54-56, 260-261
     lc.log_s0 = std::log(S);
+    lc.s_first = std::exp(lc.log_s0);
     lc.drift = (r - q - 0.5 * sigma * sigma) * dt;
     lc.vol = sigma * std::sqrt(dt);
     lc.strike = K;

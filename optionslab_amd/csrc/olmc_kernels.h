@@ -767,6 +767,8 @@ constexpr int kLsmNV = 16;          // 2d+1 + d+1 + 1 <= 15 sums, padded
 
 struct LsmContract {
     double log_s0, drift, vol;      // per step
+    double s_first;                 // value stored at t = 0: exp(ln S) for the exotics' path builder (exotic_options.py:64-67),
+                                    // S itself for simulate_gbm_paths (gbm_numpy.py:115)
     double strike, inv_strike, sign;
     double discount;                // exp(-r dt)
     int32_t degree;
@@ -781,7 +783,7 @@ __global__ __launch_bounds__(kBlock) void lsm_paths_kernel(PathRange pr, LsmCont
         const uint64_t g = pr.first + static_cast<uint64_t>(i);
         const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
         double cum = 0.0;
-        paths[i] = exp(c.log_s0);
+        paths[i] = c.s_first;
         const int32_t blocks = (pr.n_steps + 3) >> 2;
         for (int32_t b = 0; b < blocks; ++b) {
             float z[4];

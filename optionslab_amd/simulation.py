@@ -6,7 +6,7 @@ import numpy as np
 
 from . import _hip
 
-__all__ = ["simulate_gbm_hip", "simulate_gbm_hip_fast", "hip_available"]
+__all__ = ["simulate_gbm_hip", "simulate_gbm_hip_fast", "simulate_gbm_paths_hip", "hip_available"]
 
 hip_available = _hip.hip_available
 
@@ -24,3 +24,12 @@ def simulate_gbm_hip(S: float, T: float, r: float, sigma: float, q: float, n_pat
 def simulate_gbm_hip_fast(S: float, T: float, r: float, sigma: float, q: float, n_paths: int, seed: int) -> np.ndarray:
     """Single-step closed form (counterpart of simulate_gbm_numpy_fast, gbm_numpy.py:56-83)."""
     return simulate_gbm_hip(S, T, r, sigma, q, n_paths, 1, seed, True)
+
+
+def simulate_gbm_paths_hip(S: float, T: float, r: float, sigma: float, q: float, n_paths: int, n_steps: int, seed: int) -> np.ndarray:
+    """Full paths, shape (n_paths, n_steps + 1), column 0 = S (counterpart of simulate_gbm_paths,
+    gbm_numpy.py:86-118).  The device writes time-major slices (coalesced); the C-contiguous
+    (n_paths, n_steps + 1) array the reference returns is formed by one host transpose."""
+    if n_paths < 1 or n_steps < 1:
+        raise ValueError("n_paths and n_steps must be >= 1")
+    return np.ascontiguousarray(_hip.gbm_paths(S, T, r, sigma, q, n_paths, n_steps, seed).T)

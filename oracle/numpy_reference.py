@@ -93,6 +93,20 @@ def terminal_singlestep(S, T, r, sigma, q, n_paths, seed):
     return np.concatenate([np.exp(log_S0 + drift + vol * Z), np.exp(log_S0 + drift - vol * Z)])  # :80-83
 
 
+def full_paths(S, T, r, sigma, q, n_paths, n_steps, seed):
+    """src/simulation/gbm_numpy.py:86-118 -- (n_paths, n_steps + 1), column 0 = S, PCG64, no antithetic."""
+    gen = np.random.default_rng(seed)
+    dt = T / n_steps
+    drift = (r - q - 0.5 * sigma * sigma) * dt
+    vol = sigma * np.sqrt(dt)
+    Z = gen.standard_normal((n_paths, n_steps))
+    log_S = np.log(S) + np.cumsum(drift + vol * Z, axis=1)
+    out = np.empty((n_paths, n_steps + 1))
+    out[:, 0] = S
+    out[:, 1:] = np.exp(log_S)
+    return out
+
+
 def terminal_sobol(S, T, r, sigma, q, n_paths, n_steps, seed):
     """src/simulation/gbm_qmc.py:14-46 -- scrambled Sobol, no antithetic."""
     dims = min(n_steps, SOBOL_MAX_DIM)  # :30

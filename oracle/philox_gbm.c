@@ -456,3 +456,20 @@ void ol_jump_moments(double S, double K, double T, double r, double sigma, doubl
     }
     moments[0] = (double)m0; moments[1] = (double)m1;
 }
+
+/* Full paths, time-major out[t * n + i], t = 0..n_steps (gbm_numpy.py:86-118 transposed). */
+void ol_gbm_paths(double S, double T, double r, double sigma, double q, int64_t n, int32_t n_steps, uint64_t seed, double* out) {
+    const double dt = T / n_steps, drift = (r - q - 0.5 * sigma * sigma) * dt, vol = sigma * sqrt(dt) * Z_SCALE;
+    for (int64_t i = 0; i < n; ++i) {
+        double cum = 0.0;
+        out[i] = S;
+        for (int32_t b = 0; 4 * b < n_steps; ++b) {
+            float z[4];
+            raw_normals4((uint64_t)i, (uint32_t)b, seed, z);
+            for (int j = 0; j < 4 && 4 * b + j < n_steps; ++j) {
+                cum += drift + vol * (double)z[j];
+                out[(size_t)(4 * b + j + 1) * n + i] = exp(log(S) + cum);
+            }
+        }
+    }
+}

@@ -133,6 +133,13 @@ def jump_moments(S, K, T, r, sigma, q, is_call, kou, lambda_j, a1, a2, a3, n_pat
     return m[0], m[1], n_paths
 
 
+def gbm_paths(S, T, r, sigma, q, n_paths, n_steps, seed):
+    out = np.empty((n_steps + 1, n_paths), dtype=np.float64)
+    _load().ol_gbm_paths(C.c_double(S), C.c_double(T), C.c_double(r), C.c_double(sigma), C.c_double(q), C.c_int64(n_paths),
+                         C.c_int32(n_steps), C.c_uint64(int(seed) & _U64), out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
 def price_and_error(sum_x, sum_xx, n, r, T):
     """monte_carlo.py:145-150 on the moments."""
     disc, mean = math.exp(-r * T), sum_x / n

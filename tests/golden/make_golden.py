@@ -32,11 +32,12 @@ def load_reference():
     from src.pricing_models.exotic_options import (AmericanOption, AsianOption, AutocallableOption, BarrierOption, CliquetOption,
                                                     LookbackOption, price_asian, price_barrier)
     from src.pricing_models.heston import HestonPricer
+    from src.simulation.gbm_numpy import simulate_gbm_paths
     from src.pricing_models.jump_diffusion import KouJumpDiffusion, MertonJumpDiffusion
     from src.pricing_models.monte_carlo import MCMethod, MonteCarloPricer
     from src.pricing_models.monte_carlo_unified import MonteCarloPricerUni
 
-    return dict(MertonJumpDiffusion=MertonJumpDiffusion, KouJumpDiffusion=KouJumpDiffusion, HestonPricer=HestonPricer, MonteCarloPricerUni=MonteCarloPricerUni, BarrierOption=BarrierOption, LookbackOption=LookbackOption, AutocallableOption=AutocallableOption,
+    return dict(simulate_gbm_paths=simulate_gbm_paths, MertonJumpDiffusion=MertonJumpDiffusion, KouJumpDiffusion=KouJumpDiffusion, HestonPricer=HestonPricer, MonteCarloPricerUni=MonteCarloPricerUni, BarrierOption=BarrierOption, LookbackOption=LookbackOption, AutocallableOption=AutocallableOption,
                 CliquetOption=CliquetOption, AmericanOption=AmericanOption,
                 price_barrier=price_barrier, MonteCarloPricer=MonteCarloPricer, MCMethod=MCMethod, black_scholes=black_scholes,
                 AsianOption=AsianOption, price_asian=price_asian,
@@ -203,6 +204,12 @@ def main():
         doc["heston"].append(dict(model=[kappa, theta, sv, rho, v0], args=[S, K, T, r, q], option_type=typ, n_paths=n, n_steps=m, seed=42,
                                   mc=float(hp.price_monte_carlo(S, K, T, r, q, typ, n, m, 42)),
                                   semi_analytic=float(hp.price_european(S, K, T, r, q, typ))))
+
+    # -- full paths (gbm_numpy.py:86-118) ------------------------------------------------------
+    fp = ref["simulate_gbm_paths"](100.0, 1.0, 0.05, 0.2, 0.01, 1000, 12, 42)
+    doc["full_paths"] = dict(args=[100.0, 1.0, 0.05, 0.2, 0.01, 1000, 12, 42], shape=list(fp.shape), c_contiguous=bool(fp.flags["C_CONTIGUOUS"]),
+                             row0=[float(x) for x in fp[0]], row999_tail=[float(x) for x in fp[999, -3:]],
+                             col_mean=[float(x) for x in fp.mean(axis=0)])
 
     # -- jump diffusion (jump_diffusion.py) -----------------------------------------------------
     doc["merton"], doc["kou"] = [], []

@@ -503,3 +503,24 @@ def test_normal_moments_tap_agrees_with_the_normals_tap():
     big = _hip.normal_moments(9, 1 << 22, 64)              # 2.7e8 normals: variance to 9e-5
     n = (1 << 22) * 64
     assert abs(big[0] / n) < 5 / math.sqrt(n) and abs(big[1] / n - 1) < 5 * math.sqrt(2 / n) and abs(big[3] / n - 3) < 5 * math.sqrt(96 / n)
+
+
+# ------------------------------------------------------------------ full paths (simulate_gbm_paths counterpart)
+def test_full_paths_against_checker_and_reference_shape(golden):
+    g = golden["full_paths"]
+    S, T, r, v, q, N, M, seed = g["args"]
+    fp = ol.simulate_gbm_paths_hip(S, T, r, v, q, N, M, seed)
+    assert list(fp.shape) == g["shape"] and fp.flags["C_CONTIGUOUS"] == g["c_contiguous"] and fp.dtype == np.float64
+    assert np.all(fp[:, 0] == S)                                                # column 0 is the spot (gbm_numpy.py:115)
+    want = po.gbm_paths(S, T, r, v, q, N, M, seed).T
+    assert np.allclose(fp, want, rtol=2e-6, atol=0)
+    # statistically the reference's paths: E[S_t] = S e^{(r-q)t}, column means within 4 standard errors of the golden's
+    t = np.arange(M + 1) * (T / M)
+    se = fp.std(axis=0) / math.sqrt(N)
+    assert np.all(np.abs(fp.mean(axis=0) - S * np.exp((r - q) * t)) <= 4 * se + 1e-12)
+    assert np.all(np.abs(fp.mean(axis=0) - np.array(g["col_mean"])) <= 4 * math.sqrt(2) * se + 1e-12)
+    # a path's terminal value is what the terminal-only backend returns for the same stream (non-antithetic leg)
+    term = ol.simulate_gbm_hip(S, T, r, v, q, N, M, seed, antithetic=False)
+    assert np.allclose(fp[:, -1], term, rtol=1e-6)
+    odd = ol.simulate_gbm_paths_hip(S, T, r, v, q, 257, 7, 3)                  # ragged sizes, step remainder
+    assert odd.shape == (257, 8) and np.allclose(odd, po.gbm_paths(S, T, r, v, q, 257, 7, 3).T, rtol=2e-6)

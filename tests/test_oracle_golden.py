@@ -174,3 +174,11 @@ def test_jump_diffusion(golden):
         lam, p_, e1, e2 = c["model"]
         assert float(orc.kou_kappa(p_, e1, e2)) == c["kappa"]
         assert float(orc.kou_mc(S, K, T, r, v, lam, p_, e1, e2, c["option_type"], q, c["n_paths"], c["n_steps"], c["seed"])) == c["mc"]
+
+
+def test_full_paths(golden):
+    g = golden["full_paths"]
+    fp = orc.full_paths(*g["args"])
+    assert list(fp.shape) == g["shape"] and fp.flags["C_CONTIGUOUS"] == g["c_contiguous"]
+    assert [float(x) for x in fp[0]] == g["row0"] and [float(x) for x in fp[999, -3:]] == g["row999_tail"]
+    assert [float(x) for x in fp.mean(axis=0)] == g["col_mean"]

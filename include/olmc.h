@@ -257,10 +257,11 @@ int olmc_jump_diffusion(double S, double K, double T, double r, double sigma, do
 int olmc_european_qmc(double S, double K, double T, double r, double sigma, double q, int is_call,
                       int64_t point_offset, int64_t n_paths, int32_t dims,
                       const uint32_t* sv, const uint32_t* shift, int32_t bits, olmc_stats* out);
+/* antithetic != 0: simulate_gbm_qmc_antithetic (gbm_qmc.py:49-76), 2 * n_paths values [pos | neg]. */
 int olmc_european_qmc_terminal(double S, double T, double r, double sigma, double q,
                                int64_t point_offset, int64_t n_paths, int32_t dims,
                                const uint32_t* sv, const uint32_t* shift, int32_t bits,
-                               double* out_host /* [n_paths] */);
+                               int antithetic, double* out_host /* [n_paths * (1 + antithetic)] */);
 
 /* ---- multi-GPU, single process ------------------------------------------
  * n_paths split into n_gpus contiguous global path ranges, one host thread and

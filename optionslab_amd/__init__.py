@@ -13,14 +13,15 @@ from .heston import HestonAdapter, HestonPricer
 from .jump_diffusion import KouJumpDiffusion, MertonJumpDiffusion
 from .monte_carlo import NUMBA_AVAILABLE, MCMethod, MCResult, MonteCarloPricer
 from .monte_carlo_unified import MonteCarloPricerUni
-from .simulation import hip_available, simulate_gbm_hip, simulate_gbm_hip_fast, simulate_gbm_paths_hip
+from .simulation import (hip_available, simulate_gbm_hip, simulate_gbm_hip_fast, simulate_gbm_paths_hip,
+                         simulate_gbm_qmc_antithetic_hip, simulate_gbm_qmc_hip)
 from . import sharding  # noqa: E402  (torch is imported lazily inside)
 
 __version__ = "0.1.0"
 
 __all__ = [
     "MonteCarloPricer", "MonteCarloPricerUni", "MCMethod", "MCResult", "NUMBA_AVAILABLE", "compute_greeks_unified", "PricerProtocol",
-    "ExoticAdapter", "HestonPricer", "HestonAdapter", "MertonJumpDiffusion", "KouJumpDiffusion", "AsianOption", "BarrierOption", "LookbackOption", "AmericanOption", "price_american", "AutocallableOption", "CliquetOption", "price_asian", "price_barrier", "black_scholes", "simulate_gbm_hip", "simulate_gbm_hip_fast", "simulate_gbm_paths_hip",
+    "ExoticAdapter", "HestonPricer", "HestonAdapter", "MertonJumpDiffusion", "KouJumpDiffusion", "AsianOption", "BarrierOption", "LookbackOption", "AmericanOption", "price_american", "AutocallableOption", "CliquetOption", "price_asian", "price_barrier", "black_scholes", "simulate_gbm_hip", "simulate_gbm_hip_fast", "simulate_gbm_paths_hip", "simulate_gbm_qmc_hip", "simulate_gbm_qmc_antithetic_hip",
     "hip_available", "MonteCarloError", "InputValidationError", "ConvergenceError", "AccelerationError", "GreeksError",
 ]
 

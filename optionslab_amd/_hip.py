@@ -65,7 +65,7 @@ PROTOTYPES = {
     "olmc_gbm_paths": (_I, [_D] * 5 + [_I64, _I32, _U64T, C.POINTER(_D)]),
     "olmc_european_cv": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(CvMoments)]),
     "olmc_european_qmc": (_I, _SIX + [_I, _I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, C.POINTER(Stats)]),
-    "olmc_european_qmc_terminal": (_I, [_D] * 5 + [_I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, C.POINTER(_D)]),
+    "olmc_european_qmc_terminal": (_I, [_D] * 5 + [_I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, _I, C.POINTER(_D)]),
     "olmc_asian": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_barrier": (_I, _SIX + [_I, _D, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_lookback": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
@@ -270,12 +270,12 @@ def european_qmc(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv: np.ndarr
 
 
 def european_qmc_terminal(S, T, r, sigma, q, n_paths: int, sv: np.ndarray, shift: np.ndarray,
-                          point_offset: int = 0) -> np.ndarray:
+                          point_offset: int = 0, antithetic: bool = False) -> np.ndarray:
     sv, psv = _u32(sv)
     shift, psh = _u32(shift)
-    out = np.empty(int(n_paths), dtype=np.float64)
+    out = np.empty(int(n_paths) * (2 if antithetic else 1), dtype=np.float64)
     _check(lib().olmc_european_qmc_terminal(S, T, r, sigma, q, int(point_offset), int(n_paths), int(sv.shape[0]), psv, psh,
-                                            int(sv.shape[1]), out.ctypes.data_as(C.POINTER(C.c_double))))
+                                            int(sv.shape[1]), int(antithetic), out.ctypes.data_as(C.POINTER(C.c_double))))
     return out
 
 

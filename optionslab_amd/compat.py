@@ -42,6 +42,8 @@ def _targets() -> dict:
                   # the reference's backend names resolve to the device backend (same contract, src/simulation/__init__.py:5-6)
                   simulate_gbm_numpy=_sim.simulate_gbm_hip, simulate_gbm_numpy_fast=_sim.simulate_gbm_hip_fast,
                   simulate_gbm_paths=_sim.simulate_gbm_paths_hip, simulate_gbm_paths_hip=_sim.simulate_gbm_paths_hip,
+                  simulate_gbm_numba=_sim.simulate_gbm_hip, simulate_gbm_qmc=_sim.simulate_gbm_qmc_hip,
+                  simulate_gbm_qmc_antithetic=_sim.simulate_gbm_qmc_antithetic_hip,
                   NUMBA_AVAILABLE=False)
     return {
         "src.pricing_models.monte_carlo": _module("src.pricing_models.monte_carlo", MonteCarloPricer=_mc.MonteCarloPricer,

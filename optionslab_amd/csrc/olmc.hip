@@ -1049,7 +1049,7 @@ extern "C" int olmc_jump_diffusion(double S, double K, double T, double r, doubl
 namespace {
 int run_qmc(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t point_offset,
             int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
-            olmc_stats* out, double* terminal_host) {
+            olmc_stats* out, double* terminal_host, int mirror = 0) {
     if (!sv || !shift) return fail(OLMC_ERR_ARG, "null pointer");
     if (bits != kSobolBits) return fail(OLMC_ERR_ARG, "only 30-bit Sobol tables (SciPy's default) are supported");
     if (dims < 1 || dims > 21201) return fail(OLMC_ERR_ARG, "dims must be in [1, 21201]");
@@ -1062,7 +1062,7 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
     std::lock_guard<std::mutex> lock(c->mu);
     const size_t table_words = static_cast<size_t>(dims) * (kSobolBits + 1);
     const size_t table_bytes = (table_words * sizeof(uint32_t) + 255) / 256 * 256;
-    const size_t term_bytes = terminal_host ? sizeof(double) * static_cast<size_t>(n_paths) : 0;
+    const size_t term_bytes = terminal_host ? sizeof(double) * static_cast<size_t>(n_paths) * (mirror ? 2 : 1) : 0;
     rc = bulk_reserve(c, table_bytes + term_bytes);
     if (rc) return rc;
     uint32_t* d_sv = static_cast<uint32_t*>(c->d_bulk);
@@ -1075,7 +1075,8 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
     const double drift = (r - q - 0.5 * sigma * sigma) * dt;
     Contract ct;
     ct.vol = sigma * std::sqrt(dt);
-    ct.a = std::log(S) + drift * dims;
+    // gbm_qmc.py:44 (drift * steps) vs :70 (the antithetic variant multiplies the rate by T directly)
+    ct.a = mirror ? std::log(S) + (r - q - 0.5 * sigma * sigma) * T : std::log(S) + drift * dims;
     ct.strike = K;
     ct.sign = is_call ? 1.0 : -1.0;
     ct.scale = 0.0;
@@ -1083,6 +1084,7 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
     qr.first = static_cast<uint64_t>(point_offset);
     qr.count = n_paths;
     qr.dims = dims;
+    qr.mirror = mirror ? 1 : 0;
     const int32_t grid = grid_for(n_paths);
     ReduceWs ws{};
     if (!terminal_host) {
@@ -1115,9 +1117,9 @@ extern "C" int olmc_european_qmc(double S, double K, double T, double r, double 
 
 extern "C" int olmc_european_qmc_terminal(double S, double T, double r, double sigma, double q, int64_t point_offset,
                                           int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift,
-                                          int32_t bits, double* out_host) {
+                                          int32_t bits, int antithetic, double* out_host) {
     if (!out_host) return fail(OLMC_ERR_ARG, "null pointer");
-    return run_qmc(S, 0.0, T, r, sigma, q, 1, point_offset, n_paths, dims, sv, shift, bits, nullptr, out_host);
+    return run_qmc(S, 0.0, T, r, sigma, q, 1, point_offset, n_paths, dims, sv, shift, bits, nullptr, out_host, antithetic);
 }
 
 // ======================================================== multi-GPU (RCCL) ====

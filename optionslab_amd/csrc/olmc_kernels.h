@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(kBlock) void jump_kernel(PathRange pr, JumpContract
 // with sv / shift the host-built (SciPy LMS + digital shift) direction matrix of dimension t,
 // so the uniforms equal scipy.stats.qmc.Sobol(d, scramble=True, seed).random(n) bit for bit.
 // Then clip to [1e-10, 1-1e-10] (:36), z = Phi^-1(u) in fp64, sum over the dims, exp.  No
-// antithetic mirror (the reference's QMC backend has none).
+// antithetic mirror in the pricer (gbm_qmc.py:14-46); QmcRange.mirror serves simulate_gbm_qmc_antithetic (:49-76).
 constexpr int kSobolBits = 30;      // SciPy's default `bits`
 
 // Inverse normal CDF, Wichura AS241 PPND16 (|rel err| ~1e-16; checked against scipy ndtri
@@ -1099,6 +1099,7 @@ struct QmcRange {
     uint64_t first;    // index of the first Sobol point of this launch
     int64_t count;
     int32_t dims;      // effective_steps = min(n_steps, 21201)
+    int32_t mirror;    // kTerminal only: also write terminal[count + i] = exp(a - vol sum z)  (simulate_gbm_qmc_antithetic, gbm_qmc.py:49-76)
 };
 
 // Contract::a = ln S + drift * dims, Contract::vol = sigma sqrt(T / dims) (gbm_qmc.py:38-44).
@@ -1127,6 +1128,7 @@ __global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contr
         const double st = exp(c.a + c.vol * zsum);
         if constexpr (MODE == kTerminal) {
             terminal[i] = st;
+            if (qr.mirror) terminal[qr.count + i] = exp(c.a - c.vol * zsum);
         } else {
             const double x = fmax(c.sign * (st - c.strike), 0.0);
             acc[0] += x; acc[1] += x * x;

@@ -6,7 +6,8 @@ import numpy as np
 
 from . import _hip
 
-__all__ = ["simulate_gbm_hip", "simulate_gbm_hip_fast", "simulate_gbm_paths_hip", "hip_available"]
+__all__ = ["simulate_gbm_hip", "simulate_gbm_hip_fast", "simulate_gbm_paths_hip", "simulate_gbm_qmc_hip",
+           "simulate_gbm_qmc_antithetic_hip", "hip_available"]
 
 hip_available = _hip.hip_available
 
@@ -33,3 +34,21 @@ def simulate_gbm_paths_hip(S: float, T: float, r: float, sigma: float, q: float,
     if n_paths < 1 or n_steps < 1:
         raise ValueError("n_paths and n_steps must be >= 1")
     return np.ascontiguousarray(_hip.gbm_paths(S, T, r, sigma, q, n_paths, n_steps, seed).T)
+
+
+def simulate_gbm_qmc_hip(S: float, T: float, r: float, sigma: float, q: float, n_paths: int, n_steps: int, seed: int) -> np.ndarray:
+    """Scrambled-Sobol terminal prices, length n_paths (counterpart of simulate_gbm_qmc, gbm_qmc.py:14-46)."""
+    from .monte_carlo import sobol_tables
+
+    sv, shift = sobol_tables(n_steps, seed)
+    return _hip.european_qmc_terminal(S, T, r, sigma, q, n_paths, sv, shift)
+
+
+def simulate_gbm_qmc_antithetic_hip(S: float, T: float, r: float, sigma: float, q: float, n_paths: int, n_steps: int,
+                                    seed: int) -> np.ndarray:
+    """Sobol points plus their mirrored normals, length 2 * n_paths, [pos | neg]
+    (counterpart of simulate_gbm_qmc_antithetic, gbm_qmc.py:49-76)."""
+    from .monte_carlo import sobol_tables
+
+    sv, shift = sobol_tables(n_steps, seed)
+    return _hip.european_qmc_terminal(S, T, r, sigma, q, n_paths, sv, shift, antithetic=True)

@@ -119,6 +119,18 @@ def terminal_sobol(S, T, r, sigma, q, n_paths, n_steps, seed):
     return np.exp(log_S0 + drift * dims + vol * np.sum(z, axis=1))  # :44-46
 
 
+def terminal_sobol_antithetic(S, T, r, sigma, q, n_paths, n_steps, seed):
+    """src/simulation/gbm_qmc.py:49-76 -- Sobol normals and their mirror, [pos | neg]."""
+    dims = min(n_steps, SOBOL_MAX_DIM)
+    u = Sobol(d=dims, scramble=True, seed=seed).random(n_paths)
+    z = norm.ppf(np.clip(u, 1e-10, 1 - 1e-10))
+    dt = T / dims
+    drift_total = (r - q - 0.5 * sigma * sigma) * T  # :69
+    vol = sigma * np.sqrt(dt)
+    sum_z = vol * np.sum(z, axis=1)
+    return np.concatenate([np.exp(np.log(S) + drift_total + sum_z), np.exp(np.log(S) + drift_total - sum_z)])
+
+
 # --------------------------------------------------------------------------
 # a1-a3, a6-a8  the pricer (src/pricing_models/monte_carlo.py:28-186)
 # --------------------------------------------------------------------------

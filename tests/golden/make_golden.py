@@ -33,11 +33,12 @@ def load_reference():
                                                     LookbackOption, price_asian, price_barrier)
     from src.pricing_models.heston import HestonPricer
     from src.simulation.gbm_numpy import simulate_gbm_paths
+    from src.simulation.gbm_qmc import simulate_gbm_qmc_antithetic
     from src.pricing_models.jump_diffusion import KouJumpDiffusion, MertonJumpDiffusion
     from src.pricing_models.monte_carlo import MCMethod, MonteCarloPricer
     from src.pricing_models.monte_carlo_unified import MonteCarloPricerUni
 
-    return dict(simulate_gbm_paths=simulate_gbm_paths, MertonJumpDiffusion=MertonJumpDiffusion, KouJumpDiffusion=KouJumpDiffusion, HestonPricer=HestonPricer, MonteCarloPricerUni=MonteCarloPricerUni, BarrierOption=BarrierOption, LookbackOption=LookbackOption, AutocallableOption=AutocallableOption,
+    return dict(simulate_gbm_qmc_antithetic=simulate_gbm_qmc_antithetic, simulate_gbm_paths=simulate_gbm_paths, MertonJumpDiffusion=MertonJumpDiffusion, KouJumpDiffusion=KouJumpDiffusion, HestonPricer=HestonPricer, MonteCarloPricerUni=MonteCarloPricerUni, BarrierOption=BarrierOption, LookbackOption=LookbackOption, AutocallableOption=AutocallableOption,
                 CliquetOption=CliquetOption, AmericanOption=AmericanOption,
                 price_barrier=price_barrier, MonteCarloPricer=MonteCarloPricer, MCMethod=MCMethod, black_scholes=black_scholes,
                 AsianOption=AsianOption, price_asian=price_asian,
@@ -210,6 +211,14 @@ def main():
     doc["full_paths"] = dict(args=[100.0, 1.0, 0.05, 0.2, 0.01, 1000, 12, 42], shape=list(fp.shape), c_contiguous=bool(fp.flags["C_CONTIGUOUS"]),
                              row0=[float(x) for x in fp[0]], row999_tail=[float(x) for x in fp[999, -3:]],
                              col_mean=[float(x) for x in fp.mean(axis=0)])
+
+    # -- antithetic Sobol backend (gbm_qmc.py:49-76; exported, not wired to the pricer) ------------
+    import warnings as _w
+    with _w.catch_warnings():
+        _w.simplefilter("ignore")
+        qa = ref["simulate_gbm_qmc_antithetic"](100.0, 1.0, 0.05, 0.2, 0.01, 1024, 12, 42)
+    doc["qmc_antithetic"] = dict(args=[100.0, 1.0, 0.05, 0.2, 0.01, 1024, 12, 42], length=int(len(qa)), head=[float(x) for x in qa[:4]],
+                                 mid=[float(x) for x in qa[1024:1028]], mean=float(qa.mean()))
 
     # -- jump diffusion (jump_diffusion.py) -----------------------------------------------------
     doc["merton"], doc["kou"] = [], []

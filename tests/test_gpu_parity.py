@@ -179,6 +179,21 @@ def test_qmc_terminal_array_vs_oracle(N, M, seed):
     assert np.array_equal(a, got[400:700])                           # point index = global path index
 
 
+@pytest.mark.parametrize("N,M,seed", [(1024, 12, 42), (333, 40, 5)])
+def test_qmc_standalone_backends_vs_oracle(N, M, seed, golden):
+    """simulate_gbm_qmc / simulate_gbm_qmc_antithetic as exported functions (src/simulation/__init__.py)."""
+    plain = ol.simulate_gbm_qmc_hip(100.0, 1.0, 0.05, 0.2, 0.01, N, M, seed)
+    assert np.allclose(plain, orc.terminal_sobol(100.0, 1.0, 0.05, 0.2, 0.01, N, M, seed), rtol=1e-11, atol=0)
+    both = ol.simulate_gbm_qmc_antithetic_hip(100.0, 1.0, 0.05, 0.2, 0.01, N, M, seed)
+    want = orc.terminal_sobol_antithetic(100.0, 1.0, 0.05, 0.2, 0.01, N, M, seed)
+    assert both.shape == (2 * N,) and np.allclose(both, want, rtol=1e-11, atol=0)
+    # pos * neg = (S exp(drift T))^2 for every point: the mirror really is -z of the same point
+    assert np.allclose(both[:N] * both[N:], (100.0 * np.exp((0.05 - 0.01 - 0.02) * 1.0)) ** 2, rtol=1e-12)
+    if (N, M, seed) == (1024, 12, 42):
+        g = golden["qmc_antithetic"]
+        assert np.allclose(both[:4], g["head"], rtol=1e-11) and np.allclose(both[N:N + 4], g["mid"], rtol=1e-11)
+
+
 def test_qmc_greeks_and_control_variate_run_on_the_same_points():
     p = ol.MonteCarloPricer(2**14, 16, 42, ol.MCMethod.QMC)
     g = p.greeks(*ATM, "call", include_second_order=False)

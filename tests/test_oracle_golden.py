@@ -182,3 +182,10 @@ def test_full_paths(golden):
     assert list(fp.shape) == g["shape"] and fp.flags["C_CONTIGUOUS"] == g["c_contiguous"]
     assert [float(x) for x in fp[0]] == g["row0"] and [float(x) for x in fp[999, -3:]] == g["row999_tail"]
     assert [float(x) for x in fp.mean(axis=0)] == g["col_mean"]
+
+
+def test_qmc_antithetic_backend(golden):
+    g = golden["qmc_antithetic"]
+    qa = orc.terminal_sobol_antithetic(*g["args"])
+    assert len(qa) == g["length"] and [float(x) for x in qa[:4]] == g["head"] and [float(x) for x in qa[1024:1028]] == g["mid"]
+    assert float(qa.mean()) == g["mean"]

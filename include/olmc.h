@@ -225,6 +225,13 @@ int olmc_american_lsm(double S, double K, double T, double r, double sigma, doub
                       int64_t n_paths, int32_t n_steps, int32_t poly_degree, uint64_t seed,
                       olmc_stats* out);
 
+/* AmericanOption.early_exercise_boundary (src/pricing_models/exotic_options.py:309-345): per date the
+ * 10th (put) / 90th (call) percentile of the in-the-money prices of the LSM path set (same stream as
+ * olmc_american_lsm), NumPy's linear interpolation; NaN where no path is in the money.  The order
+ * statistics are selected on the device (radix select per date); boundary_host[n_steps + 1]. */
+int olmc_exercise_boundary(double S, double K, double T, double r, double sigma, double q, int is_call,
+                           int64_t n_paths, int32_t n_steps, uint64_t seed, double* boundary_host);
+
 /* ---- Heston stochastic volatility, full-truncation Euler ----------------------
  * Replaces HestonPricer.price_monte_carlo (src/pricing_models/heston.py:184-255): two
  * normals per step, (ln S, v) in fp64 registers, Philox stream tag 1.  The reference
@@ -233,6 +240,13 @@ int olmc_heston(double S, double K, double T, double r, double q, int is_call,
                 double kappa, double theta, double sigma_v, double rho, double v0,
                 int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
                 int antithetic, olmc_stats* out);
+
+/* HestonPricer.simulate_paths (heston.py:257-305): the states of olmc_heston's recursion on the same
+ * stream (non-antithetic leg), time-major: spot_host[t * n_paths + i], var_host[t * n_paths + i],
+ * t = 0 .. n_steps; row 0 = (S, v0).  The Python mirror returns the transposes, (n_paths, n_steps + 1). */
+int olmc_heston_paths(double S, double T, double r, double q, double kappa, double theta, double sigma_v,
+                      double rho, double v0, int64_t n_paths, int32_t n_steps, uint64_t seed,
+                      double* spot_host, double* var_host);
 
 /* ---- jump diffusion ----------------------------------------------------------------
  * Replaces MertonJumpDiffusion.price_monte_carlo (src/pricing_models/jump_diffusion.py:160-225)
@@ -244,6 +258,13 @@ int olmc_jump_diffusion(double S, double K, double T, double r, double sigma, do
                         int model, double lambda_j, double a1, double a2, double a3,
                         int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
                         olmc_stats* out);
+
+/* MertonJumpDiffusion.simulate_path (jump_diffusion.py:227-272) for n_paths paths (the reference draws
+ * one): the prices of olmc_jump_diffusion's recursion on the same stream, time-major
+ * out_host[t * n_paths + i], t = 0 .. n_steps, row 0 = S.  Kou paths come for free (model = 1). */
+int olmc_jump_paths(double S, double T, double r, double sigma, double q, int model, double lambda_j,
+                    double a1, double a2, double a3, int64_t n_paths, int32_t n_steps, uint64_t seed,
+                    double* out_host);
 
 /* ---- quasi-Monte Carlo (MCMethod.QMC) --------------------------------------
  * Replaces simulate_gbm_qmc (src/simulation/gbm_qmc.py:14-46): scrambled-Sobol

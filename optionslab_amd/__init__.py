@@ -9,8 +9,8 @@ from .black_scholes import black_scholes
 from .exceptions import AccelerationError, ConvergenceError, GreeksError, InputValidationError, MonteCarloError
 from .exotic import AmericanOption, price_american, AsianOption, AutocallableOption, BarrierOption, CliquetOption, LookbackOption, price_asian, price_barrier
 from .greeks import ExoticAdapter, PricerProtocol, compute_greeks_unified
-from .heston import HestonAdapter, HestonPricer
-from .jump_diffusion import KouJumpDiffusion, MertonJumpDiffusion
+from .heston import HestonAdapter, HestonPricer, greeks_heston
+from .jump_diffusion import JumpDiffusionAdapter, KouJumpDiffusion, MertonJumpDiffusion
 from .monte_carlo import NUMBA_AVAILABLE, MCMethod, MCResult, MonteCarloPricer
 from .monte_carlo_unified import MonteCarloPricerUni
 from .simulation import (hip_available, simulate_gbm_hip, simulate_gbm_hip_fast, simulate_gbm_paths_hip,
@@ -21,7 +21,7 @@ __version__ = "0.1.0"
 
 __all__ = [
     "MonteCarloPricer", "MonteCarloPricerUni", "MCMethod", "MCResult", "NUMBA_AVAILABLE", "compute_greeks_unified", "PricerProtocol",
-    "ExoticAdapter", "HestonPricer", "HestonAdapter", "MertonJumpDiffusion", "KouJumpDiffusion", "AsianOption", "BarrierOption", "LookbackOption", "AmericanOption", "price_american", "AutocallableOption", "CliquetOption", "price_asian", "price_barrier", "black_scholes", "simulate_gbm_hip", "simulate_gbm_hip_fast", "simulate_gbm_paths_hip", "simulate_gbm_qmc_hip", "simulate_gbm_qmc_antithetic_hip",
+    "ExoticAdapter", "HestonPricer", "HestonAdapter", "greeks_heston", "MertonJumpDiffusion", "KouJumpDiffusion", "JumpDiffusionAdapter", "AsianOption", "BarrierOption", "LookbackOption", "AmericanOption", "price_american", "AutocallableOption", "CliquetOption", "price_asian", "price_barrier", "black_scholes", "simulate_gbm_hip", "simulate_gbm_hip_fast", "simulate_gbm_paths_hip", "simulate_gbm_qmc_hip", "simulate_gbm_qmc_antithetic_hip",
     "hip_available", "MonteCarloError", "InputValidationError", "ConvergenceError", "AccelerationError", "GreeksError",
 ]
 

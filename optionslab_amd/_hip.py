@@ -71,6 +71,9 @@ PROTOTYPES = {
     "olmc_lookback": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_autocallable": (_I, [_D] * 9 + [_I32, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_cliquet": (_I, [_D] * 9 + [_I32, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
+    "olmc_exercise_boundary": (_I, _SIX + [_I, _I64, _I32, _U64T, C.POINTER(_D)]),
+    "olmc_heston_paths": (_I, [_D] * 9 + [_I64, _I32, _U64T, C.POINTER(_D), C.POINTER(_D)]),
+    "olmc_jump_paths": (_I, [_D] * 5 + [_I, _D, _D, _D, _D, _I64, _I32, _U64T, C.POINTER(_D)]),
     "olmc_american_lsm": (_I, _SIX + [_I, _I64, _I32, _I32, _U64T, C.POINTER(Stats)]),
     "olmc_jump_diffusion": (_I, _SIX + [_I, _I, _D, _D, _D, _D, _I64, _I64, _I32, _U64T, C.POINTER(Stats)]),
     "olmc_heston": (_I, [_D] * 5 + [_I] + [_D] * 5 + [_I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
@@ -242,6 +245,30 @@ def gbm_paths(S, T, r, sigma, q, n_paths: int, n_steps: int, seed: int) -> np.nd
     """Time-major (n_steps + 1, n_paths) array of prices, row 0 = spot."""
     out = np.empty((int(n_steps) + 1, int(n_paths)), dtype=np.float64)
     _check(lib().olmc_gbm_paths(S, T, r, sigma, q, int(n_paths), int(n_steps), seed64(seed), out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def heston_paths(S, T, r, q, kappa, theta, sigma_v, rho, v0, n_paths: int, n_steps: int, seed: int):
+    """Time-major (n_steps + 1, n_paths) spot and variance arrays, row 0 = (S, v0)."""
+    spot = np.empty((int(n_steps) + 1, int(n_paths)), dtype=np.float64)
+    var = np.empty_like(spot)
+    _check(lib().olmc_heston_paths(S, T, r, q, kappa, theta, sigma_v, rho, v0, int(n_paths), int(n_steps), seed64(seed),
+                                   spot.ctypes.data_as(C.POINTER(C.c_double)), var.ctypes.data_as(C.POINTER(C.c_double))))
+    return spot, var
+
+
+def jump_paths(S, T, r, sigma, q, kou: bool, lambda_j, a1, a2, a3, n_paths: int, n_steps: int, seed: int) -> np.ndarray:
+    """Time-major (n_steps + 1, n_paths) prices of the jump-diffusion recursion, row 0 = spot."""
+    out = np.empty((int(n_steps) + 1, int(n_paths)), dtype=np.float64)
+    _check(lib().olmc_jump_paths(S, T, r, sigma, q, int(bool(kou)), lambda_j, a1, a2, a3, int(n_paths), int(n_steps), seed64(seed),
+                                 out.ctypes.data_as(C.POINTER(C.c_double))))
+    return out
+
+
+def exercise_boundary(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int, seed: int) -> np.ndarray:
+    out = np.empty(int(n_steps) + 1, dtype=np.float64)
+    _check(lib().olmc_exercise_boundary(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(n_steps), seed64(seed),
+                                        out.ctypes.data_as(C.POINTER(C.c_double))))
     return out
 
 

@@ -63,7 +63,8 @@ def _targets() -> dict:
         "src.simulation": sim,
         "src.greeks.unified_greeks": _module("src.greeks.unified_greeks", compute_greeks_unified=_greeks.compute_greeks_unified,
                                              PricerProtocol=_greeks.PricerProtocol, ExoticAdapter=_greeks.ExoticAdapter,
-                                             HestonAdapter=_heston.HestonAdapter),
+                                             HestonAdapter=_heston.HestonAdapter, JumpDiffusionAdapter=_jump.JumpDiffusionAdapter,
+                                             greeks_heston=_heston.greeks_heston),
         "src.exceptions.montecarlo_exceptions": _module("src.exceptions.montecarlo_exceptions", MonteCarloError=_exc.MonteCarloError,
                                                         InputValidationError=_exc.InputValidationError, ConvergenceError=_exc.ConvergenceError,
                                                         AccelerationError=_exc.AccelerationError),

@@ -907,6 +907,42 @@ extern "C" int olmc_gbm_paths(double S, double T, double r, double sigma, double
     return OLMC_OK;
 }
 
+extern "C" int olmc_exercise_boundary(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                      int64_t n_paths, int32_t n_steps, uint64_t seed, double* boundary_host) {
+    if (!boundary_host) return fail(OLMC_ERR_ARG, "null pointer");
+    int rc = check_paths(0, n_paths, n_steps);
+    if (rc) return rc;
+    const double bytes = 8.0 * static_cast<double>(n_paths) * (n_steps + 1.0);
+    if (bytes > 64e9) return fail(OLMC_ERR_ARG, "path matrix would exceed 64 GB");
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const size_t rows = static_cast<size_t>(n_steps) + 1;
+    const size_t path_bytes = (static_cast<size_t>(bytes) + 255) / 256 * 256;
+    rc = bulk_reserve(c, path_bytes + rows * sizeof(double));
+    if (rc) return rc;
+    double* d_paths = static_cast<double*>(c->d_bulk);
+    double* d_boundary = reinterpret_cast<double*>(static_cast<char*>(c->d_bulk) + path_bytes);
+    LsmContract lc{};
+    const double dt = T / n_steps;                      // exotic_options.py:54-56
+    lc.log_s0 = std::log(S);
+    lc.s_first = std::exp(lc.log_s0);                   // :59-65: column 0 is exp(log S)
+    lc.drift = (r - q - 0.5 * sigma * sigma) * dt;
+    lc.vol = sigma * std::sqrt(dt);
+    lc.n_steps = n_steps;
+    const PathRange pr = make_range(0, n_paths, n_steps, seed);
+    hipLaunchKernelGGL((lsm_paths_kernel<0>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, lc, d_paths);
+    HIP_TRY(hipGetLastError());
+    // np.percentile(x, 10) for a put, 90 for a call (:337-341); NumPy divides q by 100 first
+    hipLaunchKernelGGL(exercise_boundary_kernel, dim3(static_cast<uint32_t>(rows)), dim3(kBlock), 0, c->stream, d_paths, n_paths, K,
+                       is_call ? 1.0 : -1.0, (is_call ? 90.0 : 10.0) / 100.0, d_boundary);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(boundary_host, d_boundary, rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OLMC_OK;
+}
+
 // ================================================================ American (LSM) ====
 extern "C" int olmc_american_lsm(double S, double K, double T, double r, double sigma, double q, int is_call,
                                  int64_t n_paths, int32_t n_steps, int32_t poly_degree, uint64_t seed, olmc_stats* out) {
@@ -967,19 +1003,9 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
 }
 
 // ===================================================================== Heston ====
-extern "C" int olmc_heston(double S, double K, double T, double r, double q, int is_call, double kappa, double theta,
-                           double sigma_v, double rho, double v0, int64_t path_offset, int64_t n_local, int32_t n_steps,
-                           uint64_t seed, int antithetic, olmc_stats* out) {
-    if (!out) return fail(OLMC_ERR_ARG, "null pointer");
-    if (!(rho >= -1.0 && rho <= 1.0)) return fail(OLMC_ERR_ARG, "rho must be in [-1, 1]");
-    int rc = check_paths(path_offset, n_local, n_steps);
-    if (rc) return rc;
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
-    const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
-    const int32_t grid = grid_for(n_local);
+namespace {
+HestonContract make_heston(double S, double K, double T, double r, double q, int is_call, double kappa, double theta,
+                           double sigma_v, double rho, double v0, int32_t n_steps) {
     HestonContract hc;
     const double dt = T / n_steps;                     // heston.py:218-219
     hc.log_s0 = std::log(S);
@@ -994,6 +1020,50 @@ extern "C" int olmc_heston(double S, double K, double T, double r, double q, int
     hc.rho_c = std::sqrt(1 - rho * rho);               // :228
     hc.strike = K;
     hc.sign = is_call ? 1.0 : -1.0;
+    return hc;
+}
+}  // namespace
+
+extern "C" int olmc_heston_paths(double S, double T, double r, double q, double kappa, double theta, double sigma_v, double rho,
+                                 double v0, int64_t n_paths, int32_t n_steps, uint64_t seed, double* spot_host, double* var_host) {
+    if (!spot_host || !var_host) return fail(OLMC_ERR_ARG, "null pointer");
+    if (!(rho >= -1.0 && rho <= 1.0)) return fail(OLMC_ERR_ARG, "rho must be in [-1, 1]");
+    int rc = check_paths(0, n_paths, n_steps);
+    if (rc) return rc;
+    const double bytes = 8.0 * static_cast<double>(n_paths) * (n_steps + 1.0);
+    if (2 * bytes > 64e9) return fail(OLMC_ERR_ARG, "path matrices would exceed 64 GB");
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    rc = bulk_reserve(c, 2 * static_cast<size_t>(bytes));
+    if (rc) return rc;
+    double* d_spot = static_cast<double*>(c->d_bulk);
+    double* d_var = d_spot + static_cast<size_t>(n_paths) * (n_steps + 1);
+    const HestonContract hc = make_heston(S, 0.0, T, r, q, 1, kappa, theta, sigma_v, rho, v0, n_steps);
+    const PathRange pr = make_range(0, n_paths, n_steps, seed);
+    hipLaunchKernelGGL(heston_paths_kernel, dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, hc, S, d_spot, d_var);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(spot_host, d_spot, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(var_host, d_var, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OLMC_OK;
+}
+
+extern "C" int olmc_heston(double S, double K, double T, double r, double q, int is_call, double kappa, double theta,
+                           double sigma_v, double rho, double v0, int64_t path_offset, int64_t n_local, int32_t n_steps,
+                           uint64_t seed, int antithetic, olmc_stats* out) {
+    if (!out) return fail(OLMC_ERR_ARG, "null pointer");
+    if (!(rho >= -1.0 && rho <= 1.0)) return fail(OLMC_ERR_ARG, "rho must be in [-1, 1]");
+    int rc = check_paths(path_offset, n_local, n_steps);
+    if (rc) return rc;
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
+    const int32_t grid = grid_for(n_local);
+    const HestonContract hc = make_heston(S, K, T, r, q, is_call, kappa, theta, sigma_v, rho, v0, n_steps);
     ReduceWs ws;
     rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
     if (rc) return rc;
@@ -1012,11 +1082,12 @@ extern "C" int olmc_heston(double S, double K, double T, double r, double q, int
 }
 
 // ============================================================== jump diffusion ====
-extern "C" int olmc_jump_diffusion(double S, double K, double T, double r, double sigma, double q, int is_call, int model,
-                                   double lambda_j, double a1, double a2, double a3, int64_t path_offset, int64_t n_local,
-                                   int32_t n_steps, uint64_t seed, olmc_stats* out) {
+namespace {
+int make_jump(double S, double K, double T, double r, double sigma, double q, int is_call, int model, double lambda_j,
+              double a1, double a2, double a3, int32_t n_steps, JumpContract* out) {
     if (model != OLMC_JUMP_MERTON && model != OLMC_JUMP_KOU) return fail(OLMC_ERR_ARG, "bad jump model");
     if (!(lambda_j >= 0.0)) return fail(OLMC_ERR_ARG, "lambda_j must be non-negative");
+    if (n_steps < 1) return fail(OLMC_ERR_ARG, "n_steps must be >= 1");
     JumpContract jc;
     const double dt = T / n_steps;
     double kappa;                                            // E[e^Y - 1]
@@ -1038,11 +1109,47 @@ extern "C" int olmc_jump_diffusion(double S, double K, double T, double r, doubl
     jc.sign = is_call ? 1.0 : -1.0;
     jc.lam_dt = lambda_j * dt;
     jc.p0 = std::exp(-jc.lam_dt);
+    *out = jc;
+    return OLMC_OK;
+}
+}  // namespace
+
+extern "C" int olmc_jump_diffusion(double S, double K, double T, double r, double sigma, double q, int is_call, int model,
+                                   double lambda_j, double a1, double a2, double a3, int64_t path_offset, int64_t n_local,
+                                   int32_t n_steps, uint64_t seed, olmc_stats* out) {
+    JumpContract jc;
+    int rc = make_jump(S, K, T, r, sigma, q, is_call, model, lambda_j, a1, a2, a3, n_steps, &jc);
+    if (rc) return rc;
     const bool bad = poisoned(S, K, T, r, sigma, q) || std::isnan(lambda_j + a1 + a2 + a3);
     return run_structured(path_offset, n_local, n_steps, seed, 0, r, T, bad, out,
                           [&](int32_t grid, hipStream_t st, const PathRange& pr, const ReduceWs& ws) {
                               hipLaunchKernelGGL(jump_kernel, dim3(grid), dim3(kBlock), 0, st, pr, jc, ws);
                           });
+}
+
+extern "C" int olmc_jump_paths(double S, double T, double r, double sigma, double q, int model, double lambda_j, double a1,
+                               double a2, double a3, int64_t n_paths, int32_t n_steps, uint64_t seed, double* out_host) {
+    if (!out_host) return fail(OLMC_ERR_ARG, "null pointer");
+    JumpContract jc;
+    int rc = make_jump(S, 0.0, T, r, sigma, q, 1, model, lambda_j, a1, a2, a3, n_steps, &jc);
+    if (rc) return rc;
+    rc = check_paths(0, n_paths, n_steps);
+    if (rc) return rc;
+    const double bytes = 8.0 * static_cast<double>(n_paths) * (n_steps + 1.0);
+    if (bytes > 64e9) return fail(OLMC_ERR_ARG, "path matrix would exceed 64 GB");
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    rc = bulk_reserve(c, static_cast<size_t>(bytes));
+    if (rc) return rc;
+    const PathRange pr = make_range(0, n_paths, n_steps, seed);
+    hipLaunchKernelGGL(jump_paths_kernel, dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, jc, S,
+                       static_cast<double*>(c->d_bulk));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_host, c->d_bulk, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OLMC_OK;
 }
 
 // ======================================================================= QMC ====

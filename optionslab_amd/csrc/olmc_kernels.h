@@ -800,6 +800,77 @@ __global__ __launch_bounds__(kBlock) void lsm_paths_kernel(PathRange pr, LsmCont
     }
 }
 
+// AmericanOption.early_exercise_boundary (exotic_options.py:309-345): for every date t the 10th (put) /
+// 90th (call) percentile of the in-the-money prices, np.percentile's default linear interpolation.
+// One workgroup per date over the time-major path matrix.  The order statistics come from an 8-pass
+// byte-wise radix select on the fp64 bit patterns (positive doubles order like their bits): no sort, no
+// key buffer, the in-the-money filter applied on the fly.  Exact: the selected elements ARE the sorted
+// array's entries, and the interpolation follows NumPy's _lerp term by term.
+__device__ __forceinline__ bool boundary_itm(double s, double strike, double sign) { return sign * (s - strike) > 0.0; }
+
+// k-th smallest (0-based) bit pattern among the in-the-money entries of `row`; all 256 threads call it.
+__device__ __forceinline__ uint64_t boundary_select(const double* __restrict__ row, int64_t n, double strike, double sign,
+                                                    int64_t k, uint32_t* hist, uint64_t* shared) {
+    uint64_t prefix = 0, mask = 0;
+    for (int byte = 7; byte >= 0; --byte) {
+        hist[threadIdx.x] = 0u;
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < n; i += kBlock) {
+            const double s = row[i];
+            const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(s));
+            if (boundary_itm(s, strike, sign) && (bits & mask) == prefix) atomicAdd(&hist[(bits >> (8 * byte)) & 0xFFu], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int64_t left = k;
+            uint32_t bucket = 0;
+            for (; bucket < 255u; ++bucket) {
+                if (left < static_cast<int64_t>(hist[bucket])) break;
+                left -= hist[bucket];
+            }
+            shared[0] = bucket;
+            shared[1] = static_cast<uint64_t>(left);
+        }
+        __syncthreads();
+        prefix |= shared[0] << (8 * byte);
+        mask |= 0xFFull << (8 * byte);
+        k = static_cast<int64_t>(shared[1]);
+        __syncthreads();
+    }
+    return prefix;
+}
+
+__global__ __launch_bounds__(kBlock) void exercise_boundary_kernel(const double* __restrict__ paths, int64_t n_paths, double strike,
+                                                                   double sign, double quantile, double* __restrict__ boundary) {
+    __shared__ uint32_t hist[kBlock];
+    __shared__ uint64_t shared[2];
+    __shared__ unsigned long long count;
+    const double* row = paths + static_cast<size_t>(blockIdx.x) * static_cast<size_t>(n_paths);
+    if (threadIdx.x == 0) count = 0ull;
+    __syncthreads();
+    unsigned long long mine = 0;
+    for (int64_t i = threadIdx.x; i < n_paths; i += kBlock) mine += boundary_itm(row[i], strike, sign) ? 1ull : 0ull;
+    atomicAdd(&count, mine);
+    __syncthreads();
+    const int64_t cnt = static_cast<int64_t>(count);
+    if (cnt == 0) {                                            // nobody in the money: NaN (:343)
+        if (threadIdx.x == 0) boundary[blockIdx.x] = __longlong_as_double(0x7FF8000000000000ll);
+        return;
+    }
+    const double pos = static_cast<double>(cnt - 1) * quantile;       // NumPy: virtual index (n - 1) q
+    const int64_t lo = static_cast<int64_t>(floor(pos));
+    const int64_t hi = lo + 1 < cnt ? lo + 1 : cnt - 1;
+    const double t = pos - static_cast<double>(lo);
+    const double a = __longlong_as_double(static_cast<long long>(boundary_select(row, n_paths, strike, sign, lo, hist, shared)));
+    const double b = __longlong_as_double(static_cast<long long>(boundary_select(row, n_paths, strike, sign, hi, hist, shared)));
+    if (threadIdx.x == 0) {
+        const double diff = b - a;                             // numpy.lib._function_base_impl._lerp
+        double v = a + diff * t;
+        if (t >= 0.5) v = b - diff * (1.0 - t);
+        boundary[blockIdx.x] = v;
+    }
+}
+
 struct LsmCoeffs {
     double beta[kLsmMaxDegree + 1];
     int32_t valid;                  // regression at the date being finished was fitted
@@ -948,6 +1019,14 @@ struct HestonContract {
     double strike, sign;
 };
 
+// One Euler step of one leg; w1, w2 = sqrt(dt) * (Z1, Z2) with the leg's sign applied.
+__device__ __forceinline__ void heston_step(const HestonContract& c, double w1, double w2, double& ls, double& v) {
+    const double vp = fmax(v, 0.0);
+    const double sv = sqrt(vp);
+    ls += (c.mu_dt - 0.5 * vp * c.dt) + sv * w1;
+    v = fmax(v + c.kappa_dt * (c.theta - vp) + c.sigma_v * sv * w2, 0.0);
+}
+
 template <bool ANTI>
 __global__ __launch_bounds__(kBlock) void heston_kernel(PathRange pr, HestonContract c, ReduceWs ws) {
     double acc[2] = {0.0, 0.0};
@@ -969,10 +1048,7 @@ __global__ __launch_bounds__(kBlock) void heston_kernel(PathRange pr, HestonCont
 #pragma unroll
                     for (int leg = 0; leg < (ANTI ? 2 : 1); ++leg) {
                         const double sgn = leg ? -1.0 : 1.0;
-                        const double vp = fmax(v[leg], 0.0);
-                        const double sv = sqrt(vp);
-                        ls[leg] += (c.mu_dt - 0.5 * vp * c.dt) + sv * (sgn * w1);
-                        v[leg] = fmax(v[leg] + c.kappa_dt * (c.theta - vp) + c.sigma_v * sv * (sgn * w2), 0.0);
+                        heston_step(c, sgn * w1, sgn * w2, ls[leg], v[leg]);
                     }
                 }
             }
@@ -984,6 +1060,39 @@ __global__ __launch_bounds__(kBlock) void heston_kernel(PathRange pr, HestonCont
         }
     }
     block_then_grid_reduce<2>(acc, ws);
+}
+
+// HestonPricer.simulate_paths (heston.py:257-305): the same recursion on the same stream, every state
+// written out, time-major: spot[t * count + i], var[t * count + i], t = 0 .. n_steps (coalesced per step).
+// Row 0 is (S, v0) as given (:286-287), not exp(log S).
+__global__ __launch_bounds__(kBlock) void heston_paths_kernel(PathRange pr, HestonContract c, double s_first,
+                                                              double* __restrict__ spot, double* __restrict__ var) {
+    const double zs = kZScale * c.sqrt_dt;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
+        const uint64_t g = pr.first + static_cast<uint64_t>(i);
+        const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
+        double ls = c.log_s0, v = c.v0;
+        spot[i] = s_first;
+        var[i] = c.v0;
+        const int32_t blocks = (pr.n_steps + 1) >> 1;
+        for (int32_t b = 0; b < blocks; ++b) {
+            float z[4];
+            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), kTagHeston, pr.key0, pr.key1, z);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int32_t t = 2 * b + h;
+                if (t < pr.n_steps) {
+                    const double w1 = zs * static_cast<double>(z[2 * h]);
+                    const double w2 = c.rho * w1 + c.rho_c * (zs * static_cast<double>(z[2 * h + 1]));
+                    heston_step(c, w1, w2, ls, v);
+                    const size_t at = static_cast<size_t>(t + 1) * static_cast<size_t>(pr.count) + static_cast<size_t>(i);
+                    spot[at] = exp(ls);
+                    var[at] = v;
+                }
+            }
+        }
+    }
 }
 
 // Jump diffusion (src/pricing_models/jump_diffusion.py:160-225 Merton, :325-372 Kou): per step one
@@ -1007,6 +1116,35 @@ struct JumpContract {
 
 __device__ __forceinline__ double unit_open64(uint32_t x) { return (static_cast<double>(x) + 0.5) * 2.3283064365386963e-10; }
 
+// One step of one path: the diffusion increment, the Poisson count by inversion, the jump sum.
+__device__ __forceinline__ void jump_step(const PathRange& pr, const JumpContract& c, double vol, uint32_t g_lo, uint32_t g_hi,
+                                          int32_t t, double& ls) {
+    const Words4 w = philox4x32_10(g_lo, g_hi, static_cast<uint32_t>(t), kTagJump, pr.key0, pr.key1);
+    float z_diff, z_jump;
+    box_muller_raw(w.x0, w.x1, z_diff, z_jump);
+    ls += __builtin_fma(vol, static_cast<double>(z_diff), c.drift);
+    const double u = unit_open64(w.x2);
+    if (u >= c.p0) {                                   // at least one jump
+        int32_t n = 1;
+        double pk = c.p0 * c.lam_dt, cdf = c.p0 + pk;
+        while (u >= cdf && n < 64) {
+            ++n;
+            pk *= c.lam_dt / n;
+            cdf += pk;
+        }
+        if (!c.kou) {
+            ls += n * c.mu_j + c.sigma_j * sqrt(static_cast<double>(n)) * (kZScale * static_cast<double>(z_jump));
+        } else {
+            for (int32_t j = 0; j < n; ++j) {
+                const Words4 k = philox4x32_10(g_lo, g_hi, static_cast<uint32_t>(t), kTagKou + static_cast<uint32_t>(j >> 1),
+                                               pr.key0, pr.key1);
+                const double ud = unit_open64((j & 1) ? k.x2 : k.x0), um = unit_open64((j & 1) ? k.x3 : k.x1);
+                ls += ud < c.kou_p ? -log(um) * c.inv_eta1 : log(um) * c.inv_eta2;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void jump_kernel(PathRange pr, JumpContract c, ReduceWs ws) {
     double acc[2] = {0.0, 0.0};
     const double vol = c.vol * kZScale;
@@ -1015,36 +1153,28 @@ __global__ __launch_bounds__(kBlock) void jump_kernel(PathRange pr, JumpContract
         const uint64_t g = pr.first + static_cast<uint64_t>(i);
         const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
         double ls = c.log_s0;
-        for (int32_t t = 0; t < pr.n_steps; ++t) {
-            const Words4 w = philox4x32_10(g_lo, g_hi, static_cast<uint32_t>(t), kTagJump, pr.key0, pr.key1);
-            float z_diff, z_jump;
-            box_muller_raw(w.x0, w.x1, z_diff, z_jump);
-            ls += __builtin_fma(vol, static_cast<double>(z_diff), c.drift);
-            const double u = unit_open64(w.x2);
-            if (u >= c.p0) {                                   // at least one jump
-                int32_t n = 1;
-                double pk = c.p0 * c.lam_dt, cdf = c.p0 + pk;
-                while (u >= cdf && n < 64) {
-                    ++n;
-                    pk *= c.lam_dt / n;
-                    cdf += pk;
-                }
-                if (!c.kou) {
-                    ls += n * c.mu_j + c.sigma_j * sqrt(static_cast<double>(n)) * (kZScale * static_cast<double>(z_jump));
-                } else {
-                    for (int32_t j = 0; j < n; ++j) {
-                        const Words4 k = philox4x32_10(g_lo, g_hi, static_cast<uint32_t>(t), kTagKou + static_cast<uint32_t>(j >> 1),
-                                                       pr.key0, pr.key1);
-                        const double ud = unit_open64((j & 1) ? k.x2 : k.x0), um = unit_open64((j & 1) ? k.x3 : k.x1);
-                        ls += ud < c.kou_p ? -log(um) * c.inv_eta1 : log(um) * c.inv_eta2;
-                    }
-                }
-            }
-        }
+        for (int32_t t = 0; t < pr.n_steps; ++t) jump_step(pr, c, vol, g_lo, g_hi, t, ls);
         const double x = fmax(c.sign * (exp(ls) - c.strike), 0.0);
         acc[0] += x; acc[1] += x * x;
     }
     block_then_grid_reduce<2>(acc, ws);
+}
+
+// MertonJumpDiffusion.simulate_path (jump_diffusion.py:227-272), for any number of paths: the pricing
+// kernel's recursion with every price written out, time-major out[t * count + i], row 0 = S as given (:254).
+__global__ __launch_bounds__(kBlock) void jump_paths_kernel(PathRange pr, JumpContract c, double s_first, double* __restrict__ out) {
+    const double vol = c.vol * kZScale;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
+        const uint64_t g = pr.first + static_cast<uint64_t>(i);
+        const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
+        double ls = c.log_s0;
+        out[i] = s_first;
+        for (int32_t t = 0; t < pr.n_steps; ++t) {
+            jump_step(pr, c, vol, g_lo, g_hi, t, ls);
+            out[static_cast<size_t>(t + 1) * static_cast<size_t>(pr.count) + static_cast<size_t>(i)] = exp(ls);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ QMC ----

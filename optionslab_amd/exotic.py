@@ -106,8 +106,7 @@ class LookbackOption:
 
 @dataclass
 class AmericanOption:
-    """exotic_options.py:227-305: Longstaff-Schwartz least-squares Monte Carlo on stored device paths.
-    (`early_exercise_boundary`, a percentile plot helper of the reference, is not provided.)"""
+    """exotic_options.py:227-345: Longstaff-Schwartz least-squares Monte Carlo on stored device paths."""
 
     S: float
     K: float
@@ -125,6 +124,15 @@ class AmericanOption:
         st = _hip.american_lsm(self.S, self.K, self.T, self.r, self.sigma, self.q, option_type == "call", n_paths, n_steps,
                                poly_degree, seed)
         return (np.float64(st.price), float(st.std_error)) if return_error else np.float64(st.price)
+
+    def early_exercise_boundary(self, n_paths: int = 10000, n_steps: int = 50, option_type: Literal["call", "put"] = "put"):
+        """exotic_options.py:309-345: (times, boundary): per date the 10th (put) / 90th (call) percentile of the
+        in-the-money simulated prices, NaN where none is; selected on the device from the LSM path set."""
+        if n_paths < 1 or n_steps < 1:
+            raise ValueError("n_paths and n_steps must be >= 1")
+        seed = self.seed if self.seed is not None else int(np.random.default_rng().integers(0, 2**31))
+        boundary = _hip.exercise_boundary(self.S, self.K, self.T, self.r, self.sigma, self.q, option_type == "call", n_paths, n_steps, seed)
+        return np.linspace(0, self.T, n_steps + 1), boundary
 
 
 def price_american(S: float, K: float, T: float, r: float, sigma: float, option_type: str = "put", n_paths: int = 50000,

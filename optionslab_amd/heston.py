@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import warnings
 from dataclasses import dataclass
-from typing import Literal, Optional
+from typing import Tuple, Literal, Optional
 
 import numpy as np
 
@@ -82,6 +82,17 @@ class HestonPricer:
         return (np.float64(st.price), float(st.std_error)) if return_error else np.float64(st.price)
 
 
+    def simulate_paths(self, S: float, T: float, r: float, q: float = 0.0, n_paths: int = 1000, n_steps: int = 252,
+                       seed: Optional[int] = None) -> Tuple[np.ndarray, np.ndarray]:
+        """heston.py:257-305: (spot_paths, variance_paths), each (n_paths, n_steps + 1), column 0 = (S, v0).
+        The states of price_monte_carlo's recursion for the same seed."""
+        if n_paths < 1 or n_steps < 1:
+            raise ValueError("n_paths and n_steps must be >= 1")
+        s = seed if seed is not None else int(np.random.default_rng().integers(0, 2**31))
+        spot, var = _hip.heston_paths(S, T, r, q, self.kappa, self.theta, self.sigma_v, self.rho, self.v0, n_paths, n_steps, s)
+        return np.ascontiguousarray(spot.T), np.ascontiguousarray(var.T)
+
+
 class HestonAdapter:
     """unified_greeks.py:74-104: sigma -> v0 = sigma^2, prices with the semi-analytic formula."""
 
@@ -95,3 +106,10 @@ class HestonAdapter:
             return self.heston.price_european(S, K, T, r, q, option_type)
         finally:
             self.heston.v0 = self._original_v0
+
+
+def greeks_heston(heston_pricer, S: float, K: float, T: float, r: float, sigma: float, option_type: str = "call", q: float = 0.0):
+    """unified_greeks.py:375-388"""
+    from .greeks import compute_greeks_unified
+
+    return compute_greeks_unified(HestonAdapter(heston_pricer), S, K, T, r, sigma, option_type, q)

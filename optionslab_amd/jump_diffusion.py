@@ -74,6 +74,19 @@ class MertonJumpDiffusion:
         return (np.float64(st.price), float(st.std_error)) if return_error else np.float64(st.price)
 
 
+    def simulate_paths(self, S, T, r, sigma, q: float = 0.0, n_paths: int = 1, n_steps: int = 252,
+                       seed: Optional[int] = None) -> np.ndarray:
+        """(n_paths, n_steps + 1) price paths of price_monte_carlo's recursion for the same seed, column 0 = S."""
+        if n_paths < 1 or n_steps < 1:
+            raise ValueError("n_paths and n_steps must be >= 1")
+        tm = _hip.jump_paths(S, T, r, sigma, q, False, self.lambda_j, self.mu_j, self.sigma_j, 0.0, n_paths, n_steps, _seed(seed))
+        return np.ascontiguousarray(tm.T)
+
+    def simulate_path(self, S, T, r, sigma, q: float = 0.0, n_steps: int = 252, seed: Optional[int] = None) -> np.ndarray:
+        """jump_diffusion.py:227-272: one path with jumps, shape (n_steps + 1,)."""
+        return self.simulate_paths(S, T, r, sigma, q, 1, n_steps, seed)[0]
+
+
 @dataclass
 class KouJumpDiffusion:
     lambda_j: float
@@ -100,3 +113,21 @@ class KouJumpDiffusion:
         st = _hip.jump_diffusion(S, K, T, r, sigma, q, option_type == "call", True, self.lambda_j, self.p, self.eta1, self.eta2,
                                  n_paths, n_steps, _seed(seed))
         return (np.float64(st.price), float(st.std_error)) if return_error else np.float64(st.price)
+
+    def simulate_paths(self, S, T, r, sigma, q: float = 0.0, n_paths: int = 1, n_steps: int = 252,
+                       seed: Optional[int] = None) -> np.ndarray:
+        """(n_paths, n_steps + 1) price paths of price_monte_carlo's recursion (additive: the reference has none for Kou)."""
+        if n_paths < 1 or n_steps < 1:
+            raise ValueError("n_paths and n_steps must be >= 1")
+        tm = _hip.jump_paths(S, T, r, sigma, q, True, self.lambda_j, self.p, self.eta1, self.eta2, n_paths, n_steps, _seed(seed))
+        return np.ascontiguousarray(tm.T)
+
+
+class JumpDiffusionAdapter:
+    """unified_greeks.py:155-175: PricerProtocol over a jump-diffusion model's series price."""
+
+    def __init__(self, jd_model):
+        self.jd = jd_model
+
+    def price(self, S, K, T, r, sigma, option_type, q=0.0, **kwargs) -> float:
+        return self.jd.price(S, K, T, r, sigma, option_type, q)

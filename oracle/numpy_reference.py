@@ -311,6 +311,25 @@ def american_price(S, K, T, r, sigma, q=0.0, seed=None, n_paths=50000, n_steps=5
     return np.mean(cf * discount)
 
 
+def exercise_boundary_from_paths(paths, K, option_type="put"):
+    """exotic_options.py:322-345 on a given (n_paths, n_steps + 1) matrix."""
+    intrinsic = np.maximum(paths - K, 0) if option_type == "call" else np.maximum(K - paths, 0)
+    boundary = np.zeros(paths.shape[1])
+    for t in range(paths.shape[1]):
+        itm = intrinsic[:, t] > 0
+        if np.sum(itm) > 0:
+            boundary[t] = np.percentile(paths[itm, t], 10 if option_type == "put" else 90)
+        else:
+            boundary[t] = np.nan
+    return boundary
+
+
+def american_exercise_boundary(S, K, T, r, sigma, q=0.0, seed=None, n_paths=10000, n_steps=50, option_type="put"):
+    """exotic_options.py:309-345 -- (times, boundary)."""
+    paths = asian_paths(S, T, r, sigma, q, n_paths, n_steps, seed)
+    return np.linspace(0, T, n_steps + 1), exercise_boundary_from_paths(paths, K, option_type)
+
+
 def autocallable_price(S, T, r, sigma, q=0.0, seed=None, n_paths=100000, n_steps=252, observation_freq=21,
                        autocall_barrier=1.0, coupon_barrier=0.8, coupon_rate=0.10, ki_barrier=0.6):
     """exotic_options.py:404-491"""
@@ -471,6 +490,32 @@ def heston_price_mc(S, K, T, r, q, option_type, kappa, theta, sigma_v, rho, v0, 
     return np.exp(-r * T) * np.mean(x)
 
 
+def heston_simulate_paths(S, T, r, q, kappa, theta, sigma_v, rho, v0, n_paths=1000, n_steps=252, seed=None):
+    """:257-305 -- (spot_paths, var_paths), each (n_paths, n_steps + 1); column 0 = (S, v0)."""
+    if seed is not None:
+        np.random.seed(seed)
+    dt = T / n_steps
+    sqrt_dt = np.sqrt(dt)
+    rho_sqrt = np.sqrt(1 - rho**2)
+    spot = np.zeros((n_paths, n_steps + 1))
+    var = np.zeros((n_paths, n_steps + 1))
+    spot[:, 0] = S
+    var[:, 0] = v0
+    log_S = np.log(S) * np.ones(n_paths)
+    v = v0 * np.ones(n_paths)
+    for t in range(1, n_steps + 1):
+        Z1 = np.random.standard_normal(n_paths)
+        Z2 = rho * Z1 + rho_sqrt * np.random.standard_normal(n_paths)
+        v_pos = np.maximum(v, 0)
+        sqrt_v = np.sqrt(v_pos)
+        log_S += (r - q - 0.5 * v_pos) * dt + sqrt_v * sqrt_dt * Z1
+        v += kappa * (theta - v_pos) * dt + sigma_v * sqrt_v * sqrt_dt * Z2
+        v = np.maximum(v, 0)
+        spot[:, t] = np.exp(log_S)
+        var[:, t] = v
+    return spot, var
+
+
 # --------------------------------------------------------------------------
 # Jump diffusion (src/pricing_models/jump_diffusion.py)
 # --------------------------------------------------------------------------
@@ -525,6 +570,25 @@ def merton_mc(S, K, T, r, sigma, lambda_j, mu_j, sigma_j, option_type="call", q=
     st = np.exp(log_S)
     x = np.maximum(st - K, 0) if option_type == "call" else np.maximum(K - st, 0)
     return np.exp(-r * T) * np.mean(x)
+
+
+def merton_simulate_path(S, T, r, sigma, lambda_j, mu_j, sigma_j, q=0.0, n_steps=252, seed=None):
+    """:227-272 -- one path, scalar draws from the legacy global RandomState."""
+    if seed is not None:
+        np.random.seed(seed)
+    dt = T / n_steps
+    drift = (r - q - lambda_j * merton_kappa(mu_j, sigma_j) - 0.5 * sigma**2) * dt
+    vol = sigma * np.sqrt(dt)
+    path = np.zeros(n_steps + 1)
+    path[0] = S
+    log_S = np.log(S)
+    for t in range(1, n_steps + 1):
+        log_S += drift + vol * np.random.standard_normal()
+        n_jumps = np.random.poisson(lambda_j * dt)
+        if n_jumps > 0:
+            log_S += np.sum(np.random.normal(mu_j, sigma_j, n_jumps))
+        path[t] = np.exp(log_S)
+    return path
 
 
 def kou_kappa(p, eta1, eta2):  # :293-299

@@ -251,6 +251,34 @@ void ol_heston_moments(double S, double K, double T, double r, double q, int is_
     moments[0] = (double)m0; moments[1] = (double)m1;
 }
 
+/* HestonPricer.simulate_paths (heston.py:257-305) on the stream of ol_heston_moments' first leg,
+ * time-major spot[t * n + i], var[t * n + i]; row 0 = (S, v0). */
+void ol_heston_paths(double S, double T, double r, double q, double kappa, double theta, double sigma_v, double rho, double v0,
+                     int64_t n, int32_t n_steps, uint64_t seed, double* spot, double* var) {
+    const double dt = T / n_steps, sqrt_dt = sqrt(dt), rho_c = sqrt(1 - rho * rho), zs = Z_SCALE * sqrt_dt;
+    for (int64_t i = 0; i < n; ++i) {
+        double ls = log(S), v = v0;
+        spot[i] = S;
+        var[i] = v0;
+        for (int32_t b = 0; 2 * b < n_steps; ++b) {
+            uint32_t ctr[4] = {(uint32_t)i, (uint32_t)((uint64_t)i >> 32), (uint32_t)b, 1u};
+            uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, w[4];
+            float z[4];
+            ol_philox4x32_10(ctr, key, w);
+            box_muller_raw(w[0], w[1], &z[0], &z[1]);
+            box_muller_raw(w[2], w[3], &z[2], &z[3]);
+            for (int h = 0; h < 2 && 2 * b + h < n_steps; ++h) {
+                const double w1 = zs * (double)z[2 * h], w2 = rho * w1 + rho_c * (zs * (double)z[2 * h + 1]);
+                const double vp = fmax(v, 0.0), sv = sqrt(vp);
+                ls += ((r - q) * dt - 0.5 * vp * dt) + sv * w1;
+                v = fmax(v + kappa * dt * (theta - vp) + sigma_v * sv * w2, 0.0);
+                spot[(size_t)(2 * b + h + 1) * n + i] = exp(ls);
+                var[(size_t)(2 * b + h + 1) * n + i] = v;
+            }
+        }
+    }
+}
+
 /* Autocallable (exotic_options.py:404-491): moments of the per-path DISCOUNTED payoff. */
 void ol_autocall_moments(double S, double T, double r, double sigma, double q, double autocall_b, double coupon_b,
                          double coupon_rate, double ki_b, int32_t freq, int64_t path0, int64_t n, int32_t n_steps,
@@ -416,45 +444,73 @@ int ol_american_lsm(double S, double K, double T, double r, double sigma, double
 /* Jump diffusion (jump_diffusion.py:160-225, 325-372): one Philox block per step, tag 2; Kou jumps from tag 3 + j/2. */
 static double unit_open64(uint32_t x) { return ((double)x + 0.5) * 0x1p-32; }
 
+typedef struct { int kou; double a1, a2, a3, drift, vol, lam_dt, p0; } jump_model;
+
+static jump_model jump_setup(double T, double r, double sigma, double q, int kou, double lambda_j, double a1, double a2, double a3,
+                             int32_t n_steps) {
+    jump_model m;
+    const double dt = T / n_steps;
+    const double kappa = kou ? a1 * a2 / (a2 - 1) + (1 - a1) * a3 / (a3 + 1) - 1 : exp(a1 + 0.5 * a2 * a2) - 1;
+    m.kou = kou; m.a1 = a1; m.a2 = a2; m.a3 = a3;
+    m.drift = (r - q - lambda_j * kappa - 0.5 * sigma * sigma) * dt;
+    m.vol = sigma * sqrt(dt) * Z_SCALE;
+    m.lam_dt = lambda_j * dt;
+    m.p0 = exp(-m.lam_dt);
+    return m;
+}
+
+/* step t of one path, in the device's order: diffusion increment, then the jump sum term by term */
+static void jump_step(const jump_model* m, uint64_t path, int32_t t, uint64_t seed, double* ls) {
+    uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), (uint32_t)t, 2u};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, w[4];
+    float zd, zj;
+    ol_philox4x32_10(ctr, key, w);
+    box_muller_raw(w[0], w[1], &zd, &zj);
+    *ls += m->vol * (double)zd + m->drift;
+    const double u = unit_open64(w[2]);
+    if (u < m->p0) return;
+    int nj = 1;
+    double pk = m->p0 * m->lam_dt, cdf = m->p0 + pk;
+    while (u >= cdf && nj < 64) { ++nj; pk *= m->lam_dt / nj; cdf += pk; }
+    if (!m->kou) {
+        *ls += nj * m->a1 + m->a2 * sqrt((double)nj) * (Z_SCALE * (double)zj);
+        return;
+    }
+    for (int j = 0; j < nj; ++j) {
+        uint32_t c2[4] = {(uint32_t)path, (uint32_t)(path >> 32), (uint32_t)t, 3u + (uint32_t)(j >> 1)}, k[4];
+        ol_philox4x32_10(c2, key, k);
+        const double ud = unit_open64((j & 1) ? k[2] : k[0]), um = unit_open64((j & 1) ? k[3] : k[1]);
+        *ls += ud < m->a1 ? -log(um) / m->a2 : log(um) / m->a3;
+    }
+}
+
 void ol_jump_moments(double S, double K, double T, double r, double sigma, double q, int is_call, int kou, double lambda_j,
                      double a1, double a2, double a3, int64_t path0, int64_t n, int32_t n_steps, uint64_t seed,
                      double moments[2]) {
-    const double dt = T / n_steps, sign = is_call ? 1.0 : -1.0;
-    const double kappa = kou ? a1 * a2 / (a2 - 1) + (1 - a1) * a3 / (a3 + 1) - 1 : exp(a1 + 0.5 * a2 * a2) - 1;
-    const double drift = (r - q - lambda_j * kappa - 0.5 * sigma * sigma) * dt, vol = sigma * sqrt(dt) * Z_SCALE;
-    const double lam_dt = lambda_j * dt, p0 = exp(-lam_dt);
+    const double sign = is_call ? 1.0 : -1.0;
+    const jump_model m = jump_setup(T, r, sigma, q, kou, lambda_j, a1, a2, a3, n_steps);
     long double m0 = 0, m1 = 0;
     for (int64_t i = 0; i < n; ++i) {
-        const uint64_t path = (uint64_t)(path0 + i);
         double ls = log(S);
-        for (int32_t t = 0; t < n_steps; ++t) {
-            uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), (uint32_t)t, 2u};
-            uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, w[4];
-            float zd, zj;
-            ol_philox4x32_10(ctr, key, w);
-            box_muller_raw(w[0], w[1], &zd, &zj);
-            ls += vol * (double)zd + drift;
-            const double u = unit_open64(w[2]);
-            if (u >= p0) {
-                int nj = 1;
-                double pk = p0 * lam_dt, cdf = p0 + pk;
-                while (u >= cdf && nj < 64) { ++nj; pk *= lam_dt / nj; cdf += pk; }
-                if (!kou) {
-                    ls += nj * a1 + a2 * sqrt((double)nj) * (Z_SCALE * (double)zj);
-                } else {
-                    for (int j = 0; j < nj; ++j) {
-                        uint32_t c2[4] = {(uint32_t)path, (uint32_t)(path >> 32), (uint32_t)t, 3u + (uint32_t)(j >> 1)}, k[4];
-                        ol_philox4x32_10(c2, key, k);
-                        const double ud = unit_open64((j & 1) ? k[2] : k[0]), um = unit_open64((j & 1) ? k[3] : k[1]);
-                        ls += ud < a1 ? -log(um) / a2 : log(um) / a3;
-                    }
-                }
-            }
-        }
+        for (int32_t t = 0; t < n_steps; ++t) jump_step(&m, (uint64_t)(path0 + i), t, seed, &ls);
         const double x = fmax(sign * (exp(ls) - K), 0.0);
         m0 += x; m1 += x * x;
     }
     moments[0] = (double)m0; moments[1] = (double)m1;
+}
+
+/* MertonJumpDiffusion.simulate_path (jump_diffusion.py:227-272) for n paths, time-major out[t * n + i], row 0 = S. */
+void ol_jump_paths(double S, double T, double r, double sigma, double q, int kou, double lambda_j, double a1, double a2, double a3,
+                   int64_t n, int32_t n_steps, uint64_t seed, double* out) {
+    const jump_model m = jump_setup(T, r, sigma, q, kou, lambda_j, a1, a2, a3, n_steps);
+    for (int64_t i = 0; i < n; ++i) {
+        double ls = log(S);
+        out[i] = S;
+        for (int32_t t = 0; t < n_steps; ++t) {
+            jump_step(&m, (uint64_t)i, t, seed, &ls);
+            out[(size_t)(t + 1) * n + i] = exp(ls);
+        }
+    }
 }
 
 /* Full paths, time-major out[t * n + i], t = 0..n_steps (gbm_numpy.py:86-118 transposed). */

@@ -140,6 +140,22 @@ def gbm_paths(S, T, r, sigma, q, n_paths, n_steps, seed):
     return out
 
 
+def heston_paths(S, T, r, q, kappa, theta, sigma_v, rho, v0, n_paths, n_steps, seed):
+    spot = np.empty((n_steps + 1, n_paths), dtype=np.float64)
+    var = np.empty_like(spot)
+    _load().ol_heston_paths(*(C.c_double(x) for x in (S, T, r, q, kappa, theta, sigma_v, rho, v0)), C.c_int64(n_paths), C.c_int32(n_steps),
+                            C.c_uint64(int(seed) & _U64), spot.ctypes.data_as(C.POINTER(C.c_double)), var.ctypes.data_as(C.POINTER(C.c_double)))
+    return spot, var
+
+
+def jump_paths(S, T, r, sigma, q, kou, lambda_j, a1, a2, a3, n_paths, n_steps, seed):
+    out = np.empty((n_steps + 1, n_paths), dtype=np.float64)
+    _load().ol_jump_paths(*(C.c_double(x) for x in (S, T, r, sigma, q)), C.c_int(int(kou)), C.c_double(lambda_j), C.c_double(a1),
+                          C.c_double(a2), C.c_double(a3), C.c_int64(n_paths), C.c_int32(n_steps), C.c_uint64(int(seed) & _U64),
+                          out.ctypes.data_as(C.POINTER(C.c_double)))
+    return out
+
+
 def price_and_error(sum_x, sum_xx, n, r, T):
     """monte_carlo.py:145-150 on the moments."""
     disc, mean = math.exp(-r * T), sum_x / n

@@ -206,6 +206,25 @@ def main():
                                   mc=float(hp.price_monte_carlo(S, K, T, r, q, typ, n, m, 42)),
                                   semi_analytic=float(hp.price_european(S, K, T, r, q, typ))))
 
+    # -- path generators and the exercise boundary (heston.py:257-305, jump_diffusion.py:227-272, exotic_options.py:309-345)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hp = ref["HestonPricer"](kappa=2.0, theta=0.04, sigma_v=0.3, rho=-0.7, v0=0.04)
+    sp, vp = hp.simulate_paths(100.0, 1.0, 0.05, 0.01, 2000, 12, 42)
+    doc["heston_paths"] = dict(model=[2.0, 0.04, 0.3, -0.7, 0.04], args=[100.0, 1.0, 0.05, 0.01, 2000, 12, 42], shape=list(sp.shape),
+                               spot_row0=[float(x) for x in sp[0]], var_row0=[float(x) for x in vp[0]],
+                               spot_col_mean=[float(x) for x in sp.mean(axis=0)], var_col_mean=[float(x) for x in vp.mean(axis=0)])
+    jd = ref["MertonJumpDiffusion"](lambda_j=3.0, mu_j=-0.1, sigma_j=0.2)
+    doc["merton_path"] = dict(model=[3.0, -0.1, 0.2], args=[100.0, 1.0, 0.05, 0.2, 0.01, 24, 42],
+                              path=[float(x) for x in jd.simulate_path(100.0, 1.0, 0.05, 0.2, 0.01, 24, 42)])
+    doc["exercise_boundary"] = []
+    for (S, K, T, r, v, q), typ, n, m in [((100.0, 100.0, 1.0, 0.05, 0.2, 0.0), "put", 10000, 50), ((100.0, 100.0, 1.0, 0.05, 0.2, 0.03), "call", 10000, 50),
+                                          ((120.0, 100.0, 0.5, 0.03, 0.3, 0.0), "put", 4000, 10)]:
+        o = ref["AmericanOption"](S=S, K=K, T=T, r=r, sigma=v, q=q, seed=42)
+        times, b = o.early_exercise_boundary(n, m, typ)
+        doc["exercise_boundary"].append(dict(params=[S, K, T, r, v, q], option_type=typ, n_paths=n, n_steps=m, seed=42,
+                                             times=[float(x) for x in times], boundary=[None if np.isnan(x) else float(x) for x in b]))
+
     # -- full paths (gbm_numpy.py:86-118) ------------------------------------------------------
     fp = ref["simulate_gbm_paths"](100.0, 1.0, 0.05, 0.2, 0.01, 1000, 12, 42)
     doc["full_paths"] = dict(args=[100.0, 1.0, 0.05, 0.2, 0.01, 1000, 12, 42], shape=list(fp.shape), c_contiguous=bool(fp.flags["C_CONTIGUOUS"]),

@@ -258,3 +258,77 @@ def test_jump_diffusion_against_reference_golden_and_series(golden):
     for bad in ((1, 1.5, 10, 5), (1, 0.5, 1.0, 5), (1, 0.5, 10, 0)):
         with pytest.raises(ValueError):
             ol.KouJumpDiffusion(*bad)
+
+
+# ------------------------------------------------------------------ path generators and the exercise boundary
+def test_heston_paths_against_checker_reference_and_pricer(golden):
+    import warnings
+    from oracle import numpy_reference as orc
+    g = golden["heston_paths"]
+    S, T, r, q, N, M, seed = g["args"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hp = ol.HestonPricer(*g["model"])
+    spot, var = hp.simulate_paths(S, T, r, q, N, M, seed)                       # heston.py:257-305
+    assert list(spot.shape) == g["shape"] and list(var.shape) == g["shape"] and spot.flags["C_CONTIGUOUS"]
+    assert np.all(spot[:, 0] == S) and np.all(var[:, 0] == hp.v0) and np.all(var >= 0)
+    ws, wv = po.heston_paths(S, T, r, q, *g["model"], N, M, seed)
+    assert np.allclose(spot, ws.T, rtol=4 * REL, atol=0) and np.allclose(var, wv.T, rtol=4 * REL, atol=2e-7)     # v near 0 is a difference of O(theta) terms: absolute bound
+    # the reference's paths, statistically: column means of spot and variance within 4 standard errors
+    se_s, se_v = spot.std(axis=0) / math.sqrt(N), var.std(axis=0) / math.sqrt(N)
+    assert np.all(np.abs(spot.mean(axis=0) - np.array(g["spot_col_mean"])) <= 4 * math.sqrt(2) * se_s + 1e-12)
+    assert np.all(np.abs(var.mean(axis=0) - np.array(g["var_col_mean"])) <= 4 * math.sqrt(2) * se_v + 1e-12)
+    # the terminal column is what price_monte_carlo integrates for the same seed
+    price = hp.price_monte_carlo(S, 95.0, T, r, q, "call", N, M, seed)
+    assert price == pytest.approx(math.exp(-r * T) * np.maximum(spot[:, -1] - 95.0, 0).mean(), rel=1e-12)
+    odd_s, odd_v = ol.HestonPricer(3.0, 0.02, 0.8, 0.3, 0.05).simulate_paths(S, T, r, q, 257, 7, 3)    # odd steps, truncation at 0
+    cs, cv = po.heston_paths(S, T, r, q, 3.0, 0.02, 0.8, 0.3, 0.05, 257, 7, 3)
+    assert odd_s.shape == (257, 8) and np.allclose(odd_s, cs.T, rtol=4 * REL) and np.allclose(odd_v, cv.T, rtol=4 * REL, atol=2e-7)
+    assert orc.heston_simulate_paths(S, T, r, q, *g["model"], 5, M, seed)[0].shape == (5, M + 1)           # same layout as the restatement
+
+
+def test_jump_paths_against_checker_and_martingale(golden):
+    g = golden["merton_path"]
+    S, T, r, v, q, M, seed = g["args"]
+    jd = ol.MertonJumpDiffusion(*g["model"])
+    one = jd.simulate_path(S, T, r, v, q, M, seed)                             # jump_diffusion.py:227-272
+    assert one.shape == (M + 1,) == np.array(g["path"]).shape and one[0] == S == g["path"][0]
+    N = 40_000
+    paths = jd.simulate_paths(S, T, r, v, q, N, M, seed)
+    assert paths.shape == (N, M + 1) and np.array_equal(paths[0], one)
+    assert np.allclose(paths, po.jump_paths(S, T, r, v, q, False, *g["model"], 0.0, N, M, seed).T, rtol=4 * REL)
+    t = np.arange(M + 1) * (T / M)
+    se = paths.std(axis=0) / math.sqrt(N)
+    assert np.all(np.abs(paths.mean(axis=0) - S * np.exp((r - q) * t)) <= 4 * se + 1e-12)      # compensated drift (:207)
+    price = jd.price_monte_carlo(S, 100.0, T, r, v, "put", q, N, M, seed)
+    assert price == pytest.approx(math.exp(-r * T) * np.maximum(100.0 - paths[:, -1], 0).mean(), rel=1e-12)
+    kou = ol.KouJumpDiffusion(3.0, 0.6, 25.0, 20.0)
+    kp = kou.simulate_paths(S, T, r, v, q, 20_000, 10, 5)
+    assert np.allclose(kp, po.jump_paths(S, T, r, v, q, True, 3.0, 0.6, 25.0, 20.0, 20_000, 10, 5).T, rtol=4 * REL)
+    assert np.all(np.abs(kp.mean(axis=0) - S * np.exp((r - q) * np.arange(11) * (T / 10))) <= 4 * kp.std(axis=0) / math.sqrt(20_000) + 1e-12)
+
+
+def test_early_exercise_boundary(golden):
+    from oracle import numpy_reference as orc
+    for c in golden["exercise_boundary"]:
+        S, K, T, r, v, q = c["params"]
+        N, M, typ = c["n_paths"], c["n_steps"], c["option_type"]
+        times, b = ol.AmericanOption(S, K, T, r, v, q, seed=c["seed"]).early_exercise_boundary(N, M, typ)   # exotic_options.py:309-345
+        assert np.array_equal(times, np.array(c["times"])) and b.shape == (M + 1,)
+        # exact: NumPy's percentile of the very paths the device selected from (rows t >= 1 of the LSM path set)
+        paths = _hip.gbm_paths(S, T, r, v, q, N, M, c["seed"]).T
+        want = orc.exercise_boundary_from_paths(paths, K, typ)
+        assert np.array_equal(b[1:], want[1:], equal_nan=True)
+        assert np.isnan(b[0]) or b[0] == pytest.approx(S, rel=1e-14)             # t = 0: exp(log S) vs K, as the reference
+        ref = np.array([np.nan if x is None else x for x in c["boundary"]])
+        assert np.array_equal(np.isnan(b[1:]), np.isnan(ref[1:]))
+        # the reference's own draw differs by sampling noise only: tight where many paths are in the money
+        itm = ((paths[:, 1:] > K) if typ == "call" else (paths[:, 1:] < K)).sum(axis=0)
+        rtol = np.where(itm >= 1500, 0.015, 0.06)
+        assert np.all(np.isnan(ref[1:]) | (np.abs(b[1:] - ref[1:]) <= rtol * np.abs(ref[1:])))
+    # many paths (several strides per workgroup), few in the money, and none at all
+    times, b = ol.AmericanOption(100.0, 60.0, 0.25, 0.05, 0.2, seed=1).early_exercise_boundary(300_000, 6, "put")
+    paths = _hip.gbm_paths(100.0, 0.25, 0.05, 0.2, 0.0, 300_000, 6, 1).T
+    assert np.array_equal(b[1:], orc.exercise_boundary_from_paths(paths, 60.0, "put")[1:], equal_nan=True)
+    assert np.isnan(b[0]) and np.isnan(b[1])
+    assert np.all(np.isnan(ol.AmericanOption(100.0, 1.0, 0.1, 0.05, 0.1, seed=1).early_exercise_boundary(1000, 4, "put")[1]))

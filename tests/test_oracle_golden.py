@@ -189,3 +189,20 @@ def test_qmc_antithetic_backend(golden):
     qa = orc.terminal_sobol_antithetic(*g["args"])
     assert len(qa) == g["length"] and [float(x) for x in qa[:4]] == g["head"] and [float(x) for x in qa[1024:1028]] == g["mid"]
     assert float(qa.mean()) == g["mean"]
+
+
+def test_path_generators_and_exercise_boundary(golden):
+    """heston.py:257-305, jump_diffusion.py:227-272, exotic_options.py:309-345 restated bit for bit."""
+    g = golden["heston_paths"]
+    sp, vp = orc.heston_simulate_paths(*g["args"][:4], *g["model"], *g["args"][4:])
+    assert list(sp.shape) == g["shape"] and list(vp.shape) == g["shape"]
+    assert [float(x) for x in sp[0]] == g["spot_row0"] and [float(x) for x in vp[0]] == g["var_row0"]
+    assert [float(x) for x in sp.mean(axis=0)] == g["spot_col_mean"] and [float(x) for x in vp.mean(axis=0)] == g["var_col_mean"]
+    g = golden["merton_path"]
+    S, T, r, v, q, m, seed = g["args"]
+    assert [float(x) for x in orc.merton_simulate_path(S, T, r, v, *g["model"], q, m, seed)] == g["path"]
+    for c in golden["exercise_boundary"]:
+        times, b = orc.american_exercise_boundary(*c["params"], seed=c["seed"], n_paths=c["n_paths"], n_steps=c["n_steps"],
+                                                  option_type=c["option_type"])
+        assert [float(x) for x in times] == c["times"]
+        assert [None if np.isnan(x) else float(x) for x in b] == c["boundary"]

@@ -471,9 +471,19 @@ __global__ __launch_bounds__(kBlock) void european_multi_kernel(PathRange pr, co
 
 // Asian option: running arithmetic sum of S_t (or sum of ln S_t) over t = 1..M kept in
 // registers (exotic_options.py:59-67, 119-122 without the (n_paths, n_steps) matrix).
-// The cumulative log-return is fp64; in the arithmetic case each S_t / S_0 = 2^y is one
-// fp32 v_exp_f32 of the fp64 y rounded once (relative error ~1e-7 per term, unbiased, far
-// below the Monte Carlo error) and the running sum is fp64.
+//
+// Two-level arithmetic, like the European normal sum.  Per GROUP of 16 dates the path carries its
+// cumulative log-return `base` in fp64 (advanced once per group with the fp64 vol and drift).  Inside
+// a group only the prefix sum P_t of the group's RAW normals (parameter-free, fp32) moves:
+//     y_t = base + vol * P_t + j * drift                      (j = date index within the group)
+// arithmetic:  S_t / S_0 = 2^y_t  by one v_exp_f32 of fma(vol32, P_t, fp32(base)) + fp32(j drift):
+//              4 fp32 VALU + 1 transcendental per date per leg, the group's 16 terms summed in fp32,
+//              groups in fp64.  The exponent is rounded to fp32 as before (|y| < ~2: 1.2e-7 absolute,
+//              unbiased); vol32's own rounding only touches the within-group part (< 1e-9).  The 16
+//              values fp32(j drift) live in registers: a running b += drift32 instead would drop the
+//              same sub-ulp fraction of drift32 sixteen times in a row -- a 2e-7 bias, measured.
+// geometric:   sum_t y_t over a group = n base + vol * (sum_t P_t) + drift n(n+1)/2: two fp32 adds per
+//              date for BOTH legs (the mirrored leg shares P), everything else once per group in fp64.
 struct AsianContract {
     double log_s0;
     double s0;
@@ -484,26 +494,28 @@ struct AsianContract {
     double inv_steps;  // 1 / M
 };
 
+constexpr int kAsianGroupBlocks = 4;      // Philox blocks (of four dates) per fp64 update
+
+struct AsianGroup {      // fp32 state of the group in flight
+    float p;             // prefix sum of the group's RAW normals
+    float pp;            // geometric: sum over the group's dates of p
+    float b_u, b_d;      // arithmetic: fp32(base) of the two legs
+    float e_u, e_d;      // arithmetic: sum of the group's 2^y terms
+};
+
 // One Philox block = four monitoring dates of one path.  LIVE < 4 only for the trailing block.
+// `jd` = fp32(j * drift) for the block's four dates (j counts from the start of the group).
 template <bool ANTI, bool GEOMETRIC, int LIVE>
-__device__ __forceinline__ void asian_block(const float (&z)[4], double drift, double vol, double& cum_u, double& cum_d,
-                                            double& run_u, double& run_d) {
-    float e_u = 0.0f, e_d = 0.0f;          // arithmetic: the block's four 2^y terms are summed in fp32 (each ~1)
+__device__ __forceinline__ void asian_block(const float (&z)[4], float vol32, const float* jd, AsianGroup& g) {
 #pragma unroll
     for (int j = 0; j < LIVE; ++j) {
-        const double zj = static_cast<double>(z[j]);
-        cum_u += __builtin_fma(vol, zj, drift);
-        if constexpr (GEOMETRIC) run_u += cum_u;
-        else e_u += __builtin_amdgcn_exp2f(static_cast<float>(cum_u));
-        if constexpr (ANTI) {
-            cum_d += __builtin_fma(-vol, zj, drift);
-            if constexpr (GEOMETRIC) run_d += cum_d;
-            else e_d += __builtin_amdgcn_exp2f(static_cast<float>(cum_d));
+        g.p += z[j];
+        if constexpr (GEOMETRIC) {
+            g.pp += g.p;
+        } else {
+            g.e_u += __builtin_amdgcn_exp2f(__builtin_fmaf(vol32, g.p, g.b_u) + jd[j]);
+            if constexpr (ANTI) g.e_d += __builtin_amdgcn_exp2f(__builtin_fmaf(-vol32, g.p, g.b_d) + jd[j]);
         }
-    }
-    if constexpr (!GEOMETRIC) {
-        run_u += static_cast<double>(e_u);
-        if constexpr (ANTI) run_d += static_cast<double>(e_d);
     }
 }
 
@@ -511,28 +523,65 @@ template <bool ANTI, bool GEOMETRIC>
 __global__ __launch_bounds__(kBlock) void asian_kernel(PathRange pr, AsianContract c, ReduceWs ws) {
     constexpr double kLog2e = 1.4426950408889634;
     double acc[2] = {0.0, 0.0};
-    // arithmetic: accumulate y = log2(S_t / S_0); geometric: accumulate ln(S_t / S_0)
+    // arithmetic: y = log2(S_t / S_0); geometric: y = ln(S_t / S_0)
     const double unit = GEOMETRIC ? 1.0 : kLog2e;
     const double drift = c.drift * unit;
     const double vol = c.vol * kZScale * unit;      // applied to RAW normals
+    const float vol32 = static_cast<float>(vol);
+    float jd[4 * kAsianGroupBlocks];
+#pragma unroll
+    for (int j = 0; j < 4 * kAsianGroupBlocks; ++j) jd[j] = static_cast<float>((j + 1) * drift);
     const int32_t full = pr.n_steps >> 2, rem = pr.n_steps & 3;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
-        const uint64_t g = pr.first + static_cast<uint64_t>(i);
-        const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
-        double cum_u = 0.0, cum_d = 0.0;   // cumulative log-return (in `unit`s)
-        double run_u = 0.0, run_d = 0.0;   // running sum of S_t / S_0, or of ln(S_t / S_0)
+        const uint64_t gp = pr.first + static_cast<uint64_t>(i);
+        const uint32_t g_lo = static_cast<uint32_t>(gp), g_hi = static_cast<uint32_t>(gp >> 32);
+        double base_u = 0.0, base_d = 0.0;   // cumulative log-return at the start of the group (in `unit`s)
+        double run_u = 0.0, run_d = 0.0;     // running sum of S_t / S_0, or of ln(S_t / S_0)
+        AsianGroup g{0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        // close a group of n dates: fold its fp32 sums into the fp64 running sums, advance the bases
+        auto close_group = [&](int32_t n) {
+            const double p = static_cast<double>(g.p), nd = static_cast<double>(n);
+            if constexpr (GEOMETRIC) {
+                const double tri = 0.5 * nd * (nd + 1.0), pp = static_cast<double>(g.pp);
+                run_u += __builtin_fma(vol, pp, __builtin_fma(nd, base_u, drift * tri));
+                if constexpr (ANTI) run_d += __builtin_fma(-vol, pp, __builtin_fma(nd, base_d, drift * tri));
+            } else {
+                run_u += static_cast<double>(g.e_u);
+                if constexpr (ANTI) run_d += static_cast<double>(g.e_d);
+            }
+            base_u += __builtin_fma(vol, p, nd * drift);
+            if constexpr (ANTI) base_d += __builtin_fma(-vol, p, nd * drift);
+            g.p = 0.0f; g.pp = 0.0f; g.e_u = 0.0f; g.e_d = 0.0f;
+            g.b_u = static_cast<float>(base_u);
+            g.b_d = static_cast<float>(base_d);
+        };
         float z[4];
-        for (int32_t b = 0; b < full; ++b) {           // branch-free body: the four dates schedule together
-            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1, z);
-            asian_block<ANTI, GEOMETRIC, 4>(z, drift, vol, cum_u, cum_d, run_u, run_d);
+        int32_t b = 0;
+        for (; b + kAsianGroupBlocks <= full; b += kAsianGroupBlocks) {     // branch-free body: 16 dates schedule together
+#pragma unroll
+            for (int k = 0; k < kAsianGroupBlocks; ++k) {
+                raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b + k), 0u, pr.key0, pr.key1, z);
+                asian_block<ANTI, GEOMETRIC, 4>(z, vol32, jd + 4 * k, g);
+            }
+            close_group(4 * kAsianGroupBlocks);
         }
-        if (rem) {
-            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(full), 0u, pr.key0, pr.key1, z);
-            if (rem == 1) asian_block<ANTI, GEOMETRIC, 1>(z, drift, vol, cum_u, cum_d, run_u, run_d);
-            else if (rem == 2) asian_block<ANTI, GEOMETRIC, 2>(z, drift, vol, cum_u, cum_d, run_u, run_d);
-            else asian_block<ANTI, GEOMETRIC, 3>(z, drift, vol, cum_u, cum_d, run_u, run_d);
+        // the trailing partial group: up to three full blocks, then the block holding the last n_steps % 4 dates
+        const int32_t tail_blocks = full - b;
+#pragma unroll
+        for (int k = 0; k < kAsianGroupBlocks; ++k) {
+            if (k < tail_blocks) {
+                raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b + k), 0u, pr.key0, pr.key1, z);
+                asian_block<ANTI, GEOMETRIC, 4>(z, vol32, jd + 4 * k, g);
+            } else if (k == tail_blocks && rem) {
+                raw_normals4(g_lo, g_hi, static_cast<uint32_t>(full), 0u, pr.key0, pr.key1, z);
+                if (rem == 1) asian_block<ANTI, GEOMETRIC, 1>(z, vol32, jd + 4 * k, g);
+                else if (rem == 2) asian_block<ANTI, GEOMETRIC, 2>(z, vol32, jd + 4 * k, g);
+                else asian_block<ANTI, GEOMETRIC, 3>(z, vol32, jd + 4 * k, g);
+            }
         }
+        const int32_t open_dates = 4 * tail_blocks + rem;
+        if (open_dates) close_group(open_dates);
 #pragma unroll
         for (int leg = 0; leg < (ANTI ? 2 : 1); ++leg) {
             const double mean = (leg ? run_d : run_u) * c.inv_steps;
@@ -949,19 +998,13 @@ struct LsmFit {
     }
 };
 
-// t_fit: the date whose moments are accumulated (>= 1); the date finished first is t_fit + 1
-// (skipped when t_fit + 1 == M: the terminal payoff needs no regression).  init != 0: cash flow
-// starts as the terminal intrinsic value.  `coef` is read at entry (fit of date t_fit + 1, written
-// by the previous launch) and overwritten at the very end by this launch's fit.
-__global__ __launch_bounds__(kBlock) void lsm_step_kernel(int64_t n, LsmContract c, LsmCoeffs* __restrict__ coef, int32_t t_fit,
-                                                          int32_t init, const double* __restrict__ paths,
-                                                          double* __restrict__ cash, ReduceWs ws) {
-    double acc[kLsmNV];
+// One exercise date for this thread's paths.  t_fit: the date whose moments are accumulated (>= 1);
+// the date finished first is t_fit + 1 (skipped when init: the terminal payoff needs no regression).
+// init != 0: cash flow starts as the terminal intrinsic value.  `prev` = fit of date t_fit + 1.
+__device__ __forceinline__ void lsm_date(int64_t n, const LsmContract& c, const LsmCoeffs& prev, int32_t t_fit, int32_t init,
+                                         const double* __restrict__ paths, double* __restrict__ cash, double (&acc)[kLsmNV]) {
 #pragma unroll
     for (int k = 0; k < kLsmNV; ++k) acc[k] = 0.0;
-    LsmCoeffs prev;
-    prev.valid = 0;
-    if (!init) prev = *coef;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
         double cf;
@@ -995,10 +1038,22 @@ __global__ __launch_bounds__(kBlock) void lsm_step_kernel(int64_t n, LsmContract
                 acc[kLsmNV - 2] += 1.0;       // in-the-money count
             }
         } else {
-            acc[0] += cf;                     // final launch (t_fit == 0): moments of the time-0 cash flow
+            acc[0] += cf;                     // final date (t_fit == 0): moments of the time-0 cash flow
             acc[1] += cf * cf;
         }
     }
+}
+
+// One launch per exercise date: `coef` is read at entry (fit of date t_fit + 1, written by the previous
+// launch) and overwritten at the very end by this launch's fit; stream order is the synchronisation.
+__global__ __launch_bounds__(kBlock) void lsm_step_kernel(int64_t n, LsmContract c, LsmCoeffs* __restrict__ coef, int32_t t_fit,
+                                                          int32_t init, const double* __restrict__ paths,
+                                                          double* __restrict__ cash, ReduceWs ws) {
+    double acc[kLsmNV];
+    LsmCoeffs prev;
+    prev.valid = 0;
+    if (!init) prev = *coef;
+    lsm_date(n, c, prev, t_fit, init, paths, cash, acc);
     if (t_fit >= 1) block_then_grid_reduce<kLsmNV>(acc, ws, LsmFit{coef, c.degree});
     else block_then_grid_reduce<kLsmNV>(acc, ws);
 }

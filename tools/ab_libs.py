@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of whole libolmc builds: one subprocess per (library, round), each timing the
 European path kernel with HIP events (olmc_kernel_time).  Usage (GPU box):
-    python tools/ab_libs.py libA.so libB.so ... [--n 1000000] [--m 252] [--rounds 7]"""
+    python tools/ab_libs.py libA.so libB.so ... [--n 1000000] [--m 252] [--rounds 7] [--case european|asian|asian_anti|asian_geo|barrier|heston]"""
 import argparse
 import json
 import os
@@ -16,11 +16,24 @@ sys.path.insert(0, %r)
 from optionslab_amd import _hip
 N, M = int(sys.argv[1]), int(sys.argv[2])
 _hip.lib(); _hip.profile_enable(True)
-for i in range(5): _hip.european(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, True, N, M, 1 + i, True)
+P = (100.0, 100.0, 1.0, 0.05, 0.2, 0.0)
+CASES = {
+    "european": lambda s: _hip.european(*P, True, N, M, s, True),
+    "asian": lambda s: _hip.asian(*P, True, False, N, M, s, False),
+    "asian_anti": lambda s: _hip.asian(*P, True, False, N, M, s, True),
+    "asian_geo": lambda s: _hip.asian(*P, True, True, N, M, s, False),
+    "barrier": lambda s: _hip.barrier(*P, True, 120.0, 0, N, M, s, False),
+    "heston": lambda s: _hip.heston(100.0, 100.0, 1.0, 0.05, 0.0, True, 2.0, 0.04, 0.3, -0.7, 0.04, N, M, s, False),
+}
+run = CASES[sys.argv[3]]
+import time
+for i in range(5): run(1 + i)
 _hip.profile_reset()
-for i in range(40): st = _hip.european(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, True, N, M, 42 + i, True)
+t0 = time.perf_counter()
+for i in range(30): st = run(42 + i)
+wall = (time.perf_counter() - t0) / 30
 n, ms = _hip.kernel_time()
-print(json.dumps({"us": ms / n * 1e3, "price": st.price}))
+print(json.dumps({"us": (ms / n * 1e3) if n else wall * 1e6, "price": st.price}))
 """ % ROOT
 
 ap = argparse.ArgumentParser()
@@ -28,13 +41,14 @@ ap.add_argument("libs", nargs="+")
 ap.add_argument("--n", type=int, default=1_000_000)
 ap.add_argument("--m", type=int, default=252)
 ap.add_argument("--rounds", type=int, default=7)
+ap.add_argument("--case", default="european")
 a = ap.parse_args()
 res = {l: [] for l in a.libs}
 price = {}
 for r in range(a.rounds):
     for l in a.libs:
         env = dict(os.environ, OLMC_LIBRARY=os.path.abspath(l))
-        out = subprocess.run([sys.executable, "-c", CHILD, str(a.n), str(a.m)], env=env, capture_output=True, text=True, check=True)
+        out = subprocess.run([sys.executable, "-c", CHILD, str(a.n), str(a.m), a.case], env=env, capture_output=True, text=True, check=True)
         d = json.loads(out.stdout.strip().splitlines()[-1])
         res[l].append(d["us"])
         price[l] = d["price"]

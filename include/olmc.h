@@ -165,11 +165,14 @@ int olmc_european_terminal(double S, double T, double r, double sigma, double q,
                            int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
                            double* out_host);
 
-/* Full GBM paths to caller-owned HOST memory, TIME-MAJOR: out_host[t * n_paths + i] = S_t of path i,
- * t = 0 .. n_steps (t = 0 is the spot).  Replaces simulate_gbm_paths (src/simulation/gbm_numpy.py:86-118),
- * which returns the transpose, shape (n_paths, n_steps + 1); no antithetic mirror there either. */
+/* Full GBM paths to caller-owned HOST memory; t = 0 .. n_steps, t = 0 is the spot.  Replaces
+ * simulate_gbm_paths (src/simulation/gbm_numpy.py:86-118); no antithetic mirror there either.
+ *   path_major != 0: out_host[i * (n_steps + 1) + t] -- the reference's (n_paths, n_steps + 1) C-order
+ *                    array, written in that layout by the kernel (no host transpose);
+ *   path_major == 0: out_host[t * n_paths + i] (coalesced device writes; one date per row).
+ * The same flag has the same meaning in olmc_heston_paths and olmc_jump_paths. */
 int olmc_gbm_paths(double S, double T, double r, double sigma, double q, int64_t n_paths,
-                   int32_t n_steps, uint64_t seed, double* out_host);
+                   int32_t n_steps, uint64_t seed, int path_major, double* out_host);
 
 /* Control-variate estimator, five moments reduced on device
  * (MonteCarloPricer.price_with_control_variate, monte_carlo.py:154-186). */
@@ -242,11 +245,11 @@ int olmc_heston(double S, double K, double T, double r, double q, int is_call,
                 int antithetic, olmc_stats* out);
 
 /* HestonPricer.simulate_paths (heston.py:257-305): the states of olmc_heston's recursion on the same
- * stream (non-antithetic leg), time-major: spot_host[t * n_paths + i], var_host[t * n_paths + i],
- * t = 0 .. n_steps; row 0 = (S, v0).  The Python mirror returns the transposes, (n_paths, n_steps + 1). */
+ * stream (non-antithetic leg), t = 0 .. n_steps, date 0 = (S, v0); layout as olmc_gbm_paths
+ * (path_major != 0: the reference's two (n_paths, n_steps + 1) arrays). */
 int olmc_heston_paths(double S, double T, double r, double q, double kappa, double theta, double sigma_v,
                       double rho, double v0, int64_t n_paths, int32_t n_steps, uint64_t seed,
-                      double* spot_host, double* var_host);
+                      int path_major, double* spot_host, double* var_host);
 
 /* ---- jump diffusion ----------------------------------------------------------------
  * Replaces MertonJumpDiffusion.price_monte_carlo (src/pricing_models/jump_diffusion.py:160-225)
@@ -260,11 +263,11 @@ int olmc_jump_diffusion(double S, double K, double T, double r, double sigma, do
                         olmc_stats* out);
 
 /* MertonJumpDiffusion.simulate_path (jump_diffusion.py:227-272) for n_paths paths (the reference draws
- * one): the prices of olmc_jump_diffusion's recursion on the same stream, time-major
- * out_host[t * n_paths + i], t = 0 .. n_steps, row 0 = S.  Kou paths come for free (model = 1). */
+ * one): the prices of olmc_jump_diffusion's recursion on the same stream, t = 0 .. n_steps, date 0 = S;
+ * layout as olmc_gbm_paths.  Kou paths come for free (model = 1). */
 int olmc_jump_paths(double S, double T, double r, double sigma, double q, int model, double lambda_j,
                     double a1, double a2, double a3, int64_t n_paths, int32_t n_steps, uint64_t seed,
-                    double* out_host);
+                    int path_major, double* out_host);
 
 /* ---- quasi-Monte Carlo (MCMethod.QMC) --------------------------------------
  * Replaces simulate_gbm_qmc (src/simulation/gbm_qmc.py:14-46): scrambled-Sobol

@@ -62,7 +62,7 @@ PROTOTYPES = {
     "olmc_european_multi": (_I, [C.POINTER(Option), C.POINTER(C.c_uint32), _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_european_greeks_fd": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(_D), C.POINTER(Stats)]),
     "olmc_european_terminal": (_I, [_D] * 5 + [_I64, _I32, _U64T, _I, C.POINTER(_D)]),
-    "olmc_gbm_paths": (_I, [_D] * 5 + [_I64, _I32, _U64T, C.POINTER(_D)]),
+    "olmc_gbm_paths": (_I, [_D] * 5 + [_I64, _I32, _U64T, _I, C.POINTER(_D)]),
     "olmc_european_cv": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(CvMoments)]),
     "olmc_european_qmc": (_I, _SIX + [_I, _I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, C.POINTER(Stats)]),
     "olmc_european_qmc_terminal": (_I, [_D] * 5 + [_I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, _I, C.POINTER(_D)]),
@@ -72,8 +72,8 @@ PROTOTYPES = {
     "olmc_autocallable": (_I, [_D] * 9 + [_I32, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_cliquet": (_I, [_D] * 9 + [_I32, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_exercise_boundary": (_I, _SIX + [_I, _I64, _I32, _U64T, C.POINTER(_D)]),
-    "olmc_heston_paths": (_I, [_D] * 9 + [_I64, _I32, _U64T, C.POINTER(_D), C.POINTER(_D)]),
-    "olmc_jump_paths": (_I, [_D] * 5 + [_I, _D, _D, _D, _D, _I64, _I32, _U64T, C.POINTER(_D)]),
+    "olmc_heston_paths": (_I, [_D] * 9 + [_I64, _I32, _U64T, _I, C.POINTER(_D), C.POINTER(_D)]),
+    "olmc_jump_paths": (_I, [_D] * 5 + [_I, _D, _D, _D, _D, _I64, _I32, _U64T, _I, C.POINTER(_D)]),
     "olmc_american_lsm": (_I, _SIX + [_I, _I64, _I32, _I32, _U64T, C.POINTER(Stats)]),
     "olmc_jump_diffusion": (_I, _SIX + [_I, _I, _D, _D, _D, _D, _I64, _I64, _I32, _U64T, C.POINTER(Stats)]),
     "olmc_heston": (_I, [_D] * 5 + [_I] + [_D] * 5 + [_I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
@@ -241,27 +241,34 @@ def european_terminal(S, T, r, sigma, q, n_paths: int, n_steps: int, seed: int, 
     return out
 
 
-def gbm_paths(S, T, r, sigma, q, n_paths: int, n_steps: int, seed: int) -> np.ndarray:
-    """Time-major (n_steps + 1, n_paths) array of prices, row 0 = spot."""
-    out = np.empty((int(n_steps) + 1, int(n_paths)), dtype=np.float64)
-    _check(lib().olmc_gbm_paths(S, T, r, sigma, q, int(n_paths), int(n_steps), seed64(seed), out.ctypes.data_as(C.POINTER(C.c_double))))
+def _path_matrix(n_paths: int, n_steps: int, path_major: bool) -> np.ndarray:
+    return np.empty((int(n_paths), int(n_steps) + 1) if path_major else (int(n_steps) + 1, int(n_paths)), dtype=np.float64)
+
+
+def gbm_paths(S, T, r, sigma, q, n_paths: int, n_steps: int, seed: int, path_major: bool = False) -> np.ndarray:
+    """Prices at dates 0 .. n_steps (date 0 = spot): (n_steps + 1, n_paths) time-major, or with path_major
+    the reference's (n_paths, n_steps + 1) C-order array, written in that layout by the kernel."""
+    out = _path_matrix(n_paths, n_steps, path_major)
+    _check(lib().olmc_gbm_paths(S, T, r, sigma, q, int(n_paths), int(n_steps), seed64(seed), int(path_major),
+                                out.ctypes.data_as(C.POINTER(C.c_double))))
     return out
 
 
-def heston_paths(S, T, r, q, kappa, theta, sigma_v, rho, v0, n_paths: int, n_steps: int, seed: int):
-    """Time-major (n_steps + 1, n_paths) spot and variance arrays, row 0 = (S, v0)."""
-    spot = np.empty((int(n_steps) + 1, int(n_paths)), dtype=np.float64)
+def heston_paths(S, T, r, q, kappa, theta, sigma_v, rho, v0, n_paths: int, n_steps: int, seed: int, path_major: bool = False):
+    """Spot and variance at dates 0 .. n_steps (date 0 = (S, v0)); layouts as gbm_paths."""
+    spot = _path_matrix(n_paths, n_steps, path_major)
     var = np.empty_like(spot)
-    _check(lib().olmc_heston_paths(S, T, r, q, kappa, theta, sigma_v, rho, v0, int(n_paths), int(n_steps), seed64(seed),
+    _check(lib().olmc_heston_paths(S, T, r, q, kappa, theta, sigma_v, rho, v0, int(n_paths), int(n_steps), seed64(seed), int(path_major),
                                    spot.ctypes.data_as(C.POINTER(C.c_double)), var.ctypes.data_as(C.POINTER(C.c_double))))
     return spot, var
 
 
-def jump_paths(S, T, r, sigma, q, kou: bool, lambda_j, a1, a2, a3, n_paths: int, n_steps: int, seed: int) -> np.ndarray:
-    """Time-major (n_steps + 1, n_paths) prices of the jump-diffusion recursion, row 0 = spot."""
-    out = np.empty((int(n_steps) + 1, int(n_paths)), dtype=np.float64)
+def jump_paths(S, T, r, sigma, q, kou: bool, lambda_j, a1, a2, a3, n_paths: int, n_steps: int, seed: int,
+               path_major: bool = False) -> np.ndarray:
+    """Prices of the jump-diffusion recursion at dates 0 .. n_steps (date 0 = spot); layouts as gbm_paths."""
+    out = _path_matrix(n_paths, n_steps, path_major)
     _check(lib().olmc_jump_paths(S, T, r, sigma, q, int(bool(kou)), lambda_j, a1, a2, a3, int(n_paths), int(n_steps), seed64(seed),
-                                 out.ctypes.data_as(C.POINTER(C.c_double))))
+                                 int(path_major), out.ctypes.data_as(C.POINTER(C.c_double))))
     return out
 
 

@@ -880,7 +880,7 @@ extern "C" int olmc_cliquet(double S, double T, double r, double sigma, double q
 
 // ================================================================== full paths ====
 extern "C" int olmc_gbm_paths(double S, double T, double r, double sigma, double q, int64_t n_paths, int32_t n_steps,
-                              uint64_t seed, double* out_host) {
+                              uint64_t seed, int path_major, double* out_host) {
     if (!out_host) return fail(OLMC_ERR_ARG, "null pointer");
     int rc = check_paths(0, n_paths, n_steps);
     if (rc) return rc;
@@ -900,7 +900,8 @@ extern "C" int olmc_gbm_paths(double S, double T, double r, double sigma, double
     lc.vol = sigma * std::sqrt(dt);
     lc.n_steps = n_steps;
     const PathRange pr = make_range(0, n_paths, n_steps, seed);
-    hipLaunchKernelGGL((lsm_paths_kernel<0>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, lc, static_cast<double*>(c->d_bulk));
+    if (path_major) hipLaunchKernelGGL((lsm_paths_kernel<true>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, lc, static_cast<double*>(c->d_bulk));
+    else hipLaunchKernelGGL((lsm_paths_kernel<false>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, lc, static_cast<double*>(c->d_bulk));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_host, c->d_bulk, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -932,7 +933,7 @@ extern "C" int olmc_exercise_boundary(double S, double K, double T, double r, do
     lc.vol = sigma * std::sqrt(dt);
     lc.n_steps = n_steps;
     const PathRange pr = make_range(0, n_paths, n_steps, seed);
-    hipLaunchKernelGGL((lsm_paths_kernel<0>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, lc, d_paths);
+    hipLaunchKernelGGL((lsm_paths_kernel<false>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, lc, d_paths);
     HIP_TRY(hipGetLastError());
     // np.percentile(x, 10) for a put, 90 for a call (:337-341); NumPy divides q by 100 first
     hipLaunchKernelGGL(exercise_boundary_kernel, dim3(static_cast<uint32_t>(rows)), dim3(kBlock), 0, c->stream, d_paths, n_paths, K,
@@ -979,7 +980,7 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
     const int32_t grid = std::min<int32_t>(path_grid, 2 * c->cus);
     EventPair ep{};
     if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
-    hipLaunchKernelGGL((lsm_paths_kernel<0>), dim3(path_grid), dim3(kBlock), 0, c->stream, pr, lc, d_paths);
+    hipLaunchKernelGGL((lsm_paths_kernel<false>), dim3(path_grid), dim3(kBlock), 0, c->stream, pr, lc, d_paths);
     HIP_TRY(hipGetLastError());
     // every launch reads the fit of the later date from d_coef and (its last workgroup) writes its own fit there:
     // stream order is the only synchronisation, the host waits once at the end
@@ -1025,7 +1026,8 @@ HestonContract make_heston(double S, double K, double T, double r, double q, int
 }  // namespace
 
 extern "C" int olmc_heston_paths(double S, double T, double r, double q, double kappa, double theta, double sigma_v, double rho,
-                                 double v0, int64_t n_paths, int32_t n_steps, uint64_t seed, double* spot_host, double* var_host) {
+                                 double v0, int64_t n_paths, int32_t n_steps, uint64_t seed, int path_major, double* spot_host,
+                                 double* var_host) {
     if (!spot_host || !var_host) return fail(OLMC_ERR_ARG, "null pointer");
     if (!(rho >= -1.0 && rho <= 1.0)) return fail(OLMC_ERR_ARG, "rho must be in [-1, 1]");
     int rc = check_paths(0, n_paths, n_steps);
@@ -1042,7 +1044,8 @@ extern "C" int olmc_heston_paths(double S, double T, double r, double q, double 
     double* d_var = d_spot + static_cast<size_t>(n_paths) * (n_steps + 1);
     const HestonContract hc = make_heston(S, 0.0, T, r, q, 1, kappa, theta, sigma_v, rho, v0, n_steps);
     const PathRange pr = make_range(0, n_paths, n_steps, seed);
-    hipLaunchKernelGGL(heston_paths_kernel, dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, hc, S, d_spot, d_var);
+    if (path_major) hipLaunchKernelGGL((heston_paths_kernel<true>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, hc, S, d_spot, d_var);
+    else hipLaunchKernelGGL((heston_paths_kernel<false>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, hc, S, d_spot, d_var);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(spot_host, d_spot, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(var_host, d_var, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, c->stream));
@@ -1128,7 +1131,8 @@ extern "C" int olmc_jump_diffusion(double S, double K, double T, double r, doubl
 }
 
 extern "C" int olmc_jump_paths(double S, double T, double r, double sigma, double q, int model, double lambda_j, double a1,
-                               double a2, double a3, int64_t n_paths, int32_t n_steps, uint64_t seed, double* out_host) {
+                               double a2, double a3, int64_t n_paths, int32_t n_steps, uint64_t seed, int path_major,
+                               double* out_host) {
     if (!out_host) return fail(OLMC_ERR_ARG, "null pointer");
     JumpContract jc;
     int rc = make_jump(S, 0.0, T, r, sigma, q, 1, model, lambda_j, a1, a2, a3, n_steps, &jc);
@@ -1144,8 +1148,10 @@ extern "C" int olmc_jump_paths(double S, double T, double r, double sigma, doubl
     rc = bulk_reserve(c, static_cast<size_t>(bytes));
     if (rc) return rc;
     const PathRange pr = make_range(0, n_paths, n_steps, seed);
-    hipLaunchKernelGGL(jump_paths_kernel, dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, jc, S,
-                       static_cast<double*>(c->d_bulk));
+    if (path_major) hipLaunchKernelGGL((jump_paths_kernel<true>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, jc, S,
+                                       static_cast<double*>(c->d_bulk));
+    else hipLaunchKernelGGL((jump_paths_kernel<false>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, jc, S,
+                            static_cast<double*>(c->d_bulk));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_host, c->d_bulk, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

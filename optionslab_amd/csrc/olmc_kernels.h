@@ -824,7 +824,16 @@ struct LsmContract {
     int32_t n_steps;
 };
 
-template <int DUMMY = 0>
+// Element (path i, date t) of a path matrix: time-major [t][i] (coalesced; what the device-side consumers
+// read) or path-major [i][t] (the reference's (n_paths, n_steps + 1) C order, so a host caller needs no
+// transpose: a thread then writes runs of consecutive dates, 32 B per Philox block).
+template <bool PATH_MAJOR>
+__device__ __forceinline__ size_t path_at(int64_t i, int32_t t, int64_t count, int32_t n_steps) {
+    return PATH_MAJOR ? static_cast<size_t>(i) * static_cast<size_t>(n_steps + 1) + static_cast<size_t>(t)
+                      : static_cast<size_t>(t) * static_cast<size_t>(count) + static_cast<size_t>(i);
+}
+
+template <bool PATH_MAJOR = false>
 __global__ __launch_bounds__(kBlock) void lsm_paths_kernel(PathRange pr, LsmContract c, double* __restrict__ paths) {
     const double vol = c.vol * kZScale;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
@@ -832,7 +841,7 @@ __global__ __launch_bounds__(kBlock) void lsm_paths_kernel(PathRange pr, LsmCont
         const uint64_t g = pr.first + static_cast<uint64_t>(i);
         const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
         double cum = 0.0;
-        paths[i] = c.s_first;
+        paths[path_at<PATH_MAJOR>(i, 0, pr.count, pr.n_steps)] = c.s_first;
         const int32_t blocks = (pr.n_steps + 3) >> 2;
         for (int32_t b = 0; b < blocks; ++b) {
             float z[4];
@@ -842,7 +851,7 @@ __global__ __launch_bounds__(kBlock) void lsm_paths_kernel(PathRange pr, LsmCont
                 const int32_t t = 4 * b + j + 1;
                 if (t <= pr.n_steps) {
                     cum += __builtin_fma(vol, static_cast<double>(z[j]), c.drift);
-                    paths[static_cast<size_t>(t) * pr.count + i] = exp(c.log_s0 + cum);
+                    paths[path_at<PATH_MAJOR>(i, t, pr.count, pr.n_steps)] = exp(c.log_s0 + cum);
                 }
             }
         }
@@ -1120,6 +1129,7 @@ __global__ __launch_bounds__(kBlock) void heston_kernel(PathRange pr, HestonCont
 // HestonPricer.simulate_paths (heston.py:257-305): the same recursion on the same stream, every state
 // written out, time-major: spot[t * count + i], var[t * count + i], t = 0 .. n_steps (coalesced per step).
 // Row 0 is (S, v0) as given (:286-287), not exp(log S).
+template <bool PATH_MAJOR>
 __global__ __launch_bounds__(kBlock) void heston_paths_kernel(PathRange pr, HestonContract c, double s_first,
                                                               double* __restrict__ spot, double* __restrict__ var) {
     const double zs = kZScale * c.sqrt_dt;
@@ -1128,8 +1138,8 @@ __global__ __launch_bounds__(kBlock) void heston_paths_kernel(PathRange pr, Hest
         const uint64_t g = pr.first + static_cast<uint64_t>(i);
         const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
         double ls = c.log_s0, v = c.v0;
-        spot[i] = s_first;
-        var[i] = c.v0;
+        spot[path_at<PATH_MAJOR>(i, 0, pr.count, pr.n_steps)] = s_first;
+        var[path_at<PATH_MAJOR>(i, 0, pr.count, pr.n_steps)] = c.v0;
         const int32_t blocks = (pr.n_steps + 1) >> 1;
         for (int32_t b = 0; b < blocks; ++b) {
             float z[4];
@@ -1141,7 +1151,7 @@ __global__ __launch_bounds__(kBlock) void heston_paths_kernel(PathRange pr, Hest
                     const double w1 = zs * static_cast<double>(z[2 * h]);
                     const double w2 = c.rho * w1 + c.rho_c * (zs * static_cast<double>(z[2 * h + 1]));
                     heston_step(c, w1, w2, ls, v);
-                    const size_t at = static_cast<size_t>(t + 1) * static_cast<size_t>(pr.count) + static_cast<size_t>(i);
+                    const size_t at = path_at<PATH_MAJOR>(i, t + 1, pr.count, pr.n_steps);
                     spot[at] = exp(ls);
                     var[at] = v;
                 }
@@ -1217,6 +1227,7 @@ __global__ __launch_bounds__(kBlock) void jump_kernel(PathRange pr, JumpContract
 
 // MertonJumpDiffusion.simulate_path (jump_diffusion.py:227-272), for any number of paths: the pricing
 // kernel's recursion with every price written out, time-major out[t * count + i], row 0 = S as given (:254).
+template <bool PATH_MAJOR>
 __global__ __launch_bounds__(kBlock) void jump_paths_kernel(PathRange pr, JumpContract c, double s_first, double* __restrict__ out) {
     const double vol = c.vol * kZScale;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
@@ -1224,10 +1235,10 @@ __global__ __launch_bounds__(kBlock) void jump_paths_kernel(PathRange pr, JumpCo
         const uint64_t g = pr.first + static_cast<uint64_t>(i);
         const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
         double ls = c.log_s0;
-        out[i] = s_first;
+        out[path_at<PATH_MAJOR>(i, 0, pr.count, pr.n_steps)] = s_first;
         for (int32_t t = 0; t < pr.n_steps; ++t) {
             jump_step(pr, c, vol, g_lo, g_hi, t, ls);
-            out[static_cast<size_t>(t + 1) * static_cast<size_t>(pr.count) + static_cast<size_t>(i)] = exp(ls);
+            out[path_at<PATH_MAJOR>(i, t + 1, pr.count, pr.n_steps)] = exp(ls);
         }
     }
 }

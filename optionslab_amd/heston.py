@@ -89,8 +89,7 @@ class HestonPricer:
         if n_paths < 1 or n_steps < 1:
             raise ValueError("n_paths and n_steps must be >= 1")
         s = seed if seed is not None else int(np.random.default_rng().integers(0, 2**31))
-        spot, var = _hip.heston_paths(S, T, r, q, self.kappa, self.theta, self.sigma_v, self.rho, self.v0, n_paths, n_steps, s)
-        return np.ascontiguousarray(spot.T), np.ascontiguousarray(var.T)
+        return _hip.heston_paths(S, T, r, q, self.kappa, self.theta, self.sigma_v, self.rho, self.v0, n_paths, n_steps, s, path_major=True)
 
 
 class HestonAdapter:

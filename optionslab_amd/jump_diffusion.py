@@ -79,8 +79,8 @@ class MertonJumpDiffusion:
         """(n_paths, n_steps + 1) price paths of price_monte_carlo's recursion for the same seed, column 0 = S."""
         if n_paths < 1 or n_steps < 1:
             raise ValueError("n_paths and n_steps must be >= 1")
-        tm = _hip.jump_paths(S, T, r, sigma, q, False, self.lambda_j, self.mu_j, self.sigma_j, 0.0, n_paths, n_steps, _seed(seed))
-        return np.ascontiguousarray(tm.T)
+        return _hip.jump_paths(S, T, r, sigma, q, False, self.lambda_j, self.mu_j, self.sigma_j, 0.0, n_paths, n_steps, _seed(seed),
+                               path_major=True)
 
     def simulate_path(self, S, T, r, sigma, q: float = 0.0, n_steps: int = 252, seed: Optional[int] = None) -> np.ndarray:
         """jump_diffusion.py:227-272: one path with jumps, shape (n_steps + 1,)."""
@@ -119,8 +119,8 @@ class KouJumpDiffusion:
         """(n_paths, n_steps + 1) price paths of price_monte_carlo's recursion (additive: the reference has none for Kou)."""
         if n_paths < 1 or n_steps < 1:
             raise ValueError("n_paths and n_steps must be >= 1")
-        tm = _hip.jump_paths(S, T, r, sigma, q, True, self.lambda_j, self.p, self.eta1, self.eta2, n_paths, n_steps, _seed(seed))
-        return np.ascontiguousarray(tm.T)
+        return _hip.jump_paths(S, T, r, sigma, q, True, self.lambda_j, self.p, self.eta1, self.eta2, n_paths, n_steps, _seed(seed),
+                               path_major=True)
 
 
 class JumpDiffusionAdapter:

@@ -29,11 +29,11 @@ def simulate_gbm_hip_fast(S: float, T: float, r: float, sigma: float, q: float, 
 
 def simulate_gbm_paths_hip(S: float, T: float, r: float, sigma: float, q: float, n_paths: int, n_steps: int, seed: int) -> np.ndarray:
     """Full paths, shape (n_paths, n_steps + 1), column 0 = S (counterpart of simulate_gbm_paths,
-    gbm_numpy.py:86-118).  The device writes time-major slices (coalesced); the C-contiguous
-    (n_paths, n_steps + 1) array the reference returns is formed by one host transpose."""
+    gbm_numpy.py:86-118).  The kernel writes the reference's C-order (n_paths, n_steps + 1) layout
+    itself, so the array arrives in one device-to-host copy with no host-side transpose."""
     if n_paths < 1 or n_steps < 1:
         raise ValueError("n_paths and n_steps must be >= 1")
-    return np.ascontiguousarray(_hip.gbm_paths(S, T, r, sigma, q, n_paths, n_steps, seed).T)
+    return _hip.gbm_paths(S, T, r, sigma, q, n_paths, n_steps, seed, path_major=True)
 
 
 def simulate_gbm_qmc_hip(S: float, T: float, r: float, sigma: float, q: float, n_paths: int, n_steps: int, seed: int) -> np.ndarray:

@@ -332,3 +332,16 @@ def test_early_exercise_boundary(golden):
     assert np.array_equal(b[1:], orc.exercise_boundary_from_paths(paths, 60.0, "put")[1:], equal_nan=True)
     assert np.isnan(b[0]) and np.isnan(b[1])
     assert np.all(np.isnan(ol.AmericanOption(100.0, 1.0, 0.1, 0.05, 0.1, seed=1).early_exercise_boundary(1000, 4, "put")[1]))
+
+
+def test_path_matrix_layouts_agree_bitwise():
+    """path_major: the reference's (n_paths, n_steps + 1) C order written by the kernel == the transpose of the time-major rows."""
+    for N, M in ((1000, 12), (257, 7), (70_000, 3)):
+        a = _hip.gbm_paths(100.0, 1.0, 0.05, 0.2, 0.01, N, M, 9, path_major=True)
+        assert a.shape == (N, M + 1) and a.flags["C_CONTIGUOUS"] and np.array_equal(a, _hip.gbm_paths(100.0, 1.0, 0.05, 0.2, 0.01, N, M, 9).T)
+        s1, v1 = _hip.heston_paths(100.0, 1.0, 0.05, 0.01, 2.0, 0.04, 0.3, -0.7, 0.04, N, M, 9, path_major=True)
+        s0, v0 = _hip.heston_paths(100.0, 1.0, 0.05, 0.01, 2.0, 0.04, 0.3, -0.7, 0.04, N, M, 9)
+        assert s1.shape == (N, M + 1) and np.array_equal(s1, s0.T) and np.array_equal(v1, v0.T)
+        for kou, mdl in ((False, (3.0, -0.1, 0.2, 0.0)), (True, (3.0, 0.6, 25.0, 20.0))):
+            j1 = _hip.jump_paths(100.0, 1.0, 0.05, 0.2, 0.01, kou, *mdl, N, M, 9, path_major=True)
+            assert j1.shape == (N, M + 1) and np.array_equal(j1, _hip.jump_paths(100.0, 1.0, 0.05, 0.2, 0.01, kou, *mdl, N, M, 9).T)

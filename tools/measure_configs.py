@@ -99,6 +99,20 @@ def main():
            lambda r: dict(price=float(r[0]), std_error=r[1]), reps=10)
     report("American put LSM 1M x 50, degree 3", N * 50, lambda: ol.AmericanOption(*ATM, seed=42).price(N, 50, "put", 3, return_error=True),
            lambda r: dict(price=float(r[0]), std_error=r[1]), reps=5)
+    mj = ol.MertonJumpDiffusion(0.5, -0.1, 0.2)
+    report("Merton jump diffusion 1M x 252", N * M, lambda: mj.price_monte_carlo(*ATM, "call", 0.0, N, M, 42, return_error=True),
+           lambda r: dict(price=float(r[0]), std_error=r[1], series=float(mj.price(*ATM, "call"))), reps=10)
+    kj = ol.KouJumpDiffusion(1.0, 0.4, 10.0, 5.0)
+    report("Kou jump diffusion 1M x 252", N * M, lambda: kj.price_monte_carlo(*ATM, "call", 0.0, N, M, 42, return_error=True),
+           lambda r: dict(price=float(r[0]), std_error=r[1]), reps=10)
+    report("simulate_gbm_paths 100k x 252 -> (100k, 253) fp64 on host (202 MB D2H + transpose included)", 100_000 * M,
+           lambda: ol.simulate_gbm_paths_hip(100.0, 1.0, 0.05, 0.2, 0.0, 100_000, M, 42), lambda a: dict(mean_terminal=float(a[:, -1].mean())), reps=5)
+    report("HestonPricer.simulate_paths 100k x 252 -> 2 x (100k, 253) fp64 on host", 100_000 * M,
+           lambda: hes.simulate_paths(100.0, 1.0, 0.05, 0.0, 100_000, M, 42), lambda a: dict(mean_terminal=float(a[0][:, -1].mean())), reps=5)
+    report("AmericanOption.early_exercise_boundary 10k x 50 (reference defaults)", 10_000 * 50,
+           lambda: ol.AmericanOption(*ATM, seed=42).early_exercise_boundary(10_000, 50, "put"), lambda r: dict(boundary_T=float(r[1][-1])), reps=10)
+    report("AmericanOption.early_exercise_boundary 1M x 50", N * 50,
+           lambda: ol.AmericanOption(*ATM, seed=42).early_exercise_boundary(N, 50, "put"), lambda r: dict(boundary_T=float(r[1][-1])), reps=5)
     p8 = ol.MonteCarloPricer(8_000_000, M, 42)
     report("C5 per-GPU shard: european call 8M x 252", 8_000_000 * M, lambda: p8.price(*ATM, "call", return_error=True),
            lambda r: dict(price=r.price, std_error=r.std_error, z_vs_bs=(r.price - BS) / r.std_error), reps=10)

@@ -28,6 +28,17 @@ from . import monte_carlo_unified as _uni
 from . import simulation as _sim
 
 _installed: dict = {}
+_package_attrs: list = []        # (package, name, previous value or _MISSING): names re-exported at package level
+_MISSING = object()
+
+# What the reference's package __init__ files re-export from the modules above
+# (src/pricing_models/__init__.py:23-66, src/greeks/__init__.py:11-23, src/exceptions/__init__.py).
+_PACKAGE_EXPORTS = {
+    "src.pricing_models": ["src.pricing_models.monte_carlo", "src.pricing_models.monte_carlo_unified", "src.pricing_models.black_scholes",
+                           "src.pricing_models.exotic_options", "src.pricing_models.heston", "src.pricing_models.jump_diffusion"],
+    "src.greeks": ["src.greeks.unified_greeks"],
+    "src.exceptions": ["src.exceptions.montecarlo_exceptions", "src.exceptions.greek_exceptions"],
+}
 
 
 def _module(name: str, **attrs) -> types.ModuleType:
@@ -45,7 +56,13 @@ def _targets() -> dict:
                   simulate_gbm_numba=_sim.simulate_gbm_hip, simulate_gbm_qmc=_sim.simulate_gbm_qmc_hip,
                   simulate_gbm_qmc_antithetic=_sim.simulate_gbm_qmc_antithetic_hip,
                   NUMBA_AVAILABLE=False)
+    sim_numpy = _module("src.simulation.gbm_numpy", simulate_gbm_numpy=_sim.simulate_gbm_hip, simulate_gbm_numpy_fast=_sim.simulate_gbm_hip_fast,
+                        simulate_gbm_paths=_sim.simulate_gbm_paths_hip)
+    sim_numba = _module("src.simulation.gbm_numba", simulate_gbm_numba=_sim.simulate_gbm_hip, NUMBA_AVAILABLE=False)
+    sim_qmc = _module("src.simulation.gbm_qmc", simulate_gbm_qmc=_sim.simulate_gbm_qmc_hip,
+                      simulate_gbm_qmc_antithetic=_sim.simulate_gbm_qmc_antithetic_hip)
     return {
+        "src.simulation.gbm_numpy": sim_numpy, "src.simulation.gbm_numba": sim_numba, "src.simulation.gbm_qmc": sim_qmc,
         "src.pricing_models.monte_carlo": _module("src.pricing_models.monte_carlo", MonteCarloPricer=_mc.MonteCarloPricer,
                                                   MCMethod=_mc.MCMethod, MCResult=_mc.MCResult, NUMBA_AVAILABLE=False),
         "src.pricing_models.monte_carlo_unified": _module("src.pricing_models.monte_carlo_unified", MonteCarloPricerUni=_uni.MonteCarloPricerUni,
@@ -93,9 +110,25 @@ def install() -> None:
         _installed[name] = sys.modules.get(name)
         sys.modules[name] = mod
         setattr(sys.modules[".".join(parts[:-1])], parts[-1], mod)
+    # `from src.pricing_models import MonteCarloPricer`, `from src.greeks import compute_greeks_unified, HestonAdapter` ...
+    for package, sources in _PACKAGE_EXPORTS.items():
+        pkg = sys.modules[package]
+        for source in sources:
+            for attr, value in vars(sys.modules[source]).items():
+                if attr.startswith("__"):
+                    continue
+                _package_attrs.append((pkg, attr, getattr(pkg, attr, _MISSING)))
+                setattr(pkg, attr, value)
 
 
 def uninstall() -> None:
+    for pkg, attr, previous in reversed(_package_attrs):
+        if previous is _MISSING:
+            if hasattr(pkg, attr):
+                delattr(pkg, attr)
+        else:
+            setattr(pkg, attr, previous)
+    _package_attrs.clear()
     for name, previous in reversed(list(_installed.items())):
         if previous is None:
             sys.modules.pop(name, None)

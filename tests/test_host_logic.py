@@ -174,6 +174,17 @@ def test_compat_install_makes_reference_import_paths_resolve_here():
         from src.pricing_models.monte_carlo_unified import InputValidationError as UniErr
         from src.pricing_models.monte_carlo_unified import MonteCarloPricerUni
         from src.simulation import simulate_gbm_numpy
+        # package-level re-exports of the reference's __init__ files (src/pricing_models/__init__.py:23-66, src/greeks/__init__.py:11-23)
+        from src.greeks import HestonAdapter, JumpDiffusionAdapter, greeks_heston
+        from src.greeks import compute_greeks_unified as cgu
+        from src.pricing_models import AsianOption, HestonPricer, KouJumpDiffusion
+        from src.pricing_models import MonteCarloPricer as PackageLevelPricer
+        from src.simulation.gbm_numpy import simulate_gbm_paths
+        from src.simulation.gbm_qmc import simulate_gbm_qmc_antithetic
+        assert PackageLevelPricer is ol.MonteCarloPricer and cgu is compute_greeks_unified and AsianOption is ol.AsianOption
+        assert HestonPricer is ol.HestonPricer and KouJumpDiffusion is ol.KouJumpDiffusion and HestonAdapter is ol.HestonAdapter
+        assert JumpDiffusionAdapter is ol.JumpDiffusionAdapter and greeks_heston is ol.greeks_heston
+        assert simulate_gbm_paths is ol.simulate_gbm_paths_hip and simulate_gbm_qmc_antithetic is ol.simulate_gbm_qmc_antithetic_hip
         assert MonteCarloPricer is ol.MonteCarloPricer and MCMethod is ol.MCMethod and NUMBA_AVAILABLE is False
         assert mc.MonteCarloPricer(num_simulations=10, num_steps=5, seed=1).price(120, 100, 0.0, 0.05, 0.2, "call") == 20
         assert black_scholes(100, 100, 1.0, 0.05, 0.2) == ol.black_scholes(100, 100, 1.0, 0.05, 0.2)

@@ -179,7 +179,9 @@ def test_compat_install_makes_reference_import_paths_resolve_here():
         from src.greeks import compute_greeks_unified as cgu
         from src.pricing_models import AsianOption, HestonPricer, KouJumpDiffusion
         from src.pricing_models import MonteCarloPricer as PackageLevelPricer
+        from src.pricing_models import GPU_AVAILABLE, black_scholes as page_bs          # streamlit_app/pages/1_MonteCarlo_Basic.py:51-57
         from src.simulation.gbm_numpy import simulate_gbm_paths
+        assert GPU_AVAILABLE is True and page_bs is black_scholes
         from src.simulation.gbm_qmc import simulate_gbm_qmc_antithetic
         assert PackageLevelPricer is ol.MonteCarloPricer and cgu is compute_greeks_unified and AsianOption is ol.AsianOption
         assert HestonPricer is ol.HestonPricer and KouJumpDiffusion is ol.KouJumpDiffusion and HestonAdapter is ol.HestonAdapter

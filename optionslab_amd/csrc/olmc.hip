@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -168,8 +169,15 @@ int g_grid_cap = 0;          // OLMC_TUNE_GRID_CAP: max workgroups per launch (0
 // Launch geometry: one workgroup per 256 paths, handed out by the hardware dispatcher
 // (measured faster than a fixed 8-workgroups-per-CU grid-stride); beyond kMaxGrid
 // workgroups the kernels grid-stride.
-int32_t grid_for(int64_t n_paths) {
-    const int64_t cap = g_grid_cap > 0 ? std::min<int64_t>(g_grid_cap, kMaxGrid) : kMaxGrid;
+// Short paths (n_steps <= 128, the reference's default is ONE step) are bounded by per-workgroup costs
+// (dispatch, row store, ticket), not by the step loop: there 16 workgroups per CU that grid-stride beat
+// one workgroup per 256 paths (8M x 4: 63 -> 43 us, 8M x 32: 143 -> 125 us; equal from 128 steps on,
+// tools/single_step_probe.py).
+constexpr int32_t kShortPathSteps = 128, kShortPathGrid = 4096;
+
+int32_t grid_for(int64_t n_paths, int32_t n_steps = INT32_MAX) {
+    int64_t cap = g_grid_cap > 0 ? std::min<int64_t>(g_grid_cap, kMaxGrid) : kMaxGrid;
+    if (g_grid_cap == 0 && n_steps <= kShortPathSteps) cap = kShortPathGrid;
     return static_cast<int32_t>(std::min<int64_t>((n_paths + kBlock - 1) / kBlock, cap));
 }
 
@@ -352,7 +360,7 @@ int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32
                      int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic, double* d_out, double tail,
                      int* pos /* [k]: slot of contract i in d_out, may be NULL when k == 1 */) {
     const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
-    const int32_t grid = grid_for(n_local);
+    const int32_t grid = grid_for(n_local, n_steps);
     const bool anti = antithetic != 0;
     const int nsets = k == 1 ? 1 : (k <= 8 ? 8 : 16);
     ReduceWs ws;

@@ -24,14 +24,18 @@ def ref():
 
     compat.install()
     try:
-        import src.exceptions.montecarlo_exceptions as exc
-        import src.pricing_models.black_scholes as bs
-        import src.pricing_models.exotic_options as exo
-        import src.pricing_models.monte_carlo as mc
-        import src.pricing_models.monte_carlo_unified as uni
+        import importlib
+        import types
+
+        # (importlib, not `import a.b.c as x`: as in the reference, the package re-exports the FUNCTION
+        # black_scholes under the name of its own submodule, src/pricing_models/__init__.py:24)
+        exc, exo, mc, uni = (importlib.import_module(m) for m in (
+            "src.exceptions.montecarlo_exceptions", "src.pricing_models.exotic_options", "src.pricing_models.monte_carlo",
+            "src.pricing_models.monte_carlo_unified"))
+        from src.pricing_models.black_scholes import black_scholes
 
         assert getattr(mc, "__optionslab_amd__", False) and getattr(exo, "__optionslab_amd__", False)
-        yield dict(mc=mc, uni=uni, bs=bs, exo=exo, exc=exc)
+        yield dict(mc=mc, uni=uni, bs=types.SimpleNamespace(black_scholes=black_scholes), exo=exo, exc=exc)
     finally:
         compat.uninstall()
 

@@ -1083,37 +1083,72 @@ struct HestonContract {
     double strike, sign;
 };
 
-// One Euler step of one leg; w1, w2 = sqrt(dt) * (Z1, Z2) with the leg's sign applied.
-__device__ __forceinline__ void heston_step(const HestonContract& c, double w1, double w2, double& ls, double& v) {
-    const double vp = fmax(v, 0.0);
-    const double sv = sqrt(vp);
-    ls += (c.mu_dt - 0.5 * vp * c.dt) + sv * w1;
-    v = fmax(v + c.kappa_dt * (c.theta - vp) + c.sigma_v * sv * w2, 0.0);
+// sqrt of a non-negative finite fp64 from an fp32 v_rsq_f32 seed (2^-22) and one coupled Newton/Goldschmidt
+// round plus a residual correction: 1 ulp (checked against sqrt over [1e-12, 10]), 10 instructions against
+// the 17 + v_rsq_f64 of the library expansion (which also handles inf / NaN / subnormals: not needed for a
+// truncated variance).  x = 0 gives 0; x below 1e-30 loses accuracy (sqrt < 1e-15: immaterial here).
+__device__ __forceinline__ double sqrt_nonneg(double x) {
+    const double r = static_cast<double>(__builtin_amdgcn_rsqf(fmaxf(static_cast<float>(x), 1e-30f)));
+    double g = x * r, h = 0.5 * r;
+    const double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    return __builtin_fma(__builtin_fma(-g, g, x), h, g);
+}
+
+// The recursion with its constants folded (v >= 0 holds after every step, so v+ = v):
+//   ln S' = ln S - (dt/2) v + sqrt(v) u            u = sqrt(dt) Z1                 (+ (r - q) dt, added once per path as M (r-q) dt)
+//   v'    = max(v (1 - kappa dt) + kappa theta dt + sqrt(v) w, 0)   w = sigma_v sqrt(dt) (rho Z1 + rho_c Z2')
+// 2 + 3 fp64 ops per leg per step after the square root, against 12 for the literal form.
+struct HestonStep {
+    double neg_half_dt, one_minus_kdt, kdt_theta;
+    double zs, a, b;                 // RAW normal -> u = zs z1;  w = a z1 + b z2
+    __device__ __forceinline__ explicit HestonStep(const HestonContract& c)
+        : neg_half_dt(-0.5 * c.dt), one_minus_kdt(1.0 - c.kappa_dt), kdt_theta(c.kappa_dt * c.theta),
+          zs(kZScale * c.sqrt_dt), a(c.sigma_v * c.rho * (kZScale * c.sqrt_dt)), b(c.sigma_v * c.rho_c * (kZScale * c.sqrt_dt)) {}
+    // SIGN = +1 / -1: the antithetic leg flips both normals (free source modifiers)
+    template <int SIGN>
+    __device__ __forceinline__ void advance(double u, double w, double& ls, double& v) const {
+        const double sv = sqrt_nonneg(v);
+        ls = __builtin_fma(sv, SIGN > 0 ? u : -u, __builtin_fma(neg_half_dt, v, ls));
+        v = fmax(__builtin_fma(sv, SIGN > 0 ? w : -w, __builtin_fma(v, one_minus_kdt, kdt_theta)), 0.0);
+    }
+};
+
+// v0 < 0 never comes through HestonPricer (heston.py:71-72 rejects it); at the C ABI the reference's recursion
+// is kept: its first step sees v+ = 0, so it is deterministic -- ln S += (r - q) dt, v = max(v0 + kappa theta dt, 0)
+// -- and is taken before the loop, which then skips date 0.
+__device__ __forceinline__ bool heston_start(const HestonContract& c, double& v) {
+    if (c.v0 >= 0.0) { v = c.v0; return false; }
+    v = fmax(c.v0 + c.kappa_dt * c.theta, 0.0);
+    return true;
 }
 
 template <bool ANTI>
 __global__ __launch_bounds__(kBlock) void heston_kernel(PathRange pr, HestonContract c, ReduceWs ws) {
     double acc[2] = {0.0, 0.0};
-    const double zs = kZScale * c.sqrt_dt;          // RAW normal -> sqrt(dt) * Z
+    const HestonStep hs(c);
+    double v_start;
+    const bool skip0 = heston_start(c, v_start);
+    const double ls_start = c.log_s0 + pr.n_steps * c.mu_dt;        // the drift (r - q) dt of every step, once
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
         const uint64_t g = pr.first + static_cast<uint64_t>(i);
         const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
-        double ls[2] = {c.log_s0, c.log_s0}, v[2] = {c.v0, c.v0};
+        double ls[2] = {ls_start, ls_start}, v[2] = {v_start, v_start};
         const int32_t blocks = (pr.n_steps + 1) >> 1;
         for (int32_t b = 0; b < blocks; ++b) {
             float z[4];
             raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), kTagHeston, pr.key0, pr.key1, z);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                if (2 * b + h < pr.n_steps) {
-                    const double w1 = zs * static_cast<double>(z[2 * h]);
-                    const double w2 = c.rho * w1 + c.rho_c * (zs * static_cast<double>(z[2 * h + 1]));
-#pragma unroll
-                    for (int leg = 0; leg < (ANTI ? 2 : 1); ++leg) {
-                        const double sgn = leg ? -1.0 : 1.0;
-                        heston_step(c, sgn * w1, sgn * w2, ls[leg], v[leg]);
-                    }
+                const int32_t t = 2 * b + h;
+                if (t < pr.n_steps && !(skip0 && t == 0)) {
+                    const double z1 = static_cast<double>(z[2 * h]);
+                    const double u = hs.zs * z1;
+                    const double w = __builtin_fma(hs.b, static_cast<double>(z[2 * h + 1]), hs.a * z1);
+                    hs.advance<1>(u, w, ls[0], v[0]);
+                    if constexpr (ANTI) hs.advance<-1>(u, w, ls[1], v[1]);
                 }
             }
         }
@@ -1127,17 +1162,18 @@ __global__ __launch_bounds__(kBlock) void heston_kernel(PathRange pr, HestonCont
 }
 
 // HestonPricer.simulate_paths (heston.py:257-305): the same recursion on the same stream, every state
-// written out, time-major: spot[t * count + i], var[t * count + i], t = 0 .. n_steps (coalesced per step).
-// Row 0 is (S, v0) as given (:286-287), not exp(log S).
+// written out (layouts: path_at): date 0 is (S, v0) as given (:286-287), not exp(log S).
 template <bool PATH_MAJOR>
 __global__ __launch_bounds__(kBlock) void heston_paths_kernel(PathRange pr, HestonContract c, double s_first,
                                                               double* __restrict__ spot, double* __restrict__ var) {
-    const double zs = kZScale * c.sqrt_dt;
+    const HestonStep hs(c);
+    double v_start;
+    const bool skip0 = heston_start(c, v_start);
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
         const uint64_t g = pr.first + static_cast<uint64_t>(i);
         const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
-        double ls = c.log_s0, v = c.v0;
+        double ls = c.log_s0, v = v_start;       // ls WITHOUT the (r - q) dt terms: added per date below
         spot[path_at<PATH_MAJOR>(i, 0, pr.count, pr.n_steps)] = s_first;
         var[path_at<PATH_MAJOR>(i, 0, pr.count, pr.n_steps)] = c.v0;
         const int32_t blocks = (pr.n_steps + 1) >> 1;
@@ -1148,11 +1184,12 @@ __global__ __launch_bounds__(kBlock) void heston_paths_kernel(PathRange pr, Hest
             for (int h = 0; h < 2; ++h) {
                 const int32_t t = 2 * b + h;
                 if (t < pr.n_steps) {
-                    const double w1 = zs * static_cast<double>(z[2 * h]);
-                    const double w2 = c.rho * w1 + c.rho_c * (zs * static_cast<double>(z[2 * h + 1]));
-                    heston_step(c, w1, w2, ls, v);
+                    if (!(skip0 && t == 0)) {
+                        const double z1 = static_cast<double>(z[2 * h]);
+                        hs.advance<1>(hs.zs * z1, __builtin_fma(hs.b, static_cast<double>(z[2 * h + 1]), hs.a * z1), ls, v);
+                    }
                     const size_t at = path_at<PATH_MAJOR>(i, t + 1, pr.count, pr.n_steps);
-                    spot[at] = exp(ls);
+                    spot[at] = exp(__builtin_fma(static_cast<double>(t + 1), c.mu_dt, ls));
                     var[at] = v;
                 }
             }

@@ -101,6 +101,8 @@ H = dict(kappa=2.0, theta=0.04, sigma_v=0.3, rho=-0.7, v0=0.04)
 @pytest.mark.parametrize("call,anti,N,M,model", [
     (True, False, 20000, 64, (2.0, 0.04, 0.3, -0.7, 0.04)), (False, True, 5001, 13, (1.5, 0.06, 0.5, -0.5, 0.03)),
     (False, False, 4000, 101, (3.0, 0.02, 0.8, 0.3, 0.05)),      # odd step count; Feller violated: v is truncated at 0
+    (True, True, 3000, 9, (2.0, 0.04, 0.3, -0.7, -0.01)),        # v0 < 0 (C ABI only): the first step sees v+ = 0
+    (True, False, 1000, 1, (2.0, 0.04, 0.3, -0.7, -0.5)),
 ])
 def test_heston_matches_same_stream_checker(call, anti, N, M, model):
     st = _hip.heston(100.0, 95.0, 1.5, 0.03, 0.01, call, *model, N, M, 21, anti)
@@ -285,6 +287,9 @@ def test_heston_paths_against_checker_reference_and_pricer(golden):
     cs, cv = po.heston_paths(S, T, r, q, 3.0, 0.02, 0.8, 0.3, 0.05, 257, 7, 3)
     assert odd_s.shape == (257, 8) and np.allclose(odd_s, cs.T, rtol=4 * REL) and np.allclose(odd_v, cv.T, rtol=4 * REL, atol=2e-7)
     assert orc.heston_simulate_paths(S, T, r, q, *g["model"], 5, M, seed)[0].shape == (5, M + 1)           # same layout as the restatement
+    neg_s, neg_v = _hip.heston_paths(S, T, r, q, 2.0, 0.04, 0.3, -0.7, -0.002, 300, 5, 3)                   # v0 < 0 at the C ABI
+    cs, cv = po.heston_paths(S, T, r, q, 2.0, 0.04, 0.3, -0.7, -0.002, 300, 5, 3)
+    assert np.allclose(neg_s, cs, rtol=4 * REL) and np.allclose(neg_v, cv, rtol=4 * REL, atol=2e-7) and np.all(neg_v[0] == -0.002)
 
 
 def test_jump_paths_against_checker_and_martingale(golden):

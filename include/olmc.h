@@ -255,7 +255,9 @@ int olmc_heston_paths(double S, double T, double r, double q, double kappa, doub
  * Replaces MertonJumpDiffusion.price_monte_carlo (src/pricing_models/jump_diffusion.py:160-225)
  * and KouJumpDiffusion.price_monte_carlo (:325-372): per step a diffusion normal, a
  * Poisson(lambda dt) jump count and the jump sum, compensated drift.  model = OLMC_JUMP_MERTON:
- * (a1, a2) = (mu_j, sigma_j);  OLMC_JUMP_KOU: (a1, a2, a3) = (p, eta1, eta2).  No antithetic. */
+ * (a1, a2) = (mu_j, sigma_j);  OLMC_JUMP_KOU: (a1, a2, a3) = (p, eta1, eta2).  No antithetic.
+ * Streams: Philox block (path, b, tag 2) feeds steps 2b and 2b+1 (words 0,1 -> the two diffusion normals,
+ * words 2,3 -> the two Poisson uniforms); the jump sizes of step t come from blocks (path, t, tag 3 + j/2). */
 enum { OLMC_JUMP_MERTON = 0, OLMC_JUMP_KOU = 1 };
 int olmc_jump_diffusion(double S, double K, double T, double r, double sigma, double q, int is_call,
                         int model, double lambda_j, double a1, double a2, double a3,

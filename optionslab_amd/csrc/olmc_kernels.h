@@ -1199,12 +1199,15 @@ __global__ __launch_bounds__(kBlock) void heston_paths_kernel(PathRange pr, Hest
 
 // Jump diffusion (src/pricing_models/jump_diffusion.py:160-225 Merton, :325-372 Kou): per step one
 // diffusion normal, a Poisson(lambda dt) number of jumps, and the jump sum added to ln S.
-// One Philox block PER STEP (stream tag 2): (x0, x1) -> Box-Muller pair {diffusion normal, jump normal},
-// x2 -> the Poisson uniform (inversion).  Merton: n jumps ~ N(n mu_j, n sigma_j^2), drawn exactly as
-// n mu_j + sigma_j sqrt(n) z (the sum of n iid normals).  Kou: each jump is +Exp(eta1) with probability p,
-// else -Exp(eta2); jump j takes its two uniforms from block (path, step, tag 3 + j/2), words 2(j%2), 2(j%2)+1
-// -- drawn only by the lanes that jump (lambda dt ~ 1e-3: rare, divergent, cheap).
-constexpr uint32_t kTagJump = 2u, kTagKou = 3u;
+// Every step needs a diffusion normal and a Poisson uniform; the jump sizes are needed only where a jump
+// occurs (lambda dt ~ 1e-3).  So ONE Philox block (stream tag 2) feeds TWO steps -- block b: (x0, x1) ->
+// Box-Muller pair = the diffusion normals of steps 2b, 2b+1; x2, x3 -> their Poisson uniforms (inversion) --
+// and the sizes come from a second stream drawn only by the lanes that jump (rare, divergent, cheap):
+// block (path, step, tag 3 + j/2).  Merton: n jumps ~ N(n mu_j, n sigma_j^2), drawn exactly as
+// n mu_j + sigma_j sqrt(n) z (the sum of n iid normals), z = the cosine normal of words (x0, x1) of block
+// (path, step, tag 3).  Kou: each jump is +Exp(eta1) with probability p, else -Exp(eta2); jump j takes its
+// two uniforms from words 2(j%2), 2(j%2)+1 of block (path, step, tag 3 + j/2).
+constexpr uint32_t kTagJump = 2u, kTagJumpSize = 3u;
 
 struct JumpContract {
     double log_s0, drift, vol;      // drift = (r - q - lambda kappa - sigma^2/2) dt, vol = sigma sqrt(dt)
@@ -1218,44 +1221,59 @@ struct JumpContract {
 
 __device__ __forceinline__ double unit_open64(uint32_t x) { return (static_cast<double>(x) + 0.5) * 2.3283064365386963e-10; }
 
-// One step of one path: the diffusion increment, the Poisson count by inversion, the jump sum.
-__device__ __forceinline__ void jump_step(const PathRange& pr, const JumpContract& c, double vol, uint32_t g_lo, uint32_t g_hi,
-                                          int32_t t, double& ls) {
-    const Words4 w = philox4x32_10(g_lo, g_hi, static_cast<uint32_t>(t), kTagJump, pr.key0, pr.key1);
-    float z_diff, z_jump;
-    box_muller_raw(w.x0, w.x1, z_diff, z_jump);
-    ls += __builtin_fma(vol, static_cast<double>(z_diff), c.drift);
-    const double u = unit_open64(w.x2);
-    if (u >= c.p0) {                                   // at least one jump
-        int32_t n = 1;
-        double pk = c.p0 * c.lam_dt, cdf = c.p0 + pk;
-        while (u >= cdf && n < 64) {
-            ++n;
-            pk *= c.lam_dt / n;
-            cdf += pk;
+// The jump part of step t of one path, given its Poisson uniform: the count by inversion, then the sizes.
+__device__ __forceinline__ void jump_sizes(const PathRange& pr, const JumpContract& c, uint32_t g_lo, uint32_t g_hi, int32_t t,
+                                           double u, double& ls) {
+    if (u < c.p0) return;                              // no jump (almost always)
+    int32_t n = 1;
+    double pk = c.p0 * c.lam_dt, cdf = c.p0 + pk;
+    while (u >= cdf && n < 64) {
+        ++n;
+        pk *= c.lam_dt / n;
+        cdf += pk;
+    }
+    if (!c.kou) {
+        const Words4 k = philox4x32_10(g_lo, g_hi, static_cast<uint32_t>(t), kTagJumpSize, pr.key0, pr.key1);
+        float z_jump, unused;
+        box_muller_raw(k.x0, k.x1, z_jump, unused);
+        ls += n * c.mu_j + c.sigma_j * sqrt(static_cast<double>(n)) * (kZScale * static_cast<double>(z_jump));
+    } else {
+        for (int32_t j = 0; j < n; ++j) {
+            const Words4 k = philox4x32_10(g_lo, g_hi, static_cast<uint32_t>(t), kTagJumpSize + static_cast<uint32_t>(j >> 1),
+                                           pr.key0, pr.key1);
+            const double ud = unit_open64((j & 1) ? k.x2 : k.x0), um = unit_open64((j & 1) ? k.x3 : k.x1);
+            ls += ud < c.kou_p ? -log(um) * c.inv_eta1 : log(um) * c.inv_eta2;
         }
-        if (!c.kou) {
-            ls += n * c.mu_j + c.sigma_j * sqrt(static_cast<double>(n)) * (kZScale * static_cast<double>(z_jump));
-        } else {
-            for (int32_t j = 0; j < n; ++j) {
-                const Words4 k = philox4x32_10(g_lo, g_hi, static_cast<uint32_t>(t), kTagKou + static_cast<uint32_t>(j >> 1),
-                                               pr.key0, pr.key1);
-                const double ud = unit_open64((j & 1) ? k.x2 : k.x0), um = unit_open64((j & 1) ? k.x3 : k.x1);
-                ls += ud < c.kou_p ? -log(um) * c.inv_eta1 : log(um) * c.inv_eta2;
-            }
-        }
+    }
+}
+
+// Steps 2b and 2b+1 of one path (the second only if it exists); `after(t, ls)` sees ln S after each step.
+template <typename After>
+__device__ __forceinline__ void jump_block(const PathRange& pr, const JumpContract& c, double vol, uint32_t g_lo, uint32_t g_hi,
+                                           int32_t b, double& ls, After after) {
+    const Words4 w = philox4x32_10(g_lo, g_hi, static_cast<uint32_t>(b), kTagJump, pr.key0, pr.key1);
+    float z0, z1;
+    box_muller_raw(w.x0, w.x1, z0, z1);
+    ls += __builtin_fma(vol, static_cast<double>(z0), c.drift);
+    jump_sizes(pr, c, g_lo, g_hi, 2 * b, unit_open64(w.x2), ls);
+    after(2 * b, ls);
+    if (2 * b + 1 < pr.n_steps) {
+        ls += __builtin_fma(vol, static_cast<double>(z1), c.drift);
+        jump_sizes(pr, c, g_lo, g_hi, 2 * b + 1, unit_open64(w.x3), ls);
+        after(2 * b + 1, ls);
     }
 }
 
 __global__ __launch_bounds__(kBlock) void jump_kernel(PathRange pr, JumpContract c, ReduceWs ws) {
     double acc[2] = {0.0, 0.0};
     const double vol = c.vol * kZScale;
+    const int32_t blocks = (pr.n_steps + 1) >> 1;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
         const uint64_t g = pr.first + static_cast<uint64_t>(i);
         const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
         double ls = c.log_s0;
-        for (int32_t t = 0; t < pr.n_steps; ++t) jump_step(pr, c, vol, g_lo, g_hi, t, ls);
+        for (int32_t b = 0; b < blocks; ++b) jump_block(pr, c, vol, g_lo, g_hi, b, ls, [](int32_t, double) {});
         const double x = fmax(c.sign * (exp(ls) - c.strike), 0.0);
         acc[0] += x; acc[1] += x * x;
     }
@@ -1263,20 +1281,20 @@ __global__ __launch_bounds__(kBlock) void jump_kernel(PathRange pr, JumpContract
 }
 
 // MertonJumpDiffusion.simulate_path (jump_diffusion.py:227-272), for any number of paths: the pricing
-// kernel's recursion with every price written out, time-major out[t * count + i], row 0 = S as given (:254).
+// kernel's recursion with every price written out (layouts: path_at), date 0 = S as given (:254).
 template <bool PATH_MAJOR>
 __global__ __launch_bounds__(kBlock) void jump_paths_kernel(PathRange pr, JumpContract c, double s_first, double* __restrict__ out) {
     const double vol = c.vol * kZScale;
+    const int32_t blocks = (pr.n_steps + 1) >> 1;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
         const uint64_t g = pr.first + static_cast<uint64_t>(i);
         const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
         double ls = c.log_s0;
         out[path_at<PATH_MAJOR>(i, 0, pr.count, pr.n_steps)] = s_first;
-        for (int32_t t = 0; t < pr.n_steps; ++t) {
-            jump_step(pr, c, vol, g_lo, g_hi, t, ls);
-            out[path_at<PATH_MAJOR>(i, t + 1, pr.count, pr.n_steps)] = exp(ls);
-        }
+        for (int32_t b = 0; b < blocks; ++b)
+            jump_block(pr, c, vol, g_lo, g_hi, b, ls,
+                       [&](int32_t t, double l) { out[path_at<PATH_MAJOR>(i, t + 1, pr.count, pr.n_steps)] = exp(l); });
     }
 }
 

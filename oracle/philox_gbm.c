@@ -441,7 +441,7 @@ int ol_american_lsm(double S, double K, double T, double r, double sigma, double
     return 0;
 }
 
-/* Jump diffusion (jump_diffusion.py:160-225, 325-372): one Philox block per step, tag 2; Kou jumps from tag 3 + j/2. */
+/* Jump diffusion (jump_diffusion.py:160-225, 325-372): one Philox block per TWO steps, tag 2; jump sizes from tag 3 + j/2. */
 static double unit_open64(uint32_t x) { return ((double)x + 0.5) * 0x1p-32; }
 
 typedef struct { int kou; double a1, a2, a3, drift, vol, lam_dt, p0; } jump_model;
@@ -459,20 +459,18 @@ static jump_model jump_setup(double T, double r, double sigma, double q, int kou
     return m;
 }
 
-/* step t of one path, in the device's order: diffusion increment, then the jump sum term by term */
-static void jump_step(const jump_model* m, uint64_t path, int32_t t, uint64_t seed, double* ls) {
-    uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), (uint32_t)t, 2u};
-    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, w[4];
-    float zd, zj;
-    ol_philox4x32_10(ctr, key, w);
-    box_muller_raw(w[0], w[1], &zd, &zj);
-    *ls += m->vol * (double)zd + m->drift;
-    const double u = unit_open64(w[2]);
+/* jump part of step t given its Poisson uniform: count by inversion, sizes from stream tag 3 + j/2 */
+static void jump_sizes(const jump_model* m, uint64_t path, int32_t t, uint64_t seed, double u, double* ls) {
     if (u < m->p0) return;
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     int nj = 1;
     double pk = m->p0 * m->lam_dt, cdf = m->p0 + pk;
     while (u >= cdf && nj < 64) { ++nj; pk *= m->lam_dt / nj; cdf += pk; }
     if (!m->kou) {
+        uint32_t c2[4] = {(uint32_t)path, (uint32_t)(path >> 32), (uint32_t)t, 3u}, k[4];
+        float zj, unused;
+        ol_philox4x32_10(c2, key, k);
+        box_muller_raw(k[0], k[1], &zj, &unused);
         *ls += nj * m->a1 + m->a2 * sqrt((double)nj) * (Z_SCALE * (double)zj);
         return;
     }
@@ -482,6 +480,18 @@ static void jump_step(const jump_model* m, uint64_t path, int32_t t, uint64_t se
         const double ud = unit_open64((j & 1) ? k[2] : k[0]), um = unit_open64((j & 1) ? k[3] : k[1]);
         *ls += ud < m->a1 ? -log(um) / m->a2 : log(um) / m->a3;
     }
+}
+
+/* step t of one path: block t/2 of stream tag 2 holds the diffusion normals of steps 2b, 2b+1 (cos, sin of
+ * words 0, 1) and their Poisson uniforms (words 2, 3) */
+static void jump_step(const jump_model* m, uint64_t path, int32_t t, uint64_t seed, double* ls) {
+    uint32_t ctr[4] = {(uint32_t)path, (uint32_t)(path >> 32), (uint32_t)(t >> 1), 2u};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, w[4];
+    float z0, z1;
+    ol_philox4x32_10(ctr, key, w);
+    box_muller_raw(w[0], w[1], &z0, &z1);
+    *ls += m->vol * (double)((t & 1) ? z1 : z0) + m->drift;
+    jump_sizes(m, path, t, seed, unit_open64(w[2 + (t & 1)]), ls);
 }
 
 void ol_jump_moments(double S, double K, double T, double r, double sigma, double q, int is_call, int kou, double lambda_j,

@@ -710,6 +710,21 @@ __global__ __launch_bounds__(kBlock) void autocall_kernel(PathRange pr, Autocall
         for (int32_t b = 0; b < blocks; ++b) {
             float z[4];
             raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1, z);
+            if (until_obs > 4 && 4 * b + 4 <= pr.n_steps) {
+                // no observation date among these four steps (16 of 21 blocks at monthly observation): only the
+                // cumulative return and its running minimum move -- branch-free, the four dates schedule together
+                until_obs -= 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double zj = static_cast<double>(z[j]);
+#pragma unroll
+                    for (int leg = 0; leg < LEGS; ++leg) {
+                        cum[leg] += __builtin_fma(leg ? -vol : vol, zj, c.drift);
+                        mn[leg] = fmin(mn[leg], cum[leg]);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (4 * b + j < pr.n_steps) {
@@ -754,36 +769,51 @@ struct CliquetContract {
     int32_t steps_per_period, n_periods;
 };
 
+// A period's return exp(ln S_end - ln S_start) - 1 depends on the path only through the SUM of the period's
+// normals: ln S_end - ln S_start = steps_per_period * drift +- vol * sum Z.  So blocks of four steps that hold
+// no period end run the terminal-price kernel's own accumulation (raw_block_accumulate: fp32 within 16
+// normals, fp64 across) and only the blocks with a reset date look at single steps.
 template <bool ANTI>
 __global__ __launch_bounds__(kBlock) void cliquet_kernel(PathRange pr, CliquetContract c, ReduceWs ws) {
     double acc[2] = {0.0, 0.0};
     const double vol = c.vol * kZScale;
     constexpr int LEGS = ANTI ? 2 : 1;
     const int32_t used_steps = c.steps_per_period * c.n_periods;      // trailing steps never enter a period
+    const double period_drift = c.steps_per_period * c.drift;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
         const uint64_t g = pr.first + static_cast<uint64_t>(i);
         const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
-        double cum[2] = {0.0, 0.0}, start[2] = {0.0, 0.0}, total[2] = {0.0, 0.0};
+        double total[2] = {0.0, 0.0};
+        double psum = 0.0;            // RAW normal sum of the period in flight (fp64 part)
+        float part = 0.0f;            // ... and the blocks not yet folded into it
+        int32_t part_blocks = 0;
         int32_t until_reset = c.steps_per_period;
         const int32_t blocks = (used_steps + 3) >> 2;
         for (int32_t b = 0; b < blocks; ++b) {
+            if (until_reset > 4) {                      // no period end among these four steps (and all four are used)
+                until_reset -= 4;
+                part = raw_block_accumulate(part, g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1);
+                if (++part_blocks == kGroup) { psum += static_cast<double>(part); part = 0.0f; part_blocks = 0; }
+                continue;
+            }
+            psum += static_cast<double>(part);
+            part = 0.0f;
+            part_blocks = 0;
             float z[4];
             raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1, z);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (4 * b + j < used_steps) {
-                    const double zj = static_cast<double>(z[j]);
-                    const bool reset = (--until_reset == 0);
-                    if (reset) until_reset = c.steps_per_period;
+                    psum += static_cast<double>(z[j]);
+                    if (--until_reset == 0) {
+                        until_reset = c.steps_per_period;
 #pragma unroll
-                    for (int leg = 0; leg < LEGS; ++leg) {
-                        cum[leg] += __builtin_fma(leg ? -vol : vol, zj, c.drift);
-                        if (reset) {
-                            const double local = exp(cum[leg] - start[leg]) - 1.0;      // (S_end - S_start) / S_start
+                        for (int leg = 0; leg < LEGS; ++leg) {
+                            const double local = exp(__builtin_fma(leg ? -vol : vol, psum, period_drift)) - 1.0;   // (S_end - S_start) / S_start
                             total[leg] += fmin(fmax(local, c.local_floor), c.local_cap);
-                            start[leg] = cum[leg];
                         }
+                        psum = 0.0;
                     }
                 }
             }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of whole libolmc builds: one subprocess per (library, round), each timing the
 European path kernel with HIP events (olmc_kernel_time).  Usage (GPU box):
-    python tools/ab_libs.py libA.so libB.so ... [--n 1000000] [--m 252] [--rounds 7] [--case european|asian|asian_anti|asian_geo|barrier|heston|merton|kou]"""
+    python tools/ab_libs.py libA.so libB.so ... [--n 1000000] [--m 252] [--rounds 7] [--case european|asian|asian_anti|asian_geo|barrier|heston|merton|kou|autocall[_anti]|cliquet[_anti]]"""
 import argparse
 import json
 import os
@@ -25,6 +25,10 @@ CASES = {
     "barrier": lambda s: _hip.barrier(*P, True, 120.0, 0, N, M, s, False),
     "merton": lambda s: _hip.jump_diffusion(*P, True, False, 0.5, -0.1, 0.2, 0.0, N, M, s),
     "kou": lambda s: _hip.jump_diffusion(*P, True, True, 1.0, 0.4, 10.0, 5.0, N, M, s),
+    "autocall": lambda s: _hip.autocallable(100.0, 1.0, 0.05, 0.2, 0.0, 1.0, 0.8, 0.08, 0.6, 21, N, M, s),
+    "autocall_anti": lambda s: _hip.autocallable(100.0, 1.0, 0.05, 0.2, 0.0, 1.0, 0.8, 0.08, 0.6, 21, N, M, s, True),
+    "cliquet": lambda s: _hip.cliquet(100.0, 1.0, 0.05, 0.2, 0.0, 0.05, -0.05, 0.3, 0.0, 12, N, M, s),
+    "cliquet_anti": lambda s: _hip.cliquet(100.0, 1.0, 0.05, 0.2, 0.0, 0.05, -0.05, 0.3, 0.0, 12, N, M, s, True),
     "heston": lambda s: _hip.heston(100.0, 100.0, 1.0, 0.05, 0.0, True, 2.0, 0.04, 0.3, -0.7, 0.04, N, M, s, False),
 }
 run = CASES[sys.argv[3]]

@@ -105,7 +105,7 @@ def main():
     kj = ol.KouJumpDiffusion(1.0, 0.4, 10.0, 5.0)
     report("Kou jump diffusion 1M x 252", N * M, lambda: kj.price_monte_carlo(*ATM, "call", 0.0, N, M, 42, return_error=True),
            lambda r: dict(price=float(r[0]), std_error=r[1]), reps=10)
-    report("simulate_gbm_paths 100k x 252 -> (100k, 253) fp64 on host (202 MB D2H + transpose included)", 100_000 * M,
+    report("simulate_gbm_paths 100k x 252 -> (100k, 253) fp64 on host (202 MB D2H into a fresh buffer)", 100_000 * M,
            lambda: ol.simulate_gbm_paths_hip(100.0, 1.0, 0.05, 0.2, 0.0, 100_000, M, 42), lambda a: dict(mean_terminal=float(a[:, -1].mean())), reps=5)
     report("HestonPricer.simulate_paths 100k x 252 -> 2 x (100k, 253) fp64 on host", 100_000 * M,
            lambda: hes.simulate_paths(100.0, 1.0, 0.05, 0.0, 100_000, M, 42), lambda a: dict(mean_terminal=float(a[0][:, -1].mean())), reps=5)

@@ -12,15 +12,21 @@ def short(name):
     return name.split("(")[0].replace("void ", "")[:70]
 
 
+def newest(pattern):
+    """gpurun merges every call's output into the same local directory: keep the latest run of a pass only."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
 def main(root):
     print(f"# rocprofv3 summary of {root}")
     for sub, title in (("stats", "bench.py --streams 1 (launches back to back, no overlap)"), ("stats_default", "bench.py default (8 streams; the serial pass is included, so durations mix overlapped and serial launches)")):
-      for f in glob.glob(os.path.join(root, sub, "*", "*_kernel_stats.csv")):
+      for f in newest(os.path.join(root, sub, "*", "*_kernel_stats.csv")):
         print(f"\n## kernel-trace --stats: {title}")
         for row in csv.DictReader(open(f)):
             print(f"{short(row['Name']):70s} calls {row['Calls']:>5s}  avg_ns {float(row['AverageNs']):>12.1f}  min {row['MinNs']:>8s}  max {row['MaxNs']:>8s}  {row['Percentage']}%")
     for p in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
-        files = glob.glob(os.path.join(root, p, "*", "*_counter_collection.csv"))
+        files = newest(os.path.join(root, p, "*", "*_counter_collection.csv"))
         if not files:
             continue
         agg = defaultdict(lambda: defaultdict(list))

@@ -180,6 +180,15 @@ int olmc_european_cv(double S, double K, double T, double r, double sigma, doubl
                      int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
                      olmc_cv_moments* out);
 
+/* The same for the global path range [path_offset, path_offset + n_local) (a rank's shard; out->value is
+ * the shard's own estimate), and the estimate from moments summed over shards: the all-reduce payload of
+ * the control variate is the five sums + n (count = 5). */
+int olmc_european_cv_shard(double S, double K, double T, double r, double sigma, double q, int is_call,
+                           int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
+                           int antithetic, olmc_cv_moments* out);
+int olmc_combine_cv(const olmc_cv_moments* parts, int32_t n_parts, double S, double T, double r, double q,
+                    olmc_cv_moments* out);
+
 /* ---- Asian (average over t = 1..M, t = 0 excluded) ------------------------
  * Replaces ExoticOptionBase._generate_paths + AsianOption.price
  * (src/pricing_models/exotic_options.py:40-67, 97-131): running sum of S_t

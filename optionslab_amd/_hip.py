@@ -64,6 +64,8 @@ PROTOTYPES = {
     "olmc_european_terminal": (_I, [_D] * 5 + [_I64, _I32, _U64T, _I, C.POINTER(_D)]),
     "olmc_gbm_paths": (_I, [_D] * 5 + [_I64, _I32, _U64T, _I, C.POINTER(_D)]),
     "olmc_european_cv": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(CvMoments)]),
+    "olmc_european_cv_shard": (_I, _SIX + [_I, _I64, _I64, _I32, _U64T, _I, C.POINTER(CvMoments)]),
+    "olmc_combine_cv": (_I, [C.POINTER(CvMoments), _I32, _D, _D, _D, _D, C.POINTER(CvMoments)]),
     "olmc_european_qmc": (_I, _SIX + [_I, _I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, C.POINTER(Stats)]),
     "olmc_european_qmc_terminal": (_I, [_D] * 5 + [_I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, _I, C.POINTER(_D)]),
     "olmc_asian": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
@@ -284,6 +286,22 @@ def european_cv(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int,
     out = CvMoments()
     _check(lib().olmc_european_cv(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(n_steps), seed64(seed),
                                   int(antithetic), C.byref(out)))
+    return out
+
+
+def european_cv_shard(S, K, T, r, sigma, q, is_call: bool, path_offset: int, n_local: int, n_steps: int, seed: int,
+                      antithetic: bool = True) -> CvMoments:
+    out = CvMoments()
+    _check(lib().olmc_european_cv_shard(S, K, T, r, sigma, q, int(is_call), int(path_offset), int(n_local), int(n_steps), seed64(seed),
+                                        int(antithetic), C.byref(out)))
+    return out
+
+
+def combine_cv(parts, S, T, r, q) -> CvMoments:
+    """Control-variate estimate from per-shard moments (pure host function; loads the library, not the GPU)."""
+    arr = (CvMoments * len(parts))(*parts)
+    out = CvMoments()
+    _check(load_library().olmc_combine_cv(arr, len(parts), S, T, r, q, C.byref(out)))
     return out
 
 

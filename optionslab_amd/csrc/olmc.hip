@@ -665,18 +665,32 @@ extern "C" int olmc_european_terminal(double S, double T, double r, double sigma
 }
 
 // =========================================================== control variate ====
-extern "C" int olmc_european_cv(double S, double K, double T, double r, double sigma, double q, int is_call,
-                                int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
-                                olmc_cv_moments* out) {
+namespace {
+// beta, forward and the estimate from the five (already discounted) moments: monte_carlo.py:175-184
+void cv_finish(double S, double T, double r, double q, olmc_cv_moments* m) {
+    const double n = static_cast<double>(m->n);
+    const double mean_d = m->sum_d / n, mean_s = m->sum_s / n;
+    // np.cov default ddof = 1 (monte_carlo.py:181); the n-1 cancels in beta but not in the 1e-10 guard
+    const double cov_ds = (m->sum_ds - n * mean_d * mean_s) / (n - 1.0);
+    const double var_s = (m->sum_ss - n * mean_s * mean_s) / (n - 1.0);
+    const double beta = (n > 1.0 && var_s > 1e-10) ? cov_ds / var_s : 0.0;        // :182
+    const double forward = S * std::exp((r - q) * T);                              // :179
+    m->value = mean_d - beta * (mean_s - forward);                                 // :184
+}
+}  // namespace
+
+extern "C" int olmc_european_cv_shard(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                      int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic,
+                                      olmc_cv_moments* out) {
     if (!out) return fail(OLMC_ERR_ARG, "null pointer");
-    int rc = check_paths(0, n_paths, n_steps);
+    int rc = check_paths(path_offset, n_local, n_steps);
     if (rc) return rc;
     DeviceCtx* c = nullptr;
     rc = ctx_get(&c);
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(c->mu);
-    const PathRange pr = make_range(0, n_paths, n_steps, seed);
-    const int32_t grid = grid_for(n_paths);
+    const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
+    const int32_t grid = grid_for(n_local);
     ContractSet<1> cs;
     cs.c[0] = make_contract(make_option(S, K, T, r, sigma, q, is_call), n_steps);
     ReduceWs ws;
@@ -689,22 +703,35 @@ extern "C" int olmc_european_cv(double S, double K, double T, double r, double s
     if (rc) return rc;
     // device moments are of the UNdiscounted payoff x; d = disc * x (monte_carlo.py:175)
     const double disc = std::exp(-r * T);
-    const double n = static_cast<double>(n_paths * (antithetic ? 2 : 1));
     const double sx = c->h_result[0], ss = c->h_result[1], sxx = c->h_result[2], sss = c->h_result[3], sxs = c->h_result[4];
     out->sum_d = disc * sx;
     out->sum_s = ss;
     out->sum_dd = disc * disc * sxx;
     out->sum_ss = sss;
     out->sum_ds = disc * sxs;
-    out->n = static_cast<int64_t>(n);
-    const double mean_d = out->sum_d / n, mean_s = ss / n;
-    // np.cov default ddof = 1 (monte_carlo.py:181); the n-1 cancels in beta but not in the 1e-10 guard
-    const double cov_ds = (out->sum_ds - n * mean_d * mean_s) / (n - 1.0);
-    const double var_s = (sss - n * mean_s * mean_s) / (n - 1.0);
-    const double beta = (n > 1.0 && var_s > 1e-10) ? cov_ds / var_s : 0.0;        // :182
-    const double forward = S * std::exp((r - q) * T);                              // :179
-    out->value = mean_d - beta * (mean_s - forward);                               // :184
+    out->n = n_local * (antithetic ? 2 : 1);
+    cv_finish(S, T, r, q, out);
     if (poisoned(S, K, T, r, sigma, q)) out->value = std::nan("");
+    return OLMC_OK;
+}
+
+extern "C" int olmc_european_cv(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
+                                olmc_cv_moments* out) {
+    return olmc_european_cv_shard(S, K, T, r, sigma, q, is_call, 0, n_paths, n_steps, seed, antithetic, out);
+}
+
+extern "C" int olmc_combine_cv(const olmc_cv_moments* parts, int32_t n_parts, double S, double T, double r, double q,
+                               olmc_cv_moments* out) {
+    if (!parts || !out || n_parts < 1) return fail(OLMC_ERR_ARG, "bad arguments");
+    olmc_cv_moments m{};
+    for (int i = 0; i < n_parts; ++i) {   // fixed rank order => bitwise stable
+        m.sum_d += parts[i].sum_d;  m.sum_s += parts[i].sum_s;  m.sum_dd += parts[i].sum_dd;
+        m.sum_ss += parts[i].sum_ss;  m.sum_ds += parts[i].sum_ds;  m.n += parts[i].n;
+    }
+    if (m.n < 1) return fail(OLMC_ERR_ARG, "no samples");
+    cv_finish(S, T, r, q, &m);
+    *out = m;
     return OLMC_OK;
 }
 

@@ -1,5 +1,12 @@
 """Sharding independent path batches over GPUs.
 
+    price_european_sharded      one contract: all-reduce of (sum, sumsq, n)                 count = 3
+    greeks_sharded              the 8 / 14 bumped contracts of compute_greeks_unified on the
+                                SAME normals, one launch per rank, one all-reduce            count = 2k + 1
+    control_variate_sharded     the five moments + n                                        count = 6
+    price_sharded               any entry point that takes (path_offset, n_local): Asian, barrier, lookback,
+                                autocallable, cliquet, Heston, jump diffusion               count = 3
+
 Global path index g in [0, N); rank k of P owns the contiguous block
 [k*N/P, (k+1)*N/P).  The Philox counter carries g, so every path's normals are
 the same whatever P is.  The only exchange is one all-reduce (sum) of the
@@ -61,3 +68,102 @@ def price_european_sharded(S, K, T, r, sigma, option_type, q, n_paths_global: in
     s, ss, n = buf.cpu().tolist()
     price, se = finalize(s, ss, int(n), r, T)
     return price, se, int(n)
+
+
+# --------------------------------------------------------------------------------------------------
+def _group_info(group=None):
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def _allreduce_list(values, group=None):
+    """Sum a list of floats over the group (fp64).  nccl backend -> a CUDA tensor (RCCL), otherwise CPU."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [float(v) for v in values]
+    device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor(values, dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().tolist()
+
+
+def price_sharded(shard_fn, n_paths_global: int, r_discount: float, T: float, group=None):
+    """Generic sharded pricing.  `shard_fn(path_offset, n_local)` prices this rank's block and returns an
+    object with (.sum, .sumsq, .n) -- e.g. ``lambda lo, n: _hip.asian(S, K, T, r, v, q, True, False, n, M, seed,
+    False, path_offset=lo)``.  Returns (price, std_error, n) identical on every rank; pass r_discount = 0 for
+    payoffs that carry their own discounting (autocallable, American)."""
+    rank, world = _group_info(group)
+    lo, hi = shard_bounds(n_paths_global, rank, world)
+    st = shard_fn(lo, hi - lo)
+    s, ss, n = _allreduce_list([st.sum, st.sumsq, float(st.n)], group)
+    price, se = finalize(s, ss, int(n), r_discount, T)
+    return price, se, int(n)
+
+
+class _Recorder:
+    """Stands in for a pricer while compute_greeks_unified lists the contracts it wants."""
+
+    def __init__(self):
+        self.contracts = []
+
+    def price(self, S, K, T, r, sigma, option_type, q=0.0, **kw):
+        self.contracts.append((S, K, T, r, sigma, q))
+        return 1.0 + 0.001 * len(self.contracts)      # any finite number: the formulas are evaluated again on replay
+
+
+class _Replayer:
+    def __init__(self, table):
+        self.table = table
+
+    def price(self, S, K, T, r, sigma, option_type, q=0.0, **kw):
+        return self.table[(S, K, T, r, sigma, q)]
+
+
+def _device_batch(contracts, is_call, lo, n_local, n_steps, seed, antithetic):
+    options = [(S, K, T, r, v, q, is_call) for (S, K, T, r, v, q) in contracts]
+    return [(st.sum, st.sumsq, st.n) for st in _hip.european_batch(options, n_local, n_steps, seed, antithetic, path_offset=lo)]
+
+
+def greeks_sharded(S, K, T, r, sigma, option_type, q, n_paths_global: int, n_steps: int, seed: int,
+                   include_second_order: bool = True, antithetic: bool = True, group=None, batch_fn=None):
+    """compute_greeks_unified (src/greeks/unified_greeks.py:235-367) over sharded paths: every rank prices the
+    8 / 14 bumped contracts on ITS block of the common normals in one launch, ONE all-reduce carries the 2k sums
+    and n, and every rank evaluates the same finite differences.  `batch_fn(contracts, is_call, lo, n_local,
+    n_steps, seed, antithetic) -> [(sum, sumsq, n)]` defaults to the device batch kernel (tests inject the CPU
+    checker).  Returns the reference's OrderedDict."""
+    from .greeks import compute_greeks_unified
+
+    rec = _Recorder()
+    compute_greeks_unified(rec, S, K, T, r, sigma, option_type, q, include_second_order, fused=False)
+    contracts = list(dict.fromkeys(rec.contracts))              # the reference memoises on the same key
+    rank, world = _group_info(group)
+    lo, hi = shard_bounds(n_paths_global, rank, world)
+    local = (batch_fn or _device_batch)(contracts, option_type == "call", lo, hi - lo, n_steps, seed, antithetic)
+    flat = [v for (sx, sxx, _n) in local for v in (sx, sxx)] + [float(local[0][2])]
+    red = _allreduce_list(flat, group)
+    n = int(red[-1])
+    table = {c: finalize(red[2 * i], red[2 * i + 1], n, c[3], c[2])[0] for i, c in enumerate(contracts)}
+    return compute_greeks_unified(_Replayer(table), S, K, T, r, sigma, option_type, q, include_second_order, fused=False)
+
+
+def control_variate_sharded(S, K, T, r, sigma, option_type, q, n_paths_global: int, n_steps: int, seed: int,
+                            antithetic: bool = True, group=None, shard_fn=None):
+    """MonteCarloPricer.price_with_control_variate (monte_carlo.py:154-186) over sharded paths: the five moments
+    and n are summed over ranks, beta and the estimate follow on every rank.  `shard_fn(lo, n_local)` -> an object
+    with the olmc_cv_moments fields (default: the device kernel)."""
+    rank, world = _group_info(group)
+    lo, hi = shard_bounds(n_paths_global, rank, world)
+    fn = shard_fn or (lambda lo_, n_: _hip.european_cv_shard(S, K, T, r, sigma, q, option_type == "call", lo_, n_, n_steps, seed, antithetic))
+    m = fn(lo, hi - lo)
+    sd, ss, sdd, sss, sds, n = _allreduce_list([m.sum_d, m.sum_s, m.sum_dd, m.sum_ss, m.sum_ds, float(m.n)], group)
+    n = float(int(n))
+    mean_d, mean_s = sd / n, ss / n
+    cov_ds = (sds - n * mean_d * mean_s) / (n - 1.0)            # np.cov, ddof = 1 (:181)
+    var_s = (sss - n * mean_s * mean_s) / (n - 1.0)
+    beta = cov_ds / var_s if (n > 1.0 and var_s > 1e-10) else 0.0          # :182
+    return mean_d - beta * (mean_s - S * math.exp((r - q) * T))              # :184

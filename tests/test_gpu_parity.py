@@ -469,8 +469,31 @@ def test_sharded_price_through_process_group_single_rank():
             buf = torch.empty(3, dtype=torch.float64, device="cuda")
             p2, _, _ = ol.sharding.price_european_sharded(*ATM, "call", 0.0, 300_000, 21, 11, device_buffer=buf)
         assert p2 == price
+        # Greeks, control variate and a path-dependent payoff through the same process group (SURVEY §8e payloads)
+        pricer = ol.MonteCarloPricer(300_000, 21, 11)
+        fused = pricer.greeks(*ATM, "call")
+        sharded = ol.sharding.greeks_sharded(*ATM, "call", 0.0, 300_000, 21, 11)
+        assert list(sharded) == list(fused)
+        for k in fused:
+            assert sharded[k] == pytest.approx(fused[k], rel=1e-9, abs=1e-9), k
+        assert ol.sharding.control_variate_sharded(*ATM, "call", 0.0, 300_000, 21, 11) == pytest.approx(
+            pricer.price_with_control_variate(*ATM, "call"), rel=1e-12)
+        ap, ase, an = ol.sharding.price_sharded(lambda lo, n: _hip.asian(*ATM, 0.0, True, False, n, 21, 11, False, path_offset=lo),
+                                                300_000, ATM[3], ATM[2])
+        want = _hip.asian(*ATM, 0.0, True, False, 300_000, 21, 11, False)
+        assert (ap, an) == (want.price, want.n) and ase == pytest.approx(want.std_error, rel=1e-12)
     finally:
         dist.destroy_process_group()
+
+
+def test_control_variate_shards_combine_to_the_whole():
+    whole = _hip.european_cv(*ATM, 0.01, True, 100_001, 13, 5, True)
+    parts = [_hip.european_cv_shard(*ATM, 0.01, True, lo, hi - lo, 13, 5, True)
+             for lo, hi in (ol.sharding.shard_bounds(100_001, k, 3) for k in range(3))]
+    both = _hip.combine_cv(parts, ATM[0], ATM[2], ATM[3], 0.01)
+    assert both.n == whole.n == 200_002
+    for f in ("sum_d", "sum_s", "sum_dd", "sum_ss", "sum_ds", "value"):
+        assert getattr(both, f) == pytest.approx(getattr(whole, f), rel=1e-12), f
 
 
 # ------------------------------------------------------------------ large sizes (size-independent properties)

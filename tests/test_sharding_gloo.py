@@ -20,6 +20,30 @@ def _free_port():
         return s.getsockname()[1]
 
 
+class _Triple:
+    def __init__(self, s, ss, n):
+        self.sum, self.sumsq, self.n = s, ss, n
+
+
+def _checker_batch(contracts, is_call, lo, n_local, n_steps, seed, antithetic):
+    from oracle import philox_oracle as po
+    out = []
+    for (S, K, T, r, v, q) in contracts:
+        sx, sxx, *_rest, n = po.european_moments(S, K, T, r, v, q, is_call, n_local, n_steps, seed, antithetic, lo)
+        out.append((sx, sxx, n))
+    return out
+
+
+def _checker_cv(lo, n_local):
+    import types
+
+    from oracle import philox_oracle as po
+    sx, sxx, ss, sss, sxs, n = po.european_moments(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], ARGS["q"], True, n_local,
+                                                   M, SEED, True, lo)
+    disc = math.exp(-ARGS["r"] * ARGS["T"])
+    return types.SimpleNamespace(sum_d=disc * sx, sum_s=ss, sum_dd=disc * disc * sxx, sum_ss=sss, sum_ds=disc * sxs, n=n)
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     import torch
@@ -35,8 +59,18 @@ def _worker(rank, world, port, out_dir):
     t = torch.tensor([sx, sxx, float(n)], dtype=torch.float64)
     sharding.allreduce_triple(t)
     price, se = sharding.finalize(t[0].item(), t[1].item(), int(t[2].item()), ARGS["r"], ARGS["T"])
+    # Greeks: k contracts on the common normals, one all-reduce of 2k + 1 doubles (checker stands in for the batch kernel)
+    greeks = sharding.greeks_sharded(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], "call", ARGS["q"], N, M, SEED,
+                                     include_second_order=True, batch_fn=_checker_batch)
+    # control variate: five moments + n
+    cv = sharding.control_variate_sharded(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], "call", ARGS["q"], N, M, SEED,
+                                          shard_fn=_checker_cv)
+    # any (path_offset, n_local) entry point: the Asian checker
+    asian = sharding.price_sharded(lambda lo_, n_: _Triple(*po.asian_moments(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"],
+                                                                             ARGS["q"], True, False, n_, M, SEED, False, lo_)),
+                                   N, ARGS["r"], ARGS["T"])
     with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
-        f.write(repr((lo, hi, price, se, int(t[2].item()))))
+        f.write(repr((lo, hi, price, se, int(t[2].item()), dict(greeks), cv, asian)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -70,6 +104,24 @@ def test_two_rank_gloo_allreduce_reproduces_unsharded_price(tmp_path):
     assert got[0][4] == n == 2 * N
     assert got[0][2] == pytest.approx(price, rel=1e-13)
     assert got[0][3] == pytest.approx(se, rel=1e-10)
+    # the same three quantities unsharded (no process group: world = 1) through the same helpers
+    from optionslab_amd import sharding
+    whole_greeks = sharding.greeks_sharded(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], "call", ARGS["q"], N, M, SEED,
+                                           include_second_order=True, batch_fn=_checker_batch)
+    assert list(got[0][5]) == list(whole_greeks) == ["price", "delta", "gamma", "vega", "theta", "rho", "vanna", "charm", "vomma"]
+    for k, v in whole_greeks.items():
+        # second differences divide rounding differences of the reduction order by h^2 (h_S = 1, h_sigma = 0.01)
+        tol = dict(gamma=1e-9, vomma=1e-5, vanna=1e-7, charm=1e-7).get(k, 1e-10)
+        assert got[0][5][k] == pytest.approx(v, rel=tol, abs=tol), k
+    assert whole_greeks["price"] == pytest.approx(price, rel=1e-13)
+    bs_delta = 0.6368306511756191
+    assert abs(whole_greeks["delta"] - bs_delta) < 0.05            # 4001 paths: plumbing check, not accuracy
+    whole_cv = sharding.control_variate_sharded(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], "call", ARGS["q"], N, M, SEED,
+                                                shard_fn=_checker_cv)
+    assert got[0][6] == pytest.approx(whole_cv, rel=1e-12) and abs(whole_cv - 10.450583572185565) < 0.5
+    am = po.asian_moments(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], ARGS["q"], True, False, N, M, SEED, False, 0)
+    ap, ase = po.price_and_error(am[0], am[1], am[2], ARGS["r"], ARGS["T"])
+    assert got[0][7][0] == pytest.approx(ap, rel=1e-13) and got[0][7][1] == pytest.approx(ase, rel=1e-10) and got[0][7][2] == N
 
 
 def test_finalize_matches_reference_formula():

@@ -971,7 +971,7 @@ extern "C" int olmc_exercise_boundary(double S, double K, double T, double r, do
     hipLaunchKernelGGL((lsm_paths_kernel<false>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, lc, d_paths);
     HIP_TRY(hipGetLastError());
     // np.percentile(x, 10) for a put, 90 for a call (:337-341); NumPy divides q by 100 first
-    hipLaunchKernelGGL(exercise_boundary_kernel, dim3(static_cast<uint32_t>(rows)), dim3(kBlock), 0, c->stream, d_paths, n_paths, K,
+    hipLaunchKernelGGL(exercise_boundary_kernel, dim3(static_cast<uint32_t>(rows)), dim3(kBoundaryThreads), 0, c->stream, d_paths, n_paths, K,
                        is_call ? 1.0 : -1.0, (is_call ? 90.0 : 10.0) / 100.0, d_boundary);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(boundary_host, d_boundary, rows * sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -890,55 +890,71 @@ __global__ __launch_bounds__(kBlock) void lsm_paths_kernel(PathRange pr, LsmCont
 
 // AmericanOption.early_exercise_boundary (exotic_options.py:309-345): for every date t the 10th (put) /
 // 90th (call) percentile of the in-the-money prices, np.percentile's default linear interpolation.
-// One workgroup per date over the time-major path matrix.  The order statistics come from an 8-pass
-// byte-wise radix select on the fp64 bit patterns (positive doubles order like their bits): no sort, no
+// One 1024-thread workgroup per date over the time-major path matrix.  The two order statistics the
+// interpolation needs come from ONE 8-pass byte-wise radix select on the fp64 bit patterns (positive doubles order like their bits): no sort, no
 // key buffer, the in-the-money filter applied on the fly.  Exact: the selected elements ARE the sorted
 // array's entries, and the interpolation follows NumPy's _lerp term by term.
 __device__ __forceinline__ bool boundary_itm(double s, double strike, double sign) { return sign * (s - strike) > 0.0; }
 
-// k-th smallest (0-based) bit pattern among the in-the-money entries of `row`; all 256 threads call it.
-__device__ __forceinline__ uint64_t boundary_select(const double* __restrict__ row, int64_t n, double strike, double sign,
-                                                    int64_t k, uint32_t* hist, uint64_t* shared) {
-    uint64_t prefix = 0, mask = 0;
+// The k_lo-th and k_hi-th smallest (0-based) bit patterns among the in-the-money entries of `row`, found
+// together: one traversal of the row per byte feeds two 256-bin histograms (one per order statistic; they
+// coincide until the two prefixes part, which for neighbours is usually the last byte or never).
+constexpr int kBoundaryThreads = 1024;
+
+__device__ __forceinline__ void boundary_select2(const double* __restrict__ row, int64_t n, double strike, double sign,
+                                                 int64_t k_lo, int64_t k_hi, uint32_t (*hist)[256], uint64_t* shared,
+                                                 uint64_t& out_lo, uint64_t& out_hi) {
+    uint64_t prefix[2] = {0, 0}, mask = 0;
+    int64_t k[2] = {k_lo, k_hi};
     for (int byte = 7; byte >= 0; --byte) {
-        hist[threadIdx.x] = 0u;
+        for (int b = threadIdx.x; b < 512; b += kBoundaryThreads) hist[b >> 8][b & 255] = 0u;
         __syncthreads();
-        for (int64_t i = threadIdx.x; i < n; i += kBlock) {
+        const bool same = prefix[0] == prefix[1];
+        for (int64_t i = threadIdx.x; i < n; i += kBoundaryThreads) {
             const double s = row[i];
+            if (!boundary_itm(s, strike, sign)) continue;
             const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(s));
-            if (boundary_itm(s, strike, sign) && (bits & mask) == prefix) atomicAdd(&hist[(bits >> (8 * byte)) & 0xFFu], 1u);
+            const uint32_t digit = static_cast<uint32_t>(bits >> (8 * byte)) & 0xFFu;
+            if ((bits & mask) == prefix[0]) atomicAdd(&hist[0][digit], 1u);
+            if (!same && (bits & mask) == prefix[1]) atomicAdd(&hist[1][digit], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int64_t left = k;
+        if (threadIdx.x < 2) {
+            const uint32_t* h = hist[same ? 0 : threadIdx.x];
+            int64_t left = k[threadIdx.x];
             uint32_t bucket = 0;
             for (; bucket < 255u; ++bucket) {
-                if (left < static_cast<int64_t>(hist[bucket])) break;
-                left -= hist[bucket];
+                if (left < static_cast<int64_t>(h[bucket])) break;
+                left -= h[bucket];
             }
-            shared[0] = bucket;
-            shared[1] = static_cast<uint64_t>(left);
+            shared[2 * threadIdx.x] = bucket;
+            shared[2 * threadIdx.x + 1] = static_cast<uint64_t>(left);
         }
         __syncthreads();
-        prefix |= shared[0] << (8 * byte);
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            prefix[w] |= shared[2 * w] << (8 * byte);
+            k[w] = static_cast<int64_t>(shared[2 * w + 1]);
+        }
         mask |= 0xFFull << (8 * byte);
-        k = static_cast<int64_t>(shared[1]);
         __syncthreads();
     }
-    return prefix;
+    out_lo = prefix[0];
+    out_hi = prefix[1];
 }
 
-__global__ __launch_bounds__(kBlock) void exercise_boundary_kernel(const double* __restrict__ paths, int64_t n_paths, double strike,
-                                                                   double sign, double quantile, double* __restrict__ boundary) {
-    __shared__ uint32_t hist[kBlock];
-    __shared__ uint64_t shared[2];
+__global__ __launch_bounds__(kBoundaryThreads) void exercise_boundary_kernel(const double* __restrict__ paths, int64_t n_paths,
+                                                                             double strike, double sign, double quantile,
+                                                                             double* __restrict__ boundary) {
+    __shared__ uint32_t hist[2][256];
+    __shared__ uint64_t shared[4];
     __shared__ unsigned long long count;
     const double* row = paths + static_cast<size_t>(blockIdx.x) * static_cast<size_t>(n_paths);
     if (threadIdx.x == 0) count = 0ull;
     __syncthreads();
     unsigned long long mine = 0;
-    for (int64_t i = threadIdx.x; i < n_paths; i += kBlock) mine += boundary_itm(row[i], strike, sign) ? 1ull : 0ull;
-    atomicAdd(&count, mine);
+    for (int64_t i = threadIdx.x; i < n_paths; i += kBoundaryThreads) mine += boundary_itm(row[i], strike, sign) ? 1ull : 0ull;
+    if (mine) atomicAdd(&count, mine);
     __syncthreads();
     const int64_t cnt = static_cast<int64_t>(count);
     if (cnt == 0) {                                            // nobody in the money: NaN (:343)
@@ -949,9 +965,10 @@ __global__ __launch_bounds__(kBlock) void exercise_boundary_kernel(const double*
     const int64_t lo = static_cast<int64_t>(floor(pos));
     const int64_t hi = lo + 1 < cnt ? lo + 1 : cnt - 1;
     const double t = pos - static_cast<double>(lo);
-    const double a = __longlong_as_double(static_cast<long long>(boundary_select(row, n_paths, strike, sign, lo, hist, shared)));
-    const double b = __longlong_as_double(static_cast<long long>(boundary_select(row, n_paths, strike, sign, hi, hist, shared)));
+    uint64_t bits_a, bits_b;
+    boundary_select2(row, n_paths, strike, sign, lo, hi, hist, shared, bits_a, bits_b);
     if (threadIdx.x == 0) {
+        const double a = __longlong_as_double(static_cast<long long>(bits_a)), b = __longlong_as_double(static_cast<long long>(bits_b));
         const double diff = b - a;                             // numpy.lib._function_base_impl._lerp
         double v = a + diff * t;
         if (t >= 0.5) v = b - diff * (1.0 - t);

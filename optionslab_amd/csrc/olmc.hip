@@ -69,6 +69,7 @@ struct DeviceCtx {
     double* h_result = nullptr;      // pinned + mapped [kMaxNV + 1]: the last workgroup writes the sums straight to the host
     double* d_result = nullptr;      // device alias of h_result (zero-copy: no D2H copy node, only a stream sync)
     void* d_bulk = nullptr;          // terminal prices / validation taps
+    double* d_triple = nullptr;      // {sum, sumsq, n} of this device's shard in olmc_multi_gpu_european (never reallocated)
     size_t bulk_bytes = 0;
     // independent-contract batches (european_multi_kernel)
     void* d_multi = nullptr;         // [opts | out | rows | counters]
@@ -93,6 +94,7 @@ int ctx_allocate(DeviceCtx* c) {
         HIP_TRY(hipMemset(sl.counters, 0, sizeof(uint32_t) * (kMaxGroups + 1) * kCounterStride));
         HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
+    HIP_TRY(hipMalloc(&c->d_triple, 256));
     HIP_TRY(hipHostMalloc(&c->h_result, sizeof(double) * (kMaxNV + 1), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_result), c->h_result, 0));
     return OLMC_OK;
@@ -104,6 +106,7 @@ void ctx_release(DeviceCtx* c) {
     for (auto& ep : c->ev_pending) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
     for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
     if (c->d_bulk) (void)hipFree(c->d_bulk);
+    if (c->d_triple) (void)hipFree(c->d_triple);
     if (c->d_multi) (void)hipFree(c->d_multi);
     for (auto& sl : c->slots) {
         if (sl.block_rows) (void)hipFree(sl.block_rows);
@@ -1348,9 +1351,7 @@ extern "C" int olmc_multi_gpu_european(double S, double K, double T, double r, d
     for (int d = 0; d < n_gpus; ++d) {
         DeviceCtx* c = g_ctx[d];
         HIP_TRY(hipSetDevice(d));
-        rc = bulk_reserve(c, 3 * sizeof(double));
-        if (rc) return rc;
-        triples[d] = static_cast<double*>(c->d_bulk);
+        triples[d] = c->d_triple;
         const int64_t lo = n_paths * d / n_gpus, hi = n_paths * (d + 1) / n_gpus;
         t_device = d;
         rc = olmc_european_shard_dev(S, K, T, r, sigma, q, is_call, lo, hi - lo, n_steps, seed, antithetic, triples[d], c->stream);

@@ -23,7 +23,6 @@ compute is libolmc.so through its C ABI.  With N > 1 launch as
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time

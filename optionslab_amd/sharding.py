@@ -19,7 +19,7 @@ process group); single-GPU pricing never touches it.
 from __future__ import annotations
 
 import math
-from typing import Optional, Tuple
+from typing import Tuple
 
 from . import _hip
 

@@ -1,7 +1,6 @@
 """Host-side mirror of the reference API (no GPU needed): constructor contract,
 expired-option early-out, the generic FD Greeks driver, adapters, Black-Scholes,
 and the rule that the product never reaches into oracle/."""
-import math
 import os
 import re
 

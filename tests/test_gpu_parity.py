@@ -562,3 +562,27 @@ def test_full_paths_against_checker_and_reference_shape(golden):
     assert np.allclose(fp[:, -1], term, rtol=1e-6)
     odd = ol.simulate_gbm_paths_hip(S, T, r, v, q, 257, 7, 3)                  # ragged sizes, step remainder
     assert odd.shape == (257, 8) and np.allclose(odd, po.gbm_paths(S, T, r, v, q, 257, 7, 3).T, rtol=2e-6)
+
+
+def test_repeated_calls_do_not_leak_device_memory():
+    """Scratch is grown lazily and reused: hundreds of pricings of every kind leave the device's free memory where it was."""
+    import torch
+
+    def spin(n):
+        for i in range(n):
+            _hip.european(*ATM, 0.0, True, 50_000 + (i % 7) * 1000, 16, i)
+            if i % 10 == 0:
+                _hip.asian(*ATM, 0.0, True, False, 20_000, 16, i)
+                _hip.heston(100.0, 100.0, 1.0, 0.05, 0.0, True, 2.0, 0.04, 0.3, -0.7, 0.04, 20_000, 16, i)
+                _hip.american_lsm(*ATM, 0.0, False, 5_000, 10, 3, i)
+                _hip.european_terminal(100.0, 1.0, 0.05, 0.2, 0.0, 30_000, 8, i)
+                _hip.gbm_paths(100.0, 1.0, 0.05, 0.2, 0.0, 2_000, 8, i, path_major=True)
+                ol.MonteCarloPricer(30_000, 8, i).greeks(*ATM, "call")
+
+    spin(50)                                   # every scratch buffer reaches its working size
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    spin(600)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, (free0, free1)

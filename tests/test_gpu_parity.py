@@ -335,7 +335,10 @@ def test_control_variate(golden):
 
 # ------------------------------------------------------------------ Asian
 @pytest.mark.parametrize("geometric,typ,anti,N,M", [(False, "call", False, 20000, 64), (True, "put", False, 20000, 64),
-                                                    (False, "put", True, 5001, 13), (True, "call", True, 777, 252)])
+                                                    (False, "put", True, 5001, 13), (True, "call", True, 777, 252),
+                                                    # BASELINE C4's 1024 dates (64 fp64 groups of 16), and every shape of the trailing group
+                                                    (False, "call", False, 3000, 1024), (False, "call", True, 2000, 1023), (True, "call", False, 3000, 1021)]
+                         + [(g, "call", a, 300, m) for m in (1, 3, 4, 15, 16, 17, 19, 20, 29, 31, 32, 33) for g, a in ((False, True), (True, False))])
 def test_asian_matches_same_stream_checker(geometric, typ, anti, N, M):
     st = _hip.asian(100.0, 100.0, 1.0, 0.05, 0.2, 0.02, typ == "call", geometric, N, M, 7, anti)
     sx, sxx, n = po.asian_moments(100.0, 100.0, 1.0, 0.05, 0.2, 0.02, typ == "call", geometric, N, M, 7, anti)

@@ -148,7 +148,9 @@ AC = dict(autocall_barrier=1.0, coupon_barrier=0.8, coupon_rate=0.10, ki_barrier
 
 
 @pytest.mark.parametrize("anti,N,M,freq,kw", [(False, 20000, 252, 21, {}), (True, 5001, 100, 30, dict(autocall_barrier=1.05, ki_barrier=0.9)),
-                                              (False, 3000, 50, 7, dict(coupon_barrier=0.95, coupon_rate=0.2)), (False, 2000, 13, 13, {})])
+                                              (False, 3000, 50, 7, dict(coupon_barrier=0.95, coupon_rate=0.2)), (False, 2000, 13, 13, {})]
+                         # observation dates against the four-step Philox blocks: every alignment of the fast / slow path
+                         + [(a, 600, M, f, {}) for a in (False, True) for M, f in ((1, 1), (8, 1), (9, 4), (21, 5), (23, 8), (40, 9), (64, 64), (100, 33))])
 def test_autocallable_matches_same_stream_checker(anti, N, M, freq, kw):
     k = {**AC, **kw}
     st = _hip.autocallable(100.0, 1.0, 0.05, 0.2, 0.01, k["autocall_barrier"], k["coupon_barrier"], k["coupon_rate"], k["ki_barrier"], freq, N, M, 5, anti)
@@ -159,7 +161,9 @@ def test_autocallable_matches_same_stream_checker(anti, N, M, freq, kw):
 
 
 @pytest.mark.parametrize("anti,N,M,periods,kw", [(False, 20000, 252, 12, {}), (True, 5001, 100, 7, dict(local_cap=0.03, local_floor=-0.02, global_cap=0.2, global_floor=0.02)),
-                                                 (False, 3000, 50, 50, {}), (False, 2000, 10, 3, {})])
+                                                 (False, 3000, 50, 50, {}), (False, 2000, 10, 3, {})]
+                         # reset dates against the four-step Philox blocks and the 16-normal fp32 groups; trailing unused steps
+                         + [(a, 600, M, p_, {}) for a in (False, True) for M, p_ in ((1, 1), (8, 2), (9, 2), (21, 4), (23, 1), (40, 3), (67, 1), (130, 2))])
 def test_cliquet_matches_same_stream_checker(anti, N, M, periods, kw):
     k = {**dict(local_cap=0.05, local_floor=-0.05, global_cap=0.30, global_floor=0.0), **kw}
     st = _hip.cliquet(100.0, 1.0, 0.05, 0.2, 0.01, k["local_cap"], k["local_floor"], k["global_cap"], k["global_floor"], periods, N, M, 5, anti)
@@ -225,6 +229,7 @@ def test_american_against_reference_golden_and_bounds(golden):
     (False, 0.5, -0.1, 0.2, 0.0, True, 20000, 50), (False, 40.0, 0.02, 0.1, 0.0, False, 5001, 13),      # lambda dt = 3: multi-jump steps
     (True, 1.0, 0.4, 10.0, 5.0, True, 20000, 50), (True, 60.0, 0.6, 25.0, 20.0, False, 3000, 7),         # up to ~20 jumps per step
     (False, 0.0, -0.1, 0.2, 0.0, True, 4000, 10),
+    (False, 5.0, -0.1, 0.2, 0.0, True, 3000, 1), (True, 5.0, 0.4, 10.0, 5.0, False, 3000, 1), (False, 20.0, 0.05, 0.1, 0.0, True, 3000, 2),   # one block = two steps
 ])
 def test_jump_diffusion_matches_same_stream_checker(kou, lam, a1, a2, a3, call, N, M):
     st = _hip.jump_diffusion(100.0, 100.0, 1.0, 0.05, 0.2, 0.01, call, kou, lam, a1, a2, a3, N, M, 17)

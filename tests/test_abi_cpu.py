@@ -93,3 +93,40 @@ def test_compute_fails_loudly_without_a_gpu():
     with pytest.raises(AccelerationError):
         ol.simulate_gbm_hip(100, 1.0, 0.05, 0.2, 0.0, 100, 4, 1)
     assert ol.hip_available() is False and ol.HIP_AVAILABLE is False
+
+
+def _build_c_example(tmp_path):
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    _hip.load_library()                                   # builds libolmc.so if it is stale
+    exe = str(tmp_path / "price_from_c")
+    pkg = os.path.join(root, "optionslab_amd")
+    subprocess.run([cc, "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "price_from_c.c"), "-o", exe, "-L" + pkg, "-lolmc", "-Wl,-rpath," + pkg], check=True)
+    return exe
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="GPU present: the example runs in the gpu suite")
+def test_header_is_plain_c_and_a_c_host_fails_loudly_without_a_gpu(tmp_path):
+    """include/olmc.h compiles as C99 with -Werror and links against libolmc.so; with no device the host gets a
+    status code and a message, not a crash and not a CPU answer."""
+    import subprocess
+
+    out = subprocess.run([_build_c_example(tmp_path), "1000", "10"], capture_output=True, text=True)
+    assert out.returncode == 1 and "olmc_init(0) failed" in out.stderr and "european" not in out.stdout
+
+
+@pytest.mark.gpu
+def test_c_host_example_prices_on_the_gpu(tmp_path):
+    import re
+    import subprocess
+
+    out = subprocess.run([_build_c_example(tmp_path), "200000", "50"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    price = float(re.search(r"european call\s+price ([0-9.]+)", out.stdout).group(1))
+    assert abs(price - 10.450583572185565) < 0.2 and "two shards" in out.stdout and "asian call" in out.stdout

@@ -22,3 +22,41 @@ for (S, K, T, r, v, q, call, M, seed) in [(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, Tr
     rows.append(dict(S=S, K=K, T=T, r=r, sigma=v, q=q, call=call, n_paths=n, n_steps=M, price=st.price, bs=bs,
                      std_error=st.std_error, z=(st.price - bs) / st.std_error, rel_err=(st.price - bs) / bs))
     print(json.dumps(rows[-1]), flush=True)
+
+# Path-dependent kernels against closed forms at 2^26 paths (se ~ 1e-3).  The geometric average over the dates
+# t_i = i T / M, i = 1..M is lognormal exactly: ln G ~ N(ln S + (r - q - s^2/2) T (M+1)/(2M), s^2 T (M+1)(2M+1)/(6 M^2)),
+# so the DISCRETE closed form is the target (the reference's price_geometric_closed_form, exotic_options.py:133-160, is
+# the continuous limit and sits 5e-3 lower at M = 1024).  Heston with sigma_v -> 0 and Merton against Black-Scholes / series.
+import math
+
+
+def discrete_geometric_call(S, K, T, r, v, q, M):
+    mu = (r - q - 0.5 * v * v) * T * (M + 1) / (2 * M)
+    s2 = v * v * T * (M + 1) * (2 * M + 1) / (6 * M * M)
+    s, m = math.sqrt(s2), math.log(S) + mu
+    cdf = lambda x: 0.5 * math.erfc(-x / math.sqrt(2.0))
+    d1 = (m - math.log(K) + s2) / s
+    return math.exp(-r * T) * (math.exp(m + 0.5 * s2) * cdf(d1) - K * cdf(d1 - s))
+
+
+n = 1 << 26
+a = ol.AsianOption(100.0, 100.0, 1.0, 0.05, 0.2, seed=11)
+for M in (1024, 252):
+    p, se = a.price(n, M, "geometric", "call", return_error=True)
+    cf = discrete_geometric_call(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, M)
+    rows.append(dict(kind=f"geometric asian 2^26 x {M} vs the discrete-monitoring closed form", price=float(p), closed_form=cf, std_error=se,
+                     z=(float(p) - cf) / se, continuous_closed_form=float(a.price_geometric_closed_form("call"))))
+    print(json.dumps(rows[-1]), flush=True)
+import warnings
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    h = ol.HestonPricer(kappa=2.0, theta=0.04, sigma_v=1e-7, rho=0.0, v0=0.04)
+p, se = h.price_monte_carlo(100.0, 100.0, 1.0, 0.05, 0.0, "call", n, 64, 12, return_error=True)
+bs = ol.black_scholes(100.0, 100.0, 1.0, 0.05, 0.2, "call")
+rows.append(dict(kind="heston sigma_v->0 2^26 x 64 vs Black-Scholes", price=float(p), bs=float(bs), std_error=se, z=(float(p) - float(bs)) / se))
+print(json.dumps(rows[-1]), flush=True)
+m = ol.MertonJumpDiffusion(0.5, -0.1, 0.2)
+p, se = m.price_monte_carlo(100.0, 100.0, 1.0, 0.05, 0.2, "call", 0.0, n, 64, 13, return_error=True)
+series = m.price(100.0, 100.0, 1.0, 0.05, 0.2, "call")
+rows.append(dict(kind="merton lambda=0.5 2^26 x 64 vs series", price=float(p), series=float(series), std_error=se, z=(float(p) - float(series)) / se))
+print(json.dumps(rows[-1]), flush=True)

@@ -391,3 +391,25 @@ def test_heston_monte_carlo_against_the_characteristic_function_price(golden):
         price, se = hp.price_monte_carlo(S, K, T, r, q, c["option_type"], 1 << 21, 512, 7, antithetic=True, return_error=True)
         assert abs(price - want) <= 3.5 * se + 0.01, (c["model"], price, want, se)      # + Euler bias of 512 full-truncation steps
         assert abs(c["mc"] - want) <= 0.12                                              # the reference's own Monte Carlo agrees too
+
+
+def test_american_lsm_against_a_bermudan_binomial_tree():
+    """Independent anchor for Longstaff-Schwartz: a CRR tree that allows exercise on the same 50 dates (40 tree steps
+    between dates).  LSM's two biases (sub-optimal fitted policy: low; in-sample fit: high) are ~1e-2 here."""
+    S, K, T, r, v, dates, sub = 100.0, 100.0, 1.0, 0.05, 0.2, 50, 40
+    n = dates * sub
+    dt = T / n
+    u = math.exp(v * math.sqrt(dt))
+    p = (math.exp(r * dt) - 1 / u) / (u - 1 / u)
+    disc = math.exp(-r * dt)
+    j = np.arange(n + 1)
+    val = np.maximum(K - S * u ** (2.0 * j - n), 0.0)
+    for i in range(n - 1, -1, -1):
+        val = disc * (p * val[1:] + (1 - p) * val[:-1])
+        if i % sub == 0 and i > 0:
+            val = np.maximum(val, K - S * u ** (2.0 * np.arange(i + 1) - i))
+    tree = float(val[0])
+    assert 6.07 < tree < 6.09
+    price, se = ol.AmericanOption(S, K, T, r, v, seed=5).price(1_000_000, dates, "put", 3, return_error=True)
+    assert abs(price - tree) <= 3 * se + 0.01, (price, tree, se)
+    assert price > ol.black_scholes(S, K, T, r, v, "put") + 0.4            # the early-exercise premium is there (European put 5.57)

@@ -413,3 +413,35 @@ def test_american_lsm_against_a_bermudan_binomial_tree():
     price, se = ol.AmericanOption(S, K, T, r, v, seed=5).price(1_000_000, dates, "put", 3, return_error=True)
     assert abs(price - tree) <= 3 * se + 0.01, (price, tree, se)
     assert price > ol.black_scholes(S, K, T, r, v, "put") + 0.4            # the early-exercise premium is there (European put 5.57)
+
+
+def test_autocallable_and_cliquet_against_degenerate_closed_forms():
+    """Parameter corners where the structured payoffs collapse to something with a closed form."""
+    S, K, T, r, v, q = 100.0, 100.0, 1.0, 0.05, 0.2, 0.01
+    cdf = lambda x: 0.5 * math.erfc(-x / math.sqrt(2.0))
+    N, M = 1 << 20, 252
+    # never called, coupon always paid, never knocked in: a zero-coupon bond with one coupon -- deterministic
+    p, se = ol.AutocallableOption(S, K, T, r, v, q, seed=1, autocall_barrier=1e9, coupon_barrier=0.0, coupon_rate=0.08,
+                                  ki_barrier=0.0).price(N, M, 21, return_error=True)
+    assert p == pytest.approx((1 + 0.08 * T) * math.exp(-r * T), rel=1e-12) and se < 1e-12
+    # called at the first observation whatever happens: (1 + first coupon) discounted to that date
+    p, se = ol.AutocallableOption(S, K, T, r, v, q, seed=1, autocall_barrier=0.0, coupon_rate=0.12).price(N, M, 21, return_error=True)
+    assert p == pytest.approx((1 + 0.12 * T / 12) * math.exp(-r * T * 21 / 252), rel=1e-12) and se < 1e-12
+    # never called, no coupon, knock-in certain: 1 - (ATM put on S_T / S_0)
+    p, se = ol.AutocallableOption(S, K, T, r, v, q, seed=2, autocall_barrier=1e9, coupon_barrier=1e9, ki_barrier=1e9).price(
+        N, M, 21, antithetic=True, return_error=True)
+    want = math.exp(-r * T) - ol.black_scholes(S, S, T, r, v, "put", q) / S
+    assert abs(p - want) <= 3.5 * se, (p, want, se)
+    # cliquet, ONE period, local return clipped to [0, c]: an ATM call spread
+    c = 0.10
+    p, se = ol.CliquetOption(S, K, T, r, v, q, seed=3, local_cap=c, local_floor=0.0, global_cap=1e9, global_floor=0.0).price(
+        N, M, 1, antithetic=True, return_error=True)
+    want = ol.black_scholes(S, S, T, r, v, "call", q) - ol.black_scholes(S, S * (1 + c), T, r, v, "call", q)
+    assert abs(p - want) <= 3.5 * se, (p, want, se)
+    # cliquet, 12 periods, each return floored at 0 and uncapped: 12 forward-start ATM calls
+    n, dt = 12, T / 12
+    d1 = (r - q + 0.5 * v * v) * dt / (v * math.sqrt(dt))
+    want = math.exp(-r * T) * S * n * (math.exp((r - q) * dt) * cdf(d1) - cdf(d1 - v * math.sqrt(dt)))
+    p, se = ol.CliquetOption(S, K, T, r, v, q, seed=4, local_cap=1e9, local_floor=0.0, global_cap=1e9, global_floor=0.0).price(
+        N, M, n, antithetic=True, return_error=True)
+    assert abs(p - want) <= 3.5 * se, (p, want, se)

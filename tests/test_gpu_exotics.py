@@ -445,3 +445,22 @@ def test_autocallable_and_cliquet_against_degenerate_closed_forms():
     p, se = ol.CliquetOption(S, K, T, r, v, q, seed=4, local_cap=1e9, local_floor=0.0, global_cap=1e9, global_floor=0.0).price(
         N, M, n, antithetic=True, return_error=True)
     assert abs(p - want) <= 3.5 * se, (p, want, se)
+
+
+def test_barrier_and_lookback_against_degenerate_closed_forms():
+    S, K, T, r, v, q = 100.0, 105.0, 1.0, 0.05, 0.2, 0.01
+    N = 1 << 20
+    bs_call, bs_put = ol.black_scholes(S, K, T, r, v, "call", q), ol.black_scholes(S, K, T, r, v, "put", q)
+    # a barrier nobody reaches: knock-out = European, knock-in = 0; a barrier already touched at t = 0: the other way round
+    for kind, level, typ, want in (("up-and-out", 1e9, "call", bs_call), ("down-and-out", 1e-9, "put", bs_put),
+                                   ("up-and-in", 100.0, "call", bs_call), ("down-and-in", 100.0, "put", bs_put)):
+        p, se = ol.BarrierOption(S, K, T, r, v, barrier=level, q=q, seed=3).price(N, 64, kind, typ, antithetic=True, return_error=True)
+        assert abs(p - want) <= 3.5 * se, (kind, p, want, se)
+    assert ol.BarrierOption(S, K, T, r, v, barrier=1e9, q=q, seed=3).price(10_000, 16, "up-and-in", "call") == 0.0
+    assert ol.BarrierOption(S, K, T, r, v, barrier=100.0, q=q, seed=3).price(10_000, 16, "up-and-out", "call") == 0.0
+    # ONE monitoring date: min / max over {S_0, S_T} turns both lookbacks into ATM-struck Europeans
+    atm_call, atm_put = ol.black_scholes(S, S, T, r, v, "call", q), ol.black_scholes(S, S, T, r, v, "put", q)
+    for kind, typ, strike, want in (("floating", "call", K, atm_call), ("floating", "put", K, atm_put),
+                                    ("fixed", "call", S, atm_call), ("fixed", "put", S, atm_put)):
+        p, se = ol.LookbackOption(S, strike, T, r, v, q=q, seed=4).price(N, 1, kind, typ, antithetic=True, return_error=True)
+        assert abs(p - want) <= 3.5 * se, (kind, typ, p, want, se)

@@ -12,7 +12,7 @@ they are dealt round-robin to `--streams` HIP streams so the ~15 us tail of one 
 hides under the head of the next.  The timed region ends with a full synchronise and
 includes the D2H copy of all K results, each of which is then checked (every step's
 price within 4.5 sigma of Black-Scholes).  The same K steps are then repeated on ONE
-stream with HIP events around each kernel (`serial`, and the roofline attribution).  Inputs are scalars, so
+stream with a HIP event pair attached to each dispatch (`serial`, and the roofline attribution).  Inputs are scalars, so
 nothing but the results crosses PCIe.  The JSON line also carries `sync_call`:
 the same workload through the blocking MonteCarloPricer.price() API, one host
 round trip per call.
@@ -199,7 +199,8 @@ def main():
                          "measured_on": "the single-stream pass of this run (see `serial`): with overlapping launches an event "
                                         "pair would time co-resident kernels, not one kernel",
                          "note": "VALU-issue bound (SURVEY 8d: not HBM, not MFMA); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz "
-                                 "(157.3 TF fp32 vector / 2); achieved = 32 lane-ops x path-steps per launch / HIP-event kernel time"},
+                                 "(157.3 TF fp32 vector / 2); achieved = 32 lane-ops x path-steps per launch / kernel time from a HIP event pair "
+                                 "attached to the dispatch (hipExtLaunchKernelGGL: the kernel's own begin/end timestamps on its stream)"},
             "device": info,
         }
         # blocking API at the same size (one host round trip per price() call)

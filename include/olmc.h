@@ -321,9 +321,12 @@ int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_
                  float* out_host);
 
 /* ---- measurement ----------------------------------------------------------
- * When enabled, every path-kernel launch is bracketed by HIP events on the
- * stream it runs on; olmc_kernel_time returns the number of launches timed and
- * their total milliseconds since the last reset. */
+ * When enabled, every path-kernel launch carries a pair of HIP events attached to the dispatch itself
+ * (hipExtLaunchKernelGGL): they take the kernel's own begin / end timestamps on the stream it runs on, the
+ * figures rocprofv3 reports.  (hipEventRecord brackets around a launch also time the marker packets on either
+ * side: +7..10 us at these durations.)  Multi-launch entry points (olmc_american_lsm, olmc_european_multi with
+ * more than 65535 contracts) are bracketed as a whole.  olmc_kernel_time returns the number of launches timed
+ * and their total milliseconds since the last reset. */
 int olmc_profile_enable(int on);
 /* Tuning knob for A/B measurements (results never change, only the launch shape):
  *   OLMC_TUNE_GRID_CAP  max workgroups per launch, 0 = default (larger jobs grid-stride) */

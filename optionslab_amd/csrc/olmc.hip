@@ -9,6 +9,7 @@
 #include "olmc_kernels.h"
 
 #include <dlfcn.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <climits>
@@ -239,6 +240,18 @@ int prof_begin(DeviceCtx* c, hipStream_t s, EventPair* ep) {
     return OLMC_OK;
 }
 
+// An event pair for a dispatch that carries its own timestamps (launch_one): nothing is recorded here.
+int prof_acquire(DeviceCtx* c, EventPair* ep) {
+    if (c->ev_free.empty()) {
+        HIP_TRY(hipEventCreate(&ep->start));
+        HIP_TRY(hipEventCreate(&ep->stop));
+    } else {
+        *ep = c->ev_free.back();
+        c->ev_free.pop_back();
+    }
+    return OLMC_OK;
+}
+
 int prof_end(DeviceCtx* c, hipStream_t s, const EventPair& ep) {
     HIP_TRY(hipEventRecord(ep.stop, s));
     c->ev_pending.push_back(ep);
@@ -247,11 +260,14 @@ int prof_end(DeviceCtx* c, hipStream_t s, const EventPair& ep) {
 
 int prof_drain(DeviceCtx* c) {
     for (const EventPair& ep : c->ev_pending) {
-        HIP_TRY(hipEventSynchronize(ep.stop));
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, ep.start, ep.stop));
-        c->prof_ms += ms;
-        c->prof_launches += 1;
+        // a pair whose launch failed was never recorded: it is skipped, not an error of the measurement
+        if (hipEventSynchronize(ep.stop) == hipSuccess && hipEventElapsedTime(&ms, ep.start, ep.stop) == hipSuccess) {
+            c->prof_ms += ms;
+            c->prof_launches += 1;
+        } else {
+            (void)hipGetLastError();
+        }
         c->ev_free.push_back(ep);
     }
     c->ev_pending.clear();
@@ -344,16 +360,44 @@ PathRange make_range(int64_t path_offset, int64_t n_local, int32_t n_steps, uint
     return pr;
 }
 
+// `timed` != nullptr: the dispatch itself carries the event pair (hipExtLaunchKernelGGL): the events take the
+// kernel's own begin / end timestamps, as rocprofv3 reads them.  hipEventRecord brackets around a launch also
+// time the marker packets on either side (+7..10 us at these durations: 119 vs 109 us in one and the same run).
+template <typename Kernel, int NSETS>
+void launch_one(Kernel kernel, int32_t grid, hipStream_t s, const EventPair* timed, const PathRange& pr, const ContractSet<NSETS>& cs,
+                const ReduceWs& ws, double* terminal) {
+    if (timed) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, s, timed->start, timed->stop, 0, pr, cs, ws, terminal);
+    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, s, pr, cs, ws, terminal);
+}
+
+// The same for any kernel and any launch shape.
+template <typename Kernel, typename... Args>
+void launch_timed(Kernel kernel, dim3 grid, dim3 block, hipStream_t s, const EventPair* timed, Args... args) {
+    if (timed) hipExtLaunchKernelGGL(kernel, grid, block, 0, s, timed->start, timed->stop, 0, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, 0, s, args...);
+}
+
+// Profiling on: take an event pair for the launch that follows and queue it for prof_drain.
+int prof_pair(DeviceCtx* c, EventPair* ep, const EventPair** timed) {
+    *timed = nullptr;
+    if (!g_profile) return OLMC_OK;
+    int rc = prof_acquire(c, ep);
+    if (rc) return rc;
+    c->ev_pending.push_back(*ep);
+    *timed = ep;
+    return OLMC_OK;
+}
+
 template <int NSETS, int MODE>
 void launch_european(bool anti, int32_t grid, hipStream_t s, const PathRange& pr, const ContractSet<NSETS>& cs,
-                     const ReduceWs& ws, double* terminal) {
+                     const ReduceWs& ws, double* terminal, const EventPair* timed = nullptr) {
     const bool strided = static_cast<int64_t>(grid) * kBlock < pr.count;      // the grid does not cover every path
     if (strided) {
-        if (anti) hipLaunchKernelGGL((european_path_kernel<NSETS, true, MODE, true>), dim3(grid), dim3(kBlock), 0, s, pr, cs, ws, terminal);
-        else hipLaunchKernelGGL((european_path_kernel<NSETS, false, MODE, true>), dim3(grid), dim3(kBlock), 0, s, pr, cs, ws, terminal);
+        if (anti) launch_one(european_path_kernel<NSETS, true, MODE, true>, grid, s, timed, pr, cs, ws, terminal);
+        else launch_one(european_path_kernel<NSETS, false, MODE, true>, grid, s, timed, pr, cs, ws, terminal);
     } else {
-        if (anti) hipLaunchKernelGGL((european_path_kernel<NSETS, true, MODE, false>), dim3(grid), dim3(kBlock), 0, s, pr, cs, ws, terminal);
-        else hipLaunchKernelGGL((european_path_kernel<NSETS, false, MODE, false>), dim3(grid), dim3(kBlock), 0, s, pr, cs, ws, terminal);
+        if (anti) launch_one(european_path_kernel<NSETS, true, MODE, false>, grid, s, timed, pr, cs, ws, terminal);
+        else launch_one(european_path_kernel<NSETS, false, MODE, false>, grid, s, timed, pr, cs, ws, terminal);
     }
 }
 
@@ -370,24 +414,25 @@ int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32
     int rc = make_ws(c, s, grid, 2 * nsets, d_out, tail, &ws);
     if (rc) return rc;
     EventPair ep{};
-    if (g_profile) { rc = prof_begin(c, s, &ep); if (rc) return rc; }
+    const EventPair* timed = nullptr;
+    rc = prof_pair(c, &ep, &timed);
+    if (rc) return rc;
     if (nsets == 1) {
         ContractSet<1> cs;
         cs.c[0] = make_contract(opts[0], n_steps);
         if (pos) pos[0] = 0;
-        launch_european<1, kReduce>(anti, grid, s, pr, cs, ws, nullptr);
+        launch_european<1, kReduce>(anti, grid, s, pr, cs, ws, nullptr, timed);
     } else if (nsets == 8) {
         ContractSet<8> cs;
         group_contracts<8>(opts, k, n_steps, &cs, pos);
-        launch_european<8, kReduce>(anti, grid, s, pr, cs, ws, nullptr);
+        launch_european<8, kReduce>(anti, grid, s, pr, cs, ws, nullptr, timed);
     } else {
         ContractSet<16> cs;
         group_contracts<16>(opts, k, n_steps, &cs, pos);
-        launch_european<16, kReduce>(anti, grid, s, pr, cs, ws, nullptr);
+        launch_european<16, kReduce>(anti, grid, s, pr, cs, ws, nullptr, timed);
     }
     rc = after_launch(c, s);
     if (rc) return rc;
-    if (g_profile) { rc = prof_end(c, s, ep); if (rc) return rc; }
     return OLMC_OK;
 }
 
@@ -765,15 +810,16 @@ extern "C" int olmc_asian(double S, double K, double T, double r, double sigma, 
     rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
     if (rc) return rc;
     EventPair ep{};
-    if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
+    const EventPair* timed = nullptr;
+    rc = prof_pair(c, &ep, &timed);
+    if (rc) return rc;
     const bool anti = antithetic != 0, geo = avg_kind == OLMC_AVG_GEOMETRIC;
-    if (anti && geo) hipLaunchKernelGGL((asian_kernel<true, true>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, ws);
-    else if (anti) hipLaunchKernelGGL((asian_kernel<true, false>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, ws);
-    else if (geo) hipLaunchKernelGGL((asian_kernel<false, true>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, ws);
-    else hipLaunchKernelGGL((asian_kernel<false, false>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ac, ws);
+    if (anti && geo) launch_timed(asian_kernel<true, true>, dim3(grid), dim3(kBlock), c->stream, timed, pr, ac, ws);
+    else if (anti) launch_timed(asian_kernel<true, false>, dim3(grid), dim3(kBlock), c->stream, timed, pr, ac, ws);
+    else if (geo) launch_timed(asian_kernel<false, true>, dim3(grid), dim3(kBlock), c->stream, timed, pr, ac, ws);
+    else launch_timed(asian_kernel<false, false>, dim3(grid), dim3(kBlock), c->stream, timed, pr, ac, ws);
     rc = after_launch(c, c->stream);
     if (rc) return rc;
-    if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r, T, out);
@@ -808,12 +854,13 @@ int run_extrema(double S, double K, double T, double r, double sigma, double q, 
     rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
     if (rc) return rc;
     EventPair ep{};
-    if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
-    if (antithetic) hipLaunchKernelGGL((extrema_kernel<true>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ec, ws);
-    else hipLaunchKernelGGL((extrema_kernel<false>), dim3(grid), dim3(kBlock), 0, c->stream, pr, ec, ws);
+    const EventPair* timed = nullptr;
+    rc = prof_pair(c, &ep, &timed);
+    if (rc) return rc;
+    if (antithetic) launch_timed(extrema_kernel<true>, dim3(grid), dim3(kBlock), c->stream, timed, pr, ec, ws);
+    else launch_timed(extrema_kernel<false>, dim3(grid), dim3(kBlock), c->stream, timed, pr, ec, ws);
     rc = after_launch(c, c->stream);
     if (rc) return rc;
-    if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r, T, out);
@@ -855,11 +902,12 @@ int run_structured(int64_t path_offset, int64_t n_local, int32_t n_steps, uint64
     rc = make_ws(c, c->stream, grid, nv, c->d_result, -1.0, &ws);
     if (rc) return rc;
     EventPair ep{};
-    if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
-    launch(grid, c->stream, pr, ws);
+    const EventPair* timed = nullptr;
+    rc = prof_pair(c, &ep, &timed);
+    if (rc) return rc;
+    launch(grid, c->stream, timed, pr, ws);
     rc = after_launch(c, c->stream);
     if (rc) return rc;
-    if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r_for_discount, T, out);
@@ -890,9 +938,9 @@ extern "C" int olmc_autocallable(double S, double T, double r, double sigma, dou
     const bool bad = poisoned(S, 1.0, T, r, sigma, q) || std::isnan(autocall_barrier + coupon_barrier + coupon_rate + ki_barrier);
     // payoffs are already discounted path by path (exotic_options.py:463, 489): no outer discount
     return run_structured(path_offset, n_local, n_steps, seed, antithetic, 0.0, T, bad, out,
-                          [&](int32_t grid, hipStream_t st, const PathRange& pr, const ReduceWs& ws) {
-                              if (antithetic) hipLaunchKernelGGL((autocall_kernel<true>), dim3(grid), dim3(kBlock), 0, st, pr, ac, ws);
-                              else hipLaunchKernelGGL((autocall_kernel<false>), dim3(grid), dim3(kBlock), 0, st, pr, ac, ws);
+                          [&](int32_t grid, hipStream_t st, const EventPair* timed, const PathRange& pr, const ReduceWs& ws) {
+                              if (antithetic) launch_timed(autocall_kernel<true>, dim3(grid), dim3(kBlock), st, timed, pr, ac, ws);
+                              else launch_timed(autocall_kernel<false>, dim3(grid), dim3(kBlock), st, timed, pr, ac, ws);
                           });
 }
 
@@ -910,9 +958,9 @@ extern "C" int olmc_cliquet(double S, double T, double r, double sigma, double q
     cc.n_periods = n_periods;
     const bool bad = poisoned(S, 1.0, T, r, sigma, q) || std::isnan(local_cap + local_floor + global_cap + global_floor);
     return run_structured(path_offset, n_local, n_steps, seed, antithetic, r, T, bad, out,
-                          [&](int32_t grid, hipStream_t st, const PathRange& pr, const ReduceWs& ws) {
-                              if (antithetic) hipLaunchKernelGGL((cliquet_kernel<true>), dim3(grid), dim3(kBlock), 0, st, pr, cc, ws);
-                              else hipLaunchKernelGGL((cliquet_kernel<false>), dim3(grid), dim3(kBlock), 0, st, pr, cc, ws);
+                          [&](int32_t grid, hipStream_t st, const EventPair* timed, const PathRange& pr, const ReduceWs& ws) {
+                              if (antithetic) launch_timed(cliquet_kernel<true>, dim3(grid), dim3(kBlock), st, timed, pr, cc, ws);
+                              else launch_timed(cliquet_kernel<false>, dim3(grid), dim3(kBlock), st, timed, pr, cc, ws);
                           });
 }
 
@@ -1109,12 +1157,13 @@ extern "C" int olmc_heston(double S, double K, double T, double r, double q, int
     rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
     if (rc) return rc;
     EventPair ep{};
-    if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
-    if (antithetic) hipLaunchKernelGGL((heston_kernel<true>), dim3(grid), dim3(kBlock), 0, c->stream, pr, hc, ws);
-    else hipLaunchKernelGGL((heston_kernel<false>), dim3(grid), dim3(kBlock), 0, c->stream, pr, hc, ws);
+    const EventPair* timed = nullptr;
+    rc = prof_pair(c, &ep, &timed);
+    if (rc) return rc;
+    if (antithetic) launch_timed(heston_kernel<true>, dim3(grid), dim3(kBlock), c->stream, timed, pr, hc, ws);
+    else launch_timed(heston_kernel<false>, dim3(grid), dim3(kBlock), c->stream, timed, pr, hc, ws);
     rc = after_launch(c, c->stream);
     if (rc) return rc;
-    if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r, T, out);
@@ -1163,8 +1212,8 @@ extern "C" int olmc_jump_diffusion(double S, double K, double T, double r, doubl
     if (rc) return rc;
     const bool bad = poisoned(S, K, T, r, sigma, q) || std::isnan(lambda_j + a1 + a2 + a3);
     return run_structured(path_offset, n_local, n_steps, seed, 0, r, T, bad, out,
-                          [&](int32_t grid, hipStream_t st, const PathRange& pr, const ReduceWs& ws) {
-                              hipLaunchKernelGGL(jump_kernel, dim3(grid), dim3(kBlock), 0, st, pr, jc, ws);
+                          [&](int32_t grid, hipStream_t st, const EventPair* timed, const PathRange& pr, const ReduceWs& ws) {
+                              launch_timed(jump_kernel, dim3(grid), dim3(kBlock), st, timed, pr, jc, ws);
                           });
 }
 
@@ -1399,8 +1448,8 @@ extern "C" int olmc_normal_moments(uint64_t seed, int64_t path_offset, int64_t n
     if (!out4) return fail(OLMC_ERR_ARG, "null pointer");
     olmc_stats dummy;
     int rc = run_structured(path_offset, n_paths, n_steps, seed, 0, 0.0, 1.0, false, &dummy,
-                            [&](int32_t grid, hipStream_t st, const PathRange& pr, const ReduceWs& ws) {
-                                hipLaunchKernelGGL(normal_moments_kernel, dim3(grid), dim3(kBlock), 0, st, pr, ws);
+                            [&](int32_t grid, hipStream_t st, const EventPair* timed, const PathRange& pr, const ReduceWs& ws) {
+                                launch_timed(normal_moments_kernel, dim3(grid), dim3(kBlock), st, timed, pr, ws);
                             }, 4);
     if (rc) return rc;
     DeviceCtx* c = nullptr;

@@ -25,6 +25,27 @@ def main(root):
         print(f"\n## kernel-trace --stats: {title}")
         for row in csv.DictReader(open(f)):
             print(f"{short(row['Name']):70s} calls {row['Calls']:>5s}  avg_ns {float(row['AverageNs']):>12.1f}  min {row['MinNs']:>8s}  max {row['MaxNs']:>8s}  {row['Percentage']}%")
+    # the default command by bench.py phase: only the single-stream pass (what bench.py's roofline.avg_kernel_ms times with HIP
+    # events) has one kernel on the device at a time; in the 8-stream pass a dispatch's duration includes its co-residents'
+    for f in newest(os.path.join(root, "stats_default", "*", "*_kernel_trace.csv")):
+        rows = sorted((r for r in csv.DictReader(open(f)) if "european_path_kernel" in r["Kernel_Name"]), key=lambda r: int(r["Dispatch_Id"]))
+        dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+        log = os.path.join(root, "stats_default.log")
+        steps, warm, line = None, None, None
+        if os.path.exists(log):
+            import json
+            for l in open(log):
+                if l.startswith('{"metric"'):
+                    line = json.loads(l)
+                    steps, warm = line["steps"], line["warmup"]
+        if steps and len(dur) >= warm + 2 * steps:
+            print("\n## the default command's european_path_kernel dispatches by bench.py phase (us)")
+            for name, a, b in (("warm-up, 8 streams", 0, warm), ("timed K steps, 8 streams (-> value)", warm, warm + steps),
+                               ("same K steps, 1 stream (-> serial, roofline)", warm + steps, warm + 2 * steps), ("blocking price() calls (-> sync_call)", warm + 2 * steps, len(dur))):
+                seg = dur[a:b]
+                if seg:
+                    print(f"{name:55s} n={len(seg):4d}  avg {sum(seg) / len(seg):8.1f}  min {min(seg):8.1f}  max {max(seg):8.1f}")
+            print(f"bench.py of that run reported roofline.avg_kernel_ms = {line['roofline']['avg_kernel_ms']:.4f} (HIP events, {line['roofline']['launches_timed']} launches), value = {line['value']:.4g} {line['unit']}")
     for p in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
         files = newest(os.path.join(root, p, "*", "*_counter_collection.csv"))
         if not files:

@@ -82,6 +82,9 @@ def main():
     Tb, rb, vb = rng.uniform(0.25, 2, nb), rng.uniform(0, 0.08, nb), rng.uniform(0.1, 0.5, nb)
     report("MonteCarloPricerUni.price_batch: 256 contracts x 100k x 100 (one launch)", nb * 100_000 * 100,
            lambda: uni.price_batch(Sb, Kb, Tb, rb, vb, "call", 0.01), lambda a: dict(mean_price=float(a.mean())), reps=5)
+    ub = ol.MonteCarloPricerUni(50_000, 100, 42)
+    report("MonteCarloPricerUni.price 50k x 100 (the reference's own benchmark script, tests/test_benchmarks.py:60)", 50_000 * 100,
+           lambda: ub.price(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, option_type="call"), lambda v: dict(price=float(v)))
     report("MonteCarloPricerUni.delta_gamma (3 contracts CRN, one launch) 100k x 100", 100_000 * 100,
            lambda: uni.delta_gamma(*ATM, "call", h=1.0, seed=5), lambda dg: dict(delta=dg[0], gamma=dg[1]))
     report("barrier up-and-out call 1M x 252", N * M, lambda: ol.BarrierOption(*ATM, barrier=120.0, seed=42).price(N, M, "up-and-out", "call", return_error=True),

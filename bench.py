@@ -44,10 +44,10 @@ def measured_traffic():
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
-        return None, None
+        return None, None, None
     with open(files[-1]) as f:
         d = json.load(f)
-    return d.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT)
+    return d.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT), d.get("sq_active_inst_valu_per_launch")
 
 
 def cpu_baseline():
@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--streams", type=int, default=8, help="HIP streams the K pricings are spread over (>= 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--paths-per-gpu", type=int, default=PATHS_PER_GPU,
+                    help="default 1,000,000 (BASELINE configs[1]); 8000000 reproduces configs[4]'s 8M-per-GPU shards")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,7 +103,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     info = _hip.device_info()
 
-    n_global = PATHS_PER_GPU * world
+    paths_per_gpu = args.paths_per_gpu
+    n_global = paths_per_gpu * world
     lo, hi = sharding.shard_bounds(n_global, rank, world)
     S, K, T, r, sigma, q = (WORK[k] for k in ("S", "K", "T", "r", "sigma", "q"))
     # The K pricings are independent requests: they are dealt round-robin to `--streams` HIP streams, so
@@ -176,15 +179,17 @@ def main():
         value = path_steps * K_steps / elapsed
         avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
         achieved = (hi - lo) * N_STEPS * LANE_OPS_PER_PATH_STEP / avg_kernel_s / 1e12
-        traffic, traffic_src = measured_traffic()
+        traffic, traffic_src, valu_active = measured_traffic()
+        if paths_per_gpu != PATHS_PER_GPU:       # the committed counters are per 1M-path launch
+            traffic = valu_active = None
         out = {
-            "metric": "MC path-steps/sec (1M paths x 252 steps Euro call); price vs BS |err|/sigma",
+            "metric": "MC path-steps/sec (1M paths \u00d7 252 steps Euro call); price vs BS |err|/\u03c3",      # BASELINE.json, verbatim
             "value": value, "unit": "path-steps/s", "n_gpus": world, "steps": K_steps, "warmup": W,
             "ms_per_step": elapsed / K_steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 normals / f64 prices", "data": "synthetic",
-            "config": {"workload": "European call S0=100 K=100 sigma=0.2 r=0.05 T=1, 1,000,000 paths x 252 steps per GPU, "
-                                   "antithetic on (2M payoffs per GPU), Philox4x32-10 + Box-Muller in registers, on-device reduction",
-                       "paths_per_gpu": PATHS_PER_GPU, "n_steps": N_STEPS, "global_paths": n_global,
+            "config": {"workload": f"European call S0=100 K=100 sigma=0.2 r=0.05 T=1, {paths_per_gpu:,} paths x 252 steps per GPU, "
+                                   "antithetic on (two payoffs per path), Philox4x32-10 + Box-Muller in registers, on-device reduction",
+                       "paths_per_gpu": paths_per_gpu, "n_steps": N_STEPS, "global_paths": n_global,
                        "streams": len(streams),
                        "parallelism": f"path-sharded x{world}" + (", 1 RCCL all-reduce of (sum,sumsq,n) per step" if world > 1 else "")},
             "serial": {"value": path_steps * K_steps / serial_elapsed, "ms_per_step": serial_elapsed / K_steps * 1e3, "streams": 1,
@@ -196,16 +201,20 @@ def main():
                          "launches_timed": launches, "lane_ops_per_path_step": LANE_OPS_PER_PATH_STEP,
                          "hbm_gbps": (traffic / avg_kernel_s / 1e9) if traffic else None,
                          "hbm_frac_of_8TBps": (traffic / avg_kernel_s / 8e12) if traffic else None,
+                         # VALU-active cycles of the committed PMC pass over the SIMD-cycles of this run's kernel time at 2.4 GHz
+                         "valu_busy_from_pmc": (valu_active * 4 / (1024 * avg_kernel_s * 2.4e9)) if valu_active else None,
                          "measured_on": "the single-stream pass of this run (see `serial`): with overlapping launches an event "
                                         "pair would time co-resident kernels, not one kernel",
                          "note": "VALU-issue bound (SURVEY 8d: not HBM, not MFMA); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz "
                                  "(157.3 TF fp32 vector / 2); achieved = 32 lane-ops x path-steps per launch / kernel time from a HIP event pair "
-                                 "attached to the dispatch (hipExtLaunchKernelGGL: the kernel's own begin/end timestamps on its stream)"},
+                                 "attached to the dispatch (hipExtLaunchKernelGGL: the kernel's own begin/end timestamps on its stream). "
+                                 "The kernel issues 14.5 VALU instructions per path-step, fewer than the 32 algorithmic lane-ops assume at "
+                                 "half rate, so frac saturates near 1.03 (reached at 8M paths per launch)"},
             "device": info,
         }
         # blocking API at the same size (one host round trip per price() call)
         if world == 1:
-            pricer = ol.MonteCarloPricer(PATHS_PER_GPU, N_STEPS, SEED)
+            pricer = ol.MonteCarloPricer(paths_per_gpu, N_STEPS, SEED)
             for _ in range(3):
                 pricer.price(S, K, T, r, sigma, "call")
             reps = max(10, min(K_steps, 50))
@@ -213,7 +222,7 @@ def main():
             for i in range(reps):
                 res = pricer.price(S, K, T, r, sigma, "call", seed=SEED + i, return_error=True)
             dt = (time.perf_counter() - t1) / reps
-            out["sync_call"] = {"value": PATHS_PER_GPU * N_STEPS / dt, "unit": "path-steps/s", "ms_per_call": dt * 1e3,
+            out["sync_call"] = {"value": paths_per_gpu * N_STEPS / dt, "unit": "path-steps/s", "ms_per_call": dt * 1e3,
                                 "what": "MonteCarloPricer.price(return_error=True), blocking, result on host"}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()

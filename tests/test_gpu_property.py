@@ -1,0 +1,95 @@
+"""Property-based parity: random sizes, offsets, seeds and contract parameters, device kernels against the
+same-stream C checker (hypothesis; derandomized so the driver's run is reproducible).  The parametrized
+tests pin chosen shapes; these sweep the ragged ones nobody thought of (path counts around wave / workgroup
+boundaries, step counts around the Philox-block and fp32-group boundaries, 64-bit path offsets)."""
+import math
+
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from optionslab_amd import _hip
+from oracle import philox_oracle as po
+
+pytestmark = pytest.mark.gpu
+REL = 2e-6
+import os
+
+# OLMC_PROPERTY_SCALE=30 turns this into a long, randomised hunt (not the default: the driver's run must be reproducible)
+SCALE = int(os.environ.get("OLMC_PROPERTY_SCALE", "1"))
+COMMON = dict(deadline=None, derandomize=SCALE == 1, suppress_health_check=list(HealthCheck))
+
+paths = st.one_of(st.integers(1, 130), st.sampled_from([255, 256, 257, 511, 513, 1023, 1025]), st.integers(131, 3000))
+steps = st.one_of(st.integers(1, 40), st.sampled_from([63, 64, 65, 127, 129, 252]))
+seeds = st.integers(0, 2**64 - 1)
+offsets = st.one_of(st.just(0), st.integers(0, 10_000), st.sampled_from([2**32 - 3, 2**32, 2**40 + 17]))
+spot = st.floats(50.0, 150.0)
+strike = st.floats(60.0, 140.0)
+vol = st.floats(0.05, 0.6)
+rate = st.floats(0.0, 0.08)
+div = st.floats(0.0, 0.05)
+mat = st.floats(0.1, 2.0)
+
+
+def close(a, b, scale=1.0, n=0, level=0.0, power=1):
+    """Relative 2e-6 of the sum -- or, when the sum is small because most payoffs sit near / below their kink, the
+    absolute error that n prices of size `level`, each good to 2e-6 relative (hardware log2 / sin / cos), can leave."""
+    return a == pytest.approx(b, rel=REL * scale, abs=1e-9 * scale + REL * scale * n * (3.0 * level) ** power)
+
+
+@settings(max_examples=60 * SCALE, **COMMON)
+@given(N=paths, M=steps, seed=seeds, off=offsets, S=spot, K=strike, v=vol, r=rate, q=div, T=mat, call=st.booleans(), anti=st.booleans())
+def test_european_shard(N, M, seed, off, S, K, v, r, q, T, call, anti):
+    got = _hip.european(S, K, T, r, v, q, call, N, M, seed, anti, path_offset=off)
+    sx, sxx, *_rest, n = po.european_moments(S, K, T, r, v, q, call, N, M, seed, anti, off)
+    assert got.n == n and close(got.sum, sx, 1, n, max(S, K)) and close(got.sumsq, sxx, 4, n, max(S, K), 2)
+
+
+@settings(max_examples=40 * SCALE, **COMMON)
+@given(N=paths, M=steps, seed=seeds, off=offsets, S=spot, K=strike, v=vol, r=rate, q=div, T=mat, call=st.booleans(), anti=st.booleans(),
+       geo=st.booleans())
+def test_asian(N, M, seed, off, S, K, v, r, q, T, call, anti, geo):
+    got = _hip.asian(S, K, T, r, v, q, call, geo, N, M, seed, anti, path_offset=off)
+    sx, sxx, n = po.asian_moments(S, K, T, r, v, q, call, geo, N, M, seed, anti, off)
+    assert got.n == n and close(got.sum, sx, 1, n, max(S, K)) and close(got.sumsq, sxx, 4, n, max(S, K), 2)
+
+
+@settings(max_examples=40 * SCALE, **COMMON)
+@given(N=paths, M=steps, seed=seeds, S=spot, K=strike, v=vol, r=rate, q=div, T=mat, call=st.booleans(), anti=st.booleans(),
+       payoff=st.integers(4, 5))
+def test_lookback(N, M, seed, S, K, v, r, q, T, call, anti, payoff):
+    # (barriers are excluded: a path within rounding of the barrier may legitimately land on either side)
+    got = _hip.lookback(S, K, T, r, v, q, call, payoff == 5, N, M, seed, anti)
+    sx, sxx, n = po.extrema_moments(S, K, T, r, v, q, call, payoff, 0.0, N, M, seed, anti)
+    assert got.n == n and close(got.sum, sx, 1, n, max(S, K)) and close(got.sumsq, sxx, 4, n, max(S, K), 2)
+
+
+@settings(max_examples=40 * SCALE, **COMMON)
+@given(N=paths, M=st.integers(1, 80), seed=seeds, S=spot, v=vol, r=rate, q=div, T=mat, anti=st.booleans(), periods=st.integers(1, 12),
+       cap=st.floats(0.01, 0.2), floor=st.floats(-0.2, 0.0))
+def test_cliquet(N, M, seed, S, v, r, q, T, anti, periods, cap, floor):
+    if M // periods < 1:
+        periods = M
+    got = _hip.cliquet(S, T, r, v, q, cap, floor, 0.5, 0.0, periods, N, M, seed, anti)
+    sx, sxx, n = po.cliquet_moments(S, T, r, v, q, cap, floor, 0.5, 0.0, periods, N, M, seed, anti)
+    assert got.n == n and close(got.sum, sx, 1, n, S) and close(got.sumsq, sxx, 4, n, S, 2)
+
+
+@settings(max_examples=40 * SCALE, **COMMON)
+@given(N=paths, M=st.integers(1, 60), seed=seeds, S=spot, K=strike, v=vol, r=rate, q=div, T=mat, call=st.booleans(), kou=st.booleans(),
+       lam=st.floats(0.0, 30.0))
+def test_jump_diffusion(N, M, seed, S, K, v, r, q, T, call, kou, lam):
+    a = (0.4, 10.0, 5.0) if kou else (-0.1, 0.2, 0.0)
+    got = _hip.jump_diffusion(S, K, T, r, v, q, call, kou, lam, *a, N, M, seed)
+    sx, sxx, n = po.jump_moments(S, K, T, r, v, q, call, kou, lam, *a, N, M, seed)
+    assert got.n == n and close(got.sum, sx, 2, n, max(S, K)) and close(got.sumsq, sxx, 8, n, max(S, K), 2)
+
+
+@settings(max_examples=40 * SCALE, **COMMON)
+@given(N=paths, M=st.integers(1, 60), seed=seeds, S=spot, K=strike, r=rate, q=div, T=mat, call=st.booleans(), anti=st.booleans(),
+       kappa=st.floats(0.5, 4.0), theta=st.floats(0.01, 0.1), sv=st.floats(0.05, 1.0), rho=st.floats(-0.95, 0.95), v0=st.floats(0.005, 0.15))
+def test_heston(N, M, seed, S, K, r, q, T, call, anti, kappa, theta, sv, rho, v0):
+    got = _hip.heston(S, K, T, r, q, call, kappa, theta, sv, rho, v0, N, M, seed, anti)
+    sx, sxx, n = po.heston_moments(S, K, T, r, q, call, kappa, theta, sv, rho, v0, N, M, seed, anti)
+    assert got.n == n and close(got.sum, sx, 2, n, max(S, K)) and close(got.sumsq, sxx, 8, n, max(S, K), 2)
+    assert math.isfinite(got.price)

@@ -93,3 +93,22 @@ def test_heston(N, M, seed, S, K, r, q, T, call, anti, kappa, theta, sv, rho, v0
     sx, sxx, n = po.heston_moments(S, K, T, r, q, call, kappa, theta, sv, rho, v0, N, M, seed, anti)
     assert got.n == n and close(got.sum, sx, 2, n, max(S, K)) and close(got.sumsq, sxx, 8, n, max(S, K), 2)
     assert math.isfinite(got.price)
+
+
+@settings(max_examples=20 * SCALE, **COMMON)
+@given(N=st.integers(1, 700), M=st.integers(1, 48), seed=st.integers(0, 2**31 - 1), S=spot, v=vol, r=rate, q=div, T=mat,
+       off=st.integers(0, 300))
+def test_qmc_terminal_equals_the_scipy_based_oracle(N, M, seed, S, v, r, q, T, off):
+    """Scrambled Sobol points expanded on the device from SciPy's own direction numbers: the terminal prices equal the
+    NumPy/SciPy restatement of simulate_gbm_qmc (gbm_qmc.py:14-46) to rounding, at any point offset."""
+    import warnings
+
+    import numpy as np
+
+    import optionslab_amd as ol
+    from oracle import numpy_reference as orc
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")            # SciPy: n is not a power of two
+        want = orc.terminal_sobol(S, T, r, v, q, N + off, M, seed)[off:]
+    got = _hip.european_qmc_terminal(S, T, r, v, q, N, *ol.monte_carlo.sobol_tables(M, seed), point_offset=off)
+    assert got.shape == want.shape and np.allclose(got, want, rtol=1e-11, atol=0)

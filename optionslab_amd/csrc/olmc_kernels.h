@@ -1350,47 +1350,81 @@ __global__ __launch_bounds__(kBlock) void jump_paths_kernel(PathRange pr, JumpCo
 //   x_t(k) = shift[t] ^ XOR_{b in gray(k)} sv[t][b],   u = x * 2^-30,
 // with sv / shift the host-built (SciPy LMS + digital shift) direction matrix of dimension t,
 // so the uniforms equal scipy.stats.qmc.Sobol(d, scramble=True, seed).random(n) bit for bit.
-// Then clip to [1e-10, 1-1e-10] (:36), z = Phi^-1(u) in fp64, sum over the dims, exp.  No
+// Then clip to [1e-10, 1-1e-10] (:36), z = Phi^-1(u) in fp64 (ndtri_w), sum over the dims, exp.  No
 // antithetic mirror in the pricer (gbm_qmc.py:14-46); QmcRange.mirror serves simulate_gbm_qmc_antithetic (:49-76).
 constexpr int kSobolBits = 30;      // SciPy's default `bits`
 
-// Inverse normal CDF, Wichura AS241 PPND16 (|rel err| ~1e-16; checked against scipy ndtri
-// to 4.4e-15 abs on [1e-10, 1-1e-10]).  The r > 5 branch is unreachable for clipped inputs
-// (sqrt(-ln 1e-10) = 4.80) but kept for completeness.
-__device__ __forceinline__ double ndtri_as241(double p) {
-    const double q = p - 0.5;
-    if (fabs(q) <= 0.425) {
-        const double r = 0.180625 - q * q;
-        const double num = (((((((2.5090809287301226727e+3 * r + 3.3430575583588128105e+4) * r + 6.7265770927008700853e+4) * r +
-                                4.5921953931549871457e+4) * r + 1.3731693765509461125e+4) * r + 1.9715909503065514427e+3) * r +
-                             1.3314166789178437745e+2) * r + 3.3871328727963666080e0);
-        const double den = (((((((5.2264952788528545610e+3 * r + 2.8729085735721942674e+4) * r + 3.9307895800092710610e+4) * r +
-                                2.1213794301586595867e+4) * r + 5.3941960214247511077e+3) * r + 6.8718700749205790830e+2) * r +
-                             4.2313330701600911252e+1) * r + 1.0);
-        return q * num / den;
-    }
-    double r = sqrt(-log(q < 0.0 ? p : 1.0 - p));
-    double val;
-    if (r <= 5.0) {
-        r -= 1.6;
-        const double num = (((((((7.74545014278341407640e-4 * r + 2.27238449892691845833e-2) * r + 2.41780725177450611770e-1) * r +
-                                1.27045825245236838258e0) * r + 3.64784832476320460504e0) * r + 5.76949722146069140550e0) * r +
-                             4.63033784615654529590e0) * r + 1.42343711074968357734e0);
-        const double den = (((((((1.05075007164441684324e-9 * r + 5.47593808499534494600e-4) * r + 1.51986665636164571966e-2) * r +
-                                1.48103976427480074590e-1) * r + 6.89767334985100004550e-1) * r + 1.67638483018380384940e0) * r +
-                             2.05319162663775882187e0) * r + 1.0);
-        val = num / den;
+// Inverse normal CDF for p in [1e-10, 1 - 1e-10], 1 ulp-class (max |z - mpmath| 8.9e-16, the same as SciPy's ndtri):
+//   z = sqrt(2) x f(w),   x = 2p - 1,   w = -ln(4 p (1 - p)) = -ln(1 - x^2),   f = erfinv(x) / x,
+// with f a degree-24 polynomial in (w - 3.125) for w < 6.25 (|x| < 0.99903: 99.9 % of the points, so a wave almost
+// never runs the other branch) and a degree-22 polynomial in (sqrt(w) - 3.6) beyond (the form of Giles, "Approximating
+// the erfinv function"; the coefficients are our own Chebyshev fits in 50-digit arithmetic, tools/fit_ndtri.py).  The
+// coefficients sit in constant memory so that they reach the fma as SGPR pairs (as literals each needs a v_mov_b64 and
+// the kernel 187 VGPRs).  One 33-instruction log + 24 fma on the main path, against ~280 instructions of the two-region
+// rational AS241 (whose tail, 15 % of the points, made nearly every wave execute both branches).
+constexpr double kNdtriSplit = 6.25, kNdtriCentreA = 3.125, kNdtriCentreB = 3.6;
+__constant__ double kNdtriA[25] = {
+    1.6536545626831027, 0.24015818242558834, -0.006033670871426851,
+    -0.0007407025341546431, 0.00018673420801981186, -1.3882523393957483e-05,
+    -1.3654691758785656e-06, 4.23478816822246e-07, -2.907039127564132e-08,
+    -4.1126604371632185e-09, 1.051223377050429e-09, -5.414303283919504e-11,
+    -1.2978805369932565e-11, 2.6305268312595183e-12, -8.07192593899004e-14,
+    -4.0020031087558496e-14, 6.521333511502239e-15, -3.94018812230432e-17,
+    -1.2215637192404172e-16, 1.5510787009902526e-17, 6.075050702072414e-19,
+    -3.4734793888538036e-19, 1.999259988861535e-20, 3.194015548136271e-21,
+    -3.5932028927020693e-22};
+__constant__ double kNdtriB[23] = {
+    3.4362534068011823, 1.0079663489656199, 0.0027173235759475095,
+    -0.0016859071965492362, 0.0008108055595869524, -0.0004643688234153306,
+    0.00029446662482508865, -0.00016564226708733703, 6.88768166250667e-05,
+    -1.432355652527823e-05, -4.919733756599446e-06, 6.028709084915152e-06,
+    -2.649609589349179e-06, 4.028386034223256e-07, 2.3426178285459596e-07,
+    -1.8359599682240365e-07, 5.6435684203616095e-08, -2.4148392054837038e-09,
+    -7.067895448044831e-09, 4.403960698499458e-09, -8.643938352702886e-10,
+    -3.63258949542749e-10, 1.57703474090927e-10};
+
+// -ln t for t in (2^-1000, 1]: frexp, m in [sqrt(1/2), sqrt(2)), ln m = 2 atanh(s) with s = (m - 1)/(m + 1) as 2s + s^3 Q(s^2),
+// Q of degree 6 (5.6e-17 absolute on ln m; tools/fit_ndtri.py), the division by a v_rcp_f64 seed with two Newton rounds and a
+// residual correction, e ln 2 in two pieces: ~33 instructions where the library's correctly rounded log spends ~75.
+__constant__ double kLogQ[7] = {0.666666666666667, 0.39999999999886615, 0.28571428631764334, 0.2222221019926421, 0.18182956608063458, 0.15329500754204178, 0.14643628601909797};
+
+__device__ __forceinline__ double neg_log_unit(double t) {
+    double m = __builtin_amdgcn_frexp_mant(t);          // t = m 2^e, m in [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(t);
+    const bool low = m < 0.70710678118654752;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double num = m - 1.0, den = m + 1.0;
+    double r = __builtin_amdgcn_rcp(den);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    double s = num * r;
+    s = __builtin_fma(__builtin_fma(-den, s, num), r, s);
+    const double u = s * s;
+    double q = kLogQ[6];
+#pragma unroll
+    for (int k = 5; k >= 0; --k) q = __builtin_fma(q, u, kLogQ[k]);
+    const double ln_m = __builtin_fma(s * u, q, s + s);
+    const double ed = static_cast<double>(e);
+    return -__builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, ln_m));
+}
+
+__device__ __forceinline__ double ndtri_w(double p) {
+    const double x = 2.0 * p - 1.0;                    // exact for p = k 2^-30
+    const double w = neg_log_unit(4.0 * p * (1.0 - p));        // p (1 - p) straight from p: no cancellation at either end
+    double f;
+    if (w < kNdtriSplit) {
+        const double t = w - kNdtriCentreA;
+        f = kNdtriA[24];
+#pragma unroll
+        for (int k = 23; k >= 0; --k) f = __builtin_fma(f, t, kNdtriA[k]);
     } else {
-        r -= 5.0;
-        const double num = (((((((2.01033439929228813265e-7 * r + 2.71155556874348757815e-5) * r + 1.24266094738807843860e-3) * r +
-                                2.65321895265761230930e-2) * r + 2.96560571828504891230e-1) * r + 1.78482653991729133580e0) * r +
-                             5.46378491116411436990e0) * r + 6.65790464350110377720e0);
-        const double den = (((((((2.04426310338993978564e-15 * r + 1.42151175831644588870e-7) * r + 1.84631831751005468180e-5) * r +
-                                7.86869131145613259100e-4) * r + 1.48753612908506148525e-2) * r + 1.36929880922735805310e-1) * r +
-                             5.99832206555887937690e-1) * r + 1.0);
-        val = num / den;
+        const double t = sqrt(w) - kNdtriCentreB;
+        f = kNdtriB[22];
+#pragma unroll
+        for (int k = 21; k >= 0; --k) f = __builtin_fma(f, t, kNdtriB[k]);
     }
-    return q < 0.0 ? -val : val;
+    return 1.4142135623730951 * x * f;
 }
 
 struct QmcRange {
@@ -1421,7 +1455,7 @@ __global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contr
             for (int b = 0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);   // x ^ (row & mask), one v_bitop3_b32
             double u = static_cast<double>(x) * 9.313225746154785e-10;      // 2^-30
             u = fmin(fmax(u, 1e-10), 1.0 - 1e-10);
-            zsum += ndtri_as241(u);
+            zsum += ndtri_w(u);
         }
         const double st = exp(c.a + c.vol * zsum);
         if constexpr (MODE == kTerminal) {

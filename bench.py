@@ -116,6 +116,7 @@ def main():
     streams = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
     K_steps, W = args.steps, args.warmup
     slots = torch.zeros((max(K_steps, W, 32), 3), dtype=torch.float64, device="cuda")
+    host_slots = torch.zeros(slots.shape, dtype=torch.float64).pin_memory()
 
     def fence():
         if use_dist:
@@ -145,9 +146,10 @@ def main():
                 w.wait()
         for st in use:
             main_stream.wait_stream(st)
-        res = slots[:steps].cpu()            # D2H of the triples, inside the timed region
+        host_slots[:steps].copy_(slots[:steps], non_blocking=True)     # D2H of the triples (pinned), inside the timed region
         fence()
         dt = time.perf_counter() - t0
+        res = host_slots[:steps].clone()
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         if use_dist:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -203,6 +203,7 @@ def main():
                        "parallelism": f"path-sharded x{world}" + (", 1 RCCL all-reduce of (sum,sumsq,n) per step" if world > 1 else "")},
             "serial": {"value": path_steps * K_steps / serial_elapsed, "ms_per_step": serial_elapsed / K_steps * 1e3, "streams": 1,
                        "what": "the same K pricings back to back on one stream (no overlap between launches)"},
+            "payoff_samples_per_s": 2 * n_global * K_steps / elapsed,      # the antithetic mirror doubles the payoff samples, not the path-steps
             "accuracy": {"bs_price": bs, "max_abs_err_over_sigma": worst, "payoffs_per_step": 2 * n_global},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_TLANEOPS, "unit": "Tlane-op/s",
                          "frac": achieved / PEAK_TLANEOPS, "traffic": traffic, "traffic_unit": "bytes per launch",

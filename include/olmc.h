@@ -329,8 +329,10 @@ int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_
  * and their total milliseconds since the last reset. */
 int olmc_profile_enable(int on);
 /* Tuning knob for A/B measurements (results never change, only the launch shape):
- *   OLMC_TUNE_GRID_CAP  max workgroups per launch, 0 = default (larger jobs grid-stride) */
-enum { OLMC_TUNE_GRID_CAP = 2 };
+ *   OLMC_TUNE_GRID_CAP   max workgroups per launch, 0 = default (larger jobs grid-stride)
+ *   OLMC_TUNE_QMC_BLOCK  Sobol kernels: 0 = eight consecutive points per thread from 2^20 points on (default),
+ *                        1 = always, -1 = never (one point per thread) */
+enum { OLMC_TUNE_GRID_CAP = 2, OLMC_TUNE_QMC_BLOCK = 4 };
 int olmc_tune(int knob, int value);
 int olmc_profile_reset(void);
 int olmc_kernel_time(int64_t* launches, double* total_ms);

@@ -431,6 +431,7 @@ def normals(seed: int, path_offset: int, n_paths: int, n_steps: int) -> np.ndarr
 
 
 TUNE_GRID_CAP = 2
+TUNE_QMC_BLOCK = 4
 
 
 def tune(knob: int, value: int) -> None:

@@ -169,6 +169,7 @@ int bulk_reserve(DeviceCtx* c, size_t bytes) {
 
 // Tuning knob (olmc_tune): 0 = automatic.
 int g_grid_cap = 0;          // OLMC_TUNE_GRID_CAP: max workgroups per launch (0 = kMaxGrid)
+int g_qmc_block = 0;         // OLMC_TUNE_QMC_BLOCK: 0 = by size, 1 = always eight points per thread, -1 = never
 
 // Launch geometry: one workgroup per 256 paths, handed out by the hardware dispatcher
 // (measured faster than a fixed 8-workgroups-per-CU grid-stride); beyond kMaxGrid
@@ -1285,14 +1286,20 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
     qr.count = n_paths;
     qr.dims = dims;
     qr.mirror = mirror ? 1 : 0;
-    const int32_t grid = grid_for(n_paths);
+    // from 2^20 points on (measured crossover between 2^19 and 2^20) a thread takes an aligned block of eight
+    // consecutive points (european_qmc_block_kernel); smaller launches need the threads more than the saved instructions
+    const bool blocks = g_qmc_block > 0 ? true : (g_qmc_block < 0 ? false : n_paths >= (int64_t(1) << 20));
+    const int64_t units = blocks ? (point_offset + n_paths + kQmcBlock - 1) / kQmcBlock - point_offset / kQmcBlock : n_paths;
+    const int32_t grid = grid_for(units);
     ReduceWs ws{};
     if (!terminal_host) {
         rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
         if (rc) return rc;
-        hipLaunchKernelGGL((european_qmc_kernel<kReduce>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, nullptr);
+        if (blocks) hipLaunchKernelGGL((european_qmc_block_kernel<kReduce>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, nullptr);
+        else hipLaunchKernelGGL((european_qmc_kernel<kReduce>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, nullptr);
     } else {
-        hipLaunchKernelGGL((european_qmc_kernel<kTerminal>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
+        if (blocks) hipLaunchKernelGGL((european_qmc_block_kernel<kTerminal>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
+        else hipLaunchKernelGGL((european_qmc_kernel<kTerminal>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
     }
     rc = after_launch(c, c->stream);
     if (rc) return rc;
@@ -1482,6 +1489,7 @@ extern "C" int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths,
 // ================================================================ measurement ====
 extern "C" int olmc_tune(int knob, int value) {
     if (knob == OLMC_TUNE_GRID_CAP && value >= 0) { g_grid_cap = value; return OLMC_OK; }
+    if (knob == OLMC_TUNE_QMC_BLOCK && value >= -1 && value <= 1) { g_qmc_block = value; return OLMC_OK; }
     return fail(OLMC_ERR_ARG, "unknown tuning knob or value");
 }
 

@@ -1469,6 +1469,62 @@ __global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contr
     if constexpr (MODE != kTerminal) block_then_grid_reduce<2>(acc, ws);
 }
 
+// Large launches: a thread takes the EIGHT consecutive points k0 .. k0+7 of an aligned block (k0 = 8j).  In Gray-code order
+// consecutive points differ in one direction number, and inside an aligned block of eight those are sv[t][0], [1], [0], [2],
+// [0], [1], [0] -- the same for every lane, i.e. scalar operands: 28 + 7 v_bitop3 / v_xor per dimension for eight points
+// instead of 8 x 30, and eight independent inverse normals in flight per thread.  Same points, same uniforms, same z as
+// the one-point kernel; only the order in which a workgroup's payoffs are added differs (1e-16).
+constexpr int kQmcBlock = 8;
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void european_qmc_block_kernel(QmcRange qr, Contract c, const uint32_t* __restrict__ sv,
+                                                                    const uint32_t* __restrict__ shift, ReduceWs ws,
+                                                                    double* __restrict__ terminal) {
+    double acc[2] = {0.0, 0.0};
+    const uint64_t base = qr.first / kQmcBlock;                                   // first block (may start before qr.first)
+    const uint64_t last = qr.first + static_cast<uint64_t>(qr.count);             // one past the last point
+    const int64_t n_blocks = static_cast<int64_t>((last + kQmcBlock - 1) / kQmcBlock - base);
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n_blocks; i += stride) {
+        const uint64_t k0 = (base + static_cast<uint64_t>(i)) * kQmcBlock;
+        const uint32_t gray = static_cast<uint32_t>(k0 ^ (k0 >> 1));              // bits 0 and 1 are zero for k0 = 8j
+        uint32_t mask[kSobolBits];
+#pragma unroll
+        for (int b = 2; b < kSobolBits; ++b) mask[b] = 0u - ((gray >> b) & 1u);
+        double zsum[kQmcBlock];
+#pragma unroll
+        for (int p = 0; p < kQmcBlock; ++p) zsum[p] = 0.0;
+        for (int32_t t = 0; t < qr.dims; ++t) {
+            const uint32_t* __restrict__ row = sv + static_cast<size_t>(t) * kSobolBits;
+            uint32_t x = shift[t];
+#pragma unroll
+            for (int b = 2; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);
+#pragma unroll
+            for (int p = 0; p < kQmcBlock; ++p) {
+                if (p) x ^= row[__builtin_ctz(static_cast<unsigned>(p))];          // gray(k + 1) = gray(k) ^ (1 << ctz(k + 1))
+                double u = static_cast<double>(x) * 9.313225746154785e-10;      // 2^-30
+                u = fmin(fmax(u, 1e-10), 1.0 - 1e-10);
+                zsum[p] += ndtri_w(u);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < kQmcBlock; ++p) {
+            const uint64_t k = k0 + static_cast<uint64_t>(p);
+            if (k < qr.first || k >= last) continue;                            // the ragged ends of the range
+            const double st = exp(c.a + c.vol * zsum[p]);
+            if constexpr (MODE == kTerminal) {
+                const int64_t at = static_cast<int64_t>(k - qr.first);
+                terminal[at] = st;
+                if (qr.mirror) terminal[qr.count + at] = exp(c.a - c.vol * zsum[p]);
+            } else {
+                const double xpay = fmax(c.sign * (st - c.strike), 0.0);
+                acc[0] += xpay; acc[1] += xpay * xpay;
+            }
+        }
+    }
+    if constexpr (MODE != kTerminal) block_then_grid_reduce<2>(acc, ws);
+}
+
 // Power sums of the normal stream (validation tap): out[m-1] = sum over paths and steps of z^m, m = 1..4,
 // z = kZScale * z' in fp64.  At 2^36 normals the second moment is resolved to 5e-6: a bias hunt.
 __global__ __launch_bounds__(kBlock) void normal_moments_kernel(PathRange pr, ReduceWs ws) {

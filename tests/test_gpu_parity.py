@@ -609,3 +609,28 @@ def test_repeated_calls_do_not_leak_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20, (free0, free1)
+
+
+def test_qmc_eight_point_blocks_give_the_same_points():
+    """european_qmc_block_kernel (eight consecutive Sobol points per thread, Gray-code increments) against the one-point
+    kernel: identical terminal prices bit for bit at ragged offsets and sizes, prices equal to reduction-order rounding."""
+    try:
+        for N, M, off in ((1, 1, 0), (7, 3, 0), (8, 5, 8), (9, 2, 7), (1000, 16, 3), (4097, 64, 12345), (70_000, 7, 1)):
+            tables = ol.monte_carlo.sobol_tables(M, 11)
+            _hip.tune(_hip.TUNE_QMC_BLOCK, -1)
+            one = _hip.european_qmc_terminal(100.0, 1.0, 0.05, 0.2, 0.01, N, *tables, point_offset=off)
+            mir = _hip.european_qmc_terminal(100.0, 1.0, 0.05, 0.2, 0.01, N, *tables, point_offset=off, antithetic=True)
+            _hip.tune(_hip.TUNE_QMC_BLOCK, 1)
+            assert np.array_equal(_hip.european_qmc_terminal(100.0, 1.0, 0.05, 0.2, 0.01, N, *tables, point_offset=off), one), (N, M, off)
+            assert np.array_equal(_hip.european_qmc_terminal(100.0, 1.0, 0.05, 0.2, 0.01, N, *tables, point_offset=off, antithetic=True), mir)
+        for N, M in ((2**14, 16), (100_003, 33)):
+            _hip.tune(_hip.TUNE_QMC_BLOCK, -1)
+            a = ol.MonteCarloPricer(N, M, 42, ol.MCMethod.QMC).price(*ATM, "call", return_error=True)
+            _hip.tune(_hip.TUNE_QMC_BLOCK, 1)
+            b = ol.MonteCarloPricer(N, M, 42, ol.MCMethod.QMC).price(*ATM, "call", return_error=True)
+            assert b.price == pytest.approx(a.price, rel=1e-13) and b.std_error == pytest.approx(a.std_error, rel=1e-10) and b.n_paths == a.n_paths
+        _hip.tune(_hip.TUNE_QMC_BLOCK, 0)
+        big = ol.MonteCarloPricer(2**20, 8, 42, ol.MCMethod.QMC).price(*ATM, "call", return_error=True)     # the size that switches by itself
+        assert abs(big.price - BS_CALL) < 2e-3
+    finally:
+        _hip.tune(_hip.TUNE_QMC_BLOCK, 0)

@@ -151,7 +151,7 @@ def test_argument_errors():
 # ------------------------------------------------------------------ QMC (scrambled Sobol)
 def test_qmc_matches_reference_sobol(golden):
     """The device expands SciPy's own scrambled direction matrix, so uniforms are bit-equal to the
-    reference's and the only differences are the inverse normal (AS241 vs Cephes ndtri, ~4e-15)
+    reference's and the only differences are the inverse normal (ndtri_w vs Cephes ndtri, ~2e-15)
     and the summation order over dims: prices agree to 1e-10 relative, not merely 3 sigma."""
     for c in golden["price"]:
         N, M, seed, method = c["ctor"]

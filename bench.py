@@ -22,6 +22,7 @@ compute is libolmc.so through its C ABI.  With N > 1 launch as
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N`.
 """
 import argparse
+import faulthandler
 import json
 import os
 import sys
@@ -34,7 +35,7 @@ WORK = dict(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, q=0.0, option_type="call
 PATHS_PER_GPU = 1_000_000
 N_STEPS = 252
 SEED = 42
-PRE_WARM_MS = 150.0
+PRE_WARM_PASSES = 45          # x 32 pricings of 1M x 252: about 150 ms of load before anything is timed
 LANE_OPS_PER_PATH_STEP = 32          # algorithmic VALU lane-ops per path-step
 PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 (MI355X_MICROARCH.md: 157.3 TF fp32 = 2 flop/FMA)
 
@@ -70,6 +71,7 @@ def cpu_baseline():
 
 
 def main():
+    faulthandler.enable()             # a crash in native code (HIP, RCCL) leaves a Python traceback on stderr instead of nothing
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
@@ -155,12 +157,14 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item()), res
 
-    # Before the W warm-up steps the device gets PRE_WARM_MS of the same work (untimed, reported as `pre_warm_ms`): an idle
+    # Before the W warm-up steps the device gets ~150 ms of the same work (untimed, reported as `pre_warm_ms`): an idle
     # MI355X needs tens of milliseconds of load to reach its sustained clocks, and with a small K / W the timed region would
     # otherwise measure the ramp (kernel 130 us instead of 108 us), not the steady state the default K = 400 sees anyway.
+    # (a FIXED number of passes, not a clock: every rank must enter the same collectives the same number of times)
     t_pre = time.perf_counter()
-    while (time.perf_counter() - t_pre) * 1e3 < PRE_WARM_MS:
+    for _ in range(PRE_WARM_PASSES):
         run_pass(len(streams), 32, SEED + 5000, False)
+    pre_warm_ms = (time.perf_counter() - t_pre) * 1e3
     run_pass(len(streams), W, SEED + 1000, False)                 # warm-up (untimed)
     elapsed, results = run_pass(len(streams), K_steps, SEED, False)          # THE timed K steps -> `value`
     # same K steps on ONE stream with HIP events around every path kernel: launches do not overlap here, so
@@ -194,7 +198,7 @@ def main():
         out = {
             "metric": "MC path-steps/sec (1M paths \u00d7 252 steps Euro call); price vs BS |err|/\u03c3",      # BASELINE.json, verbatim
             "value": value, "unit": "path-steps/s", "n_gpus": world, "steps": K_steps, "warmup": W,
-            "ms_per_step": elapsed / K_steps * 1e3, "pre_warm_ms": PRE_WARM_MS, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / K_steps * 1e3, "pre_warm_ms": pre_warm_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 normals / f64 prices", "data": "synthetic",
             "config": {"workload": f"European call S0=100 K=100 sigma=0.2 r=0.05 T=1, {paths_per_gpu:,} paths x 252 steps per GPU, "
                                    "antithetic on (two payoffs per path), Philox4x32-10 + Box-Muller in registers, on-device reduction",

@@ -84,6 +84,11 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 control flow on a ONE-GPU box (never the driver's mode): OLMC_BENCH_REHEARSAL=1 puts every
+    # rank on device 0 and carries the collectives over gloo (RCCL refuses two ranks on one device).
+    rehearsal = os.environ.get("OLMC_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -103,7 +108,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     info = _hip.device_info()
 
     paths_per_gpu = args.paths_per_gpu
@@ -204,7 +212,8 @@ def main():
                                    "antithetic on (two payoffs per path), Philox4x32-10 + Box-Muller in registers, on-device reduction",
                        "paths_per_gpu": paths_per_gpu, "n_steps": N_STEPS, "global_paths": n_global,
                        "streams": len(streams),
-                       "parallelism": f"path-sharded x{world}" + (", 1 RCCL all-reduce of (sum,sumsq,n) per step" if world > 1 else "")},
+                       "parallelism": f"path-sharded x{world}" + (", 1 RCCL all-reduce of (sum,sumsq,n) per step" if world > 1 else "")
+                                      + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")},
             "serial": {"value": path_steps * K_steps / serial_elapsed, "ms_per_step": serial_elapsed / K_steps * 1e3, "streams": 1,
                        "what": "the same K pricings back to back on one stream (no overlap between launches)"},
             "payoff_samples_per_s": 2 * n_global * K_steps / elapsed,      # the antithetic mirror doubles the payoff samples, not the path-steps

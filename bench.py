@@ -143,6 +143,11 @@ def main():
                 _hip.european_shard_dev(S, K, T, r, sigma, q, True, lo, hi - lo, N_STEPS, seed0 + k, True,
                                         slots[k].data_ptr(), st.cuda_stream)
                 if use_dist:
+                    if rehearsal:
+                        # gloo's asynchronous CUDA all-reduce was measured NOT to be ordered behind work queued on the
+                        # caller's current stream (3 and 4 ranks: stale triples, 1e-3 off); RCCL's is (it is enqueued
+                        # behind the current stream by construction), so only the rehearsal pays for a host sync here
+                        st.synchronize()
                     return dist.all_reduce(slots[k], op=dist.ReduceOp.SUM, async_op=True)
             return None
 
@@ -180,10 +185,18 @@ def main():
     serial_elapsed, serial_results = run_pass(1, K_steps, SEED, True)
     launches, kernel_ms = _hip.kernel_time()
     _hip.profile_enable(False)
-    if world == 1:
-        assert torch.equal(results, serial_results), "overlapped and serial passes must give identical bits"
-    else:   # the collective's summation order is RCCL's
-        assert torch.allclose(results, serial_results, rtol=1e-13, atol=0)
+    # The overlapped pass must reproduce the serial pass: bit for bit on one GPU, to the collective's summation order on
+    # several.  If it ever does not (a stream-ordering problem between a kernel and its all-reduce), the overlapped timing
+    # is not a measurement: the line then reports the SERIAL pass as `value` and says so, instead of dying without a line.
+    rel = ((results - serial_results).abs() / serial_results.abs().clamp_min(1e-300)).max().item()
+    overlap_ok = rel == 0.0 if world == 1 else rel <= 1e-13
+    if use_dist:
+        flag = torch.tensor([0.0 if overlap_ok else 1.0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        overlap_ok = flag.item() == 0.0
+    if not overlap_ok:
+        print(f"[bench] rank {rank}: overlapped and serial passes differ by {rel:.3e} relative -- reporting the serial pass", file=sys.stderr)
+        elapsed, results = serial_elapsed, serial_results
 
     # every step's result must be a valid price
     bs = ol.black_scholes(S, K, T, r, sigma, "call", q)
@@ -216,6 +229,7 @@ def main():
                                       + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")},
             "serial": {"value": path_steps * K_steps / serial_elapsed, "ms_per_step": serial_elapsed / K_steps * 1e3, "streams": 1,
                        "what": "the same K pricings back to back on one stream (no overlap between launches)"},
+            "overlap_consistent": overlap_ok,
             "payoff_samples_per_s": 2 * n_global * K_steps / elapsed,      # the antithetic mirror doubles the payoff samples, not the path-steps
             "accuracy": {"bs_price": bs, "max_abs_err_over_sigma": worst, "payoffs_per_step": 2 * n_global},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_TLANEOPS, "unit": "Tlane-op/s",

@@ -219,7 +219,7 @@ def main():
         out = {
             "metric": "MC path-steps/sec (1M paths \u00d7 252 steps Euro call); price vs BS |err|/\u03c3",      # BASELINE.json, verbatim
             "value": value, "unit": "path-steps/s", "n_gpus": world, "steps": K_steps, "warmup": W,
-            "ms_per_step": elapsed / K_steps * 1e3, "pre_warm_ms": pre_warm_ms, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / K_steps * 1e3, "pre_warm_ms": pre_warm_ms, "pre_warm_pricings": PRE_WARM_PASSES * 32, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 normals / f64 prices", "data": "synthetic",
             "config": {"workload": f"European call S0=100 K=100 sigma=0.2 r=0.05 T=1, {paths_per_gpu:,} paths x 252 steps per GPU, "
                                    "antithetic on (two payoffs per path), Philox4x32-10 + Box-Muller in registers, on-device reduction",

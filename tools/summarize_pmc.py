@@ -38,8 +38,10 @@ def main(root):
                 if l.startswith('{"metric"'):
                     line = json.loads(l)
                     steps, warm = line["steps"], line["warmup"]
+        pre = line.get("pre_warm_pricings", 0) if line else 0
+        dur = dur[pre:]                                   # untimed clock pre-warm of bench.py
         if steps and len(dur) >= warm + 2 * steps:
-            print("\n## the default command's european_path_kernel dispatches by bench.py phase (us)")
+            print(f"\n## the default command's european_path_kernel dispatches by bench.py phase (us), after {pre} pre-warm dispatches")
             for name, a, b in (("warm-up, 8 streams", 0, warm), ("timed K steps, 8 streams (-> value)", warm, warm + steps),
                                ("same K steps, 1 stream (-> serial, roofline)", warm + steps, warm + 2 * steps), ("blocking price() calls (-> sync_call)", warm + 2 * steps, len(dur))):
                 seg = dur[a:b]

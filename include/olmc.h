@@ -292,6 +292,12 @@ int olmc_jump_paths(double S, double T, double r, double sigma, double q, int mo
 int olmc_european_qmc(double S, double K, double T, double r, double sigma, double q, int is_call,
                       int64_t point_offset, int64_t n_paths, int32_t dims,
                       const uint32_t* sv, const uint32_t* shift, int32_t bits, olmc_stats* out);
+/* price_with_control_variate on the Sobol points (monte_carlo.py:154-186 with MCMethod.QMC): the five moments
+ * and the estimate, reduced on the device like olmc_european_cv. */
+int olmc_european_qmc_cv(double S, double K, double T, double r, double sigma, double q, int is_call,
+                         int64_t point_offset, int64_t n_paths, int32_t dims,
+                         const uint32_t* sv, const uint32_t* shift, int32_t bits, olmc_cv_moments* out);
+
 /* antithetic != 0: simulate_gbm_qmc_antithetic (gbm_qmc.py:49-76), 2 * n_paths values [pos | neg]. */
 int olmc_european_qmc_terminal(double S, double T, double r, double sigma, double q,
                                int64_t point_offset, int64_t n_paths, int32_t dims,

@@ -67,6 +67,7 @@ PROTOTYPES = {
     "olmc_european_cv_shard": (_I, _SIX + [_I, _I64, _I64, _I32, _U64T, _I, C.POINTER(CvMoments)]),
     "olmc_combine_cv": (_I, [C.POINTER(CvMoments), _I32, _D, _D, _D, _D, C.POINTER(CvMoments)]),
     "olmc_european_qmc": (_I, _SIX + [_I, _I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, C.POINTER(Stats)]),
+    "olmc_european_qmc_cv": (_I, _SIX + [_I, _I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, C.POINTER(CvMoments)]),
     "olmc_european_qmc_terminal": (_I, [_D] * 5 + [_I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, _I, C.POINTER(_D)]),
     "olmc_asian": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_barrier": (_I, _SIX + [_I, _D, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
@@ -318,6 +319,15 @@ def european_qmc(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv: np.ndarr
     out = Stats()
     _check(lib().olmc_european_qmc(S, K, T, r, sigma, q, int(is_call), int(point_offset), int(n_paths), int(sv.shape[0]),
                                    psv, psh, int(sv.shape[1]), C.byref(out)))
+    return out
+
+
+def european_qmc_cv(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv: np.ndarray, shift: np.ndarray, point_offset: int = 0) -> CvMoments:
+    sv, psv = _u32(sv)
+    shift, psh = _u32(shift)
+    out = CvMoments()
+    _check(lib().olmc_european_qmc_cv(S, K, T, r, sigma, q, int(is_call), int(point_offset), int(n_paths), int(sv.shape[0]), psv, psh,
+                                      int(sv.shape[1]), C.byref(out)))
     return out
 
 

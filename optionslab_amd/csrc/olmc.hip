@@ -1250,7 +1250,7 @@ extern "C" int olmc_jump_paths(double S, double T, double r, double sigma, doubl
 namespace {
 int run_qmc(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t point_offset,
             int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
-            olmc_stats* out, double* terminal_host, int mirror = 0) {
+            olmc_stats* out, double* terminal_host, int mirror = 0, olmc_cv_moments* cv = nullptr) {
     if (!sv || !shift) return fail(OLMC_ERR_ARG, "null pointer");
     if (bits != kSobolBits) return fail(OLMC_ERR_ARG, "only 30-bit Sobol tables (SciPy's default) are supported");
     if (dims < 1 || dims > 21201) return fail(OLMC_ERR_ARG, "dims must be in [1, 21201]");
@@ -1292,7 +1292,12 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
     const int64_t units = blocks ? (point_offset + n_paths + kQmcBlock - 1) / kQmcBlock - point_offset / kQmcBlock : n_paths;
     const int32_t grid = grid_for(units);
     ReduceWs ws{};
-    if (!terminal_host) {
+    if (cv) {
+        rc = make_ws(c, c->stream, grid, 5, c->d_result, -1.0, &ws);
+        if (rc) return rc;
+        if (blocks) hipLaunchKernelGGL((european_qmc_block_kernel<kControlVariate>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, nullptr);
+        else hipLaunchKernelGGL((european_qmc_kernel<kControlVariate>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, nullptr);
+    } else if (!terminal_host) {
         rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
         if (rc) return rc;
         if (blocks) hipLaunchKernelGGL((european_qmc_block_kernel<kReduce>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, nullptr);
@@ -1309,11 +1314,30 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
     }
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
+    if (cv) {       // device moments are of the UNdiscounted payoff x; d = disc * x (monte_carlo.py:175)
+        const double disc = std::exp(-r * T);
+        cv->sum_d = disc * c->h_result[0];
+        cv->sum_s = c->h_result[1];
+        cv->sum_dd = disc * disc * c->h_result[2];
+        cv->sum_ss = c->h_result[3];
+        cv->sum_ds = disc * c->h_result[4];
+        cv->n = n_paths;
+        cv_finish(S, T, r, q, cv);
+        if (poisoned(S, K, T, r, sigma, q)) cv->value = std::nan("");
+        return OLMC_OK;
+    }
     finish_stats(c->h_result[0], c->h_result[1], n_paths, r, T, out);
     if (poisoned(S, K, T, r, sigma, q)) nan_stats(n_paths, out);
     return OLMC_OK;
 }
 }  // namespace
+
+extern "C" int olmc_european_qmc_cv(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                    int64_t point_offset, int64_t n_paths, int32_t dims, const uint32_t* sv,
+                                    const uint32_t* shift, int32_t bits, olmc_cv_moments* out) {
+    if (!out) return fail(OLMC_ERR_ARG, "null pointer");
+    return run_qmc(S, K, T, r, sigma, q, is_call, point_offset, n_paths, dims, sv, shift, bits, nullptr, nullptr, 0, out);
+}
 
 extern "C" int olmc_european_qmc(double S, double K, double T, double r, double sigma, double q, int is_call,
                                  int64_t point_offset, int64_t n_paths, int32_t dims, const uint32_t* sv,

@@ -1439,7 +1439,8 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contract c, const uint32_t* __restrict__ sv,
                                                               const uint32_t* __restrict__ shift, ReduceWs ws,
                                                               double* __restrict__ terminal) {
-    double acc[2] = {0.0, 0.0};
+    constexpr int NV = MODE == kControlVariate ? 5 : 2;
+    double acc[NV] = {};
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < qr.count; i += stride) {
         const uint64_t k = qr.first + static_cast<uint64_t>(i);
@@ -1462,11 +1463,10 @@ __global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contr
             terminal[i] = st;
             if (qr.mirror) terminal[qr.count + i] = exp(c.a - c.vol * zsum);
         } else {
-            const double x = fmax(c.sign * (st - c.strike), 0.0);
-            acc[0] += x; acc[1] += x * x;
+            add_sample<MODE>(acc, fmax(c.sign * (st - c.strike), 0.0), st);
         }
     }
-    if constexpr (MODE != kTerminal) block_then_grid_reduce<2>(acc, ws);
+    if constexpr (MODE != kTerminal) block_then_grid_reduce<NV>(acc, ws);
 }
 
 // Large launches: a thread takes the EIGHT consecutive points k0 .. k0+7 of an aligned block (k0 = 8j).  In Gray-code order
@@ -1480,7 +1480,8 @@ template <int MODE>
 __global__ __launch_bounds__(kBlock) void european_qmc_block_kernel(QmcRange qr, Contract c, const uint32_t* __restrict__ sv,
                                                                     const uint32_t* __restrict__ shift, ReduceWs ws,
                                                                     double* __restrict__ terminal) {
-    double acc[2] = {0.0, 0.0};
+    constexpr int NV = MODE == kControlVariate ? 5 : 2;
+    double acc[NV] = {};
     const uint64_t base = qr.first / kQmcBlock;                                   // first block (may start before qr.first)
     const uint64_t last = qr.first + static_cast<uint64_t>(qr.count);             // one past the last point
     const int64_t n_blocks = static_cast<int64_t>((last + kQmcBlock - 1) / kQmcBlock - base);
@@ -1517,12 +1518,11 @@ __global__ __launch_bounds__(kBlock) void european_qmc_block_kernel(QmcRange qr,
                 terminal[at] = st;
                 if (qr.mirror) terminal[qr.count + at] = exp(c.a - c.vol * zsum[p]);
             } else {
-                const double xpay = fmax(c.sign * (st - c.strike), 0.0);
-                acc[0] += xpay; acc[1] += xpay * xpay;
+                add_sample<MODE>(acc, fmax(c.sign * (st - c.strike), 0.0), st);
             }
         }
     }
-    if constexpr (MODE != kTerminal) block_then_grid_reduce<2>(acc, ws);
+    if constexpr (MODE != kTerminal) block_then_grid_reduce<NV>(acc, ws);
 }
 
 // Power sums of the normal stream (validation tap): out[m-1] = sum over paths and steps of z^m, m = 1..4,

@@ -125,13 +125,9 @@ class MonteCarloPricer:
                                    seed: Optional[int] = None) -> float:
         """Terminal spot as control, E[S_T] = S e^{(r-q)T} (monte_carlo.py:154-186)."""
         actual_seed = seed if seed is not None else self.seed
-        if self.method == MCMethod.QMC:   # five moments on the host from the device terminal array (N values)
-            st = self._simulate(S, T, r, sigma, q, seed)
-            x = np.maximum(st - K, 0.0) if option_type == "call" else np.maximum(K - st, 0.0)
-            d = np.exp(-r * T) * x
-            cov = np.cov(d, st)
-            beta = cov[0, 1] / cov[1, 1] if cov[1, 1] > 1e-10 else 0.0
-            return float(np.mean(d) - beta * (np.mean(st) - S * np.exp((r - q) * T)))
+        if self.method == MCMethod.QMC:   # the same five-moment reduction on the Sobol points (N samples, no mirror)
+            sv, shift = sobol_tables(self.num_steps, actual_seed)
+            return float(_hip.european_qmc_cv(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift).value)
         m = _hip.european_cv(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(),
                              actual_seed, True)
         return float(m.value)

@@ -51,7 +51,7 @@ enum {
 };
 
 enum { OLMC_STREAM_GBM = 0, OLMC_STREAM_HESTON = 1, OLMC_STREAM_JUMP = 2, OLMC_STREAM_KOU = 3 };   /* counter word 3 (stream_tag); batches use tag = contract index */
-enum { OLMC_AVG_ARITHMETIC = 0, OLMC_AVG_GEOMETRIC = 1 };
+enum { OLMC_AVG_ARITHMETIC = 0, OLMC_AVG_GEOMETRIC = 1, OLMC_AVG_ARITHMETIC_FAST = 2 };
 #define OLMC_MAX_BATCH 16                        /* parameter sets per fused launch      */
 
 /* Result of one reduction.  Mirrors what MonteCarloPricer.price() derives from
@@ -192,7 +192,13 @@ int olmc_combine_cv(const olmc_cv_moments* parts, int32_t n_parts, double S, dou
 /* ---- Asian (average over t = 1..M, t = 0 excluded) ------------------------
  * Replaces ExoticOptionBase._generate_paths + AsianOption.price
  * (src/pricing_models/exotic_options.py:40-67, 97-131): running sum of S_t
- * (arithmetic) or of log S_t (geometric) in registers, no path matrix. */
+ * (arithmetic) or of log S_t (geometric) in registers, no path matrix.
+ * avg_kind: OLMC_AVG_ARITHMETIC      the reference's arithmetic -- fp64 cumulative log-return advanced date by date,
+ *                                    one full fp64 exponential per date (np.exp(log_S), :62-67), fp64 running sum;
+ *           OLMC_AVG_GEOMETRIC       sum of log S_t, fp64 across groups of 16 dates;
+ *           OLMC_AVG_ARITHMETIC_FAST opt-in: one hardware v_exp_f32 per date on an exponent rounded to fp32
+ *                                    (~1e-7 relative per term, unbiased; 2e-6 on a price against the fp64 form,
+ *                                    CRN finite differences smooth: tests/test_gpu_exotics.py) -- 1.6x faster. */
 int olmc_asian(double S, double K, double T, double r, double sigma, double q, int is_call,
                int avg_kind, int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
                int antithetic, olmc_stats* out);
@@ -337,8 +343,13 @@ int olmc_profile_enable(int on);
 /* Tuning knob for A/B measurements (results never change, only the launch shape):
  *   OLMC_TUNE_GRID_CAP   max workgroups per launch, 0 = default (larger jobs grid-stride)
  *   OLMC_TUNE_QMC_BLOCK  Sobol kernels: 0 = eight consecutive points per thread from 2^20 points on (default),
- *                        1 = always, -1 = never (one point per thread) */
-enum { OLMC_TUNE_GRID_CAP = 2, OLMC_TUNE_QMC_BLOCK = 4 };
+ *                        1 = always, -1 = never (one point per thread)
+ * and two fault-injection knobs for the tests of the error paths (0 = off, the default):
+ *   OLMC_TUNE_FAULT_SHARD  k > 0: shard k - 1 of olmc_multi_gpu_european fails before it launches
+ *   OLMC_TUNE_FORCE_NV     v > 0: reduction workspaces REPORT a capacity of v values per workgroup row, so a kernel
+ *                          that reduces more than v values trips its device-side bound check (result NaN, nothing
+ *                          written out of bounds, library usable afterwards) */
+enum { OLMC_TUNE_GRID_CAP = 2, OLMC_TUNE_QMC_BLOCK = 4, OLMC_TUNE_FAULT_SHARD = 5, OLMC_TUNE_FORCE_NV = 6 };
 int olmc_tune(int knob, int value);
 int olmc_profile_reset(void);
 int olmc_kernel_time(int64_t* launches, double* total_ms);

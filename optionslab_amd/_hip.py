@@ -21,7 +21,7 @@ from .exceptions import AccelerationError
 # $OLMC_LIBRARY overrides the in-tree build (A/B measurements of alternative builds)
 LIBRARY_PATH = os.environ.get("OLMC_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libolmc.so")
 MAX_BATCH = 16
-AVG_ARITHMETIC, AVG_GEOMETRIC = 0, 1
+AVG_ARITHMETIC, AVG_GEOMETRIC, AVG_ARITHMETIC_FAST = 0, 1, 2
 _U64 = (1 << 64) - 1
 
 
@@ -342,9 +342,11 @@ def european_qmc_terminal(S, T, r, sigma, q, n_paths: int, sv: np.ndarray, shift
 
 
 def asian(S, K, T, r, sigma, q, is_call: bool, geometric: bool, n_paths: int, n_steps: int, seed: int,
-          antithetic: bool = False, path_offset: int = 0) -> Stats:
+          antithetic: bool = False, path_offset: int = 0, fast: bool = False) -> Stats:
+    """fast=True (arithmetic only): the fp32-exponent kernel (OLMC_AVG_ARITHMETIC_FAST); default = reference precision."""
     out = Stats()
-    _check(lib().olmc_asian(S, K, T, r, sigma, q, int(is_call), AVG_GEOMETRIC if geometric else AVG_ARITHMETIC,
+    kind = AVG_GEOMETRIC if geometric else (AVG_ARITHMETIC_FAST if fast else AVG_ARITHMETIC)
+    _check(lib().olmc_asian(S, K, T, r, sigma, q, int(is_call), kind,
                             int(path_offset), int(n_paths), int(n_steps), seed64(seed), int(antithetic), C.byref(out)))
     return out
 
@@ -442,6 +444,8 @@ def normals(seed: int, path_offset: int, n_paths: int, n_steps: int) -> np.ndarr
 
 TUNE_GRID_CAP = 2
 TUNE_QMC_BLOCK = 4
+TUNE_FAULT_SHARD = 5
+TUNE_FORCE_NV = 6
 
 
 def tune(knob: int, value: int) -> None:

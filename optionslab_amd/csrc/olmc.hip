@@ -10,6 +10,7 @@
 
 #include <dlfcn.h>
 #include <hip/hip_ext.h>
+#include <rccl/rccl.h>      // types and enum values only: the library itself is dlopen()ed on first multi-GPU use
 
 #include <algorithm>
 #include <climits>
@@ -64,7 +65,7 @@ struct DeviceCtx {
         hipEvent_t done = nullptr;     // recorded after the slot's latest launch
         bool used = false;
     };
-    static constexpr int kSlots = 4;
+    static constexpr int kSlots = 8;    // = the deepest overlap bench.py's `pipelined` pass asks for (--streams 8)
     WsSlot slots[kSlots];
     int next_slot = 0, cur_slot = 0;
     double* h_result = nullptr;      // pinned + mapped [kMaxNV + 1]: the last workgroup writes the sums straight to the host
@@ -170,6 +171,8 @@ int bulk_reserve(DeviceCtx* c, size_t bytes) {
 // Tuning knob (olmc_tune): 0 = automatic.
 int g_grid_cap = 0;          // OLMC_TUNE_GRID_CAP: max workgroups per launch (0 = kMaxGrid)
 int g_qmc_block = 0;         // OLMC_TUNE_QMC_BLOCK: 0 = by size, 1 = always eight points per thread, -1 = never
+int g_fault_shard = 0;       // OLMC_TUNE_FAULT_SHARD: k > 0 makes shard k - 1 of olmc_multi_gpu_european fail (tests of the error path)
+int g_force_nv = 0;          // OLMC_TUNE_FORCE_NV: > 0 sizes the next workspaces for this many values per row (test of the device guard)
 
 // Launch geometry: one workgroup per 256 paths, handed out by the hardware dispatcher
 // (measured faster than a fixed 8-workgroups-per-CU grid-stride); beyond kMaxGrid
@@ -207,7 +210,7 @@ int make_ws(DeviceCtx* c, hipStream_t stream, int32_t grid, int nv, double* d_ou
     ws->counters = sl.counters;
     ws->out = d_out;
     ws->tail = tail;
-    ws->row_capacity = sl.cap;
+    ws->row_capacity = g_force_nv > 0 ? static_cast<uint64_t>(grid) * g_force_nv : sl.cap;   // the knob UNDER-reports (test of the guard)
     return OLMC_OK;
 }
 
@@ -335,8 +338,16 @@ void finish_stats(double sum, double sumsq, int64_t n, double r, double T, olmc_
 // The reference validates nothing at call time (tests/test_monte_carlo.py:143-151 skip it): a negative
 // spot or a NaN input makes np.log / the arithmetic produce NaN, np.maximum PROPAGATES it, and the price
 // is NaN.  Device fmax() would swallow the NaN (payoff 0), so such inputs are answered on the host.
+// T < 0 is the same case one step later: sqrt(dt) is NaN in the reference (gbm_numpy.py:37) and so is every price.
 bool poisoned(double S, double K, double T, double r, double sigma, double q) {
-    return std::isnan(S + K + T + r + sigma + q) || S < 0.0;
+    return std::isnan(S + K + T + r + sigma + q) || S < 0.0 || T < 0.0;
+}
+
+// ln of a barrier LEVEL the reference compares in price space (exotic_options.py:455-480): a level <= 0 lies below
+// every price, so `S_t >= level` always holds and `S_t < level` never does -- which is what -inf gives in log space
+// (log() itself would answer NaN for a negative level and every comparison would be false).
+double log_level(double level) {
+    return level > 0.0 ? std::log(level) : (std::isnan(level) ? level : -INFINITY);
 }
 
 void nan_stats(int64_t n, olmc_stats* out) {
@@ -789,7 +800,8 @@ extern "C" int olmc_asian(double S, double K, double T, double r, double sigma, 
                           int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic,
                           olmc_stats* out) {
     if (!out) return fail(OLMC_ERR_ARG, "null pointer");
-    if (avg_kind != OLMC_AVG_ARITHMETIC && avg_kind != OLMC_AVG_GEOMETRIC) return fail(OLMC_ERR_ARG, "bad avg_kind");
+    if (avg_kind != OLMC_AVG_ARITHMETIC && avg_kind != OLMC_AVG_GEOMETRIC && avg_kind != OLMC_AVG_ARITHMETIC_FAST)
+        return fail(OLMC_ERR_ARG, "bad avg_kind");
     int rc = check_paths(path_offset, n_local, n_steps);
     if (rc) return rc;
     DeviceCtx* c = nullptr;
@@ -814,11 +826,13 @@ extern "C" int olmc_asian(double S, double K, double T, double r, double sigma, 
     const EventPair* timed = nullptr;
     rc = prof_pair(c, &ep, &timed);
     if (rc) return rc;
-    const bool anti = antithetic != 0, geo = avg_kind == OLMC_AVG_GEOMETRIC;
+    const bool anti = antithetic != 0, geo = avg_kind == OLMC_AVG_GEOMETRIC, fast = avg_kind == OLMC_AVG_ARITHMETIC_FAST;
     if (anti && geo) launch_timed(asian_kernel<true, true>, dim3(grid), dim3(kBlock), c->stream, timed, pr, ac, ws);
-    else if (anti) launch_timed(asian_kernel<true, false>, dim3(grid), dim3(kBlock), c->stream, timed, pr, ac, ws);
     else if (geo) launch_timed(asian_kernel<false, true>, dim3(grid), dim3(kBlock), c->stream, timed, pr, ac, ws);
-    else launch_timed(asian_kernel<false, false>, dim3(grid), dim3(kBlock), c->stream, timed, pr, ac, ws);
+    else if (anti && fast) launch_timed(asian_kernel<true, false>, dim3(grid), dim3(kBlock), c->stream, timed, pr, ac, ws);
+    else if (fast) launch_timed(asian_kernel<false, false>, dim3(grid), dim3(kBlock), c->stream, timed, pr, ac, ws);
+    else if (anti) launch_timed(asian_exp64_kernel<true>, dim3(grid), dim3(kBlock), c->stream, timed, pr, ac, ws);      // reference precision
+    else launch_timed(asian_exp64_kernel<false>, dim3(grid), dim3(kBlock), c->stream, timed, pr, ac, ws);
     rc = after_launch(c, c->stream);
     if (rc) return rc;
     rc = sync_or_recover(c, c->stream);
@@ -889,7 +903,7 @@ extern "C" int olmc_lookback(double S, double K, double T, double r, double sigm
 namespace {
 template <typename Launch>
 int run_structured(int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic, double r_for_discount,
-                   double T, bool poisoned_inputs, olmc_stats* out, Launch launch, int nv = 2) {
+                   double T, bool poisoned_inputs, olmc_stats* out, Launch launch, int nv = 2, double* raw_sums = nullptr) {
     if (!out) return fail(OLMC_ERR_ARG, "null pointer");
     int rc = check_paths(path_offset, n_local, n_steps);
     if (rc) return rc;
@@ -912,6 +926,7 @@ int run_structured(int64_t path_offset, int64_t n_local, int32_t n_steps, uint64
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r_for_discount, T, out);
+    if (raw_sums) for (int m = 0; m < nv; ++m) raw_sums[m] = c->h_result[m];     // still under c->mu
     if (poisoned_inputs) nan_stats(out->n, out);
     return OLMC_OK;
 }
@@ -927,9 +942,9 @@ extern "C" int olmc_autocallable(double S, double T, double r, double sigma, dou
     const double dt = T / n_steps;
     ac.drift = (r - q - 0.5 * sigma * sigma) * dt;
     ac.vol = sigma * std::sqrt(dt);
-    ac.log_autocall = std::log(autocall_barrier);
-    ac.log_coupon = std::log(coupon_barrier);
-    ac.log_ki = std::log(ki_barrier);
+    ac.log_autocall = log_level(autocall_barrier);
+    ac.log_coupon = log_level(coupon_barrier);
+    ac.log_ki = log_level(ki_barrier);
     ac.obs_freq = observation_freq;
     ac.n_obs = n_steps / observation_freq;                      // len(range(f, M + 1, f))
     ac.coupon_unit = coupon_rate * T / ac.n_obs;                // coupon_rate * ((i+1)/n_obs) * T, accrued per observation (:459-460)
@@ -1199,6 +1214,10 @@ int make_jump(double S, double K, double T, double r, double sigma, double q, in
     jc.strike = K;
     jc.sign = is_call ? 1.0 : -1.0;
     jc.lam_dt = lambda_j * dt;
+    // the device draws the jump count by inversion from p0 = exp(-lambda dt), at most kJumpCap = 64 jumps per step:
+    // exact to 1e-15 of probability mass up to lambda dt = 20, silently truncated beyond (and p0 underflows at 745).
+    // The reference's np.random.poisson has no such limit, so larger rates are refused rather than mispriced.
+    if (jc.lam_dt > 20.0) return fail(OLMC_ERR_ARG, "lambda_j * T / n_steps must be <= 20 jumps per step: raise n_steps");
     jc.p0 = std::exp(-jc.lam_dt);
     *out = jc;
     return OLMC_OK;
@@ -1306,12 +1325,13 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
         if (blocks) hipLaunchKernelGGL((european_qmc_block_kernel<kTerminal>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
         else hipLaunchKernelGGL((european_qmc_kernel<kTerminal>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
     }
-    rc = after_launch(c, c->stream);
-    if (rc) return rc;
-    if (terminal_host) {
+    if (terminal_host) {            // no reduction workspace was handed out: only the launch status matters
+        HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(terminal_host, d_term, term_bytes, hipMemcpyDeviceToHost, c->stream));
         return sync_or_recover(c, c->stream);
     }
+    rc = after_launch(c, c->stream);
+    if (rc) return rc;
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     if (cv) {       // device moments are of the UNdiscounted payoff x; d = disc * x (monte_carlo.py:175)
@@ -1354,22 +1374,21 @@ extern "C" int olmc_european_qmc_terminal(double S, double T, double r, double s
 }
 
 // ======================================================== multi-GPU (RCCL) ====
-// librccl is resolved lazily so single-GPU users never load it.
+// librccl is resolved lazily (dlopen) so single-GPU users never load it; the TYPES and ENUM VALUES come from
+// <rccl/rccl.h> at compile time, so a header / library mismatch is a build-time matter, not a guessed constant.
 namespace {
 struct Rccl {
     void* lib = nullptr;
-    int (*CommInitAll)(void**, int, const int*) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char* (*GetErrorString)(int) = nullptr;
-    std::vector<void*> comms;      // cached communicator set
-    int n_comms = 0;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::vector<ncclComm_t> comms;      // cached communicator set ...
+    std::vector<int> devices;           // ... of exactly this device list
 };
 Rccl g_rccl;
-constexpr int kNcclFloat64 = 8;    // ncclDouble (rccl.h: ncclFloat64 = 8)
-constexpr int kNcclSum = 0;        // ncclSum
 
 int rccl_load() {
     if (g_rccl.lib) return OLMC_OK;
@@ -1383,19 +1402,81 @@ int rccl_load() {
     g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(dlsym(h, "ncclGroupStart"));
     g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
     g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-    if (!g_rccl.CommInitAll || !g_rccl.AllReduce || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.CommDestroy)
+    if (!g_rccl.CommInitAll || !g_rccl.AllReduce || !g_rccl.GroupStart || !g_rccl.GroupEnd || !g_rccl.CommDestroy) {
+        dlclose(h);
         return fail(OLMC_ERR_RCCL, "librccl is missing required symbols");
+    }
     g_rccl.lib = h;
     return OLMC_OK;
 }
 
 #define RCCL_TRY(expr)                                                                                   \
     do {                                                                                                 \
-        int r_ = (expr);                                                                                 \
-        if (r_ != 0)                                                                                     \
+        ncclResult_t r_ = (expr);                                                                        \
+        if (r_ != ncclSuccess)                                                                           \
             return fail(OLMC_ERR_RCCL, std::string(#expr) + ": " +                                       \
                                            (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error")); \
     } while (0)
+
+// Whatever way olmc_multi_gpu_european leaves (any of its error returns included), the calling thread gets back
+// the library device and the HIP current device it came in with, and every stream a kernel was already queued on
+// has been drained, so no launch of a failed call is still running behind the caller's next one.
+struct MultiGpuScope {
+    int saved_lib_device, saved_hip_device = -1;
+    std::vector<int> launched;          // devices with work queued by this call
+    explicit MultiGpuScope(int lib_device) : saved_lib_device(lib_device) { (void)hipGetDevice(&saved_hip_device); }
+    ~MultiGpuScope() {
+        for (int d : launched)
+            if (g_ctx[d] && hipSetDevice(d) == hipSuccess) {
+                if (hipStreamSynchronize(g_ctx[d]->stream) != hipSuccess) ws_recover(g_ctx[d]);
+            }
+        t_device = saved_lib_device;
+        if (saved_hip_device >= 0) (void)hipSetDevice(saved_hip_device);
+        (void)hipGetLastError();
+    }
+};
+
+int multi_gpu_body(MultiGpuScope& scope, double S, double K, double T, double r, double sigma, double q, int is_call,
+                   int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic, int n_gpus, olmc_stats* out) {
+    int rc = rccl_load();
+    if (rc) return rc;
+    std::vector<int> devs(n_gpus);
+    for (int d = 0; d < n_gpus; ++d) devs[d] = d;
+    if (g_rccl.devices != devs) {                  // the cache is keyed on the device LIST, not its length
+        for (ncclComm_t cm : g_rccl.comms) if (cm) g_rccl.CommDestroy(cm);
+        g_rccl.comms.assign(n_gpus, nullptr);
+        g_rccl.devices.clear();
+        RCCL_TRY(g_rccl.CommInitAll(g_rccl.comms.data(), n_gpus, devs.data()));
+        g_rccl.devices = devs;
+    }
+    // contiguous global path ranges: rank d owns [d*N/P, (d+1)*N/P)  (SURVEY §8e)
+    std::vector<double*> triples(n_gpus, nullptr);
+    for (int d = 0; d < n_gpus; ++d) {
+        DeviceCtx* c = g_ctx[d];
+        HIP_TRY(hipSetDevice(d));
+        triples[d] = c->d_triple;
+        const int64_t lo = n_paths * d / n_gpus, hi = n_paths * (d + 1) / n_gpus;
+        t_device = d;
+        if (g_fault_shard == d + 1) return fail(OLMC_ERR_HIP, "injected shard failure (OLMC_TUNE_FAULT_SHARD)");
+        scope.launched.push_back(d);
+        rc = olmc_european_shard_dev(S, K, T, r, sigma, q, is_call, lo, hi - lo, n_steps, seed, antithetic, triples[d], c->stream);
+        if (rc) return rc;
+    }
+    RCCL_TRY(g_rccl.GroupStart());
+    for (int d = 0; d < n_gpus; ++d)
+        RCCL_TRY(g_rccl.AllReduce(triples[d], triples[d], 3, ncclFloat64, ncclSum, g_rccl.comms[d], g_ctx[d]->stream));
+    RCCL_TRY(g_rccl.GroupEnd());
+    double host[3] = {0, 0, 0};
+    for (int d = n_gpus - 1; d >= 0; --d) {
+        HIP_TRY(hipSetDevice(d));
+        if (d == 0) HIP_TRY(hipMemcpyAsync(host, triples[0], sizeof(host), hipMemcpyDeviceToHost, g_ctx[0]->stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx[d]->stream));
+    }
+    scope.launched.clear();                        // everything drained: nothing left for the guard to wait for
+    finish_stats(host[0], host[1], static_cast<int64_t>(host[2]), r, T, out);
+    if (poisoned(S, K, T, r, sigma, q)) nan_stats(out->n, out);
+    return OLMC_OK;
+}
 }  // namespace
 
 extern "C" int olmc_multi_gpu_european(double S, double K, double T, double r, double sigma, double q, int is_call,
@@ -1410,47 +1491,11 @@ extern "C" int olmc_multi_gpu_european(double S, double K, double T, double r, d
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count < n_gpus)
         return fail(OLMC_ERR_HIP, "requested " + std::to_string(n_gpus) + " GPUs, " + std::to_string(count) + " visible");
-    const int saved_device = t_device;
-    for (int d = 0; d < n_gpus; ++d) { rc = olmc_init(d); if (rc) return rc; }
-    t_device = saved_device >= 0 ? saved_device : 0;
     static std::mutex multi_mu;
     std::lock_guard<std::mutex> lock(multi_mu);
-    rc = rccl_load();
-    if (rc) return rc;
-    if (g_rccl.n_comms != n_gpus) {
-        for (void* cm : g_rccl.comms) g_rccl.CommDestroy(cm);
-        g_rccl.comms.assign(n_gpus, nullptr);
-        g_rccl.n_comms = 0;
-        std::vector<int> devs(n_gpus);
-        for (int d = 0; d < n_gpus; ++d) devs[d] = d;
-        RCCL_TRY(g_rccl.CommInitAll(g_rccl.comms.data(), n_gpus, devs.data()));
-        g_rccl.n_comms = n_gpus;
-    }
-    // contiguous global path ranges: rank d owns [d*N/P, (d+1)*N/P)  (SURVEY §8e)
-    std::vector<double*> triples(n_gpus, nullptr);
-    for (int d = 0; d < n_gpus; ++d) {
-        DeviceCtx* c = g_ctx[d];
-        HIP_TRY(hipSetDevice(d));
-        triples[d] = c->d_triple;
-        const int64_t lo = n_paths * d / n_gpus, hi = n_paths * (d + 1) / n_gpus;
-        t_device = d;
-        rc = olmc_european_shard_dev(S, K, T, r, sigma, q, is_call, lo, hi - lo, n_steps, seed, antithetic, triples[d], c->stream);
-        if (rc) return rc;
-    }
-    RCCL_TRY(g_rccl.GroupStart());
-    for (int d = 0; d < n_gpus; ++d)
-        RCCL_TRY(g_rccl.AllReduce(triples[d], triples[d], 3, kNcclFloat64, kNcclSum, g_rccl.comms[d], g_ctx[d]->stream));
-    RCCL_TRY(g_rccl.GroupEnd());
-    double host[3] = {0, 0, 0};
-    for (int d = n_gpus - 1; d >= 0; --d) {
-        HIP_TRY(hipSetDevice(d));
-        if (d == 0) HIP_TRY(hipMemcpyAsync(host, triples[0], sizeof(host), hipMemcpyDeviceToHost, g_ctx[0]->stream));
-        HIP_TRY(hipStreamSynchronize(g_ctx[d]->stream));
-    }
-    t_device = saved_device >= 0 ? saved_device : 0;
-    HIP_TRY(hipSetDevice(t_device));
-    finish_stats(host[0], host[1], static_cast<int64_t>(host[2]), r, T, out);
-    return OLMC_OK;
+    MultiGpuScope scope(t_device >= 0 ? t_device : (g_default_device >= 0 ? g_default_device : 0));
+    for (int d = 0; d < n_gpus; ++d) { rc = olmc_init(d); if (rc) return rc; }      // olmc_init moves t_device: the guard puts it back
+    return multi_gpu_body(scope, S, K, T, r, sigma, q, is_call, n_paths, n_steps, seed, antithetic, n_gpus, out);
 }
 
 // ============================================================ validation taps ====
@@ -1478,16 +1523,10 @@ extern "C" int olmc_philox_words(uint64_t seed, int64_t path_offset, int64_t n_p
 extern "C" int olmc_normal_moments(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps, double* out4) {
     if (!out4) return fail(OLMC_ERR_ARG, "null pointer");
     olmc_stats dummy;
-    int rc = run_structured(path_offset, n_paths, n_steps, seed, 0, 0.0, 1.0, false, &dummy,
-                            [&](int32_t grid, hipStream_t st, const EventPair* timed, const PathRange& pr, const ReduceWs& ws) {
-                                launch_timed(normal_moments_kernel, dim3(grid), dim3(kBlock), st, timed, pr, ws);
-                            }, 4);
-    if (rc) return rc;
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
-    if (rc) return rc;
-    for (int m = 0; m < 4; ++m) out4[m] = c->h_result[m];     // still there: the next launch has not happened (same thread)
-    return OLMC_OK;
+    return run_structured(path_offset, n_paths, n_steps, seed, 0, 0.0, 1.0, false, &dummy,
+                          [&](int32_t grid, hipStream_t st, const EventPair* timed, const PathRange& pr, const ReduceWs& ws) {
+                              launch_timed(normal_moments_kernel, dim3(grid), dim3(kBlock), st, timed, pr, ws);
+                          }, 4, out4);
 }
 
 extern "C" int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps, float* out_host) {
@@ -1514,6 +1553,8 @@ extern "C" int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths,
 extern "C" int olmc_tune(int knob, int value) {
     if (knob == OLMC_TUNE_GRID_CAP && value >= 0) { g_grid_cap = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_QMC_BLOCK && value >= -1 && value <= 1) { g_qmc_block = value; return OLMC_OK; }
+    if (knob == OLMC_TUNE_FAULT_SHARD && value >= 0 && value <= kMaxDevices) { g_fault_shard = value; return OLMC_OK; }
+    if (knob == OLMC_TUNE_FORCE_NV && value >= 0 && value <= kMaxNV) { g_force_nv = value; return OLMC_OK; }
     return fail(OLMC_ERR_ARG, "unknown tuning knob or value");
 }
 

@@ -31,13 +31,18 @@ class AsianOption:
     def price(self, n_paths: int = 100000, n_steps: int = 252,
               avg_type: Literal["arithmetic", "geometric"] = "arithmetic",
               option_type: Literal["call", "put"] = "call", antithetic: bool = False,
-              return_error: bool = False):
+              return_error: bool = False, precision: Literal["fp64", "fp32"] = "fp64"):
+        """precision (additive, arithmetic average only): "fp64" = the reference's arithmetic (fp64 cumulative
+        log-return, one fp64 exponential per monitoring date, :62-67); "fp32" = the opt-in fast kernel (one
+        hardware fp32 exponential per date: ~2e-6 on the price, 1.6x faster)."""
         if n_paths < 1 or n_steps < 1:
             raise ValueError("n_paths and n_steps must be >= 1")
+        if precision not in ("fp64", "fp32"):
+            raise ValueError("precision must be 'fp64' or 'fp32'")
         # seed=None: the reference leaves the global RandomState unseeded (:51-52) => fresh draw
         seed = self.seed if self.seed is not None else int(np.random.default_rng().integers(0, 2**31))
         st = _hip.asian(self.S, self.K, self.T, self.r, self.sigma, self.q, option_type == "call",
-                        avg_type != "arithmetic", n_paths, n_steps, seed, antithetic)
+                        avg_type != "arithmetic", n_paths, n_steps, seed, antithetic, fast=precision == "fp32")
         if return_error:
             return np.float64(st.price), float(st.std_error)
         return np.float64(st.price)

@@ -20,6 +20,9 @@ from . import _hip
 from .exceptions import AccelerationError
 
 SOBOL_MAX_DIM = 21201            # src/simulation/gbm_qmc.py:29-30
+SOBOL_VALIDATED_SCIPY = "1.15.3"  # the SciPy whose private Sobol tables (_sv, _shift) this layout was validated against
+                                  # (the golden QMC vectors of tests/golden were captured with it); other versions are
+                                  # accepted only if they pass _check_sobol_tables
 _sobol_cache: "OrderedDict[tuple, tuple]" = OrderedDict()
 
 
@@ -35,16 +38,52 @@ def sobol_tables(n_steps: int, seed: int):
     if hit is not None:
         _sobol_cache.move_to_end(key)
         return hit
-    from scipy.stats.qmc import Sobol
+    from scipy.stats import qmc
 
-    eng = Sobol(d=d, scramble=True, seed=seed)
-    if eng.bits != 30 or not hasattr(eng, "_sv") or not hasattr(eng, "_shift"):
-        raise AccelerationError("this SciPy's Sobol engine does not expose 30-bit _sv/_shift tables", backend="hip")
+    eng = qmc.Sobol(d=d, scramble=True, seed=seed)
+    if getattr(eng, "bits", None) != 30 or not hasattr(eng, "_sv") or not hasattr(eng, "_shift"):
+        raise AccelerationError("this SciPy's Sobol engine does not expose 30-bit _sv/_shift tables "
+                                f"(validated with SciPy {SOBOL_VALIDATED_SCIPY})", backend="hip")
     val = (np.ascontiguousarray(eng._sv, dtype=np.uint32), np.ascontiguousarray(eng._shift, dtype=np.uint32))
+    _check_sobol_tables(val, eng, d)
     _sobol_cache[key] = val
     while len(_sobol_cache) > 8:
         _sobol_cache.popitem(last=False)
     return val
+
+
+def expand_sobol_points(sv: np.ndarray, shift: np.ndarray, first: int, count: int) -> np.ndarray:
+    """Host restatement of what the device does with the tables (olmc.h, olmc_european_qmc): point k =
+    shift ^ XOR over the set bits b of gray(k) = k ^ (k >> 1) of sv[:, b]; u = x * 2^-30.  Used only to CHECK the
+    tables against SciPy's own points on a few points, never to price."""
+    out = np.empty((count, sv.shape[0]), dtype=np.float64)
+    for i in range(count):
+        k = first + i
+        g, x, b = k ^ (k >> 1), shift.copy(), 0
+        while g:
+            if g & 1:
+                x ^= sv[:, b]
+            g >>= 1
+            b += 1
+        out[i] = x.astype(np.float64) * 2.0 ** -30
+    return out
+
+
+def _check_sobol_tables(val, eng, d: int) -> None:
+    """`_sv` / `_shift` are SciPy privates: a SciPy release may keep the names and change what they mean, which no
+    hasattr() sees.  So the tables are checked by BEHAVIOUR on every (uncached) construction: the first 8 points
+    expanded from them must equal, bit for bit, the points the very same engine returns from .random(8) (a fresh
+    engine has drawn nothing, so this consumes only `eng`, which is discarded).  Any mismatch disables MCMethod.QMC
+    loudly instead of pricing on a different point set than the reference's."""
+    sv, shift = val
+    if sv.shape != (d, 30) or shift.shape != (d,):
+        raise AccelerationError(f"SciPy Sobol tables have shape {sv.shape} / {shift.shape}, expected ({d}, 30) / ({d},) "
+                                f"(validated with SciPy {SOBOL_VALIDATED_SCIPY})", backend="hip")
+    want = np.asarray(eng.random(8), dtype=np.float64)
+    if not np.array_equal(expand_sobol_points(sv, shift, 0, 8), want):
+        import scipy
+        raise AccelerationError(f"SciPy {scipy.__version__}: the Sobol engine's _sv/_shift tables no longer reproduce its own points "
+                                f"(layout validated with SciPy {SOBOL_VALIDATED_SCIPY}); MCMethod.QMC is unavailable", backend="hip")
 
 
 NUMBA_AVAILABLE = False          # kept for `from ...monte_carlo import NUMBA_AVAILABLE` (monte_carlo.py:189)

@@ -243,6 +243,30 @@ def test_shards_add_up_to_the_whole():
         assert comb.std_error == pytest.approx(whole.std_error, rel=1e-9)
 
 
+def test_config5_eight_shards_of_8m_x_252_equal_the_64m_launch():
+    """BASELINE configs[4] at size on one GPU: 64M paths x 252 steps as the 8 contiguous 8M-path shards the 8 ranks
+    would own (path_offset = k * 8M; gbm_numpy.py:43-51 is the shape being sharded, monte_carlo.py:140-150 the
+    reduction), combined in rank order, against the single 64M-path launch."""
+    S, K, T, r, v = ATM
+    M, per, world, seed = 252, 8_000_000, 8, 42
+    parts = []
+    for k in range(world):
+        lo, hi = ol.sharding.shard_bounds(per * world, k, world)
+        assert (lo, hi) == (k * per, (k + 1) * per)
+        st = _hip.european(S, K, T, r, v, 0.0, True, hi - lo, M, seed, True, path_offset=lo)
+        assert st.n == 2 * per and abs(st.price - BS_CALL) <= 4 * st.std_error        # each shard is itself a valid 8M-path pricing
+        parts.append((st.sum, st.sumsq, st.n))
+    comb = _hip.combine_stats(parts, r, T)
+    whole = _hip.european(S, K, T, r, v, 0.0, True, per * world, M, seed, True)
+    assert comb.n == whole.n == 128_000_000
+    assert comb.price == pytest.approx(whole.price, rel=1e-12)
+    assert comb.std_error == pytest.approx(whole.std_error, rel=1e-9)
+    assert 1.25e-3 < comb.std_error < 1.35e-3                       # SURVEY 8c: se ~ 1.3e-3 at 64M paths
+    assert abs(comb.price - BS_CALL) <= 3 * comb.std_error
+    # the shards are disjoint streams: no two of them may return the same sums
+    assert len({p[0] for p in parts}) == world
+
+
 def test_large_path_offsets_use_the_high_counter_word():
     S, K, T, r, v = ATM
     off = (1 << 32) - 100
@@ -258,6 +282,45 @@ def test_single_process_multi_gpu_entry_point_on_one_gpu():
     assert (a.sum, a.sumsq, a.n, a.price, a.std_error) == (b.sum, b.sumsq, b.n, b.price, b.std_error)
     with pytest.raises(ol.AccelerationError):
         _hip.multi_gpu_european(S, K, T, r, v, 0.0, True, 1000, 4, 5, True, 64)
+
+
+def test_a_failing_shard_leaves_the_thread_and_the_library_usable():
+    """Error returns of olmc_multi_gpu_european go through a scope guard: queued streams drained, the thread's library
+    device and HIP device restored.  A shard is made to fail by the fault-injection knob (one GPU here, so shard 0)."""
+    S, K, T, r, v = ATM
+    before = _hip.european(S, K, T, r, v, 0.0, True, 50_000, 16, 5, True)
+    _hip.tune(_hip.TUNE_FAULT_SHARD, 1)
+    try:
+        with pytest.raises(ol.AccelerationError, match="injected shard failure"):
+            _hip.multi_gpu_european(S, K, T, r, v, 0.0, True, 200_000, 16, 5, True, 1)
+    finally:
+        _hip.tune(_hip.TUNE_FAULT_SHARD, 0)
+    again = _hip.multi_gpu_european(S, K, T, r, v, 0.0, True, 50_000, 16, 5, True, 1)
+    after = _hip.european(S, K, T, r, v, 0.0, True, 50_000, 16, 5, True)
+    assert (before.sum, before.sumsq) == (after.sum, after.sumsq) == (again.sum, again.sumsq)
+    assert _hip.device_info()["device"] == 0
+    with pytest.raises(ol.AccelerationError):               # a bad shard argument (n_steps = 0) is refused before any launch
+        _hip.multi_gpu_european(S, K, T, r, v, 0.0, True, 1000, 0, 5, True, 1)
+    assert _hip.european(S, K, T, r, v, 0.0, True, 50_000, 16, 5, True).sum == before.sum
+
+
+def test_device_side_row_capacity_guard_answers_nan_and_keeps_the_library_usable():
+    """A launch whose rows would not fit the workspace it was given (the r1 fault: NV = 4 rows on an NV = 2 workspace)
+    must not store: olmc_kernels.h grid_reduce answers NaN instead.  The knob makes the workspace REPORT one value per
+    row while really holding enough, so tripping the guard is safe."""
+    S, K, T, r, v = ATM
+    ok = _hip.european(S, K, T, r, v, 0.0, True, 300_000, 8, 3, True)
+    _hip.tune(_hip.TUNE_FORCE_NV, 1)
+    try:
+        bad = _hip.european(S, K, T, r, v, 0.0, True, 300_000, 8, 3, True)
+        assert math.isnan(bad.sum) and math.isnan(bad.price)
+        bad4 = _hip.normal_moments(3, 50_000, 8)             # NV = 4
+        assert math.isnan(bad4[0])
+    finally:
+        _hip.tune(_hip.TUNE_FORCE_NV, 0)
+    again = _hip.european(S, K, T, r, v, 0.0, True, 300_000, 8, 3, True)
+    assert (again.sum, again.sumsq, again.n) == (ok.sum, ok.sumsq, ok.n)
+    assert all(math.isfinite(m) for m in _hip.normal_moments(3, 50_000, 8))
 
 
 # ------------------------------------------------------------------ Greeks
@@ -340,10 +403,42 @@ def test_control_variate(golden):
                                                     (False, "call", False, 3000, 1024), (False, "call", True, 2000, 1023), (True, "call", False, 3000, 1021)]
                          + [(g, "call", a, 300, m) for m in (1, 3, 4, 15, 16, 17, 19, 20, 29, 31, 32, 33) for g, a in ((False, True), (True, False))])
 def test_asian_matches_same_stream_checker(geometric, typ, anti, N, M):
-    st = _hip.asian(100.0, 100.0, 1.0, 0.05, 0.2, 0.02, typ == "call", geometric, N, M, 7, anti)
     sx, sxx, n = po.asian_moments(100.0, 100.0, 1.0, 0.05, 0.2, 0.02, typ == "call", geometric, N, M, 7, anti)
-    assert st.n == n
-    assert st.sum == pytest.approx(sx, rel=REL_STREAM_TOL) and st.sumsq == pytest.approx(sxx, rel=4 * REL_STREAM_TOL)
+    # default = the reference's arithmetic (fp64 cumsum + fp64 exp per date); fast = the opt-in fp32-exponent kernel
+    for fast in ((False,) if geometric else (False, True)):
+        st = _hip.asian(100.0, 100.0, 1.0, 0.05, 0.2, 0.02, typ == "call", geometric, N, M, 7, anti, fast=fast)
+        assert st.n == n
+        assert st.sum == pytest.approx(sx, rel=REL_STREAM_TOL) and st.sumsq == pytest.approx(sxx, rel=4 * REL_STREAM_TOL)
+
+
+def test_asian_fp64_exponent_tracks_the_checker_more_closely_than_the_fp32_one():
+    """Same device normals in both kernels, so what separates them from the fp64 checker beyond the normals' own
+    2e-5 hardware-transcendental error is the per-date exponential: the reference-precision kernel must not be the
+    worse of the two, and the two must agree to the fp32 form's stated 2e-6."""
+    args = (100.0, 100.0, 1.0, 0.05, 0.2, 0.0, True, False, 40_000, 1024, 11, False)
+    sx, _sxx, _n = po.asian_moments(*args)
+    f64, f32 = _hip.asian(*args), _hip.asian(*args, fast=True)
+    assert abs(f64.sum - sx) <= abs(f32.sum - sx) + 1e-9 * sx
+    assert f32.price == pytest.approx(f64.price, rel=2e-6)
+
+
+def test_asian_fp32_exponent_keeps_crn_finite_differences_smooth_at_c4_size():
+    """BASELINE configs[3] (1M paths x 1024 dates).  Common random numbers, the steps of
+    unified_greeks.py:274-277 (h_S = 0.01 S, h_sigma = 0.01): delta, gamma and vega of the fp32-exponent kernel against
+    the fp64 kernel on the SAME normals.  This is the licence under which OLMC_AVG_ARITHMETIC_FAST stays in the library;
+    the default everywhere (AsianOption.price, ExoticAdapter Greeks) is the fp64 kernel regardless."""
+    S, K, T, r, v, q, N, M, seed = 100.0, 100.0, 1.0, 0.05, 0.2, 0.0, 1_000_000, 1024, 42
+    h_s, h_v = 0.01 * S, 0.01
+
+    def greeks(fast):
+        P = lambda s_, v_: _hip.asian(s_, K, T, r, v_, q, True, False, N, M, seed, False, fast=fast).price
+        mid, up, dn, vu, vd = P(S, v), P(S + h_s, v), P(S - h_s, v), P(S, v + h_v), P(S, v - h_v)
+        return dict(price=mid, delta=(up - dn) / (2 * h_s), gamma=(up - 2 * mid + dn) / (h_s * h_s), vega=(vu - vd) / (2 * h_v))
+
+    g64, g32 = greeks(False), greeks(True)
+    assert 5.6 < g64["price"] < 5.9 and 0.5 < g64["delta"] < 0.65 and g64["gamma"] > 0 and 15 < g64["vega"] < 30
+    for name in ("price", "delta", "gamma", "vega"):
+        assert g32[name] == pytest.approx(g64[name], rel=1e-6), (name, g32[name], g64[name])
 
 
 def test_geometric_asian_against_the_exact_discrete_closed_form():

@@ -47,9 +47,9 @@ def test_european_shard(N, M, seed, off, S, K, v, r, q, T, call, anti):
 
 @settings(max_examples=40 * SCALE, **COMMON)
 @given(N=paths, M=steps, seed=seeds, off=offsets, S=spot, K=strike, v=vol, r=rate, q=div, T=mat, call=st.booleans(), anti=st.booleans(),
-       geo=st.booleans())
-def test_asian(N, M, seed, off, S, K, v, r, q, T, call, anti, geo):
-    got = _hip.asian(S, K, T, r, v, q, call, geo, N, M, seed, anti, path_offset=off)
+       geo=st.booleans(), fast=st.booleans())
+def test_asian(N, M, seed, off, S, K, v, r, q, T, call, anti, geo, fast):
+    got = _hip.asian(S, K, T, r, v, q, call, geo, N, M, seed, anti, path_offset=off, fast=fast and not geo)
     sx, sxx, n = po.asian_moments(S, K, T, r, v, q, call, geo, N, M, seed, anti, off)
     assert got.n == n and close(got.sum, sx, 1, n, max(S, K)) and close(got.sumsq, sxx, 4, n, max(S, K), 2)
 

@@ -198,3 +198,56 @@ def test_compat_install_makes_reference_import_paths_resolve_here():
             del sys.modules[k]
         sys.modules.update(saved)
     assert "src.pricing_models.monte_carlo" not in sys.modules or not getattr(sys.modules["src.pricing_models.monte_carlo"], "__optionslab_amd__", False)
+
+
+# ---- MCMethod.QMC leans on SciPy privates (Sobol._sv / ._shift): the guard around them ----
+def test_sobol_tables_reproduce_scipys_own_points():
+    import numpy as np
+    from scipy.stats.qmc import Sobol
+    from optionslab_amd import monte_carlo as mc
+
+    mc._sobol_cache.clear()
+    sv, shift = mc.sobol_tables(16, 42)                      # passes the behavioural self-check on construction
+    assert sv.shape == (16, 30) and shift.shape == (16,) and sv.dtype == np.uint32
+    pts = Sobol(d=16, scramble=True, seed=42).random(64)     # gbm_qmc.py:32-33
+    assert np.array_equal(mc.expand_sobol_points(sv, shift, 0, 64), pts)
+    assert np.array_equal(mc.expand_sobol_points(sv, shift, 37, 5), pts[37:42])
+    import scipy
+    assert mc.SOBOL_VALIDATED_SCIPY.count(".") == 2
+    if scipy.__version__ != mc.SOBOL_VALIDATED_SCIPY:        # another SciPy is fine exactly as long as the check above held
+        assert np.array_equal(mc.expand_sobol_points(sv, shift, 0, 8), pts[:8])
+
+
+@pytest.mark.parametrize("breakage", ["no_tables", "wrong_bits", "reordered_columns", "wrong_shape"])
+def test_sobol_guard_refuses_an_engine_whose_private_tables_changed(monkeypatch, breakage):
+    """A SciPy bump that removes or re-lays-out the private tables must disable QMC loudly (AccelerationError), never
+    price on other points: the guard checks behaviour, not just attribute names."""
+    import numpy as np
+    from scipy.stats import qmc
+    from optionslab_amd import monte_carlo as mc
+
+    real = qmc.Sobol
+
+    class Stub:
+        def __init__(self, d, scramble=True, seed=None):
+            self._eng = real(d=d, scramble=scramble, seed=seed)
+            self.bits = 30 if breakage != "wrong_bits" else 64
+            if breakage != "no_tables":
+                sv = np.array(self._eng._sv)
+                if breakage == "reordered_columns":
+                    sv = sv[:, ::-1]                         # same name, same shape, different meaning
+                if breakage == "wrong_shape":
+                    sv = sv[:, :20]
+                self._sv, self._shift = sv, np.array(self._eng._shift)
+
+        def random(self, n):
+            return self._eng.random(n)
+
+    monkeypatch.setattr(qmc, "Sobol", Stub)
+    mc._sobol_cache.clear()
+    with pytest.raises(ol.AccelerationError) as e:
+        mc.sobol_tables(12, 5)
+    assert e.value.backend == "hip" and mc.SOBOL_VALIDATED_SCIPY in str(e.value)
+    assert not mc._sobol_cache                               # nothing bad was cached
+    monkeypatch.setattr(qmc, "Sobol", real)
+    assert mc.sobol_tables(12, 5)[0].shape == (12, 30)       # and the real engine still works afterwards

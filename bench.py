@@ -1,86 +1,259 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: GBM path-steps/s, European call, 1M paths x 252 steps
-per GPU (BASELINE.json configs[1]), antithetic on, on-device reduction.
+"""bench.py -- headline benchmark: GBM path-steps/s, European call, 1M paths x 252 steps per GPU
+(BASELINE.json configs[1]), antithetic on, on-device reduction.
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one complete pricing of the contract over this rank's block of
-1,000,000 global paths x 252 steps: ONE path kernel with fused on-device reduction ->
-(N > 1: one all-reduce of the 24-byte (sum, sumsq, n) triple over RCCL/xGMI) -> the
-triple lands in a per-step device slot.  The K steps are independent pricing requests;
-they are dealt round-robin to `--streams` HIP streams so the ~15 us tail of one launch
-hides under the head of the next.  The timed region ends with a full synchronise and
-includes the D2H copy of all K results, each of which is then checked (every step's
-price within 4.5 sigma of Black-Scholes).  The same K steps are then repeated on ONE
-stream with a HIP event pair attached to each dispatch (`serial`, and the roofline attribution).  Inputs are scalars, so
-nothing but the results crosses PCIe.  The JSON line also carries `sync_call`:
-the same workload through the blocking MonteCarloPricer.price() API, one host
-round trip per call.
+ONE pass defines the line: a "step" is one complete BLOCKING pricing --
+`MonteCarloPricer.price(S, K, T, r, sigma, "call", seed=..., return_error=True)` at N = 1 (one path kernel with its
+fused reduction, result on the host), and at N > 1 the same thing sharded: this rank's kernel on its block of the
+global paths -> ONE all-reduce of the 24-byte (sum, sumsq, n) triple over RCCL/xGMI -> result on the host of every
+rank.  After W untimed warm-up steps a pass times EXACTLY K steps between barrier + synchronise fences (max over
+ranks); the pass is repeated so that short passes (K = 20 is 2.5 ms) are not a one-shot sample, and
 
-torch is plumbing here (device result slots, stream handle, process group); the
-compute is libolmc.so through its C ABI.  With N > 1 launch as
+    value                  = global paths x 252 x K / median pass time
+    ms_per_step            = median pass time / K
+    roofline.avg_kernel_ms = HIP events attached to the dispatches of those very calls
+
+so `avg_kernel_ms <= ms_per_step` by construction.  `roofline.frac` is an issue-cycle fraction: VALU-active
+SIMD-cycles per launch (rocprofv3 PMC, collected LIVE by a child pass of this script before the parent touches the
+GPU) over the SIMD-cycles of the measured kernel time at the 2.4 GHz peak clock -- <= 1 by construction.  Secondary
+keys: `pipelined` (the same K pricings dealt over --streams HIP streams, tails overlapping), `c3_greeks`, `c4_asian`
+(BASELINE configs[2], [3]; N = 1 only), `c5_weak` / `c5_strong` (configs[4]: 8M paths per GPU, and 64M paths split
+over the ranks), `clock` (shader clock held under the kernel's load, s_memtime / s_memrealtime), `cpu_baseline`.
+
+torch is plumbing here (device result slots, stream handle, process group); the compute is libolmc.so through its
+C ABI.  With N > 1 launch as
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N`.
 """
 import argparse
+import csv
 import faulthandler
+import glob
 import json
+import math
 import os
+import shutil
+import statistics
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORK = dict(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, q=0.0, option_type="call")
+ATM = (100.0, 100.0, 1.0, 0.05, 0.2)
 PATHS_PER_GPU = 1_000_000
 N_STEPS = 252
+ASIAN_STEPS = 1024
+C5_PATHS_PER_GPU = 8_000_000
+C5_TOTAL = 64_000_000
 SEED = 42
 PRE_WARM_PASSES = 45          # x 32 pricings of 1M x 252: about 150 ms of load before anything is timed
-LANE_OPS_PER_PATH_STEP = 32          # algorithmic VALU lane-ops per path-step
-PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12   # 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 (MI355X_MICROARCH.md: 157.3 TF fp32 = 2 flop/FMA)
+PEAK_GHZ = 2.4                # MI355X_MICROARCH.md chip table: max clock 2400 MHz
+N_SIMD = 256 * 4              # 256 CU x 4 SIMD
+LANE_OPS_PER_PATH_STEP = 32   # SURVEY 8(d)'s algorithmic count (kept as a secondary, model figure)
+PEAK_TLANEOPS = N_SIMD * 32 * PEAK_GHZ * 1e9 / 1e12   # 78.6: SIMD-32 x 2.4 GHz (guide: 157.3 TF fp32 vector = 2 flop/FMA);
+                                                      # SURVEY 8(d) assumed 64 lanes x 256 CU x 2.4 GHz = 39.3 (a SIMD-16 machine)
+
+# Static instruction mix of the headline kernel's step loop per Philox block (= 4 normals), read off the gfx950 ISA of
+# this build (hipcc -S), with the issue cost per wave64 instruction measured by
+# tools/valu_microbench.hip at 8 waves/SIMD (profiles/r01_valu_issue_microbench.txt).
+ISSUE_MODEL = {
+    "per_4_normals": {"v_mad_u64_u32": 17, "v_bitop3_b32": 19, "v_cvt_f32_u32+v_fmamk_f32+v_and_or_b32": 6,
+                      "v_log/v_sqrt/v_sin/v_cos_f32": 8, "v_add_f32+v_fma_f32": 4, "v_cvt_f64_f32+v_add_f64 (per 16 normals)": 0.5},
+    "issue_cycles": {"v_mad_u64_u32": 4.4, "v_bitop3_b32": 4.2, "v_cvt_f32_u32+v_fmamk_f32+v_and_or_b32": 4.3,
+                     "v_log/v_sqrt/v_sin/v_cos_f32": 8.2, "v_add_f32+v_fma_f32": 4.0, "v_cvt_f64_f32+v_add_f64 (per 16 normals)": 4.5},
+}
+
+PMC_KERNELS = {         # substring of the demangled kernel name -> key in the JSON
+    "european_path_kernel<1, true, 0, false>": "c2_european",
+    "european_path_kernel<8, true, 0, false>": "c3_fused8",
+    "european_path_kernel<16, true, 0, false>": "c3_fused14",
+    "asian_exp64_kernel<false>": "c4_asian_fp64",
+    "asian_exp64_kernel<true>": "c4_asian_fp64_antithetic",
+    "asian_kernel<false, false>": "c4_asian_fp32",
+    "asian_kernel<true, false>": "c4_asian_fp32_antithetic",
+}
+PMC_PASSES = [("sq", ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]),
+              ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])]
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary
-    (profiles/*_traffic.json; collected with tools/profile_gpu.sh, separate --pmc passes)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+# ------------------------------------------------------------------------------------------------ PMC (child + parent)
+def pmc_child():
+    """The workload rocprofv3 counts: a few launches of every kernel bench.py reports a roofline for.  No torch."""
+    import optionslab_amd as ol
+    p = ol.MonteCarloPricer(PATHS_PER_GPU, N_STEPS, SEED)
+    for i in range(12):
+        p.price(*ATM, "call", seed=SEED + i, return_error=True)
+    for second in (False, True):
+        for _ in range(4):
+            p.greeks(*ATM, "call", include_second_order=second)
+    a = ol.AsianOption(*ATM, seed=SEED)
+    for precision in ("fp64", "fp32"):
+        for anti in (False, True):
+            for _ in range(3):
+                a.price(PATHS_PER_GPU, ASIAN_STEPS, "arithmetic", "call", antithetic=anti, precision=precision)
+    print("pmc-child done", flush=True)
+
+
+def collect_pmc(keep_dir=None):
+    """Runs `rocprofv3 --pmc ... -- python3 bench.py --pmc-child` once per counter pass (separate passes, as the guide
+    prescribes) and returns {key: {counter: mean per dispatch}} -- or {"error": ...}.  Called BEFORE this process touches
+    the GPU."""
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    base = keep_dir or tempfile.mkdtemp(prefix="olmc_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("RANK", None)
+    out = {}
+    t0 = time.perf_counter()
+    for name, counters in PMC_PASSES:
+        d = os.path.join(base, name)
+        cmd = [exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "--",
+               sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child"]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+        except (OSError, subprocess.TimeoutExpired) as e:
+            return {"error": f"pass {name}: {type(e).__name__}: {e}"}
+        if r.returncode != 0 or "pmc-child done" not in r.stdout:
+            return {"error": f"pass {name}: rc {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            return {"error": f"pass {name}: no counter_collection.csv under {d}"}
+        agg = {}
+        for f in files:
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    key = next((k for pat, k in PMC_KERNELS.items() if pat in row["Kernel_Name"]), None)
+                    if key:
+                        agg.setdefault((key, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+        for (key, ctr), vals in agg.items():
+            out.setdefault(key, {})[ctr] = sum(vals) / len(vals)
+            out[key]["dispatches_" + name] = len(vals)
+    out["seconds"] = time.perf_counter() - t0
+    out["source"] = "live: rocprofv3 --kernel-trace --pmc child passes of this run (bench.py --pmc-child), mean per dispatch"
+    if keep_dir:
+        with open(os.path.join(base, "pmc.json"), "w") as f:
+            json.dump(out, f, indent=1)
+    else:
+        shutil.rmtree(base, ignore_errors=True)
+    return out
+
+
+def committed_pmc():
+    """Fallback when the live passes are unavailable: the newest profiles/r*_pmc.json (same layout), labelled as such."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not files:
-        return None, None, None
+        return None
     with open(files[-1]) as f:
         d = json.load(f)
-    return d.get("hbm_bytes_per_launch"), os.path.relpath(files[-1], ROOT), d.get("sq_active_inst_valu_per_launch")
+    d["source"] = f"COMMITTED {os.path.relpath(files[-1], ROOT)} (another run of the same build; the live rocprofv3 passes failed)"
+    return d
 
 
-def cpu_baseline():
-    """Reference-pinned NumPy oracle (oracle/numpy_reference.py) timed on this host: 1 core
-    (NumPy's Generator is serial).  Bounded sample: warm-up at 100k x 252, then one full
-    1M x 252 pricing (about 5-15 s)."""
+def roofline_for(pmc, key, avg_kernel_s, clock_ghz=None):
+    """Issue-cycle roofline of one kernel: VALU-active SIMD-cycles / SIMD-cycles available in the measured kernel time."""
+    c = (pmc or {}).get(key)
+    if not c or "SQ_ACTIVE_INST_VALU" not in c or not avg_kernel_s:
+        return None
+    active = c["SQ_ACTIVE_INST_VALU"] * 4.0            # the counter ticks in quad-cycles, summed over the 1024 SIMDs
+    peak = N_SIMD * PEAK_GHZ * 1e9
+    r = {"bound": "valu", "achieved": active / avg_kernel_s / 1e9, "peak": peak / 1e9, "unit": "G VALU-active SIMD-cycles/s",
+         "frac": active / avg_kernel_s / peak, "avg_kernel_ms": avg_kernel_s * 1e3,
+         "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "valu_active_quad_cycles_per_launch": c["SQ_ACTIVE_INST_VALU"],
+         "cycles_per_valu_inst": (active / c["SQ_INSTS_VALU"]) if c.get("SQ_INSTS_VALU") else None,
+         "waves_per_launch": c.get("SQ_WAVES")}
+    if clock_ghz:
+        r["frac_at_measured_clock"] = active / avg_kernel_s / (N_SIMD * clock_ghz * 1e9)
+    if c.get("GRBM_GUI_ACTIVE"):
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs and spans the dispatch, not just the waves: on ~0.1 ms dispatches it reads
+        # ~8 us long (the guide: "reads high on dispatches shorter than about 0.3 ms"), so this one is a LOWER estimate
+        r["frac_by_grbm_cycles"] = active / (N_SIMD * c["GRBM_GUI_ACTIVE"] / 8.0)
+    fetch, write = c.get("FETCH_SIZE"), c.get("WRITE_SIZE")
+    if fetch is not None and write is not None:
+        # rocprofv3 reports both in KB; gfx950 tallies a 128-B read request as 64 B (MI355X_MICROARCH.md, HBM): x2 on FETCH
+        r["traffic"] = (2.0 * fetch + write) * 1024.0
+        r["traffic_unit"] = "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE)"
+        r["hbm_gbps"] = r["traffic"] / avg_kernel_s / 1e9
+        r["hbm_frac_of_8TBps"] = r["traffic"] / avg_kernel_s / 8e12
+    else:
+        r["traffic"] = None
+    return r
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def _cpu_worker(args):
+    n, seed = args
     from oracle import numpy_reference as orc
-    p = orc.OraclePricer(100_000, N_STEPS, SEED)
-    p.price(WORK["S"], WORK["K"], WORK["T"], WORK["r"], WORK["sigma"], "call")
-    n = 1_000_000
-    t0 = time.perf_counter()
-    res = orc.OraclePricer(n, N_STEPS, SEED).price(WORK["S"], WORK["K"], WORK["T"], WORK["r"], WORK["sigma"], "call",
-                                                   return_error=True)
-    dt = time.perf_counter() - t0
-    return dict(value=n * N_STEPS / dt, unit="path-steps/s", cores=1, kind="port",
-                sample=f"1 x price() at {n} paths x {N_STEPS} steps, NumPy oracle pinned bitwise to the reference "
-                       f"(price {res.price:.6f}); host has {os.cpu_count()} logical cores, NumPy RNG uses 1",
-                seconds=dt)
+    res = orc.OraclePricer(n, N_STEPS, seed).price(WORK["S"], WORK["K"], WORK["T"], WORK["r"], WORK["sigma"], "call", return_error=True)
+    return res.price, res.std_error, res.n_paths
 
 
+def _cpu_ready(_):
+    from oracle import numpy_reference  # noqa: F401  (pays the import inside the pool, outside the timed region)
+    return os.getpid()
+
+
+def cpu_baseline(all_cores=True):
+    """Reference-pinned NumPy oracle (oracle/numpy_reference.py == the reference bit for bit) timed on this host.
+    Headline: 1 core (NumPy's Generator is serial), median of 3 full 1M x 252 pricings after a 100k warm-up.
+    Beside it, labelled: `procs` worker processes each pricing 500k paths with its own seed (embarrassingly parallel)."""
+    from oracle import numpy_reference as orc
+    orc.OraclePricer(100_000, N_STEPS, SEED).price(WORK["S"], WORK["K"], WORK["T"], WORK["r"], WORK["sigma"], "call")
+    n, times, res = 1_000_000, [], None
+    for i in range(3):
+        t0 = time.perf_counter()
+        res = orc.OraclePricer(n, N_STEPS, SEED).price(WORK["S"], WORK["K"], WORK["T"], WORK["r"], WORK["sigma"], "call", return_error=True)
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times)
+    out = dict(value=n * N_STEPS / dt, unit="path-steps/s", cores=1, kind="port",
+               sample=f"median of 3 x price() at {n} paths x {N_STEPS} steps, NumPy oracle pinned bitwise to the reference "
+                      f"(price {res.price:.6f}); host has {os.cpu_count()} logical cores, NumPy's RNG uses 1",
+               seconds=dt, seconds_each=times)
+    if all_cores:
+        try:
+            import concurrent.futures as cf
+            import multiprocessing as mp
+            procs = max(1, min(os.cpu_count() or 1, 16))         # a one-GPU box's CPU share
+            per = 500_000                                        # 1 GB of normals per worker
+            with cf.ProcessPoolExecutor(procs, mp_context=mp.get_context("spawn")) as pool:
+                list(pool.map(_cpu_ready, range(procs)))
+                t0 = time.perf_counter()
+                parts = list(pool.map(_cpu_worker, [(per, SEED + 100 + i) for i in range(procs)]))
+                wall = time.perf_counter() - t0
+            out["all_cores"] = dict(value=procs * per * N_STEPS / wall, unit="path-steps/s", cores=procs, seconds=wall,
+                                    sample=f"{procs} processes x {per} paths x {N_STEPS} steps, distinct seeds, one wall clock "
+                                           f"(mean price {sum(p[0] for p in parts) / procs:.4f})")
+        except Exception as e:      # the baseline beside the baseline must never cost the line
+            out["all_cores"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     faulthandler.enable()             # a crash in native code (HIP, RCCL) leaves a Python traceback on stderr instead of nothing
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--streams", type=int, default=8, help="HIP streams the K pricings are spread over (>= 1)")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=8, help="HIP streams of the secondary `pipelined` pass (>= 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live rocprofv3 counter passes (use under a profiler)")
+    ap.add_argument("--no-extras", action="store_true", help="skip pipelined / C3 / C4 / C5 (profiling runs)")
+    ap.add_argument("--pmc-keep", default=None, help="directory to keep the rocprofv3 CSVs of the live passes in")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--paths-per-gpu", type=int, default=PATHS_PER_GPU,
                     help="default 1,000,000 (BASELINE configs[1]); 8000000 reproduces configs[4]'s 8M-per-GPU shards")
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child()
+    if args.steps < 1 or args.warmup < 0:
+        raise SystemExit("--steps must be >= 1 and --warmup >= 0")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -93,6 +266,20 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     os.environ["OLMC_DEVICE"] = str(local_rank)
+    use_dist = world > 1 or os.environ.get("OLMC_BENCH_FORCE_DIST") == "1"
+
+    # Child-process work first, while this process has not touched the GPU: the live PMC passes and the CPU baseline's pool.
+    pmc, cpu = None, None
+    if world == 1 and rank == 0:
+        if not args.no_pmc:
+            pmc = collect_pmc(args.pmc_keep)
+            if "error" in pmc:
+                print(f"[bench] live PMC passes unavailable: {pmc['error']}", file=sys.stderr)
+                pmc = committed_pmc() or pmc
+        if not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+    elif rank == 0 and not args.no_pmc:
+        pmc = committed_pmc()           # N > 1 ranks run no profiler passes: counters of the committed run of this build, labelled
 
     import torch
     import torch.distributed as dist
@@ -101,8 +288,6 @@ def main():
     from optionslab_amd import _hip, sharding
 
     torch.cuda.set_device(local_rank)
-    # OLMC_BENCH_FORCE_DIST=1 exercises the process-group + all-reduce code path with a single rank
-    use_dist = world > 1 or os.environ.get("OLMC_BENCH_FORCE_DIST") == "1"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -113,161 +298,339 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     info = _hip.device_info()
-
-    paths_per_gpu = args.paths_per_gpu
-    n_global = paths_per_gpu * world
-    lo, hi = sharding.shard_bounds(n_global, rank, world)
     S, K, T, r, sigma, q = (WORK[k] for k in ("S", "K", "T", "r", "sigma", "q"))
-    # The K pricings are independent requests: they are dealt round-robin to `--streams` HIP streams, so
-    # the ~15 us tail of one launch (its last lone workgroup + the reduction chain) hides under the head
-    # of the next.  The library rotates event-guarded reduction workspaces, so launches never share state.
+    bs = ol.black_scholes(S, K, T, r, sigma, "call", q)
     main_stream = torch.cuda.Stream()
     torch.cuda.set_stream(main_stream)
-    streams = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
     K_steps, W = args.steps, args.warmup
-    slots = torch.zeros((max(K_steps, W, 32), 3), dtype=torch.float64, device="cuda")
-    host_slots = torch.zeros(slots.shape, dtype=torch.float64).pin_memory()
+    dbuf = torch.zeros(3, dtype=torch.float64, device="cuda")
+    hbuf = torch.zeros(3, dtype=torch.float64).pin_memory()
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_pass(n_streams, steps, seed0, events):
-        """Enqueue `steps` pricings round-robin over the first n_streams streams; returns (seconds, triples)."""
-        use = streams[:n_streams]
+    def max_over_ranks(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        if rehearsal:
+            torch.cuda.synchronize()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
+    def make_step(n_global):
+        """step(k) -> (price, std_error, n): ONE blocking pricing of n_global paths x 252 steps, result on the host."""
+        if not use_dist:
+            pricer = ol.MonteCarloPricer(n_global, N_STEPS, SEED)
+
+            def step(k):
+                res = pricer.price(S, K, T, r, sigma, "call", seed=SEED + k, return_error=True)     # monte_carlo.py:108-152
+                return res.price, res.std_error, res.n_paths
+            return step
+        lo, hi = sharding.shard_bounds(n_global, rank, world)
+
+        def step(k):
+            st = torch.cuda.current_stream()
+            _hip.european_shard_dev(S, K, T, r, sigma, q, True, lo, hi - lo, N_STEPS, SEED + k, True, dbuf.data_ptr(), st.cuda_stream)
+            if rehearsal:
+                st.synchronize()        # gloo does not order itself behind the caller's stream; RCCL does
+            dist.all_reduce(dbuf, op=dist.ReduceOp.SUM)                  # the ONE collective: 3 x fp64 over RCCL/xGMI
+            hbuf.copy_(dbuf, non_blocking=True)
+            st.synchronize()
+            s, ss, n = hbuf.tolist()
+            price, se = sharding.finalize(s, ss, int(n), r, T)
+            return price, se, int(n)
+        return step
+
+    def timed_passes(step, n_global, steps, warm, min_total_s=0.05, max_passes=25, seed0=0):
+        """warm untimed steps, then passes of EXACTLY `steps` blocking steps, each between fences; max over ranks per pass.
+        Returns (pass times, per-call times of rank 0, avg kernel seconds from the events of these dispatches, launches,
+        worst |price - BS| / se)."""
+        worst, calls, first = 0.0, [], []
+
+        def check(res):
+            nonlocal worst
+            price, se, n = res
+            assert n == 2 * n_global, (n, n_global)
+            worst = max(worst, abs(price - bs) / se)
+
+        for k in range(warm):
+            check(step(seed0 + 100_000 + k))
+        _hip.profile_enable(True)
+        _hip.profile_reset()
+        passes, n_pass = [], None
+        while n_pass is None or len(passes) < n_pass:
+            base = seed0 + len(passes) * steps
+            fence()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                c0 = time.perf_counter()
+                res = step(base + k)
+                calls.append(time.perf_counter() - c0)
+                check(res)
+                if not passes:
+                    first.append(res[0])
+            torch.cuda.synchronize()
+            dt = max_over_ranks(time.perf_counter() - t0)
+            fence()
+            passes.append(dt)
+            if n_pass is None:          # every rank derives the same count from the same max-reduced time
+                n_pass = max(3, min(max_passes, int(math.ceil(min_total_s / max(dt, 1e-9)))))
+        launches, kernel_ms = _hip.kernel_time()
+        _hip.profile_enable(False)
+        avg_kernel_s = kernel_ms / 1e3 / launches if launches else None
+        return passes, calls, avg_kernel_s, launches, worst, first
+
+    # Before anything is timed the device gets ~150 ms of the same work (untimed, `pre_warm_ms`): an idle MI355X needs tens
+    # of milliseconds of load to reach its sustained clocks.  A FIXED count, not a clock: every rank enters the same
+    # collectives the same number of times.
+    step_main = make_step(args.paths_per_gpu * world)
+    t_pre = time.perf_counter()
+    for k in range(PRE_WARM_PASSES * 32):
+        step_main(500_000 + k)
+    pre_warm_ms = (time.perf_counter() - t_pre) * 1e3
+
+    ranks_seen = 1
+    if use_dist:
+        ones = torch.ones(1, dtype=torch.float64, device="cuda")
+        if rehearsal:
+            torch.cuda.synchronize()
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(ones.item())
+
+    n_global = args.paths_per_gpu * world
+    passes, calls, avg_kernel_s, launches, worst, first_prices = timed_passes(step_main, n_global, K_steps, W)        # THE measured pass
+    assert worst <= 5.0, f"a step's price is {worst:.2f} sigma from Black-Scholes"     # max of up to ~2,500 draws of |N(0,1)|: P(> 5) ~ 1e-3
+    pass_s = statistics.median(passes)
+    path_steps = n_global * N_STEPS
+    value = path_steps * K_steps / pass_s
+
+    clock = None
+    try:
+        for _ in range(3):
+            clock = _hip.clock_probe(args.paths_per_gpu, N_STEPS, SEED)
+    except Exception as e:
+        clock = {"error": f"{type(e).__name__}: {e}"}
+    clock_ghz = clock.get("ghz") if clock else None
+
+    out = None
+    if rank == 0:
+        model_cycles = sum(ISSUE_MODEL["per_4_normals"][k] * ISSUE_MODEL["issue_cycles"][k] for k in ISSUE_MODEL["per_4_normals"])
+        local_paths = sharding.shard_bounds(n_global, 0, world)[1]
+        roof = roofline_for(pmc, "c2_european", avg_kernel_s, clock_ghz) if args.paths_per_gpu == PATHS_PER_GPU else None
+        if roof is None:
+            roof = {"bound": "valu", "achieved": None, "peak": N_SIMD * PEAK_GHZ, "unit": "G VALU-active SIMD-cycles/s", "frac": None,
+                    "traffic": None, "avg_kernel_ms": avg_kernel_s * 1e3 if avg_kernel_s else None,
+                    "why_null": (pmc or {}).get("error", "no PMC counters for this launch size (N > 1 ranks and non-default sizes do not run the rocprofv3 passes)")}
+        roof.update({
+            "kernel": "european_path_kernel<1,true,kReduce,false>", "launches_timed": launches,
+            "pmc_source": (pmc or {}).get("source"),
+            "note": "VALU-issue bound (SURVEY 8d: neither HBM nor MFMA). frac = SQ_ACTIVE_INST_VALU x 4 (VALU-active cycles summed over the "
+                    "1024 SIMDs, per launch) / (1024 SIMDs x kernel time x 2.4 GHz peak clock): <= 1 by construction. Kernel time = HIP "
+                    "events attached to the dispatches of the timed blocking calls (hipExtLaunchKernelGGL: the kernel's own begin/end "
+                    "timestamps). frac_at_measured_clock uses the shader clock held under this kernel's load (`clock`).",
+            "issue_model": dict(ISSUE_MODEL, cycles_per_4_normals=model_cycles,
+                                model_kernel_us_at_2p4GHz=(local_paths * N_STEPS / 4 / 64) * model_cycles / N_SIMD / (PEAK_GHZ * 1e3),
+                                what="static instruction mix of the step loop (ISA of this build) x issue cost per wave64 instruction "
+                                     "(tools/valu_microbench.hip); every SIMD busy from first to last cycle"),
+            "lane_op_model": {"lane_ops_per_path_step": LANE_OPS_PER_PATH_STEP, "peak_tlaneops": PEAK_TLANEOPS,
+                              "achieved_tlaneops": (local_paths * N_STEPS * LANE_OPS_PER_PATH_STEP / avg_kernel_s / 1e12) if avg_kernel_s else None,
+                              "frac": (local_paths * N_STEPS * LANE_OPS_PER_PATH_STEP / avg_kernel_s / 1e12 / PEAK_TLANEOPS) if avg_kernel_s else None,
+                              "what": "SURVEY 8(d)'s algorithmic count (32 lane-ops per path-step) over 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T "
+                                      "(the guide's 157.3 TF fp32 / 2; SURVEY's own 39.3 T assumed SIMD-16). A MODEL, not a bound: the kernel "
+                                      "issues 14.5 instructions per path-step, so this ratio can exceed 1"}})
+        out = {
+            "metric": "MC path-steps/sec (1M paths × 252 steps Euro call); price vs BS |err|/σ",      # BASELINE.json, verbatim
+            "value": value, "unit": "path-steps/s", "n_gpus": world, "steps": K_steps, "warmup": W,
+            "ms_per_step": pass_s / K_steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 normals / f64 prices", "data": "synthetic",
+            "config": {"workload": f"European call S0=100 K=100 sigma=0.2 r=0.05 T=1, {args.paths_per_gpu:,} paths x 252 steps per GPU, "
+                                   "antithetic on (two payoffs per path), Philox4x32-10 + Box-Muller in registers, on-device reduction; "
+                                   "a step = one blocking price(return_error=True) call, result on the host",
+                       "paths_per_gpu": args.paths_per_gpu, "n_steps": N_STEPS, "global_paths": n_global,
+                       "parallelism": f"path-sharded x{world}" + (", 1 RCCL all-reduce of (sum,sumsq,n) per step" if world > 1 else "")
+                                      + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")},
+            "passes": {"n": len(passes), "seconds": passes, "what": f"each = exactly {K_steps} blocking steps between fences, max over ranks; "
+                                                                    "value and ms_per_step use the median pass"},
+            "per_call": {"median_ms": statistics.median(calls) * 1e3, "min_ms": min(calls) * 1e3, "p90_ms": sorted(calls)[int(0.9 * (len(calls) - 1))] * 1e3,
+                         "n": len(calls), "what": "wall of the individual blocking calls of the timed passes (rank 0)"},
+            "pre_warm_ms": pre_warm_ms, "pre_warm_pricings": PRE_WARM_PASSES * 32,
+            "ranks_seen": ranks_seen,
+            "payoff_samples_per_s": 2 * n_global * K_steps / pass_s,      # SURVEY 8d: the antithetic mirror doubles the payoff samples, not the path-steps
+            "accuracy": {"bs_price": bs, "max_abs_err_over_sigma": worst, "payoffs_per_step": 2 * n_global, "steps_checked": len(calls) + W},
+            "roofline": roof,
+            "clock": clock,
+            "device": info,
+        }
+        if cpu:
+            out["cpu_baseline"] = cpu
+            out["gpu_over_cpu"] = value / cpu["value"]
+
+    # ---- everything below is secondary: it must never cost the line.  A watchdog prints what exists if a section hangs.
+    printed = threading.Event()
+
+    def emit():
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            print(json.dumps(out), flush=True)
+
+    def watchdog_fire():
+        if rank == 0 and out is not None:
+            out.setdefault("errors", []).append("a secondary section did not finish within its time limit; line printed by the watchdog")
+        emit()
+        os._exit(0)
+
+    dog = threading.Timer(600.0 if world == 1 else 240.0, watchdog_fire)
+    dog.daemon = True
+    dog.start()
+
+    def section(name, fn):
+        try:
+            res = fn()
+        except Exception as e:          # recorded, not raised
+            res = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0 and res is not None:
+            out[name] = res
+
+    def c5(n_glob, steps, what):
+        step = make_step(n_glob)
+        ps, cs, ks, ln, wst, _first = timed_passes(step, n_glob, steps, 2, min_total_s=0.03, max_passes=5, seed0=7_000_000)
+        med = statistics.median(ps)
+        return {"value": n_glob * N_STEPS * steps / med, "unit": "path-steps/s", "ms_per_step": med / steps * 1e3, "steps": steps, "passes": len(ps),
+                "global_paths": n_glob, "paths_per_gpu": n_glob // world, "n_gpus": world, "avg_kernel_ms": ks * 1e3 if ks else None,
+                "max_abs_err_over_sigma": wst, "dtype": "f32 normals / f64 prices", "workload": what}
+
+    if not args.no_extras:
+        # BASELINE configs[4] -- so that a scaling run lands on it at every N: 8M paths per GPU (weak), 64M paths in total (strong)
+        section("c5_weak", lambda: c5(C5_PATHS_PER_GPU * world, 5,
+                                      f"configs[4] weak: European call, {C5_PATHS_PER_GPU:,} paths x 252 steps per GPU x {world} GPU(s), blocking sharded price(), one all-reduce of the triple per step"))
+        section("c5_strong", lambda: c5(C5_TOTAL, 3,
+                                        f"configs[4] strong: European call, {C5_TOTAL:,} paths x 252 steps in total split over {world} GPU(s), blocking sharded price(), one all-reduce of the triple per step"))
+        section("pipelined", lambda: pipelined(args, torch, dist, _hip, sharding, use_dist, rehearsal, world, rank, main_stream, fence, max_over_ranks,
+                                               n_global, K_steps, W, bs, first_prices))
+        if world == 1 and not use_dist:
+            section("c3_greeks", lambda: c3_greeks(ol, _hip, pmc, clock_ghz))
+            section("c4_asian", lambda: c4_asian(ol, _hip, pmc, clock_ghz))
+    dog.cancel()
+    emit()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ secondary sections
+def pipelined(args, torch, dist, _hip, sharding, use_dist, rehearsal, world, rank, main_stream, fence, max_over_ranks, n_global, K_steps, W, bs,
+              blocking_prices):
+    """The same K pricings as independent requests dealt round-robin over --streams HIP streams: the ~15 us tail of one
+    launch (its last lone workgroup + the reduction chain + the host round trip) hides under the head of the next.
+    Triples land in per-step device slots; the timed region ends with their D2H copy and a full synchronise."""
+    S, K, T, r, sigma, q = (WORK[k] for k in ("S", "K", "T", "r", "sigma", "q"))
+    lo, hi = sharding.shard_bounds(n_global, rank, world)
+    streams = [torch.cuda.Stream() for _ in range(max(1, args.streams))]
+    slots = torch.zeros((max(K_steps, W, 1), 3), dtype=torch.float64, device="cuda")
+    host_slots = torch.zeros(slots.shape, dtype=torch.float64).pin_memory()
+
+    def run_pass(steps, seed0):
         def enq(k):
-            st = use[k % n_streams]
+            st = streams[k % len(streams)]
             with torch.cuda.stream(st):
-                _hip.european_shard_dev(S, K, T, r, sigma, q, True, lo, hi - lo, N_STEPS, seed0 + k, True,
-                                        slots[k].data_ptr(), st.cuda_stream)
+                _hip.european_shard_dev(S, K, T, r, sigma, q, True, lo, hi - lo, N_STEPS, seed0 + k, True, slots[k].data_ptr(), st.cuda_stream)
                 if use_dist:
                     if rehearsal:
-                        # gloo's asynchronous CUDA all-reduce was measured NOT to be ordered behind work queued on the
-                        # caller's current stream (3 and 4 ranks: stale triples, 1e-3 off); RCCL's is (it is enqueued
-                        # behind the current stream by construction), so only the rehearsal pays for a host sync here
                         st.synchronize()
                     return dist.all_reduce(slots[k], op=dist.ReduceOp.SUM, async_op=True)
             return None
 
-        _hip.profile_enable(events)
-        _hip.profile_reset()
         fence()
         t0 = time.perf_counter()
         pend = [enq(k) for k in range(steps)]
         for w in pend:
             if w is not None:
                 w.wait()
-        for st in use:
+        for st in streams:
             main_stream.wait_stream(st)
-        host_slots[:steps].copy_(slots[:steps], non_blocking=True)     # D2H of the triples (pinned), inside the timed region
+        host_slots[:steps].copy_(slots[:steps], non_blocking=True)
+        torch.cuda.synchronize()
+        dt = max_over_ranks(time.perf_counter() - t0)
         fence()
-        dt = time.perf_counter() - t0
-        res = host_slots[:steps].clone()
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        if use_dist:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt.item()), res
+        return dt, host_slots[:steps].clone()
 
-    # Before the W warm-up steps the device gets ~150 ms of the same work (untimed, reported as `pre_warm_ms`): an idle
-    # MI355X needs tens of milliseconds of load to reach its sustained clocks, and with a small K / W the timed region would
-    # otherwise measure the ramp (kernel 130 us instead of 108 us), not the steady state the default K = 400 sees anyway.
-    # (a FIXED number of passes, not a clock: every rank must enter the same collectives the same number of times)
-    t_pre = time.perf_counter()
-    for _ in range(PRE_WARM_PASSES):
-        run_pass(len(streams), 32, SEED + 5000, False)
-    pre_warm_ms = (time.perf_counter() - t_pre) * 1e3
-    run_pass(len(streams), W, SEED + 1000, False)                 # warm-up (untimed)
-    elapsed, results = run_pass(len(streams), K_steps, SEED, False)          # THE timed K steps -> `value`
-    # same K steps on ONE stream with HIP events around every path kernel: launches do not overlap here, so
-    # an event pair measures the kernel's own duration -> roofline attribution (and the `serial` figures)
-    serial_elapsed, serial_results = run_pass(1, K_steps, SEED, True)
-    launches, kernel_ms = _hip.kernel_time()
-    _hip.profile_enable(False)
-    # The overlapped pass must reproduce the serial pass: bit for bit on one GPU, to the collective's summation order on
-    # several.  If it ever does not (a stream-ordering problem between a kernel and its all-reduce), the overlapped timing
-    # is not a measurement: the line then reports the SERIAL pass as `value` and says so, instead of dying without a line.
-    rel = ((results - serial_results).abs() / serial_results.abs().clamp_min(1e-300)).max().item()
-    overlap_ok = rel == 0.0 if world == 1 else rel <= 1e-13
-    if use_dist:
-        flag = torch.tensor([0.0 if overlap_ok else 1.0], dtype=torch.float64, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        overlap_ok = flag.item() == 0.0
-    if not overlap_ok:
-        print(f"[bench] rank {rank}: overlapped and serial passes differ by {rel:.3e} relative -- reporting the serial pass", file=sys.stderr)
-        elapsed, results = serial_elapsed, serial_results
-
-    # every step's result must be a valid price
-    bs = ol.black_scholes(S, K, T, r, sigma, "call", q)
-    worst = 0.0
-    for row in results.tolist():
+    if W:
+        run_pass(W, SEED + 1000)
+    times, res = [], None
+    n_pass = None
+    while n_pass is None or len(times) < n_pass:
+        dt, res = run_pass(K_steps, SEED)        # the seeds of the blocking pass's first K steps
+        times.append(dt)
+        if n_pass is None:
+            n_pass = max(3, min(25, int(math.ceil(0.05 / max(dt, 1e-9)))))
+    worst, drift = 0.0, 0.0
+    for k, row in enumerate(res.tolist()):
         price, se = sharding.finalize(row[0], row[1], int(row[2]), r, T)
         assert int(row[2]) == 2 * n_global, row
         worst = max(worst, abs(price - bs) / se)
-    assert worst <= 4.5, f"a step's price is {worst:.2f} sigma from Black-Scholes"   # max of K draws of |N(0,1)|
+        if k < len(blocking_prices):            # same seeds as the blocking pass: the overlapped launches must reproduce it
+            drift = max(drift, abs(price - blocking_prices[k]) / abs(blocking_prices[k]))
+    med = statistics.median(times)
+    return {"value": n_global * N_STEPS * K_steps / med, "unit": "path-steps/s", "ms_per_step": med / K_steps * 1e3, "streams": len(streams),
+            "passes": len(times), "max_abs_err_over_sigma": worst, "max_rel_diff_vs_blocking": drift, "consistent_with_blocking": drift <= 1e-12,
+            "what": "K independent pricings in flight over several HIP streams (results stay on the device until one D2H at the end); "
+                    "NOT the blocking call SURVEY 8(d) defines the metric on -- `value` is"}
 
-    out = None
-    if rank == 0:
-        path_steps = n_global * N_STEPS
-        value = path_steps * K_steps / elapsed
-        avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
-        achieved = (hi - lo) * N_STEPS * LANE_OPS_PER_PATH_STEP / avg_kernel_s / 1e12
-        traffic, traffic_src, valu_active = measured_traffic()
-        if paths_per_gpu != PATHS_PER_GPU:       # the committed counters are per 1M-path launch
-            traffic = valu_active = None
-        out = {
-            "metric": "MC path-steps/sec (1M paths \u00d7 252 steps Euro call); price vs BS |err|/\u03c3",      # BASELINE.json, verbatim
-            "value": value, "unit": "path-steps/s", "n_gpus": world, "steps": K_steps, "warmup": W,
-            "ms_per_step": elapsed / K_steps * 1e3, "pre_warm_ms": pre_warm_ms, "pre_warm_pricings": PRE_WARM_PASSES * 32, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 normals / f64 prices", "data": "synthetic",
-            "config": {"workload": f"European call S0=100 K=100 sigma=0.2 r=0.05 T=1, {paths_per_gpu:,} paths x 252 steps per GPU, "
-                                   "antithetic on (two payoffs per path), Philox4x32-10 + Box-Muller in registers, on-device reduction",
-                       "paths_per_gpu": paths_per_gpu, "n_steps": N_STEPS, "global_paths": n_global,
-                       "streams": len(streams),
-                       "parallelism": f"path-sharded x{world}" + (", 1 RCCL all-reduce of (sum,sumsq,n) per step" if world > 1 else "")
-                                      + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")},
-            "serial": {"value": path_steps * K_steps / serial_elapsed, "ms_per_step": serial_elapsed / K_steps * 1e3, "streams": 1,
-                       "what": "the same K pricings back to back on one stream (no overlap between launches)"},
-            "overlap_consistent": overlap_ok,
-            "payoff_samples_per_s": 2 * n_global * K_steps / elapsed,      # SURVEY 8d: the antithetic mirror doubles the payoff samples, not the path-steps
-            "accuracy": {"bs_price": bs, "max_abs_err_over_sigma": worst, "payoffs_per_step": 2 * n_global},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_TLANEOPS, "unit": "Tlane-op/s",
-                         "frac": achieved / PEAK_TLANEOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                         "traffic_source": traffic_src, "kernel": "european_path_kernel<1,true,kReduce>", "avg_kernel_ms": avg_kernel_s * 1e3,
-                         "launches_timed": launches, "lane_ops_per_path_step": LANE_OPS_PER_PATH_STEP,
-                         "hbm_gbps": (traffic / avg_kernel_s / 1e9) if traffic else None,
-                         "hbm_frac_of_8TBps": (traffic / avg_kernel_s / 8e12) if traffic else None,
-                         # VALU-active cycles of the committed PMC pass over the SIMD-cycles of this run's kernel time at 2.4 GHz
-                         "valu_busy_from_pmc": (valu_active * 4 / (1024 * avg_kernel_s * 2.4e9)) if valu_active else None,
-                         "measured_on": "the single-stream pass of this run (see `serial`): with overlapping launches an event "
-                                        "pair would time co-resident kernels, not one kernel",
-                         "note": "VALU-issue bound (SURVEY 8d: not HBM, not MFMA); peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz "
-                                 "(157.3 TF fp32 vector / 2); achieved = 32 lane-ops x path-steps per launch / kernel time from a HIP event pair "
-                                 "attached to the dispatch (hipExtLaunchKernelGGL: the kernel's own begin/end timestamps on its stream). "
-                                 "The kernel issues 14.5 VALU instructions per path-step, fewer than the 32 algorithmic lane-ops assume at "
-                                 "half rate, so frac saturates near 1.03 (reached at 8M paths per launch)"},
-            "device": info,
-        }
-        # blocking API at the same size (one host round trip per price() call)
-        if world == 1:
-            pricer = ol.MonteCarloPricer(paths_per_gpu, N_STEPS, SEED)
-            for _ in range(3):
-                pricer.price(S, K, T, r, sigma, "call")
-            reps = max(10, min(K_steps, 50))
-            t1 = time.perf_counter()
-            for i in range(reps):
-                res = pricer.price(S, K, T, r, sigma, "call", seed=SEED + i, return_error=True)
-            dt = (time.perf_counter() - t1) / reps
-            out["sync_call"] = {"value": paths_per_gpu * N_STEPS / dt, "unit": "path-steps/s", "ms_per_call": dt * 1e3,
-                                "what": "MonteCarloPricer.price(return_error=True), blocking, result on host"}
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline()
-                out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+
+def _timed_calls(_hip, fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    _hip.profile_enable(True)
+    _hip.profile_reset()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    launches, kernel_ms = _hip.kernel_time()
+    _hip.profile_enable(False)
+    return statistics.median(ts), (kernel_ms / 1e3 / launches if launches else None), launches // reps
+
+
+def c3_greeks(ol, _hip, pmc, clock_ghz):
+    """BASELINE configs[2]: finite-difference Greeks at 1M paths x 252 steps, common Philox key.  fused = the 8 / 14 bumped
+    contracts of unified_greeks.py:295-358 priced on the SAME normals in ONE launch; literal = the 8 price() calls."""
+    p = ol.MonteCarloPricer(PATHS_PER_GPU, N_STEPS, SEED)
+    ps = PATHS_PER_GPU * N_STEPS
+    out = {"dtype": "f32 normals / f64 prices and differences"}
+    for key, second, pk in (("fused_8", False, "c3_fused8"), ("fused_14", True, "c3_fused14")):
+        med, ks, per = _timed_calls(_hip, lambda: p.greeks(*ATM, "call", include_second_order=second), 20)
+        g = p.greeks(*ATM, "call", include_second_order=second)
+        out[key] = {"ms_per_call": med * 1e3, "path_steps_per_s": ps / med, "contract_path_steps_per_s": (14 if second else 8) * ps / med,
+                    "avg_kernel_ms": ks * 1e3 if ks else None, "launches_per_call": per, "roofline": roofline_for(pmc, pk, ks, clock_ghz),
+                    "delta": g["delta"], "gamma": g["gamma"], "vega": g["vega"], "theta": g["theta"], "rho": g["rho"]}
+    med, ks, per = _timed_calls(_hip, lambda: ol.compute_greeks_unified(p, *ATM, "call", include_second_order=False, fused=False), 10)
+    out["literal_8"] = {"ms_per_call": med * 1e3, "path_steps_per_s": 8 * ps / med, "avg_kernel_ms": ks * 1e3 if ks else None, "launches_per_call": per,
+                        "what": "8 blocking price() calls, path-steps counted 8x (SURVEY 8d)"}
+    out["workload"] = "configs[2]: FD Greeks (delta gamma vega theta rho), 2-sided bump-and-reprice, 1,000,000 paths x 252 steps, antithetic, common key"
+    return out
+
+
+def c4_asian(ol, _hip, pmc, clock_ghz):
+    """BASELINE configs[3]: arithmetic Asian call, 1M paths x 1024 dates.  fp64 = the reference's arithmetic (the default);
+    fp32 = the opt-in fast kernel, reported beside it, never instead of it."""
+    a = ol.AsianOption(*ATM, seed=SEED)
+    ps = PATHS_PER_GPU * ASIAN_STEPS
+    out = {"workload": "configs[3]: arithmetic Asian call, 1,000,000 paths x 1024 monitoring dates (t = 1..M), running sum in registers"}
+    for key, precision, anti, pk in (("fp64", "fp64", False, "c4_asian_fp64"), ("fp64_antithetic", "fp64", True, "c4_asian_fp64_antithetic"),
+                                     ("fp32_fast", "fp32", False, "c4_asian_fp32"), ("fp32_fast_antithetic", "fp32", True, "c4_asian_fp32_antithetic")):
+        fn = lambda: a.price(PATHS_PER_GPU, ASIAN_STEPS, "arithmetic", "call", antithetic=anti, return_error=True, precision=precision)
+        med, ks, per = _timed_calls(_hip, fn, 8, warm=2)
+        price, se = fn()
+        out[key] = {"ms_per_call": med * 1e3, "path_steps_per_s": ps / med, "avg_kernel_ms": ks * 1e3 if ks else None, "price": float(price), "std_error": se,
+                    "dtype": "f32 normals / f64 cumulative log-return, f64 exp per date, f64 sums" if precision == "fp64"
+                             else "f32 normals / f32 exponent + v_exp_f32 per date inside groups of 16 dates, f64 across groups",
+                    "roofline": roofline_for(pmc, pk, ks, clock_ghz)}
+    out["headline"] = "fp64"
+    return out
 
 
 if __name__ == "__main__":

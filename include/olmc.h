@@ -332,6 +332,11 @@ int olmc_normal_moments(uint64_t seed, int64_t path_offset, int64_t n_paths, int
 int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps,
                  float* out_host);
 
+/* Shader clock the device holds while every SIMD runs the headline kernel's step loop (n_paths x n_steps, one
+ * workgroup per 256 paths): out3 = {median shader cycles of a workgroup's loop (s_memtime), median 100 MHz ticks of
+ * the same interval (s_memrealtime), median of their quotient in GHz}.  Feeds bench.py's roofline; prices nothing. */
+int olmc_clock_probe(int64_t n_paths, int32_t n_steps, uint64_t seed, double* out3);
+
 /* ---- measurement ----------------------------------------------------------
  * When enabled, every path-kernel launch carries a pair of HIP events attached to the dispatch itself
  * (hipExtLaunchKernelGGL): they take the kernel's own begin / end timestamps on the stream it runs on, the

@@ -85,6 +85,7 @@ PROTOTYPES = {
     "olmc_philox_words": (_I, [_U64T, _I64, _I64, _I32, _I32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "olmc_normal_moments": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(_D)]),
     "olmc_normals": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(C.c_float)]),
+    "olmc_clock_probe": (_I, [_I64, _I32, _U64T, C.POINTER(_D)]),
     "olmc_profile_enable": (_I, [_I]),
     "olmc_tune": (_I, [_I, _I]),
     "olmc_profile_reset": (_I, []),
@@ -457,6 +458,13 @@ def normal_moments(seed: int, n_paths: int, n_steps: int, path_offset: int = 0):
     out = (C.c_double * 4)()
     _check(lib().olmc_normal_moments(seed64(seed), int(path_offset), int(n_paths), int(n_steps), out))
     return tuple(out)
+
+
+def clock_probe(n_paths: int = 1_000_000, n_steps: int = 252, seed: int = 42) -> dict:
+    """Shader clock held under the headline kernel's load: s_memtime / s_memrealtime around the step loop, median over workgroups."""
+    out = (C.c_double * 3)()
+    _check(lib().olmc_clock_probe(int(n_paths), int(n_steps), seed64(seed), out))
+    return dict(loop_cycles=out[0], loop_ticks_100mhz=out[1], ghz=out[2])
 
 
 def profile_enable(on: bool) -> None:

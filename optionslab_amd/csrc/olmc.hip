@@ -1549,6 +1549,44 @@ extern "C" int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths,
     return OLMC_OK;
 }
 
+// Shader clock held under the headline kernel's load (see clock_probe_kernel): median over workgroups.
+extern "C" int olmc_clock_probe(int64_t n_paths, int32_t n_steps, uint64_t seed, double* out3) {
+    if (!out3) return fail(OLMC_ERR_ARG, "null pointer");
+    int rc = check_paths(0, n_paths, n_steps);
+    if (rc) return rc;
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const int32_t grid = static_cast<int32_t>(std::min<int64_t>((n_paths + kBlock - 1) / kBlock, kMaxGrid));
+    const size_t bytes = sizeof(uint64_t) * 2 * static_cast<size_t>(grid) + 256;
+    rc = bulk_reserve(c, bytes);
+    if (rc) return rc;
+    uint64_t* d_stamps = static_cast<uint64_t*>(c->d_bulk);
+    double* d_sink = reinterpret_cast<double*>(d_stamps + 2 * static_cast<size_t>(grid));
+    const PathRange pr = make_range(0, static_cast<int64_t>(grid) * kBlock, n_steps, seed);
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(grid), dim3(kBlock), 0, c->stream, pr, d_stamps, d_sink);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint64_t> h(2 * static_cast<size_t>(grid));
+    HIP_TRY(hipMemcpyAsync(h.data(), d_stamps, sizeof(uint64_t) * h.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<double> cyc(grid), tick(grid), ghz;
+    for (int32_t b = 0; b < grid; ++b) {
+        cyc[b] = static_cast<double>(h[2 * b]);
+        tick[b] = static_cast<double>(h[2 * b + 1]);
+        if (tick[b] > 0) ghz.push_back(cyc[b] / tick[b] * 0.1);     // cycles per 10 ns tick -> GHz
+    }
+    auto median = [](std::vector<double>& v) {
+        if (v.empty()) return 0.0;
+        std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
+        return v[v.size() / 2];
+    };
+    out3[0] = median(cyc);
+    out3[1] = median(tick);
+    out3[2] = median(ghz);
+    return OLMC_OK;
+}
+
 // ================================================================ measurement ====
 extern "C" int olmc_tune(int knob, int value) {
     if (knob == OLMC_TUNE_GRID_CAP && value >= 0) { g_grid_cap = value; return OLMC_OK; }
@@ -1560,6 +1598,20 @@ extern "C" int olmc_tune(int knob, int value) {
 
 extern "C" int olmc_profile_enable(int on) {
     g_profile = on != 0;
+    if (g_profile && (t_device >= 0 || g_default_device >= 0)) {
+        // pre-create the event pairs a measurement pass will consume, so that no hipEventCreate lands inside a timed call
+        DeviceCtx* c = nullptr;
+        int rc = ctx_get(&c);
+        if (rc) return rc;
+        std::lock_guard<std::mutex> lock(c->mu);
+        constexpr size_t kPool = 4096;
+        while (c->ev_free.size() + c->ev_pending.size() < kPool) {
+            EventPair ep{};
+            HIP_TRY(hipEventCreate(&ep.start));
+            HIP_TRY(hipEventCreate(&ep.stop));
+            c->ev_free.push_back(ep);
+        }
+    }
     return OLMC_OK;
 }
 

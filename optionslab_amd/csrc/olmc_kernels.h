@@ -1626,6 +1626,23 @@ __global__ __launch_bounds__(kBlock) void normal_moments_kernel(PathRange pr, Re
     block_then_grid_reduce<4>(acc, ws);
 }
 
+// Measurement tap (bench.py; never on a pricing path): the shader clock the chip HOLDS while every SIMD runs the
+// headline kernel's own step loop.  s_memtime counts shader cycles, s_memrealtime a constant 100 MHz, so
+// clock = d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS give-back item 6).  One stamp pair per
+// workgroup around path_normal_sum; the stamps go to a buffer of their own and no priced value depends on them.
+__global__ __launch_bounds__(kBlock) void clock_probe_kernel(PathRange pr, uint64_t* __restrict__ stamps, double* __restrict__ sink) {
+    const uint64_t t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    const uint64_t g = pr.first + static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const double zsum = path_normal_sum(static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32), pr.n_steps, pr.key0, pr.key1);
+    if (zsum == 1.2345678e300) sink[0] = zsum;          // never true: keeps the loop from being optimised away
+    __builtin_amdgcn_s_waitcnt(0);
+    const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        stamps[2 * static_cast<size_t>(blockIdx.x)] = t1 - t0;
+        stamps[2 * static_cast<size_t>(blockIdx.x) + 1] = r1 - r0;
+    }
+}
+
 // ------------------------------------------------------- validation taps ----
 __global__ void philox_words_kernel(uint64_t first, int64_t n_paths, int32_t block0, int32_t n_blocks,
                                     uint32_t tag, uint32_t k0, uint32_t k1, uint32_t* __restrict__ out) {

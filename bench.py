@@ -59,15 +59,14 @@ LANE_OPS_PER_PATH_STEP = 32   # SURVEY 8(d)'s algorithmic count (kept as a secon
 PEAK_TLANEOPS = N_SIMD * 32 * PEAK_GHZ * 1e9 / 1e12   # 78.6: SIMD-32 x 2.4 GHz (guide: 157.3 TF fp32 vector = 2 flop/FMA);
                                                       # SURVEY 8(d) assumed 64 lanes x 256 CU x 2.4 GHz = 39.3 (a SIMD-16 machine)
 
-# Static instruction mix of the headline kernel's step loop per Philox block (= 4 normals), read off the gfx950 ISA of
-# this build (hipcc -S), with the issue cost per wave64 instruction measured by
-# tools/valu_microbench.hip at 8 waves/SIMD (profiles/r01_valu_issue_microbench.txt).
-ISSUE_MODEL = {
-    "per_4_normals": {"v_mad_u64_u32": 17, "v_bitop3_b32": 19, "v_cvt_f32_u32+v_fmamk_f32+v_and_or_b32": 6,
-                      "v_log/v_sqrt/v_sin/v_cos_f32": 8, "v_add_f32+v_fma_f32": 4, "v_cvt_f64_f32+v_add_f64 (per 16 normals)": 0.5},
-    "issue_cycles": {"v_mad_u64_u32": 4.4, "v_bitop3_b32": 4.2, "v_cvt_f32_u32+v_fmamk_f32+v_and_or_b32": 4.3,
-                     "v_log/v_sqrt/v_sin/v_cos_f32": 8.2, "v_add_f32+v_fma_f32": 4.0, "v_cvt_f64_f32+v_add_f64 (per 16 normals)": 4.5},
-}
+def load_isa_mix():
+    """Static instruction mix of each kernel's step loop (tools/isa_mix.py: hipcc -S of this build, parsed)."""
+    try:
+        with open(os.path.join(ROOT, "optionslab_amd", "isa_mix.json")) as f:
+            return json.load(f)
+    except OSError:
+        return {}
+
 
 PMC_KERNELS = {         # substring of the demangled kernel name -> key in the JSON
     "european_path_kernel<1, true, 0, false>": "c2_european",
@@ -107,7 +106,8 @@ def collect_pmc(keep_dir=None):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return {"error": "rocprofv3 not found"}
-    base = keep_dir or tempfile.mkdtemp(prefix="olmc_pmc_", dir="/tmp")
+    base = os.path.abspath(keep_dir) if keep_dir else tempfile.mkdtemp(prefix="olmc_pmc_", dir="/tmp")   # the passes run with cwd = /tmp
+    os.makedirs(base, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     env.pop("RANK", None)
     out = {}
@@ -156,24 +156,66 @@ def committed_pmc():
     return d
 
 
-def roofline_for(pmc, key, avg_kernel_s, clock_ghz=None):
-    """Issue-cycle roofline of one kernel: VALU-active SIMD-cycles / SIMD-cycles available in the measured kernel time."""
+# Issue passes of a wave64 VALU instruction on a gfx950 SIMD (32 lanes wide): the MINIMUM number of cycles the SIMD's vector
+# issue port is held.  2 = full rate (plain VOP1/VOP2 fp32 / int32 operations on VGPR or literal operands: the guide's
+# "v_fma_f32 (wave64) 2 cyc"), 8 = transcendental unit (quarter rate), 4 = everything else that was measured (64-bit
+# multiply-add, three-operand VOP3 integer ops, conversions, every fp64 operation = the 78.6 TF fp64 vector peak).  The
+# live olmc_issue_probe figures (JSON: issue_costs_ns) are the evidence that no class issues faster than its entry: at the
+# clock the chip holds they read 2.3-2.7 / 3.9-4.6 / 7.5-8.4 cycles.  Unclassified instructions are priced at 2.
+ISSUE_PASSES = {"v_mad_u64_u32": 4, "v_bitop3_b32": 4, "v_cvt_f32_u32": 4, "v_fmamk_f32": 2, "v_and_or_b32": 4, "v_log_f32": 8, "v_sqrt_f32": 8,
+                "v_sin_f32": 8, "v_cos_f32": 8, "v_exp_f32": 8, "v_add_f32": 2, "v_fma_f32": 4, "v_cvt_f64_f32": 4, "v_add_f64": 4, "v_fma_f64": 4,
+                "v_rndne_f64": 4, "v_ldexp_f64": 4, "v_cvt_i32_f64": 4, "other": 2}
+OUTSIDE_LOOP_PASSES = 4       # per-path prologue / epilogue (fp64 exp, payoff, reduction): fp64 class
+
+
+def roofline_for(pmc, key, avg_kernel_s, n_steps, costs=None, mixes=None, clock_ghz=None):
+    """Issue-cycle roofline of one kernel, <= 1 by construction.
+
+    achieved = VALU issue cycles the kernel's instruction stream NEEDS per launch / measured kernel time, where
+               needed cycles = sum over instructions of the class's issue passes (ISSUE_PASSES: 2 / 4 / 8).  The
+               instruction stream: SQ_INSTS_VALU and SQ_WAVES from the live PMC pass give the instructions per wave;
+               the step loop's share is the static mix of its body (tools/isa_mix.py) x trips, the per-path remainder
+               is priced at 4.
+    peak     = 1024 SIMDs x 2.4 GHz (one issue cycle per SIMD per clock at the peak engine clock).
+    Since no instruction can hold the port for less than its class's passes and no SIMD can run above 2.4 GHz,
+    frac <= 1; what is missing from 1 is clock give-back under load (`clock`), issue bubbles and the launch's tail.
+    Beside it: `frac_vs_isolated_rates` prices the same stream with the per-class issue TIMES olmc_issue_probe measured in
+    isolation in this run (an empirical ceiling at the clock actually held; mixes can beat isolated classes by a few
+    per cent, so it is not a bound), and `frac_valu_active_pmc` is the VALUBusy formula (SQ_ACTIVE_INST_VALU x 4 /
+    (1024 SIMDs x kernel time x 2.4 GHz)) -- that counter charges 4 cycles per instruction (8 per transcendental:
+    (4 n + 4 n_trans) / n reproduces its cycles-per-instruction on every kernel here to 1 %) whatever the SIMD-32
+    needed, so it is not bounded by 1 either (the fp32 Asian kernel reads 1.05)."""
     c = (pmc or {}).get(key)
     if not c or "SQ_ACTIVE_INST_VALU" not in c or not avg_kernel_s:
         return None
-    active = c["SQ_ACTIVE_INST_VALU"] * 4.0            # the counter ticks in quad-cycles, summed over the 1024 SIMDs
     peak = N_SIMD * PEAK_GHZ * 1e9
-    r = {"bound": "valu", "achieved": active / avg_kernel_s / 1e9, "peak": peak / 1e9, "unit": "G VALU-active SIMD-cycles/s",
-         "frac": active / avg_kernel_s / peak, "avg_kernel_ms": avg_kernel_s * 1e3,
-         "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "valu_active_quad_cycles_per_launch": c["SQ_ACTIVE_INST_VALU"],
-         "cycles_per_valu_inst": (active / c["SQ_INSTS_VALU"]) if c.get("SQ_INSTS_VALU") else None,
-         "waves_per_launch": c.get("SQ_WAVES")}
+    r = {"bound": "valu", "achieved": None, "peak": peak / 1e9, "unit": "G VALU issue-cycles/s (peak = 1024 SIMDs x 2.4 GHz)", "frac": None,
+         "avg_kernel_ms": avg_kernel_s * 1e3, "valu_insts_per_launch": c.get("SQ_INSTS_VALU"), "waves_per_launch": c.get("SQ_WAVES"),
+         "frac_valu_active_pmc": c["SQ_ACTIVE_INST_VALU"] * 4.0 / avg_kernel_s / peak,
+         "pmc_cycles_per_valu_inst": (c["SQ_ACTIVE_INST_VALU"] * 4.0 / c["SQ_INSTS_VALU"]) if c.get("SQ_INSTS_VALU") else None}
+    mix = (mixes or {}).get(key)
+    if mix and c.get("SQ_INSTS_VALU") and c.get("SQ_WAVES") and mix.get("steps_per_trip"):
+        trips = n_steps // mix["steps_per_trip"]
+        per_wave = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+        rest = max(per_wave - trips * mix["loop_valu_instructions"], 0.0)
+        loop_cycles = sum(n * ISSUE_PASSES[cls] for cls, n in mix["by_class"].items())
+        need = c["SQ_WAVES"] * (trips * loop_cycles + rest * OUTSIDE_LOOP_PASSES)          # issue cycles per launch, all SIMDs
+        r.update({"achieved": need / avg_kernel_s / 1e9, "frac": need / avg_kernel_s / peak,
+                  "issue_cycles_needed_per_launch": need, "speed_of_light_kernel_ms": need / peak * 1e3,
+                  "issue_model": {"loop_trips_per_path": trips, "loop_valu_instructions": mix["loop_valu_instructions"], "loop_mix": mix["by_class"],
+                                  "loop_issue_cycles_per_trip": loop_cycles, "issue_passes": ISSUE_PASSES, "valu_instructions_per_wave": per_wave,
+                                  "outside_the_loop_per_wave": rest, "outside_the_loop_passes": OUTSIDE_LOOP_PASSES}})
+        if costs:
+            loop_ns = sum(n * costs.get(cls, costs["v_fmamk_f32"]) for cls, n in mix["by_class"].items())
+            model_s = c["SQ_WAVES"] * (trips * loop_ns + rest * costs["v_fma_f64"]) / N_SIMD * 1e-9
+            r["frac_vs_isolated_rates"] = model_s / avg_kernel_s
+            r["isolated_rates_kernel_ms"] = model_s * 1e3
+            if clock_ghz:
+                r["issue_costs_cycles_at_held_clock"] = {k: v * clock_ghz for k, v in costs.items()}
     if clock_ghz:
-        r["frac_at_measured_clock"] = active / avg_kernel_s / (N_SIMD * clock_ghz * 1e9)
-    if c.get("GRBM_GUI_ACTIVE"):
-        # GRBM_GUI_ACTIVE is summed over the 8 XCDs and spans the dispatch, not just the waves: on ~0.1 ms dispatches it reads
-        # ~8 us long (the guide: "reads high on dispatches shorter than about 0.3 ms"), so this one is a LOWER estimate
-        r["frac_by_grbm_cycles"] = active / (N_SIMD * c["GRBM_GUI_ACTIVE"] / 8.0)
+        r["clock_ghz_under_load"] = clock_ghz         # s_memtime / s_memrealtime around the headline kernel's step loop (`clock`)
+    if c.get("SQ_BUSY_CYCLES"):
+        r["sq_busy_cycles_per_se"] = c["SQ_BUSY_CYCLES"] / 32.0        # ~ the kernel's duration in shader cycles (32 shader engines)
     fetch, write = c.get("FETCH_SIZE"), c.get("WRITE_SIZE")
     if fetch is not None and write is not None:
         # rocprofv3 reports both in KB; gfx950 tallies a 128-B read request as 64 B (MI355X_MICROARCH.md, HBM): x2 on FETCH
@@ -346,8 +388,12 @@ def main():
 
     def timed_passes(step, n_global, steps, warm, min_total_s=0.05, max_passes=25, seed0=0):
         """warm untimed steps, then passes of EXACTLY `steps` blocking steps, each between fences; max over ranks per pass.
-        Returns (pass times, per-call times of rank 0, avg kernel seconds from the events of these dispatches, launches,
-        worst |price - BS| / se)."""
+        Passes ALTERNATE plain / instrumented: an instrumented pass is the same loop with a HIP event pair attached to
+        every dispatch (the kernel's own begin / end timestamps).  Attaching the pair puts a marker packet in front of the
+        kernel, which costs a blocking call several microseconds, so the events ride on every other pass instead of
+        on all of them: `value` comes from the plain passes, the kernel duration from the instrumented ones, and both
+        pass times are reported.  Returns (plain pass times, instrumented pass times, per-call times of the plain passes
+        on this rank, avg kernel seconds, launches timed, worst |price - BS| / se, prices of the first pass)."""
         worst, calls, first = 0.0, [], []
 
         def check(res):
@@ -358,30 +404,33 @@ def main():
 
         for k in range(warm):
             check(step(seed0 + 100_000 + k))
-        _hip.profile_enable(True)
+        _hip.profile_enable(True)       # pre-creates the event pool outside the timed region
         _hip.profile_reset()
-        passes, n_pass = [], None
-        while n_pass is None or len(passes) < n_pass:
-            base = seed0 + len(passes) * steps
+        passes, inst_passes, n_pass = [], [], None
+        while n_pass is None or len(inst_passes) < n_pass:
+            instrumented = len(passes) > len(inst_passes)          # plain, instrumented, plain, ...
+            _hip.profile_enable(instrumented)
+            base = seed0 + len(passes if not instrumented else inst_passes) * steps     # both kinds walk the same seeds
             fence()
             t0 = time.perf_counter()
             for k in range(steps):
                 c0 = time.perf_counter()
                 res = step(base + k)
-                calls.append(time.perf_counter() - c0)
+                if not instrumented:
+                    calls.append(time.perf_counter() - c0)
                 check(res)
                 if not passes:
                     first.append(res[0])
             torch.cuda.synchronize()
             dt = max_over_ranks(time.perf_counter() - t0)
             fence()
-            passes.append(dt)
+            (inst_passes if instrumented else passes).append(dt)
             if n_pass is None:          # every rank derives the same count from the same max-reduced time
                 n_pass = max(3, min(max_passes, int(math.ceil(min_total_s / max(dt, 1e-9)))))
         launches, kernel_ms = _hip.kernel_time()
         _hip.profile_enable(False)
         avg_kernel_s = kernel_ms / 1e3 / launches if launches else None
-        return passes, calls, avg_kernel_s, launches, worst, first
+        return passes, inst_passes, calls, avg_kernel_s, launches, worst, first
 
     # Before anything is timed the device gets ~150 ms of the same work (untimed, `pre_warm_ms`): an idle MI355X needs tens
     # of milliseconds of load to reach its sustained clocks.  A FIXED count, not a clock: every rank enters the same
@@ -401,7 +450,7 @@ def main():
         ranks_seen = int(ones.item())
 
     n_global = args.paths_per_gpu * world
-    passes, calls, avg_kernel_s, launches, worst, first_prices = timed_passes(step_main, n_global, K_steps, W)        # THE measured pass
+    passes, inst_passes, calls, avg_kernel_s, launches, worst, first_prices = timed_passes(step_main, n_global, K_steps, W)     # THE measured passes
     assert worst <= 5.0, f"a step's price is {worst:.2f} sigma from Black-Scholes"     # max of up to ~2,500 draws of |N(0,1)|: P(> 5) ~ 1e-3
     pass_s = statistics.median(passes)
     path_steps = n_global * N_STEPS
@@ -414,27 +463,28 @@ def main():
     except Exception as e:
         clock = {"error": f"{type(e).__name__}: {e}"}
     clock_ghz = clock.get("ghz") if clock else None
+    costs, mixes = None, load_isa_mix()
+    try:
+        costs = _hip.issue_probe(8)         # ns per wave64 instruction per SIMD, per class, on this device, now
+    except Exception as e:
+        print(f"[bench] issue probes unavailable: {type(e).__name__}: {e}", file=sys.stderr)
 
     out = None
     if rank == 0:
-        model_cycles = sum(ISSUE_MODEL["per_4_normals"][k] * ISSUE_MODEL["issue_cycles"][k] for k in ISSUE_MODEL["per_4_normals"])
         local_paths = sharding.shard_bounds(n_global, 0, world)[1]
-        roof = roofline_for(pmc, "c2_european", avg_kernel_s, clock_ghz) if args.paths_per_gpu == PATHS_PER_GPU else None
+        roof = roofline_for(pmc, "c2_european", avg_kernel_s, N_STEPS, costs, mixes, clock_ghz) if args.paths_per_gpu == PATHS_PER_GPU else None
         if roof is None:
-            roof = {"bound": "valu", "achieved": None, "peak": N_SIMD * PEAK_GHZ, "unit": "G VALU-active SIMD-cycles/s", "frac": None,
+            roof = {"bound": "valu", "achieved": None, "peak": N_SIMD * PEAK_GHZ, "unit": "G VALU issue-cycles/s (peak = 1024 SIMDs x 2.4 GHz)", "frac": None,
                     "traffic": None, "avg_kernel_ms": avg_kernel_s * 1e3 if avg_kernel_s else None,
-                    "why_null": (pmc or {}).get("error", "no PMC counters for this launch size (N > 1 ranks and non-default sizes do not run the rocprofv3 passes)")}
+                    "why_null": (pmc or {}).get("error", "no PMC counters for this launch size (non-default sizes do not run the rocprofv3 passes)")}
         roof.update({
             "kernel": "european_path_kernel<1,true,kReduce,false>", "launches_timed": launches,
-            "pmc_source": (pmc or {}).get("source"),
-            "note": "VALU-issue bound (SURVEY 8d: neither HBM nor MFMA). frac = SQ_ACTIVE_INST_VALU x 4 (VALU-active cycles summed over the "
-                    "1024 SIMDs, per launch) / (1024 SIMDs x kernel time x 2.4 GHz peak clock): <= 1 by construction. Kernel time = HIP "
-                    "events attached to the dispatches of the timed blocking calls (hipExtLaunchKernelGGL: the kernel's own begin/end "
-                    "timestamps). frac_at_measured_clock uses the shader clock held under this kernel's load (`clock`).",
-            "issue_model": dict(ISSUE_MODEL, cycles_per_4_normals=model_cycles,
-                                model_kernel_us_at_2p4GHz=(local_paths * N_STEPS / 4 / 64) * model_cycles / N_SIMD / (PEAK_GHZ * 1e3),
-                                what="static instruction mix of the step loop (ISA of this build) x issue cost per wave64 instruction "
-                                     "(tools/valu_microbench.hip); every SIMD busy from first to last cycle"),
+            "pmc_source": (pmc or {}).get("source"), "issue_costs_ns": costs,
+            "note": "VALU-issue bound (SURVEY 8d: neither HBM nor MFMA). frac = issue cycles the kernel's VALU instruction stream needs (live "
+                    "SQ_INSTS_VALU / SQ_WAVES, the step loop's static mix from the ISA, 2 / 4 / 8 issue passes per class) / (1024 SIMDs x kernel "
+                    "time x 2.4 GHz): <= 1 by construction. Kernel time = HIP events attached to the dispatches of the instrumented passes (the "
+                    "kernel's own begin / end timestamps). issue_costs_ns = the per-class issue times measured in isolation in this run; "
+                    "frac_vs_isolated_rates and frac_valu_active_pmc are secondary readings, neither bounded by 1 (see bench.py roofline_for).",
             "lane_op_model": {"lane_ops_per_path_step": LANE_OPS_PER_PATH_STEP, "peak_tlaneops": PEAK_TLANEOPS,
                               "achieved_tlaneops": (local_paths * N_STEPS * LANE_OPS_PER_PATH_STEP / avg_kernel_s / 1e12) if avg_kernel_s else None,
                               "frac": (local_paths * N_STEPS * LANE_OPS_PER_PATH_STEP / avg_kernel_s / 1e12 / PEAK_TLANEOPS) if avg_kernel_s else None,
@@ -454,6 +504,10 @@ def main():
                                       + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")},
             "passes": {"n": len(passes), "seconds": passes, "what": f"each = exactly {K_steps} blocking steps between fences, max over ranks; "
                                                                     "value and ms_per_step use the median pass"},
+            "instrumented_passes": {"n": len(inst_passes), "ms_per_step": statistics.median(inst_passes) / K_steps * 1e3,
+                                    "what": "the same loop, same seeds, interleaved with the plain passes, with a HIP event pair attached to every "
+                                            "dispatch -> roofline.avg_kernel_ms. The pair's start marker is an extra packet in front of the kernel: "
+                                            "the difference to ms_per_step is its price, which is why `value` is not taken from these passes"},
             "per_call": {"median_ms": statistics.median(calls) * 1e3, "min_ms": min(calls) * 1e3, "p90_ms": sorted(calls)[int(0.9 * (len(calls) - 1))] * 1e3,
                          "n": len(calls), "what": "wall of the individual blocking calls of the timed passes (rank 0)"},
             "pre_warm_ms": pre_warm_ms, "pre_warm_pricings": PRE_WARM_PASSES * 32,
@@ -496,7 +550,7 @@ def main():
 
     def c5(n_glob, steps, what):
         step = make_step(n_glob)
-        ps, cs, ks, ln, wst, _first = timed_passes(step, n_glob, steps, 2, min_total_s=0.03, max_passes=5, seed0=7_000_000)
+        ps, _ips, cs, ks, ln, wst, _first = timed_passes(step, n_glob, steps, 2, min_total_s=0.03, max_passes=5, seed0=7_000_000)
         med = statistics.median(ps)
         return {"value": n_glob * N_STEPS * steps / med, "unit": "path-steps/s", "ms_per_step": med / steps * 1e3, "steps": steps, "passes": len(ps),
                 "global_paths": n_glob, "paths_per_gpu": n_glob // world, "n_gpus": world, "avg_kernel_ms": ks * 1e3 if ks else None,
@@ -511,8 +565,8 @@ def main():
         section("pipelined", lambda: pipelined(args, torch, dist, _hip, sharding, use_dist, rehearsal, world, rank, main_stream, fence, max_over_ranks,
                                                n_global, K_steps, W, bs, first_prices))
         if world == 1 and not use_dist:
-            section("c3_greeks", lambda: c3_greeks(ol, _hip, pmc, clock_ghz))
-            section("c4_asian", lambda: c4_asian(ol, _hip, pmc, clock_ghz))
+            section("c3_greeks", lambda: c3_greeks(ol, _hip, pmc, costs, mixes, clock_ghz))
+            section("c4_asian", lambda: c4_asian(ol, _hip, pmc, costs, mixes, clock_ghz))
     dog.cancel()
     emit()
     if use_dist:
@@ -595,7 +649,7 @@ def _timed_calls(_hip, fn, reps, warm=3):
     return statistics.median(ts), (kernel_ms / 1e3 / launches if launches else None), launches // reps
 
 
-def c3_greeks(ol, _hip, pmc, clock_ghz):
+def c3_greeks(ol, _hip, pmc, costs, mixes, clock_ghz):
     """BASELINE configs[2]: finite-difference Greeks at 1M paths x 252 steps, common Philox key.  fused = the 8 / 14 bumped
     contracts of unified_greeks.py:295-358 priced on the SAME normals in ONE launch; literal = the 8 price() calls."""
     p = ol.MonteCarloPricer(PATHS_PER_GPU, N_STEPS, SEED)
@@ -605,7 +659,7 @@ def c3_greeks(ol, _hip, pmc, clock_ghz):
         med, ks, per = _timed_calls(_hip, lambda: p.greeks(*ATM, "call", include_second_order=second), 20)
         g = p.greeks(*ATM, "call", include_second_order=second)
         out[key] = {"ms_per_call": med * 1e3, "path_steps_per_s": ps / med, "contract_path_steps_per_s": (14 if second else 8) * ps / med,
-                    "avg_kernel_ms": ks * 1e3 if ks else None, "launches_per_call": per, "roofline": roofline_for(pmc, pk, ks, clock_ghz),
+                    "avg_kernel_ms": ks * 1e3 if ks else None, "launches_per_call": per, "roofline": roofline_for(pmc, pk, ks, N_STEPS, costs, mixes, clock_ghz),
                     "delta": g["delta"], "gamma": g["gamma"], "vega": g["vega"], "theta": g["theta"], "rho": g["rho"]}
     med, ks, per = _timed_calls(_hip, lambda: ol.compute_greeks_unified(p, *ATM, "call", include_second_order=False, fused=False), 10)
     out["literal_8"] = {"ms_per_call": med * 1e3, "path_steps_per_s": 8 * ps / med, "avg_kernel_ms": ks * 1e3 if ks else None, "launches_per_call": per,
@@ -614,7 +668,7 @@ def c3_greeks(ol, _hip, pmc, clock_ghz):
     return out
 
 
-def c4_asian(ol, _hip, pmc, clock_ghz):
+def c4_asian(ol, _hip, pmc, costs, mixes, clock_ghz):
     """BASELINE configs[3]: arithmetic Asian call, 1M paths x 1024 dates.  fp64 = the reference's arithmetic (the default);
     fp32 = the opt-in fast kernel, reported beside it, never instead of it."""
     a = ol.AsianOption(*ATM, seed=SEED)
@@ -628,7 +682,7 @@ def c4_asian(ol, _hip, pmc, clock_ghz):
         out[key] = {"ms_per_call": med * 1e3, "path_steps_per_s": ps / med, "avg_kernel_ms": ks * 1e3 if ks else None, "price": float(price), "std_error": se,
                     "dtype": "f32 normals / f64 cumulative log-return, f64 exp per date, f64 sums" if precision == "fp64"
                              else "f32 normals / f32 exponent + v_exp_f32 per date inside groups of 16 dates, f64 across groups",
-                    "roofline": roofline_for(pmc, pk, ks, clock_ghz)}
+                    "roofline": roofline_for(pmc, pk, ks, ASIAN_STEPS, costs, mixes, clock_ghz)}
     out["headline"] = "fp64"
     return out
 

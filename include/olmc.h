@@ -337,6 +337,15 @@ int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_
  * the same interval (s_memrealtime), median of their quotient in GHz}.  Feeds bench.py's roofline; prices nothing. */
 int olmc_clock_probe(int64_t n_paths, int32_t n_steps, uint64_t seed, double* out3);
 
+/* Issue cost of one VALU instruction class on this device: *ns_per_instr = nanoseconds one SIMD needs per wave64
+ * instruction of class `op` with waves_per_simd (1..8) waves resident, measured by a kernel of independent instructions
+ * of that class in the operand form the path kernels use.  Calibrates bench.py's issue-time roofline live. */
+enum { OLMC_PROBE_MAD_U64_U32 = 0, OLMC_PROBE_BITOP3_B32, OLMC_PROBE_CVT_F32_U32, OLMC_PROBE_FMAMK_F32, OLMC_PROBE_AND_OR_B32,
+       OLMC_PROBE_LOG_F32, OLMC_PROBE_SQRT_F32, OLMC_PROBE_SIN_F32, OLMC_PROBE_COS_F32, OLMC_PROBE_EXP_F32, OLMC_PROBE_ADD_F32,
+       OLMC_PROBE_FMA_F32, OLMC_PROBE_CVT_F64_F32, OLMC_PROBE_ADD_F64, OLMC_PROBE_FMA_F64, OLMC_PROBE_RNDNE_F64,
+       OLMC_PROBE_LDEXP_F64, OLMC_PROBE_CVT_I32_F64, OLMC_PROBE_COUNT };
+int olmc_issue_probe(int op, int waves_per_simd, double* ns_per_instr);
+
 /* ---- measurement ----------------------------------------------------------
  * When enabled, every path-kernel launch carries a pair of HIP events attached to the dispatch itself
  * (hipExtLaunchKernelGGL): they take the kernel's own begin / end timestamps on the stream it runs on, the

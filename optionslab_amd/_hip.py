@@ -86,6 +86,7 @@ PROTOTYPES = {
     "olmc_normal_moments": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(_D)]),
     "olmc_normals": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(C.c_float)]),
     "olmc_clock_probe": (_I, [_I64, _I32, _U64T, C.POINTER(_D)]),
+    "olmc_issue_probe": (_I, [_I, _I, C.POINTER(_D)]),
     "olmc_profile_enable": (_I, [_I]),
     "olmc_tune": (_I, [_I, _I]),
     "olmc_profile_reset": (_I, []),
@@ -465,6 +466,21 @@ def clock_probe(n_paths: int = 1_000_000, n_steps: int = 252, seed: int = 42) ->
     out = (C.c_double * 3)()
     _check(lib().olmc_clock_probe(int(n_paths), int(n_steps), seed64(seed), out))
     return dict(loop_cycles=out[0], loop_ticks_100mhz=out[1], ghz=out[2])
+
+
+PROBE_CLASSES = ("v_mad_u64_u32", "v_bitop3_b32", "v_cvt_f32_u32", "v_fmamk_f32", "v_and_or_b32", "v_log_f32", "v_sqrt_f32",
+                 "v_sin_f32", "v_cos_f32", "v_exp_f32", "v_add_f32", "v_fma_f32", "v_cvt_f64_f32", "v_add_f64", "v_fma_f64",
+                 "v_rndne_f64", "v_ldexp_f64", "v_cvt_i32_f64")           # order = the OLMC_PROBE_* enum of include/olmc.h
+
+
+def issue_probe(waves_per_simd: int = 8) -> dict:
+    """{instruction class: ns per wave64 instruction per SIMD} measured on this device (olmc_issue_probe)."""
+    out = {}
+    for op, name in enumerate(PROBE_CLASSES):
+        ns = C.c_double(0.0)
+        _check(lib().olmc_issue_probe(op, int(waves_per_simd), C.byref(ns)))
+        out[name] = ns.value
+    return out
 
 
 def profile_enable(on: bool) -> None:

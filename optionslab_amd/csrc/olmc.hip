@@ -54,9 +54,12 @@ struct DeviceCtx {
     int device = -1;
     int cus = 0;
     hipStream_t stream = nullptr;
-    // Reduction workspaces.  Launches rotate over kSlots of them, each guarded by an event, so
+    // Reduction workspaces.  Launches on CALLER streams rotate over kSlots of them, each guarded by an event, so
     // independent pricings enqueued on DIFFERENT streams may overlap on the device (the tail of
-    // one launch hides under the head of the next) without sharing rows or counters.
+    // one launch hides under the head of the next) without sharing rows or counters.  Launches on the library's
+    // OWN stream (every blocking entry point) use slot kSlots and no event at all: the stream is in-order, so a
+    // launch finds the workspace free by construction -- and a blocking call is spared the two barrier packets
+    // (hipStreamWaitEvent in front of the kernel, hipEventRecord behind it) that cost ~3 us each on the device.
     struct WsSlot {
         double* block_rows = nullptr;  // [cap] doubles, grown on demand (grid x NV)
         size_t cap = 0;
@@ -66,7 +69,7 @@ struct DeviceCtx {
         bool used = false;
     };
     static constexpr int kSlots = 8;    // = the deepest overlap bench.py's `pipelined` pass asks for (--streams 8)
-    WsSlot slots[kSlots];
+    WsSlot slots[kSlots + 1];
     int next_slot = 0, cur_slot = 0;
     double* h_result = nullptr;      // pinned + mapped [kMaxNV + 1]: the last workgroup writes the sums straight to the host
     double* d_result = nullptr;      // device alias of h_result (zero-copy: no D2H copy node, only a stream sync)
@@ -191,12 +194,15 @@ int32_t grid_for(int64_t n_paths, int32_t n_steps = INT32_MAX) {
 
 // Workspace of the fused grid reduction for a launch of `grid` workgroups x nv values.
 int make_ws(DeviceCtx* c, hipStream_t stream, int32_t grid, int nv, double* d_out, double tail, ReduceWs* ws) {
-    DeviceCtx::WsSlot& sl = c->slots[c->next_slot];
-    c->cur_slot = c->next_slot;
-    c->next_slot = (c->next_slot + 1) % DeviceCtx::kSlots;
+    const bool own = stream == c->stream;
+    const int idx = own ? DeviceCtx::kSlots : c->next_slot;
+    DeviceCtx::WsSlot& sl = c->slots[idx];
+    c->cur_slot = idx;
+    if (!own) c->next_slot = (c->next_slot + 1) % DeviceCtx::kSlots;
     const size_t need = static_cast<size_t>(grid) * nv;
     if (need > sl.cap) {
-        if (sl.used) HIP_TRY(hipEventSynchronize(sl.done));
+        if (own) HIP_TRY(hipStreamSynchronize(c->stream));
+        else if (sl.used) HIP_TRY(hipEventSynchronize(sl.done));
         if (sl.block_rows) HIP_TRY(hipFree(sl.block_rows));
         sl.block_rows = nullptr;
         sl.cap = 0;
@@ -204,7 +210,7 @@ int make_ws(DeviceCtx* c, hipStream_t stream, int32_t grid, int nv, double* d_ou
         HIP_TRY(hipMalloc(&sl.block_rows, sizeof(double) * cap));
         sl.cap = cap;
     }
-    if (sl.used) HIP_TRY(hipStreamWaitEvent(stream, sl.done, 0));   // previous user of this slot, whatever its stream
+    if (!own && sl.used) HIP_TRY(hipStreamWaitEvent(stream, sl.done, 0));   // previous user of this slot, whatever its stream
     ws->block_rows = sl.block_rows;
     ws->group_rows = sl.group_rows;
     ws->counters = sl.counters;
@@ -225,6 +231,7 @@ void ws_recover(DeviceCtx* c) {
 int after_launch(DeviceCtx* c, hipStream_t stream) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
+    if (c->cur_slot == DeviceCtx::kSlots) return OLMC_OK;          // the library stream's own slot: stream order is the guard
     DeviceCtx::WsSlot& sl = c->slots[c->cur_slot];
     HIP_TRY(hipEventRecord(sl.done, stream));
     sl.used = true;
@@ -1584,6 +1591,40 @@ extern "C" int olmc_clock_probe(int64_t n_paths, int32_t n_steps, uint64_t seed,
     out3[0] = median(cyc);
     out3[1] = median(tick);
     out3[2] = median(ghz);
+    return OLMC_OK;
+}
+
+// Issue cost of one instruction class on this device (see the probe kernels): nanoseconds one SIMD needs per wave64
+// instruction of the class with `waves_per_simd` waves resident.
+extern "C" int olmc_issue_probe(int op, int waves_per_simd, double* ns_per_instr) {
+    using Probe = void (*)(uint32_t*, uint32_t, uint32_t);
+    static const Probe table[] = {probe_mad_u64_u32, probe_bitop3, probe_cvt_f32_u32, probe_fmamk_f32, probe_and_or, probe_log_f32,
+                                  probe_sqrt_f32, probe_sin_f32, probe_cos_f32, probe_exp_f32, probe_add_f32, probe_fma_f32,
+                                  probe_cvt_f64_f32, probe_add_f64, probe_fma_f64, probe_rndne_f64, probe_ldexp_f64, probe_cvt_i32_f64};
+    constexpr int kOps = static_cast<int>(sizeof(table) / sizeof(table[0]));
+    static_assert(kOps == OLMC_PROBE_COUNT, "include/olmc.h lists the probe classes");
+    if (!ns_per_instr) return fail(OLMC_ERR_ARG, "null pointer");
+    if (op < 0 || op >= kOps) return fail(OLMC_ERR_ARG, "unknown probe class");
+    if (waves_per_simd < 1 || waves_per_simd > 8) return fail(OLMC_ERR_ARG, "waves_per_simd must be in [1, 8]");
+    DeviceCtx* c = nullptr;
+    int rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    rc = bulk_reserve(c, 256);
+    if (rc) return rc;
+    const dim3 grid(static_cast<uint32_t>(c->cus * waves_per_simd)), block(kBlock);    // one 4-wave workgroup per (CU, resident wave slot)
+    EventPair ep{};
+    rc = prof_acquire(c, &ep);
+    if (rc) return rc;
+    for (int rep = 0; rep < 2; ++rep) {          // first launch warms the instruction cache
+        hipExtLaunchKernelGGL(table[op], grid, block, 0, c->stream, ep.start, ep.stop, 0, static_cast<uint32_t*>(c->d_bulk), 1u, 0xD2511F53u);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ep.start, ep.stop));
+    c->ev_free.push_back(ep);
+    *ns_per_instr = static_cast<double>(ms) * 1e6 / (static_cast<double>(kProbeIters) * 16.0 * waves_per_simd);
     return OLMC_OK;
 }
 

@@ -1643,6 +1643,102 @@ __global__ __launch_bounds__(kBlock) void clock_probe_kernel(PathRange pr, uint6
     }
 }
 
+// Measurement tap (bench.py): the issue cost of ONE instruction class on this device, in the form the path kernels
+// use it (SGPR multipliers / keys where hipcc puts them there).  Every wave runs kProbeIters x 16 independent
+// instructions of the class; with `w` workgroups per CU (= w waves per SIMD) the kernel's duration / (iters x 16 x w) is
+// the time one SIMD needs per wave64 instruction of that class with w waves to pick from.  This calibrates the
+// roofline's issue model on the chip and at the clock the benchmark itself runs at.
+constexpr int kProbeIters = 2000;
+
+#define OLMC_PROBE(NAME, TYPE, INIT, ASM)                                                                           \
+    __global__ __launch_bounds__(kBlock) void NAME(uint32_t* __restrict__ sink, uint32_t seed, uint32_t kconst) {   \
+        TYPE r[16];                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) r[i] = INIT;                                                 \
+        for (int it = 0; it < kProbeIters; ++it) {                                                                  \
+            _Pragma("unroll") for (int i = 0; i < 16; ++i) { ASM; }                                                 \
+        }                                                                                                           \
+        TYPE acc = r[0];                                                                                            \
+        _Pragma("unroll") for (int i = 1; i < 16; ++i) acc = acc + r[i];                                            \
+        if (acc == static_cast<TYPE>(12345.678)) sink[0] = 1u;                                                      \
+    }
+
+#define OLMC_PF (static_cast<float>(threadIdx.x + i + seed) * 0.37f + 2.0f)
+#define OLMC_PU (threadIdx.x * 2654435761u + i + seed)
+#define OLMC_PD (static_cast<double>(threadIdx.x + i + seed) * 0.37 + 2.0)
+OLMC_PROBE(probe_bitop3, uint32_t, OLMC_PU, asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(r[i]) : "v"(seed + i), "s"(kconst)))
+OLMC_PROBE(probe_cvt_f32_u32, float, OLMC_PF, asm volatile("v_cvt_f32_u32_e32 %0, %0" : "+v"(r[i])))
+OLMC_PROBE(probe_fmamk_f32, float, OLMC_PF, asm volatile("v_fmamk_f32 %0, %0, 0x2f800000, %1" : "+v"(r[i]) : "v"(1.0001f)))
+OLMC_PROBE(probe_and_or, uint32_t, OLMC_PU, asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(r[i]) : "s"(kconst), "v"(0x3F800000u)))
+OLMC_PROBE(probe_log_f32, float, OLMC_PF, asm volatile("v_log_f32_e32 %0, %0" : "+v"(r[i])))
+OLMC_PROBE(probe_sqrt_f32, float, OLMC_PF, asm volatile("v_sqrt_f32_e32 %0, %0" : "+v"(r[i])))
+OLMC_PROBE(probe_sin_f32, float, OLMC_PF, asm volatile("v_sin_f32_e32 %0, %0" : "+v"(r[i])))
+OLMC_PROBE(probe_cos_f32, float, OLMC_PF, asm volatile("v_cos_f32_e32 %0, %0" : "+v"(r[i])))
+OLMC_PROBE(probe_exp_f32, float, OLMC_PF, asm volatile("v_exp_f32_e32 %0, %0" : "+v"(r[i])))
+OLMC_PROBE(probe_add_f32, float, OLMC_PF, asm volatile("v_add_f32_e32 %0, %1, %0" : "+v"(r[i]) : "v"(1.0001f)))
+OLMC_PROBE(probe_fma_f32, float, OLMC_PF, asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(r[i]) : "v"(1.0001f)))
+OLMC_PROBE(probe_add_f64, double, OLMC_PD, asm volatile("v_add_f64 %0, %0, %1" : "+v"(r[i]) : "v"(1.5)))
+OLMC_PROBE(probe_fma_f64, double, OLMC_PD, asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(r[i]) : "v"(1.0000001)))
+OLMC_PROBE(probe_rndne_f64, double, OLMC_PD, asm volatile("v_rndne_f64_e32 %0, %0" : "+v"(r[i])))
+OLMC_PROBE(probe_ldexp_f64, double, OLMC_PD, asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(r[i]) : "v"(1)))
+#undef OLMC_PF
+#undef OLMC_PU
+#undef OLMC_PD
+
+// v_mad_u64_u32 (64-bit destination, SGPR multiplier as in the Philox rounds) and the two width-changing conversions
+__global__ __launch_bounds__(kBlock) void probe_mad_u64_u32(uint32_t* __restrict__ sink, uint32_t seed, uint32_t kconst) {
+    uint64_t r[16];
+    uint32_t a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { r[i] = threadIdx.x + i + seed; a[i] = threadIdx.x * 7u + i; }
+    for (int it = 0; it < kProbeIters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            uint64_t carry;         // the carry-out goes to an SGPR pair, as hipcc emits it in the Philox rounds
+            asm volatile("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r[i]), "=s"(carry) : "v"(a[i]), "s"(kconst));
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(r[i]));      // sixteen live destinations per iteration, no extra instruction
+    }
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += r[i];
+    if (acc == 12345u) sink[0] = 1u;
+}
+
+__global__ __launch_bounds__(kBlock) void probe_cvt_f64_f32(uint32_t* __restrict__ sink, uint32_t seed, uint32_t) {
+    double r[16];
+    float a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a[i] = static_cast<float>(threadIdx.x + i + seed); r[i] = 0.0; }
+    for (int it = 0; it < kProbeIters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_cvt_f64_f32_e32 %0, %1" : "=v"(r[i]) : "v"(a[i]));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(r[i]));
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += r[i];
+    if (acc == 12345.5) sink[0] = 1u;
+}
+
+__global__ __launch_bounds__(kBlock) void probe_cvt_i32_f64(uint32_t* __restrict__ sink, uint32_t seed, uint32_t) {
+    int32_t r[16];
+    double a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a[i] = static_cast<double>(threadIdx.x + i + seed) * 0.37; r[i] = 0; }
+    for (int it = 0; it < kProbeIters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_cvt_i32_f64_e32 %0, %1" : "=v"(r[i]) : "v"(a[i]));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(r[i]));
+    }
+    int32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += r[i];
+    if (acc == 12345) sink[0] = 1u;
+}
+
 // ------------------------------------------------------- validation taps ----
 __global__ void philox_words_kernel(uint64_t first, int64_t n_paths, int32_t block0, int32_t n_blocks,
                                     uint32_t tag, uint32_t k0, uint32_t k1, uint32_t* __restrict__ out) {

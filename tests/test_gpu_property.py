@@ -9,6 +9,7 @@ from hypothesis import HealthCheck, given, settings
 from hypothesis import strategies as st
 
 from optionslab_amd import _hip
+from optionslab_amd.exceptions import AccelerationError
 from oracle import philox_oracle as po
 
 pytestmark = pytest.mark.gpu
@@ -80,6 +81,10 @@ def test_cliquet(N, M, seed, S, v, r, q, T, anti, periods, cap, floor):
        lam=st.floats(0.0, 30.0))
 def test_jump_diffusion(N, M, seed, S, K, v, r, q, T, call, kou, lam):
     a = (0.4, 10.0, 5.0) if kou else (-0.1, 0.2, 0.0)
+    if lam * (T / M) > 20.0:        # more than 20 expected jumps per step: refused (the inversion sampler caps at 64 jumps), not mispriced
+        with pytest.raises(AccelerationError, match="jumps per step"):
+            _hip.jump_diffusion(S, K, T, r, v, q, call, kou, lam, *a, N, M, seed)
+        return
     got = _hip.jump_diffusion(S, K, T, r, v, q, call, kou, lam, *a, N, M, seed)
     sx, sxx, n = po.jump_moments(S, K, T, r, v, q, call, kou, lam, *a, N, M, seed)
     assert got.n == n and close(got.sum, sx, 2, n, max(S, K)) and close(got.sumsq, sxx, 8, n, max(S, K), 2)

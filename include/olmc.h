@@ -343,7 +343,10 @@ int olmc_clock_probe(int64_t n_paths, int32_t n_steps, uint64_t seed, double* ou
 enum { OLMC_PROBE_MAD_U64_U32 = 0, OLMC_PROBE_BITOP3_B32, OLMC_PROBE_CVT_F32_U32, OLMC_PROBE_FMAMK_F32, OLMC_PROBE_AND_OR_B32,
        OLMC_PROBE_LOG_F32, OLMC_PROBE_SQRT_F32, OLMC_PROBE_SIN_F32, OLMC_PROBE_COS_F32, OLMC_PROBE_EXP_F32, OLMC_PROBE_ADD_F32,
        OLMC_PROBE_FMA_F32, OLMC_PROBE_CVT_F64_F32, OLMC_PROBE_ADD_F64, OLMC_PROBE_FMA_F64, OLMC_PROBE_RNDNE_F64,
-       OLMC_PROBE_LDEXP_F64, OLMC_PROBE_CVT_I32_F64, OLMC_PROBE_COUNT };
+       OLMC_PROBE_LDEXP_F64, OLMC_PROBE_CVT_I32_F64,
+       /* two-instruction bodies (the figure is per PAIR) and operand-form variants: do classes overlap in a mix? */
+       OLMC_PROBE_MIX_LOG_ADD, OLMC_PROBE_MIX_LOG_BITOP3, OLMC_PROBE_BITOP3_VVV, OLMC_PROBE_BITOP3_VVC, OLMC_PROBE_XOR_VV,
+       OLMC_PROBE_MIX_BITOP3_ADD, OLMC_PROBE_MIX_MAD_BITOP3, OLMC_PROBE_MAD_U64_U32_VV, OLMC_PROBE_COUNT };
 int olmc_issue_probe(int op, int waves_per_simd, double* ns_per_instr);
 
 /* ---- measurement ----------------------------------------------------------
@@ -358,12 +361,14 @@ int olmc_profile_enable(int on);
  *   OLMC_TUNE_GRID_CAP   max workgroups per launch, 0 = default (larger jobs grid-stride)
  *   OLMC_TUNE_QMC_BLOCK  Sobol kernels: 0 = eight consecutive points per thread from 2^20 points on (default),
  *                        1 = always, -1 = never (one point per thread)
+ *   OLMC_TUNE_SPLIT_TAIL European launches: 0 = the paths beyond a whole number of workgroups per compute unit go to split
+ *                        workgroups (64 paths, each wave a quarter of the steps; default), -1 = never (one shape throughout)
  * and two fault-injection knobs for the tests of the error paths (0 = off, the default):
  *   OLMC_TUNE_FAULT_SHARD  k > 0: shard k - 1 of olmc_multi_gpu_european fails before it launches
  *   OLMC_TUNE_FORCE_NV     v > 0: reduction workspaces REPORT a capacity of v values per workgroup row, so a kernel
  *                          that reduces more than v values trips its device-side bound check (result NaN, nothing
  *                          written out of bounds, library usable afterwards) */
-enum { OLMC_TUNE_GRID_CAP = 2, OLMC_TUNE_QMC_BLOCK = 4, OLMC_TUNE_FAULT_SHARD = 5, OLMC_TUNE_FORCE_NV = 6 };
+enum { OLMC_TUNE_GRID_CAP = 2, OLMC_TUNE_QMC_BLOCK = 4, OLMC_TUNE_FAULT_SHARD = 5, OLMC_TUNE_FORCE_NV = 6, OLMC_TUNE_SPLIT_TAIL = 7 };
 int olmc_tune(int knob, int value);
 int olmc_profile_reset(void);
 int olmc_kernel_time(int64_t* launches, double* total_ms);

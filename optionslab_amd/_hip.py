@@ -448,6 +448,7 @@ TUNE_GRID_CAP = 2
 TUNE_QMC_BLOCK = 4
 TUNE_FAULT_SHARD = 5
 TUNE_FORCE_NV = 6
+TUNE_SPLIT_TAIL = 7
 
 
 def tune(knob: int, value: int) -> None:
@@ -470,7 +471,9 @@ def clock_probe(n_paths: int = 1_000_000, n_steps: int = 252, seed: int = 42) ->
 
 PROBE_CLASSES = ("v_mad_u64_u32", "v_bitop3_b32", "v_cvt_f32_u32", "v_fmamk_f32", "v_and_or_b32", "v_log_f32", "v_sqrt_f32",
                  "v_sin_f32", "v_cos_f32", "v_exp_f32", "v_add_f32", "v_fma_f32", "v_cvt_f64_f32", "v_add_f64", "v_fma_f64",
-                 "v_rndne_f64", "v_ldexp_f64", "v_cvt_i32_f64")           # order = the OLMC_PROBE_* enum of include/olmc.h
+                 "v_rndne_f64", "v_ldexp_f64", "v_cvt_i32_f64",
+                 "pair:v_log_f32+v_add_f32", "pair:v_log_f32+v_bitop3_b32", "v_bitop3_b32(v,v,v)", "v_bitop3_b32(v,v,const)", "v_xor_b32(v,v)",
+                 "pair:v_bitop3_b32+v_add_u32", "pair:v_mad_u64_u32+v_bitop3_b32", "v_mad_u64_u32(v,v)")   # order = the OLMC_PROBE_* enum of include/olmc.h
 
 
 def issue_probe(waves_per_simd: int = 8) -> dict:

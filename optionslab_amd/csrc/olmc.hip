@@ -174,6 +174,7 @@ int bulk_reserve(DeviceCtx* c, size_t bytes) {
 // Tuning knob (olmc_tune): 0 = automatic.
 int g_grid_cap = 0;          // OLMC_TUNE_GRID_CAP: max workgroups per launch (0 = kMaxGrid)
 int g_qmc_block = 0;         // OLMC_TUNE_QMC_BLOCK: 0 = by size, 1 = always eight points per thread, -1 = never
+int g_split_tail = 0;        // OLMC_TUNE_SPLIT_TAIL: 0 = split workgroups for the remainder of a European launch (default), -1 = never
 int g_fault_shard = 0;       // OLMC_TUNE_FAULT_SHARD: k > 0 makes shard k - 1 of olmc_multi_gpu_european fail (tests of the error path)
 int g_force_nv = 0;          // OLMC_TUNE_FORCE_NV: > 0 sizes the next workspaces for this many values per row (test of the device guard)
 
@@ -190,6 +191,25 @@ int32_t grid_for(int64_t n_paths, int32_t n_steps = INT32_MAX) {
     int64_t cap = g_grid_cap > 0 ? std::min<int64_t>(g_grid_cap, kMaxGrid) : kMaxGrid;
     if (g_grid_cap == 0 && n_steps <= kShortPathSteps) cap = kShortPathGrid;
     return static_cast<int32_t>(std::min<int64_t>((n_paths + kBlock - 1) / kBlock, cap));
+}
+
+// Launch shape of european_path_kernel for pr.count paths: returns the grid and sets pr->split_from.  When one workgroup
+// per 256 paths covers the launch (no grid-striding) the first F = floor(whole workgroups / CUs) * CUs workgroups own 256
+// paths each and the remaining paths go to split workgroups of 64 paths (four waves x a quarter of the steps each; see
+// the kernel) -- unless the paths have fewer than four full fp32 groups (64 steps) to hand out.
+int32_t european_launch_shape(const DeviceCtx* c, PathRange* pr) {
+    pr->split_from = INT32_MAX;
+    const int32_t grid = grid_for(pr->count, pr->n_steps);
+    const int64_t wgs = (pr->count + kBlock - 1) / kBlock;
+    if (g_split_tail < 0 || g_grid_cap != 0 || wgs != grid) return grid;           // tuned or grid-striding launches keep their shape
+    if ((pr->n_steps >> 2) / kGroup < 4 || c->cus < 1) return grid;
+    const int64_t full = (pr->count / kBlock) / c->cus * c->cus;                    // whole 256-path workgroups, a multiple of the CU count
+    const int64_t rest = pr->count - full * kBlock;
+    if (rest == 0) return grid;
+    const int64_t split = (rest + kWave - 1) / kWave;
+    if (full + split > kMaxGrid) return grid;
+    pr->split_from = static_cast<int32_t>(full);
+    return static_cast<int32_t>(full + split);
 }
 
 // Workspace of the fused grid reduction for a launch of `grid` workgroups x nv values.
@@ -376,6 +396,7 @@ PathRange make_range(int64_t path_offset, int64_t n_local, int32_t n_steps, uint
     pr.n_steps = n_steps;
     pr.key0 = static_cast<uint32_t>(seed);
     pr.key1 = static_cast<uint32_t>(seed >> 32);
+    pr.split_from = INT32_MAX;
     return pr;
 }
 
@@ -425,8 +446,8 @@ void launch_european(bool anti, int32_t grid, hipStream_t s, const PathRange& pr
 int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32_t k, int64_t path_offset,
                      int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic, double* d_out, double tail,
                      int* pos /* [k]: slot of contract i in d_out, may be NULL when k == 1 */) {
-    const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
-    const int32_t grid = grid_for(n_local, n_steps);
+    PathRange pr = make_range(path_offset, n_local, n_steps, seed);
+    const int32_t grid = european_launch_shape(c, &pr);
     const bool anti = antithetic != 0;
     const int nsets = k == 1 ? 1 : (k <= 8 ? 8 : 16);
     ReduceWs ws;
@@ -719,12 +740,12 @@ extern "C" int olmc_european_terminal(double S, double T, double r, double sigma
     const size_t bytes = sizeof(double) * static_cast<size_t>(n_paths) * (antithetic ? 2 : 1);
     rc = bulk_reserve(c, bytes);
     if (rc) return rc;
-    const PathRange pr = make_range(0, n_paths, n_steps, seed);
+    PathRange pr = make_range(0, n_paths, n_steps, seed);
+    const int32_t grid = european_launch_shape(c, &pr);
     ContractSet<1> cs;
     cs.c[0] = make_contract(make_option(S, 0.0, T, r, sigma, q, 1), n_steps);
     ReduceWs ws{};   // unused in kTerminal mode
-    launch_european<1, kTerminal>(antithetic != 0, grid_for(n_paths), c->stream, pr, cs, ws,
-                                  static_cast<double*>(c->d_bulk));
+    launch_european<1, kTerminal>(antithetic != 0, grid, c->stream, pr, cs, ws, static_cast<double*>(c->d_bulk));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_host, c->d_bulk, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -756,8 +777,8 @@ extern "C" int olmc_european_cv_shard(double S, double K, double T, double r, do
     rc = ctx_get(&c);
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(c->mu);
-    const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
-    const int32_t grid = grid_for(n_local);
+    PathRange pr = make_range(path_offset, n_local, n_steps, seed);
+    const int32_t grid = european_launch_shape(c, &pr);
     ContractSet<1> cs;
     cs.c[0] = make_contract(make_option(S, K, T, r, sigma, q, is_call), n_steps);
     ReduceWs ws;
@@ -1600,7 +1621,9 @@ extern "C" int olmc_issue_probe(int op, int waves_per_simd, double* ns_per_instr
     using Probe = void (*)(uint32_t*, uint32_t, uint32_t);
     static const Probe table[] = {probe_mad_u64_u32, probe_bitop3, probe_cvt_f32_u32, probe_fmamk_f32, probe_and_or, probe_log_f32,
                                   probe_sqrt_f32, probe_sin_f32, probe_cos_f32, probe_exp_f32, probe_add_f32, probe_fma_f32,
-                                  probe_cvt_f64_f32, probe_add_f64, probe_fma_f64, probe_rndne_f64, probe_ldexp_f64, probe_cvt_i32_f64};
+                                  probe_cvt_f64_f32, probe_add_f64, probe_fma_f64, probe_rndne_f64, probe_ldexp_f64, probe_cvt_i32_f64,
+                                  probe_mix_log_add, probe_mix_log_bitop3, probe_bitop3_vvv, probe_bitop3_vvc, probe_xor_vv, probe_mix_bitop3_add,
+                                  probe_mix_mad_bitop3, probe_mad_u64_u32_vv};
     constexpr int kOps = static_cast<int>(sizeof(table) / sizeof(table[0]));
     static_assert(kOps == OLMC_PROBE_COUNT, "include/olmc.h lists the probe classes");
     if (!ns_per_instr) return fail(OLMC_ERR_ARG, "null pointer");
@@ -1632,6 +1655,7 @@ extern "C" int olmc_issue_probe(int op, int waves_per_simd, double* ns_per_instr
 extern "C" int olmc_tune(int knob, int value) {
     if (knob == OLMC_TUNE_GRID_CAP && value >= 0) { g_grid_cap = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_QMC_BLOCK && value >= -1 && value <= 1) { g_qmc_block = value; return OLMC_OK; }
+    if (knob == OLMC_TUNE_SPLIT_TAIL && value >= -1 && value <= 0) { g_split_tail = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_FAULT_SHARD && value >= 0 && value <= kMaxDevices) { g_fault_shard = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_FORCE_NV && value >= 0 && value <= kMaxNV) { g_force_nv = value; return OLMC_OK; }
     return fail(OLMC_ERR_ARG, "unknown tuning knob or value");

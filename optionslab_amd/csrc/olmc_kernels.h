@@ -111,34 +111,60 @@ __device__ __forceinline__ float raw_block_accumulate(float acc, uint32_t g_lo, 
 // sum_t Z_t (true normals) of one path.  Block b covers steps 4b..4b+3; fp32 within a group of
 // kGroup blocks (16 normals, interleaved by hipcc for ILP), fp64 across groups; a trailing
 // partial block contributes its first n_steps % 4 normals.
+//
+// The fp64 sum over groups has ONE canonical association, whoever computes it:
+//     sum = ((Q0 + Q1) + Q2) + Q3,    Q_w = the full groups [w gq, (w+1) gq) added in order, gq = ceil(#full groups / 4),
+// Q3 additionally taking the trailing partial group and the partial block.  A thread that owns a whole path evaluates
+// the four quarters one after the other (path_normal_sum); in a SPLIT workgroup the four waves evaluate one quarter each
+// of the same 64 paths (path_normal_quarter) and combine through LDS -- the same additions in the same order, hence
+// the same bits.  (Group sums are fp32 values added in fp64: the association would matter only for a group sum below
+// ~5e-7, about one path in ten million -- but "equal seeds give equal bits" must not depend on the launch shape.)
 constexpr int kGroup = 4;   // measured: 2 is 2 % slower, 8 no faster
+
+// Quarters [w0, w1) of one path's canonical sum, UNSCALED (multiply by kZScale once all four are in).  w0 = 0, w1 = 4 is the
+// whole path: ((0 + Q0) + Q1) + Q2, then + Q3.  A single quarter w returns 0 + Q_w = Q_w exactly.  One loop nest serves both.
+__device__ __forceinline__ double path_normal_quarters(uint32_t g_lo, uint32_t g_hi, int32_t n_steps, int32_t w0, int32_t w1, uint32_t k0,
+                                                       uint32_t k1, uint32_t tag = 0u) {
+    const int32_t full = n_steps >> 2;                 // blocks whose four steps all count
+    const int32_t n_groups = full / kGroup;            // full groups
+    const int32_t gq = (n_groups + 3) >> 2;            // groups per quarter
+    double acc = 0.0, q = 0.0;
+#pragma unroll 1
+    for (int32_t w = w0; w < w1; ++w) {
+        q = 0.0;
+        const int32_t b1 = min((w + 1) * gq, n_groups) * kGroup;
+        for (int32_t b = min(w * gq, n_groups) * kGroup; b < b1; b += kGroup) {
+            float s = 0.0f;
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) s = raw_block_accumulate(s, g_lo, g_hi, static_cast<uint32_t>(b + j), tag, k0, k1);
+            q += static_cast<double>(s);
+        }
+        if (w < 3) acc += q;
+    }
+    if (w1 == 4) {                                     // whoever owns quarter 3 also owns the trailing partial group and block
+        int32_t b = n_groups * kGroup;
+        if (b < full) {
+            float s = 0.0f;
+            for (; b < full; ++b) s = raw_block_accumulate(s, g_lo, g_hi, static_cast<uint32_t>(b), tag, k0, k1);
+            q += static_cast<double>(s);
+        }
+        const int32_t rem = n_steps & 3;
+        if (rem) {
+            float z[4];
+            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(full), tag, k0, k1, z);
+            float s = z[0];
+            if (rem > 1) s += z[1];
+            if (rem > 2) s += z[2];
+            q += static_cast<double>(s);
+        }
+        acc += q;
+    }
+    return acc;
+}
 
 __device__ __forceinline__ double path_normal_sum(uint32_t g_lo, uint32_t g_hi, int32_t n_steps, uint32_t k0, uint32_t k1,
                                                   uint32_t tag = 0u) {
-    const int32_t full = n_steps >> 2;         // blocks whose four steps all count
-    double acc = 0.0;
-    int32_t b = 0;
-    for (; b + kGroup <= full; b += kGroup) {
-        float s = 0.0f;
-#pragma unroll
-        for (int j = 0; j < kGroup; ++j) s = raw_block_accumulate(s, g_lo, g_hi, static_cast<uint32_t>(b + j), tag, k0, k1);
-        acc += static_cast<double>(s);
-    }
-    if (b < full) {
-        float s = 0.0f;
-        for (; b < full; ++b) s = raw_block_accumulate(s, g_lo, g_hi, static_cast<uint32_t>(b), tag, k0, k1);
-        acc += static_cast<double>(s);
-    }
-    const int32_t rem = n_steps & 3;
-    if (rem) {
-        float z[4];
-        raw_normals4(g_lo, g_hi, static_cast<uint32_t>(full), tag, k0, k1, z);
-        float s = z[0];
-        if (rem > 1) s += z[1];
-        if (rem > 2) s += z[2];
-        acc += static_cast<double>(s);
-    }
-    return acc * kZScale;
+    return path_normal_quarters(g_lo, g_hi, n_steps, 0, 4, k0, k1, tag) * kZScale;
 }
 
 // ------------------------------------------------------------ reductions ----
@@ -346,6 +372,8 @@ struct PathRange {
     int64_t count;     // paths in this launch
     int32_t n_steps;
     uint32_t key0, key1;
+    int32_t split_from;   // european_path_kernel (grid covers every path): workgroups >= split_from are SPLIT workgroups (see
+                          // there); INT32_MAX = none.  Other kernels ignore it.
 };
 
 enum Mode : int { kReduce = 0, kTerminal = 1, kControlVariate = 2 };
@@ -363,53 +391,85 @@ __device__ __forceinline__ void add_sample(double (&acc)[MODE == kControlVariate
 //   kReduce          out[2s], out[2s+1] = sum x, sum x^2 of contract s (x = UNdiscounted payoff)
 //   kTerminal        terminal[i] = S_T^+, terminal[count + i] = S_T^-  (coalesced [pos | neg], gbm_numpy.py:51)
 //   kControlVariate  out[0..4] = sum x, sum s, sum x^2, sum s^2, sum x*s  (NSETS == 1)
-// A variant in which the four waves of a workgroup split one 64-path tile's steps (4x finer
-// scheduling unit) was built and measured: never faster (121 vs 117.5 us), so it is gone.
+// (Round 1 built a variant in which EVERY workgroup split one 64-path tile's steps over its four waves: never faster,
+// 121 vs 117.5 us, because every path then pays the LDS meeting and three idle waves in the epilogue.  Only the
+// remainder of a launch is split now -- see SPLIT workgroups below.)
 // STRIDED = false: the grid covers every path (one per thread), so the accumulators are born AFTER
 // the step loop and do not occupy registers during it -- with 8 / 16 contracts (16 / 32 fp64 sums)
 // that is the difference between 5 and 7-8 waves per SIMD in the loop that matters.
+//
+// SPLIT workgroups (STRIDED = false only).  A launch of W = ceil(count / 256) equal workgroups on C compute units takes
+// ceil(W / C) workgroup-times per CU whatever the remainder is: 1M paths = 3906.25 workgroups = 15.26 per CU costs 16
+// (+4.8 %).  So the host lets the first F = floor(W / C) * C workgroups own 256 whole paths each, as ever, and hands the
+// remaining paths to split workgroups of 64 paths whose four waves each walk a QUARTER of the steps (one quarter of the
+// canonical sum above) and meet in LDS: a quarter of the duration on all four SIMDs of a CU, so the remainder spreads
+// over the chip in units four times finer -- and a launch smaller than one round of the chip (the interactive sizes)
+// finishes its step loops in a quarter of the time.  Wave 0 of a split workgroup evaluates the payoffs of its 64 paths.
+// Payoffs of one path (both legs) for every contract of the set, given its normal sum.
+template <int NSETS, bool ANTI, int MODE>
+__device__ __forceinline__ void european_payoffs(const ContractSet<NSETS>& cs, double zsum, bool live, int64_t i, int64_t count,
+                                                 double* __restrict__ terminal, double (&acc)[(MODE == kControlVariate) ? 5 : 2 * NSETS]) {
+    constexpr int NC = (MODE == kControlVariate) ? 5 : 2;
+    double base_st[2] = {0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s) {
+        const Contract c = cs.c[s];
+        const bool is_base = NSETS == 1 || c.scale == 0.0;          // wave-uniform
+        if (is_base) {
+            const double dz = c.vol * zsum;
+            base_st[0] = exp(c.a + dz);
+            if constexpr (ANTI) base_st[1] = exp(c.a - dz);
+        }
+#pragma unroll
+        for (int leg = 0; leg < (ANTI ? 2 : 1); ++leg) {
+            const double st = is_base ? base_st[leg] : c.scale * base_st[leg];
+            if constexpr (MODE == kTerminal) {
+                if (live) terminal[leg * count + i] = st;
+            } else {
+                const double x = fmax(c.sign * (st - c.strike), 0.0);
+                double (&slot)[NC] = *reinterpret_cast<double (*)[NC]>(&acc[(MODE == kControlVariate) ? 0 : 2 * s]);
+                add_sample<MODE>(slot, live ? x : 0.0, live ? st : 0.0);
+            }
+        }
+    }
+}
+
 template <int NSETS, bool ANTI, int MODE, bool STRIDED>
 __global__ __launch_bounds__(kBlock) void european_path_kernel(PathRange pr, ContractSet<NSETS> cs, ReduceWs ws,
                                                                double* __restrict__ terminal) {
     constexpr int NV = (MODE == kControlVariate) ? 5 : 2 * NSETS;
-    constexpr int NC = (MODE == kControlVariate) ? 5 : 2;
     double acc[NV];
     if constexpr (STRIDED) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) acc[i] = 0.0;
-    }
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; STRIDED ? i < pr.count : i == static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-         i += stride) {
-        const bool live = i < pr.count;                 // always true when STRIDED
+        for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+        const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+        for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < pr.count; i += stride) {
+            const uint64_t g = pr.first + static_cast<uint64_t>(i);
+            const double zsum = path_normal_sum(static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32), pr.n_steps, pr.key0, pr.key1);
+            european_payoffs<NSETS, ANTI, MODE>(cs, zsum, true, i, pr.count, terminal, acc);
+        }
+    } else {
+        __shared__ double quarter_sum[kWavesPerBlock][kWave];
+        // readfirstlane: the wave index is uniform, and the compiler must KNOW it -- the Philox block counter derives from it in
+        // a split workgroup, and a counter in SGPRs keeps the first round's multiply on the scalar unit (17 instead of 18
+        // v_mad_u64_u32 per block)
+        const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / kWave), lane = threadIdx.x & (kWave - 1);
+        const bool split = static_cast<int32_t>(blockIdx.x) >= pr.split_from;                    // workgroup-uniform
+        const int64_t i = split ? static_cast<int64_t>(pr.split_from) * kBlock + (static_cast<int64_t>(blockIdx.x) - pr.split_from) * kWave + lane
+                                : static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
         const uint64_t g = pr.first + static_cast<uint64_t>(i);
-        const double zsum = path_normal_sum(static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32), pr.n_steps, pr.key0, pr.key1);
-        if constexpr (!STRIDED) {
-#pragma unroll
-            for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+        double zsum = path_normal_quarters(static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32), pr.n_steps, split ? wave : 0,
+                                           split ? wave + 1 : 4, pr.key0, pr.key1);
+        if (split) {
+            quarter_sum[wave][lane] = zsum;
+            __syncthreads();
+            zsum = ((quarter_sum[0][lane] + quarter_sum[1][lane]) + quarter_sum[2][lane]) + quarter_sum[3][lane];
         }
-        double base_st[2] = {0.0, 0.0};
+        zsum *= kZScale;
 #pragma unroll
-        for (int s = 0; s < NSETS; ++s) {
-            const Contract c = cs.c[s];
-            const bool is_base = NSETS == 1 || c.scale == 0.0;          // wave-uniform
-            if (is_base) {
-                const double dz = c.vol * zsum;
-                base_st[0] = exp(c.a + dz);
-                if constexpr (ANTI) base_st[1] = exp(c.a - dz);
-            }
-#pragma unroll
-            for (int leg = 0; leg < (ANTI ? 2 : 1); ++leg) {
-                const double st = is_base ? base_st[leg] : c.scale * base_st[leg];
-                if constexpr (MODE == kTerminal) {
-                    if (live) terminal[leg * pr.count + i] = st;
-                } else {
-                    const double x = fmax(c.sign * (st - c.strike), 0.0);
-                    double (&slot)[NC] = *reinterpret_cast<double (*)[NC]>(&acc[(MODE == kControlVariate) ? 0 : 2 * s]);
-                    add_sample<MODE>(slot, live ? x : 0.0, live ? st : 0.0);
-                }
-            }
-        }
+        for (int k = 0; k < NV; ++k) acc[k] = 0.0;      // born after the step loop
+        // waves 1..3 of a split workgroup carry no path through the payoffs (wave-uniform branch)
+        if (!split || wave == 0) european_payoffs<NSETS, ANTI, MODE>(cs, zsum, i < pr.count, i, pr.count, terminal, acc);
     }
     if constexpr (MODE != kTerminal) block_then_grid_reduce<NV>(acc, ws);
 }
@@ -1680,9 +1740,61 @@ OLMC_PROBE(probe_add_f64, double, OLMC_PD, asm volatile("v_add_f64 %0, %0, %1" :
 OLMC_PROBE(probe_fma_f64, double, OLMC_PD, asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(r[i]) : "v"(1.0000001)))
 OLMC_PROBE(probe_rndne_f64, double, OLMC_PD, asm volatile("v_rndne_f64_e32 %0, %0" : "+v"(r[i])))
 OLMC_PROBE(probe_ldexp_f64, double, OLMC_PD, asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(r[i]) : "v"(1)))
+// Mixed bodies (TWO instructions per body: the reported figure is nanoseconds per PAIR): do classes overlap?
+// log+add: a transcendental beside a full-rate fp32 add;  log+bitop3: beside a three-operand integer op;
+// operand-form variants of the two integer workhorses of Philox.
+OLMC_PROBE(probe_mix_log_add, float, OLMC_PF, asm volatile("v_log_f32_e32 %0, %0\n\tv_add_f32_e32 %0, %1, %0" : "+v"(r[i]) : "v"(1.0001f)))
+OLMC_PROBE(probe_mix_log_bitop3, float, OLMC_PF, asm volatile("v_log_f32_e32 %0, %0\n\tv_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(r[i]) : "v"(seed + i), "s"(kconst)))
+OLMC_PROBE(probe_bitop3_vvv, uint32_t, OLMC_PU, asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(r[i]) : "v"(seed + i), "v"(kconst + i)))
+OLMC_PROBE(probe_bitop3_vvc, uint32_t, OLMC_PU, asm volatile("v_bitop3_b32 %0, %0, %1, 2 bitop3:0x96" : "+v"(r[i]) : "v"(seed + i)))
+OLMC_PROBE(probe_xor_vv, uint32_t, OLMC_PU, asm volatile("v_xor_b32_e32 %0, %1, %0" : "+v"(r[i]) : "v"(seed + i)))
+OLMC_PROBE(probe_mix_bitop3_add, uint32_t, OLMC_PU, asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96\n\tv_add_u32_e32 %0, %1, %0" : "+v"(r[i]) : "v"(seed + i), "s"(kconst)))
 #undef OLMC_PF
 #undef OLMC_PU
 #undef OLMC_PD
+
+// mad + bitop3 alternating, as in a Philox round (pair cost)
+__global__ __launch_bounds__(kBlock) void probe_mix_mad_bitop3(uint32_t* __restrict__ sink, uint32_t seed, uint32_t kconst) {
+    uint64_t r[16];
+    uint32_t a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { r[i] = threadIdx.x + i + seed; a[i] = threadIdx.x * 7u + i; }
+    for (int it = 0; it < kProbeIters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            uint64_t carry;
+            asm volatile("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_bitop3_b32 %2, %2, %4, %3 bitop3:0x96" : "=v"(r[i]), "=s"(carry), "+v"(a[i]) : "s"(kconst), "v"(seed + i));
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(r[i]));
+    }
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += r[i] + a[i];
+    if (acc == 12345u) sink[0] = 1u;
+}
+
+// v_mad_u64_u32 with the multiplier in a VGPR instead of an SGPR
+__global__ __launch_bounds__(kBlock) void probe_mad_u64_u32_vv(uint32_t* __restrict__ sink, uint32_t seed, uint32_t kconst) {
+    uint64_t r[16];
+    uint32_t a[16];
+    const uint32_t kv = kconst + (threadIdx.x >> 8);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { r[i] = threadIdx.x + i + seed; a[i] = threadIdx.x * 7u + i; }
+    for (int it = 0; it < kProbeIters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            uint64_t carry;
+            asm volatile("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r[i]), "=s"(carry) : "v"(a[i]), "v"(kv));
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(r[i]));
+    }
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += r[i];
+    if (acc == 12345u) sink[0] = 1u;
+}
 
 // v_mad_u64_u32 (64-bit destination, SGPR multiplier as in the Philox rounds) and the two width-changing conversions
 __global__ __launch_bounds__(kBlock) void probe_mad_u64_u32(uint32_t* __restrict__ sink, uint32_t seed, uint32_t kconst) {

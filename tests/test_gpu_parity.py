@@ -267,6 +267,35 @@ def test_config5_eight_shards_of_8m_x_252_equal_the_64m_launch():
     assert len({p[0] for p in parts}) == world
 
 
+@pytest.mark.parametrize("N,M", [(1_000_000, 252), (70_001, 64), (65_536, 100), (300, 1024), (63, 67), (1, 64), (262_144 + 77, 129), (5_000, 63)])
+def test_split_workgroups_return_the_bits_of_whole_path_workgroups(N, M):
+    """The paths beyond a whole number of workgroups per compute unit are priced by SPLIT workgroups (64 paths, each wave a
+    quarter of the steps, meeting in LDS: olmc_kernels.h european_path_kernel).  The fp64 sum over the fp32 groups has one
+    canonical association, so the launch shape must not show in a single bit: sums, Greeks batch, control variate and the
+    terminal array with the knob off (one shape throughout) == the default.  M = 63 has fewer than four groups: never split."""
+    S, K, T, r, v = ATM
+    def everything():
+        st = _hip.european(S, K, T, r, v, 0.01, True, N, M, 9, True, path_offset=12345)
+        na = _hip.european(S, K, T, r, v, 0.01, False, N, M, 9, False)
+        cv = _hip.european_cv(S, K, T, r, v, 0.0, True, N, M, 9)
+        out = [st.sum, st.sumsq, st.n, na.sum, na.sumsq, cv.sum_d, cv.sum_s, cv.sum_ds, cv.value]
+        if N <= 300_000:
+            g, evals = _hip.european_greeks_fd(S, K, T, r, v, 0.0, True, N, M, 9, True)
+            out += g + [e.sum for e in evals]
+            out.append(_hip.european_terminal(S, T, r, v, 0.0, N, M, 9, True).tobytes())
+        return out
+    split = everything()
+    _hip.tune(_hip.TUNE_SPLIT_TAIL, -1)
+    try:
+        whole = everything()
+    finally:
+        _hip.tune(_hip.TUNE_SPLIT_TAIL, 0)
+    assert split == whole
+    sx, sxx, *_m, n = po.european_moments(S, K, T, r, v, 0.01, True, min(N, 70_001), M, 9, True, 12345)
+    if N <= 70_001:
+        assert split[0] == pytest.approx(sx, rel=REL_STREAM_TOL) and split[2] == n
+
+
 def test_large_path_offsets_use_the_high_counter_word():
     S, K, T, r, v = ATM
     off = (1 << 32) - 100

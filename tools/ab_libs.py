@@ -32,14 +32,21 @@ CASES = {
     "heston": lambda s: _hip.heston(100.0, 100.0, 1.0, 0.05, 0.0, True, 2.0, 0.04, 0.3, -0.7, 0.04, N, M, s, False),
 }
 run = CASES[sys.argv[3]]
-import time
-for i in range(5): run(1 + i)
-_hip.profile_reset()
+import os, time
+if os.environ.get("OLMC_AB_TUNE"):                      # "knob=value,knob=value" applied before anything runs
+    for kv in os.environ["OLMC_AB_TUNE"].split(","):
+        k, v = kv.split("=")
+        _hip.tune(int(k), int(v))
+_hip.profile_enable(False)
+for i in range(400): run(1 + i)                          # clocks up (an idle device needs tens of ms of load)
 t0 = time.perf_counter()
-for i in range(30): st = run(42 + i)
-wall = (time.perf_counter() - t0) / 30
+for i in range(100): st = run(42 + i)
+wall = (time.perf_counter() - t0) / 100
+_hip.profile_enable(True)
+_hip.profile_reset()
+for i in range(60): st = run(42 + i)
 n, ms = _hip.kernel_time()
-print(json.dumps({"us": (ms / n * 1e3) if n else wall * 1e6, "price": st.price}))
+print(json.dumps({"us": (ms / n * 1e3) if n else wall * 1e6, "wall_us": wall * 1e6, "price": st.price, "sum": st.sum}))
 """ % ROOT
 
 ap = argparse.ArgumentParser()
@@ -49,15 +56,22 @@ ap.add_argument("--m", type=int, default=252)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--case", default="european")
 a = ap.parse_args()
+# a library may carry a tuning suffix: "libolmc.so@7=-1" runs it with olmc_tune(7, -1) (e.g. split workgroups off)
 res = {l: [] for l in a.libs}
+wall = {l: [] for l in a.libs}
 price = {}
 for r in range(a.rounds):
     for l in a.libs:
-        env = dict(os.environ, OLMC_LIBRARY=os.path.abspath(l))
+        path, _, tune = l.partition("@")
+        env = dict(os.environ, OLMC_LIBRARY=os.path.abspath(path))
+        if tune:
+            env["OLMC_AB_TUNE"] = tune
         out = subprocess.run([sys.executable, "-c", CHILD, str(a.n), str(a.m), a.case], env=env, capture_output=True, text=True, check=True)
         d = json.loads(out.stdout.strip().splitlines()[-1])
         res[l].append(d["us"])
-        price[l] = d["price"]
+        wall[l].append(d["wall_us"])
+        price[l] = (d["price"], d["sum"])
 for l in a.libs:
-    v = res[l]
-    print(f"{os.path.basename(l):28s} median {statistics.median(v):8.2f} us  min {min(v):8.2f}  max {max(v):8.2f}  price {price[l]:.9f}", flush=True)
+    v, w = res[l], wall[l]
+    print(f"{os.path.basename(l):34s} kernel median {statistics.median(v):8.2f} us  min {min(v):8.2f}  max {max(v):8.2f} | blocking call median "
+          f"{statistics.median(w):8.2f} us | price {price[l][0]:.12f} sum {price[l][1]!r}", flush=True)

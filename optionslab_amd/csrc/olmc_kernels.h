@@ -57,6 +57,45 @@ __device__ __forceinline__ Words4 philox4x32_10(uint32_t c0, uint32_t c1, uint32
     return Words4{c0, c1, c2, c3};
 }
 
+// The twenty round keys of one (seed) pinned in VGPRs.  They are wave-uniform, so hipcc keeps them in SGPRs and every
+// round's XOR3 reads two VGPRs and an SGPR -- and on gfx950 a VALU instruction with an SGPR operand holds the issue port
+// for ~4.4 cycles where the same instruction on three VGPRs takes ~2.6 (olmc_issue_probe: v_bitop3_b32 1.90 vs 1.12 ns
+// at 8 waves/SIMD).  Twenty v_mov per kernel buy that back on 19 XOR3s per Philox call: 1M x 252 European 103.4 -> 100.0 us,
+// fused 8 / 14 contracts 119.1 -> 115.1 / 133.8 -> 130.5 us (interleaved A/B, one device, identical sums).  66 VGPRs
+// instead of 46, i.e. 7 waves per SIMD instead of 8: pinning only 18 / 16 / 12 keys to stay at 64 was slower (100.7 /
+// 101.1 / 101.3 us), forcing 64 by launch bounds 100.9.  Also measured and NOT adopted: the mantissa mask of the angle in
+// a VGPR (100.5 us, no gain) and the two multipliers in VGPRs (102.3 us, worse: v_mad_u64_u32 costs the same with an SGPR
+// multiplier, the copies only add pressure).
+struct RoundKeys {
+    uint32_t k[20];
+};
+
+__device__ __forceinline__ RoundKeys pin_round_keys(uint32_t k0, uint32_t k1) {
+    RoundKeys rk;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t a = k0 + static_cast<uint32_t>(r) * kPhiloxW0, b = k1 + static_cast<uint32_t>(r) * kPhiloxW1;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(rk.k[2 * r]) : "s"(a));          // volatile: must not be folded back into an SGPR operand
+        asm volatile("v_mov_b32 %0, %1" : "=v"(rk.k[2 * r + 1]) : "s"(b));
+    }
+    return rk;
+}
+
+__device__ __forceinline__ Words4 philox4x32_10_pinned(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, const RoundKeys& rk) {
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const uint64_t p0 = static_cast<uint64_t>(kPhiloxM0) * c0;
+        const uint64_t p1 = static_cast<uint64_t>(kPhiloxM1) * c2;
+        const uint32_t n0 = xor3(static_cast<uint32_t>(p1 >> 32), c1, rk.k[2 * round]);
+        const uint32_t n2 = xor3(static_cast<uint32_t>(p0 >> 32), c3, rk.k[2 * round + 1]);
+        c1 = static_cast<uint32_t>(p1);
+        c3 = static_cast<uint32_t>(p0);
+        c0 = n0;
+        c2 = n2;
+    }
+    return Words4{c0, c1, c2, c3};
+}
+
 // ------------------------------------------------------------ Box-Muller ----
 // Radius word:  u_a = (x_a + 0.5) * 2^-32 in fp32 (never 0, so the log is finite; may
 //               round to 1); |z| <= sqrt(2*33*ln 2) = 6.76.
@@ -92,11 +131,9 @@ __device__ __forceinline__ void raw_normals4(uint32_t g_lo, uint32_t g_hi, uint3
 //   fma(rad_b, cos_b + sin_b, fma(rad_a, cos_a + sin_a, acc)):
 // two adds and two fmas per block INCLUDING the accumulation (the packed-math form needed
 // register-pair moves: 5.25 instructions per block against 4).
-__device__ __forceinline__ float raw_block_accumulate(float acc, uint32_t g_lo, uint32_t g_hi, uint32_t block, uint32_t tag,
-                                                      uint32_t k0, uint32_t k1) {
+__device__ __forceinline__ float raw_block_sum_of_words(float acc, const Words4& w) {
     constexpr float kTwoM32 = 2.3283064365386963e-10f;   // 2^-32
     constexpr float kTwoM33 = 1.1641532182693481e-10f;   // 2^-33
-    const Words4 w = philox4x32_10(g_lo, g_hi, block, tag, k0, k1);
     const float ua = __builtin_fmaf(static_cast<float>(w.x0), kTwoM32, kTwoM33);
     const float ub = __builtin_fmaf(static_cast<float>(w.x2), kTwoM32, kTwoM33);
     const float ta = __uint_as_float((w.x1 & 0x007FFFFFu) | 0x3F800000u);
@@ -106,6 +143,11 @@ __device__ __forceinline__ float raw_block_accumulate(float acc, uint32_t g_lo, 
     const float sum_a = __builtin_amdgcn_cosf(ta) + __builtin_amdgcn_sinf(ta);
     const float sum_b = __builtin_amdgcn_cosf(tb) + __builtin_amdgcn_sinf(tb);
     return __builtin_fmaf(rad_b, sum_b, __builtin_fmaf(rad_a, sum_a, acc));
+}
+
+__device__ __forceinline__ float raw_block_accumulate(float acc, uint32_t g_lo, uint32_t g_hi, uint32_t block, uint32_t tag,
+                                                      uint32_t k0, uint32_t k1) {
+    return raw_block_sum_of_words(acc, philox4x32_10(g_lo, g_hi, block, tag, k0, k1));
 }
 
 // sum_t Z_t (true normals) of one path.  Block b covers steps 4b..4b+3; fp32 within a group of
@@ -128,6 +170,7 @@ __device__ __forceinline__ double path_normal_quarters(uint32_t g_lo, uint32_t g
     const int32_t full = n_steps >> 2;                 // blocks whose four steps all count
     const int32_t n_groups = full / kGroup;            // full groups
     const int32_t gq = (n_groups + 3) >> 2;            // groups per quarter
+    const RoundKeys rk = pin_round_keys(k0, k1);
     double acc = 0.0, q = 0.0;
 #pragma unroll 1
     for (int32_t w = w0; w < w1; ++w) {
@@ -136,7 +179,7 @@ __device__ __forceinline__ double path_normal_quarters(uint32_t g_lo, uint32_t g
         for (int32_t b = min(w * gq, n_groups) * kGroup; b < b1; b += kGroup) {
             float s = 0.0f;
 #pragma unroll
-            for (int j = 0; j < kGroup; ++j) s = raw_block_accumulate(s, g_lo, g_hi, static_cast<uint32_t>(b + j), tag, k0, k1);
+            for (int j = 0; j < kGroup; ++j) s = raw_block_sum_of_words(s, philox4x32_10_pinned(g_lo, g_hi, static_cast<uint32_t>(b + j), tag, rk));
             q += static_cast<double>(s);
         }
         if (w < 3) acc += q;
@@ -145,13 +188,15 @@ __device__ __forceinline__ double path_normal_quarters(uint32_t g_lo, uint32_t g
         int32_t b = n_groups * kGroup;
         if (b < full) {
             float s = 0.0f;
-            for (; b < full; ++b) s = raw_block_accumulate(s, g_lo, g_hi, static_cast<uint32_t>(b), tag, k0, k1);
+            for (; b < full; ++b) s = raw_block_sum_of_words(s, philox4x32_10_pinned(g_lo, g_hi, static_cast<uint32_t>(b), tag, rk));
             q += static_cast<double>(s);
         }
         const int32_t rem = n_steps & 3;
         if (rem) {
             float z[4];
-            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(full), tag, k0, k1, z);
+            const Words4 wd = philox4x32_10_pinned(g_lo, g_hi, static_cast<uint32_t>(full), tag, rk);
+            box_muller_raw(wd.x0, wd.x1, z[0], z[1]);
+            box_muller_raw(wd.x2, wd.x3, z[2], z[3]);
             float s = z[0];
             if (rem > 1) s += z[1];
             if (rem > 2) s += z[2];

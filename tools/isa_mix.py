@@ -32,7 +32,7 @@ KERNELS = {      # key in bench.py's JSON -> mangled-name regex
 
 # mnemonic (encoding suffix stripped) -> probe class of optionslab_amd/_hip.py PROBE_CLASSES
 CLASS_OF = {
-    "v_mad_u64_u32": "v_mad_u64_u32", "v_bitop3_b32": "v_bitop3_b32", "v_cvt_f32_u32": "v_cvt_f32_u32", "v_fmamk_f32": "v_fmamk_f32",
+    "v_mad_u64_u32": "v_mad_u64_u32", "v_bitop3_b32": "v_bitop3_b32(v,v,v)", "v_bitop3_b32(sgpr)": "v_bitop3_b32", "v_cvt_f32_u32": "v_cvt_f32_u32", "v_fmamk_f32": "v_fmamk_f32",
     "v_fmaak_f32": "v_fmamk_f32", "v_and_or_b32": "v_and_or_b32", "v_log_f32": "v_log_f32", "v_sqrt_f32": "v_sqrt_f32",
     "v_sin_f32": "v_sin_f32", "v_cos_f32": "v_cos_f32", "v_exp_f32": "v_exp_f32", "v_rcp_f32": "v_exp_f32", "v_rsq_f32": "v_exp_f32",
     "v_add_f32": "v_add_f32", "v_sub_f32": "v_add_f32", "v_subrev_f32": "v_add_f32", "v_mul_f32": "v_add_f32",
@@ -82,6 +82,8 @@ def mix_of(body, span):
         if not m:
             continue
         op = re.sub(r"_(e32|e64|dpp|sdwa)$", "", m.group(1))
+        if op == "v_bitop3_b32" and re.search(r"\bs\d+\b|\bs\[", l.split(op, 1)[1]):
+            op = "v_bitop3_b32(sgpr)"        # an SGPR operand makes it a 4-cycle instruction; three VGPRs issue in ~2.6
         ops[op] += 1
     classes = Counter()
     for op, n in ops.items():

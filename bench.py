@@ -172,14 +172,14 @@ ISSUE_PASSES = {"v_mad_u64_u32": 4, "v_bitop3_b32": 4, "v_bitop3_b32(v,v,v)": 2,
 OUTSIDE_LOOP_PASSES = 4       # per-path prologue / epilogue (fp64 exp, payoff, reduction): fp64 class
 
 
-def roofline_for(pmc, key, avg_kernel_s, n_steps, costs=None, mixes=None, clock_ghz=None):
+def roofline_for(pmc, key, avg_kernel_s, n_steps, n_paths, costs=None, mixes=None, clock_ghz=None):
     """Issue-cycle roofline of one kernel, <= 1 by construction.
 
     achieved = VALU issue cycles the kernel's instruction stream NEEDS per launch / measured kernel time, where
                needed cycles = sum over instructions of the class's issue passes (ISSUE_PASSES: 2 / 4 / 8).  The
-               instruction stream: SQ_INSTS_VALU and SQ_WAVES from the live PMC pass give the instructions per wave;
-               the step loop's share is the static mix of its body (tools/isa_mix.py) x trips, the per-path remainder
-               is priced at 4.
+               instruction stream: SQ_INSTS_VALU from the live PMC pass is the total; the step loop's share is the static
+               mix of its body (tools/isa_mix.py) x trips per path x paths / 64, the remainder (per-path prologue and
+               epilogue, trailing blocks, reduction) is priced at 4.
     peak     = 1024 SIMDs x 2.4 GHz (one issue cycle per SIMD per clock at the peak engine clock).
     Since no instruction can hold the port for less than its class's passes and no SIMD can run above 2.4 GHz,
     frac <= 1; what is missing from 1 is clock give-back under load (`clock`), issue bubbles and the launch's tail.
@@ -200,18 +200,19 @@ def roofline_for(pmc, key, avg_kernel_s, n_steps, costs=None, mixes=None, clock_
     mix = (mixes or {}).get(key)
     if mix and c.get("SQ_INSTS_VALU") and c.get("SQ_WAVES") and mix.get("steps_per_trip"):
         trips = n_steps // mix["steps_per_trip"]
-        per_wave = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
-        rest = max(per_wave - trips * mix["loop_valu_instructions"], 0.0)
+        path_waves = n_paths / 64.0                     # whole-path wave equivalents (a split workgroup's four waves share 64 paths)
+        rest = max(c["SQ_INSTS_VALU"] - path_waves * trips * mix["loop_valu_instructions"], 0.0)      # instructions outside the hot loop, per launch
         loop_cycles = sum(n * ISSUE_PASSES[cls] for cls, n in mix["by_class"].items())
-        need = c["SQ_WAVES"] * (trips * loop_cycles + rest * OUTSIDE_LOOP_PASSES)          # issue cycles per launch, all SIMDs
+        need = path_waves * trips * loop_cycles + rest * OUTSIDE_LOOP_PASSES                          # issue cycles per launch, all SIMDs
         r.update({"achieved": need / avg_kernel_s / 1e9, "frac": need / avg_kernel_s / peak,
                   "issue_cycles_needed_per_launch": need, "speed_of_light_kernel_ms": need / peak * 1e3,
                   "issue_model": {"loop_trips_per_path": trips, "loop_valu_instructions": mix["loop_valu_instructions"], "loop_mix": mix["by_class"],
-                                  "loop_issue_cycles_per_trip": loop_cycles, "issue_passes": ISSUE_PASSES, "valu_instructions_per_wave": per_wave,
-                                  "outside_the_loop_per_wave": rest, "outside_the_loop_passes": OUTSIDE_LOOP_PASSES}})
+                                  "loop_issue_cycles_per_trip": loop_cycles, "issue_passes": ISSUE_PASSES,
+                                  "valu_instructions_in_the_loop_per_launch": path_waves * trips * mix["loop_valu_instructions"],
+                                  "valu_instructions_outside_the_loop_per_launch": rest, "outside_the_loop_passes": OUTSIDE_LOOP_PASSES}})
         if costs:
             loop_ns = sum(n * costs.get(cls, costs["v_fmamk_f32"]) for cls, n in mix["by_class"].items())
-            model_s = c["SQ_WAVES"] * (trips * loop_ns + rest * costs["v_fma_f64"]) / N_SIMD * 1e-9
+            model_s = (path_waves * trips * loop_ns + rest * costs["v_fma_f64"]) / N_SIMD * 1e-9
             r["frac_vs_isolated_rates"] = model_s / avg_kernel_s
             r["isolated_rates_kernel_ms"] = model_s * 1e3
             if clock_ghz:
@@ -476,7 +477,7 @@ def main():
     out = None
     if rank == 0:
         local_paths = sharding.shard_bounds(n_global, 0, world)[1]
-        roof = roofline_for(pmc, "c2_european", avg_kernel_s, N_STEPS, costs, mixes, clock_ghz) if args.paths_per_gpu == PATHS_PER_GPU else None
+        roof = roofline_for(pmc, "c2_european", avg_kernel_s, N_STEPS, args.paths_per_gpu, costs, mixes, clock_ghz) if args.paths_per_gpu == PATHS_PER_GPU else None
         if roof is None:
             roof = {"bound": "valu", "achieved": None, "peak": N_SIMD * PEAK_GHZ, "unit": "G VALU issue-cycles/s (peak = 1024 SIMDs x 2.4 GHz)", "frac": None,
                     "traffic": None, "avg_kernel_ms": avg_kernel_s * 1e3 if avg_kernel_s else None,
@@ -663,7 +664,7 @@ def c3_greeks(ol, _hip, pmc, costs, mixes, clock_ghz):
         med, ks, per = _timed_calls(_hip, lambda: p.greeks(*ATM, "call", include_second_order=second), 20)
         g = p.greeks(*ATM, "call", include_second_order=second)
         out[key] = {"ms_per_call": med * 1e3, "path_steps_per_s": ps / med, "contract_path_steps_per_s": (14 if second else 8) * ps / med,
-                    "avg_kernel_ms": ks * 1e3 if ks else None, "launches_per_call": per, "roofline": roofline_for(pmc, pk, ks, N_STEPS, costs, mixes, clock_ghz),
+                    "avg_kernel_ms": ks * 1e3 if ks else None, "launches_per_call": per, "roofline": roofline_for(pmc, pk, ks, N_STEPS, PATHS_PER_GPU, costs, mixes, clock_ghz),
                     "delta": g["delta"], "gamma": g["gamma"], "vega": g["vega"], "theta": g["theta"], "rho": g["rho"]}
     med, ks, per = _timed_calls(_hip, lambda: ol.compute_greeks_unified(p, *ATM, "call", include_second_order=False, fused=False), 10)
     out["literal_8"] = {"ms_per_call": med * 1e3, "path_steps_per_s": 8 * ps / med, "avg_kernel_ms": ks * 1e3 if ks else None, "launches_per_call": per,
@@ -686,7 +687,7 @@ def c4_asian(ol, _hip, pmc, costs, mixes, clock_ghz):
         out[key] = {"ms_per_call": med * 1e3, "path_steps_per_s": ps / med, "avg_kernel_ms": ks * 1e3 if ks else None, "price": float(price), "std_error": se,
                     "dtype": "f32 normals / f64 cumulative log-return, f64 exp per date, f64 sums" if precision == "fp64"
                              else "f32 normals / f32 exponent + v_exp_f32 per date inside groups of 16 dates, f64 across groups",
-                    "roofline": roofline_for(pmc, pk, ks, ASIAN_STEPS, costs, mixes, clock_ghz)}
+                    "roofline": roofline_for(pmc, pk, ks, ASIAN_STEPS, PATHS_PER_GPU, costs, mixes, clock_ghz)}
     out["headline"] = "fp64"
     return out
 

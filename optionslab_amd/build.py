@@ -34,6 +34,9 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    # the static instruction mix of the step loops (bench.py's issue-cycle roofline) belongs to this very build
+    subprocess.run([os.environ.get("PYTHON", "python3"), os.path.join(ROOT, "tools", "isa_mix.py")], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     return LIBRARY
 
 

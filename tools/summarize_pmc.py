@@ -1,64 +1,75 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 CSV output of tools/profile_gpu.sh into one text table per kernel.
+"""Summarise the output of tools/profile_gpu.sh into one text file.
 Usage: tools/summarize_pmc.py gpurun_out/prof_<tag> > profiles/<name>.txt"""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "")[:70]
+    return name.split("(")[0].replace("void ", "")[:78]
 
 
 def newest(pattern):
     """gpurun merges every call's output into the same local directory: keep the latest run of a pass only."""
-    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
     return files[-1:]
 
 
+def bench_line(path):
+    try:
+        for l in open(path):
+            if l.startswith('{"metric"'):
+                return json.loads(l)
+    except OSError:
+        pass
+    return None
+
+
 def main(root):
-    print(f"# rocprofv3 summary of {root}")
-    for sub, title in (("stats", "bench.py --streams 1 (launches back to back, no overlap)"), ("stats_default", "bench.py default (8 streams; the serial pass is included, so durations mix overlapped and serial launches)")):
-      for f in newest(os.path.join(root, sub, "*", "*_kernel_stats.csv")):
-        print(f"\n## kernel-trace --stats: {title}")
-        for row in csv.DictReader(open(f)):
-            print(f"{short(row['Name']):70s} calls {row['Calls']:>5s}  avg_ns {float(row['AverageNs']):>12.1f}  min {row['MinNs']:>8s}  max {row['MaxNs']:>8s}  {row['Percentage']}%")
-    # the default command by bench.py phase: only the single-stream pass (what bench.py's roofline.avg_kernel_ms times with HIP
-    # events) has one kernel on the device at a time; in the 8-stream pass a dispatch's duration includes its co-residents'
-    for f in newest(os.path.join(root, "stats_default", "*", "*_kernel_trace.csv")):
-        rows = sorted((r for r in csv.DictReader(open(f)) if "european_path_kernel" in r["Kernel_Name"]), key=lambda r: int(r["Dispatch_Id"]))
-        dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
-        log = os.path.join(root, "stats_default.log")
-        steps, warm, line = None, None, None
-        if os.path.exists(log):
-            import json
-            for l in open(log):
-                if l.startswith('{"metric"'):
-                    line = json.loads(l)
-                    steps, warm = line["steps"], line["warmup"]
-        pre = line.get("pre_warm_pricings", 0) if line else 0
-        dur = dur[pre:]                                   # untimed clock pre-warm of bench.py
-        if steps and len(dur) >= warm + 2 * steps:
-            print(f"\n## the default command's european_path_kernel dispatches by bench.py phase (us), after {pre} pre-warm dispatches")
-            for name, a, b in (("warm-up, 8 streams", 0, warm), ("timed K steps, 8 streams (-> value)", warm, warm + steps),
-                               ("same K steps, 1 stream (-> serial, roofline)", warm + steps, warm + 2 * steps), ("blocking price() calls (-> sync_call)", warm + 2 * steps, len(dur))):
-                seg = dur[a:b]
-                if seg:
-                    print(f"{name:55s} n={len(seg):4d}  avg {sum(seg) / len(seg):8.1f}  min {min(seg):8.1f}  max {max(seg):8.1f}")
-            print(f"bench.py of that run reported roofline.avg_kernel_ms = {line['roofline']['avg_kernel_ms']:.4f} (HIP events, {line['roofline']['launches_timed']} launches), value = {line['value']:.4g} {line['unit']}")
-    for p in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
-        files = newest(os.path.join(root, p, "*", "*_counter_collection.csv"))
+    print(f"# rocprofv3 summary of {root} (tools/profile_gpu.sh)")
+    for sub, title in (("stats", "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 10 --no-pmc --no-cpu-baseline --no-extras"),
+                       ("stats_full", "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-pmc --no-cpu-baseline   (all sections)")):
+        for f in newest(os.path.join(root, sub, "**", "*_kernel_stats.csv")):
+            print(f"\n## {title}")
+            for row in csv.DictReader(open(f)):
+                print(f"{short(row['Name']):78s} calls {row['Calls']:>5s}  avg_ns {float(row['AverageNs']):>12.1f}  min {row['MinNs']:>9s}  max {row['MaxNs']:>9s}  {row['Percentage']}%")
+        line = bench_line(os.path.join(root, sub + ".log"))
+        if line:
+            r = line["roofline"]
+            print(f"bench.py of that (profiled) run: value {line['value']:.4g} {line['unit']}, ms_per_step {line['ms_per_step']:.4f}, "
+                  f"roofline.avg_kernel_ms {r['avg_kernel_ms']:.4f} (HIP events attached to {r['launches_timed']} dispatches)")
+        # the headline kernel's dispatches by bench.py phase: pre-warm / warm-up / timed passes
+        for f in newest(os.path.join(root, sub, "**", "*_kernel_trace.csv")):
+            rows = sorted((r for r in csv.DictReader(open(f)) if "european_path_kernel<1, true, 0, false>" in r["Kernel_Name"]), key=lambda r: int(r["Dispatch_Id"]))
+            dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+            if line and sub == "stats" and dur:
+                pre = line.get("pre_warm_pricings", 0)
+                timed = dur[pre + line["warmup"]:]
+                print(f"european_path_kernel<1> dispatches of that run: {len(dur)} in all; the {pre} pre-warm ones avg {sum(dur[:pre]) / max(pre, 1):.2f} us; "
+                      f"the {len(timed)} of the timed passes (plain + instrumented) avg {sum(timed) / max(len(timed), 1):.2f} us, min {min(timed):.2f}, max {max(timed):.2f}")
+    line = bench_line(os.path.join(root, "bench.json"))
+    if line:
+        r = line["roofline"]
+        print("\n## python3 bench.py --steps 20 --warmup 5 (unprofiled; its live PMC passes are the tables below)")
+        print(f"value {line['value']:.4g} {line['unit']}  ms_per_step {line['ms_per_step']:.4f}  avg_kernel_ms {r['avg_kernel_ms']:.4f}  frac {r['frac']:.4f}  "
+              f"frac_vs_isolated_rates {r.get('frac_vs_isolated_rates')}  frac_valu_active_pmc {r.get('frac_valu_active_pmc')}  traffic {r.get('traffic')} B/launch")
+    for p in ("sq", "fetch", "write"):
+        files = newest(os.path.join(root, "pmc", p, "**", "*_counter_collection.csv"))
         if not files:
             continue
         agg = defaultdict(lambda: defaultdict(list))
         for row in csv.DictReader(open(files[0])):
             agg[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
-        print(f"\n## --pmc pass {p} (mean per dispatch)")
+        print(f"\n## live --pmc pass '{p}' of that bench.py run (rocprofv3 --kernel-trace --pmc ... -- python3 bench.py --pmc-child; mean per dispatch)")
         for k, ctrs in agg.items():
+            if "olmc::" not in k:
+                continue
             for c, v in sorted(ctrs.items()):
-                print(f"{k:70s} {c:24s} n={len(v):4d} mean={sum(v)/len(v):.6g}")
+                print(f"{k:78s} {c:22s} n={len(v):4d} mean={sum(v) / len(v):.6g}")
 
 
 if __name__ == "__main__":

@@ -361,6 +361,8 @@ int olmc_profile_enable(int on);
  *   OLMC_TUNE_GRID_CAP   max workgroups per launch, 0 = default (larger jobs grid-stride)
  *   OLMC_TUNE_QMC_BLOCK  Sobol kernels: 0 = eight consecutive points per thread from 2^20 points on (default),
  *                        1 = always, -1 = never (one point per thread)
+ *   OLMC_TUNE_POLL       blocking calls: 0 = wait by polling the host-mapped flag the kernel raises behind its results
+ *                        (default), -1 = hipStreamSynchronize
  *   OLMC_TUNE_SPLIT_TAIL European launches: 0 = the paths beyond a whole number of workgroups per compute unit go to split
  *                        workgroups (64 paths, each wave a quarter of the steps; default), -1 = never (one shape throughout)
  * and two fault-injection knobs for the tests of the error paths (0 = off, the default):
@@ -368,7 +370,7 @@ int olmc_profile_enable(int on);
  *   OLMC_TUNE_FORCE_NV     v > 0: reduction workspaces REPORT a capacity of v values per workgroup row, so a kernel
  *                          that reduces more than v values trips its device-side bound check (result NaN, nothing
  *                          written out of bounds, library usable afterwards) */
-enum { OLMC_TUNE_GRID_CAP = 2, OLMC_TUNE_QMC_BLOCK = 4, OLMC_TUNE_FAULT_SHARD = 5, OLMC_TUNE_FORCE_NV = 6, OLMC_TUNE_SPLIT_TAIL = 7 };
+enum { OLMC_TUNE_GRID_CAP = 2, OLMC_TUNE_QMC_BLOCK = 4, OLMC_TUNE_FAULT_SHARD = 5, OLMC_TUNE_FORCE_NV = 6, OLMC_TUNE_SPLIT_TAIL = 7, OLMC_TUNE_POLL = 8 };
 int olmc_tune(int knob, int value);
 int olmc_profile_reset(void);
 int olmc_kernel_time(int64_t* launches, double* total_ms);

@@ -449,6 +449,7 @@ TUNE_QMC_BLOCK = 4
 TUNE_FAULT_SHARD = 5
 TUNE_FORCE_NV = 6
 TUNE_SPLIT_TAIL = 7
+TUNE_POLL = 8
 
 
 def tune(knob: int, value: int) -> None:

@@ -13,6 +13,7 @@
 #include <rccl/rccl.h>      // types and enum values only: the library itself is dlopen()ed on first multi-GPU use
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -71,7 +72,14 @@ struct DeviceCtx {
     static constexpr int kSlots = 8;    // = the deepest overlap bench.py's `pipelined` pass asks for (--streams 8)
     WsSlot slots[kSlots + 1];
     int next_slot = 0, cur_slot = 0;
-    double* h_result = nullptr;      // pinned + mapped [kMaxNV + 1]: the last workgroup writes the sums straight to the host
+    // Completion by polling: a blocking call on the library stream arms done_flag (a word of the same pinned buffer) with a
+    // fresh sequence number; the wave that writes the results raises it, and the host reads the results the moment it
+    // sees the number instead of waiting for the kernel's completion signal to travel through the runtime.
+    uint64_t* h_flag = nullptr;      // host view of the flag word
+    uint64_t* d_flag = nullptr;      // device alias
+    uint64_t seq = 0;                // last sequence number handed out
+    uint64_t armed = 0;              // != 0: the launch just made raises h_flag to this value
+    double* h_result = nullptr;      // pinned + mapped [kMaxNV + 1 (+ flag)]: the last workgroup writes the sums straight to the host
     double* d_result = nullptr;      // device alias of h_result (zero-copy: no D2H copy node, only a stream sync)
     void* d_bulk = nullptr;          // terminal prices / validation taps
     double* d_triple = nullptr;      // {sum, sumsq, n} of this device's shard in olmc_multi_gpu_european (never reallocated)
@@ -100,8 +108,11 @@ int ctx_allocate(DeviceCtx* c) {
         HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
     HIP_TRY(hipMalloc(&c->d_triple, 256));
-    HIP_TRY(hipHostMalloc(&c->h_result, sizeof(double) * (kMaxNV + 1), hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc(&c->h_result, sizeof(double) * (kMaxNV + 1 + 15), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_result), c->h_result, 0));
+    c->h_flag = reinterpret_cast<uint64_t*>(c->h_result + kMaxNV + 8);      // a cache line of its own
+    c->d_flag = reinterpret_cast<uint64_t*>(c->d_result + kMaxNV + 8);
+    *c->h_flag = 0;
     return OLMC_OK;
 }
 
@@ -174,6 +185,7 @@ int bulk_reserve(DeviceCtx* c, size_t bytes) {
 // Tuning knob (olmc_tune): 0 = automatic.
 int g_grid_cap = 0;          // OLMC_TUNE_GRID_CAP: max workgroups per launch (0 = kMaxGrid)
 int g_qmc_block = 0;         // OLMC_TUNE_QMC_BLOCK: 0 = by size, 1 = always eight points per thread, -1 = never
+int g_poll = 0;              // OLMC_TUNE_POLL: 0 = blocking calls poll a host-mapped flag for completion (default), -1 = hipStreamSynchronize
 int g_split_tail = 0;        // OLMC_TUNE_SPLIT_TAIL: 0 = split workgroups for the remainder of a European launch (default), -1 = never
 int g_fault_shard = 0;       // OLMC_TUNE_FAULT_SHARD: k > 0 makes shard k - 1 of olmc_multi_gpu_european fail (tests of the error path)
 int g_force_nv = 0;          // OLMC_TUNE_FORCE_NV: > 0 sizes the next workspaces for this many values per row (test of the device guard)
@@ -237,11 +249,20 @@ int make_ws(DeviceCtx* c, hipStream_t stream, int32_t grid, int nv, double* d_ou
     ws->out = d_out;
     ws->tail = tail;
     ws->row_capacity = g_force_nv > 0 ? static_cast<uint64_t>(grid) * g_force_nv : sl.cap;   // the knob UNDER-reports (test of the guard)
+    ws->done_flag = nullptr;
+    ws->done_value = 0;
+    c->armed = 0;
+    if (own && d_out == c->d_result && g_poll >= 0) {      // a blocking call: results and flag land in the same pinned buffer
+        c->armed = ++c->seq;
+        ws->done_flag = c->d_flag;
+        ws->done_value = c->armed;
+    }
     return OLMC_OK;
 }
 
 // After a failed launch the self-resetting counters may be left dirty.
 void ws_recover(DeviceCtx* c) {
+    c->armed = 0;
     (void)hipDeviceSynchronize();
     (void)hipGetLastError();
     for (auto& sl : c->slots) (void)hipMemset(sl.counters, 0, sizeof(uint32_t) * (kMaxGroups + 1) * kCounterStride);
@@ -476,7 +497,32 @@ int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32
     return OLMC_OK;
 }
 
+// Waits for the launch just made on stream s.  If it was armed (make_ws), the host spins on the flag word in pinned memory:
+// the results are there as soon as the flag shows the launch's sequence number.  The stream itself is left to drain on its
+// own (it is in-order, so the next launch still starts after this kernel has retired).  Insurance: after 2 ms of spinning
+// the stream is queried every ~100 us -- an error is reported as such, and a stream that reports completion without the
+// flag having shown up falls back to the runtime's own wait.
 int sync_or_recover(DeviceCtx* c, hipStream_t s) {
+    if (c->armed != 0 && s == c->stream) {
+        const uint64_t want = c->armed;
+        c->armed = 0;
+        using clock = std::chrono::steady_clock;
+        const auto t0 = clock::now();
+        auto next_query = t0 + std::chrono::milliseconds(2);
+        for (uint32_t spins = 0;; ++spins) {
+            if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == want) return OLMC_OK;
+            __builtin_ia32_pause();
+            if ((spins & 0xFF) == 0xFF && clock::now() >= next_query) {
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess) break;                                  // retired: fall through to the runtime's wait
+                if (q != hipErrorNotReady) {
+                    ws_recover(c);
+                    return fail(OLMC_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
+                }
+                next_query = clock::now() + std::chrono::microseconds(100);
+            }
+        }
+    }
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)); }
     return OLMC_OK;
@@ -1119,6 +1165,8 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
         ReduceWs ws;
         rc = make_ws(c, c->stream, grid, kLsmNV, c->d_result, -1.0, &ws);
         if (rc) return rc;
+        ws.done_flag = nullptr;                       // one call = many launches sharing d_result: the call waits for the stream itself
+        c->armed = 0;
         hipLaunchKernelGGL(lsm_step_kernel, dim3(grid), dim3(kBlock), 0, c->stream, n_paths, lc, d_coef, t_fit, init, d_paths, d_cash, ws);
         rc = after_launch(c, c->stream);
         if (rc) return rc;
@@ -1655,6 +1703,7 @@ extern "C" int olmc_issue_probe(int op, int waves_per_simd, double* ns_per_instr
 extern "C" int olmc_tune(int knob, int value) {
     if (knob == OLMC_TUNE_GRID_CAP && value >= 0) { g_grid_cap = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_QMC_BLOCK && value >= -1 && value <= 1) { g_qmc_block = value; return OLMC_OK; }
+    if (knob == OLMC_TUNE_POLL && value >= -1 && value <= 0) { g_poll = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_SPLIT_TAIL && value >= -1 && value <= 0) { g_split_tail = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_FAULT_SHARD && value >= 0 && value <= kMaxDevices) { g_fault_shard = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_FORCE_NV && value >= 0 && value <= kMaxNV) { g_force_nv = value; return OLMC_OK; }

@@ -254,7 +254,16 @@ struct ReduceWs {
     double tail;            // if >= 0, written to out[NV] (the sample count of the triple)
     uint64_t row_capacity;  // doubles allocated behind block_rows: a launch whose gridDim.x * NV exceeds it
                             // refuses to store (out[] = NaN) instead of writing out of bounds
+    uint64_t* done_flag;    // host-mapped; when not NULL the wave that wrote out[] then stores done_value there (system-scope
+    uint64_t done_value;    // release): a blocking caller polls it instead of waiting for the kernel's completion signal
 };
+
+// After out[] is written (by this very wave): make it visible system-wide, then raise the caller's flag.
+__device__ __forceinline__ void signal_done(const ReduceWs& ws) {
+    if (ws.done_flag == nullptr) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: out[] has reached host memory before the flag can
+    if (threadIdx.x == 0) __hip_atomic_store(ws.done_flag, ws.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ __forceinline__ void store_sc1(double* p, double v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -307,7 +316,10 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws, Epilog
     const int32_t group_size = min(kGroupBlocks, n_blocks - group * kGroupBlocks);
 
     if (static_cast<uint64_t>(n_blocks) * NV > ws.row_capacity || n_groups * NV > kGroupRowsCapacity) {   // host/kernel NV mismatch
-        if (blockIdx.x == 0 && lane < NV) ws.out[lane] = __builtin_nan("");
+        if (blockIdx.x == 0) {
+            if (lane < NV) ws.out[lane] = __builtin_nan("");
+            signal_done(ws);
+        }
         return;
     }
     if (lane < NV) store_sc1(ws.block_rows + static_cast<size_t>(blockIdx.x) * NV + lane, v);
@@ -326,6 +338,7 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws, Epilog
             __hip_atomic_store(ws.counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         done(g);
+        signal_done(ws);
         return;
     }
     if (lane < NV) store_sc1(ws.group_rows + static_cast<size_t>(group) * NV + lane, g);
@@ -345,6 +358,7 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws, Epilog
         __hip_atomic_store(ws.counters + static_cast<size_t>(n_groups) * kCounterStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     done(total);
+    signal_done(ws);
 }
 
 // Wave-wide sums of P (a power of two) per-lane values in P-1 + (6 - log2 P) shuffle-adds instead of

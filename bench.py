@@ -328,6 +328,12 @@ def main():
     elif rank == 0 and not args.no_pmc:
         pmc = committed_pmc()           # N > 1 ranks run no profiler passes: counters of the committed run of this build, labelled
 
+    # stdout carries ONE JSON line and nothing else: libraries that talk on fd 1 (RCCL's version banner, gloo's connection
+    # notes) are sent to stderr until the line is printed
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -533,7 +539,8 @@ def main():
     def emit():
         if rank == 0 and not printed.is_set():
             printed.set()
-            print(json.dumps(out), flush=True)
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     def watchdog_fire():
         if rank == 0 and out is not None:

@@ -303,6 +303,33 @@ def test_split_workgroups_return_the_bits_of_whole_path_workgroups(N, M):
         assert split[0] == pytest.approx(sx, rel=REL_STREAM_TOL) and split[2] == n
 
 
+def test_completion_by_polled_flag_equals_completion_by_stream_synchronize():
+    """Blocking entry points return as soon as the kernel's last wave has raised a flag in pinned host memory behind its
+    results (system-scope release; olmc.hip sync_or_recover), not when the runtime has seen the kernel retire.  Same
+    numbers either way -- for one-launch calls, for the many-launch LSM call (never armed) and across a change of
+    workspace size -- and a tiny launch right behind a large one must not read the large one's results."""
+    S, K, T, r, v = ATM
+
+    def everything():
+        big = _hip.european(S, K, T, r, v, 0.0, True, 2_000_000, 64, 3, True)
+        tiny = _hip.european(S, K, T, r, v, 0.0, False, 7, 5, 4, True)           # right behind the big one
+        out = [big.sum, big.sumsq, big.n, tiny.sum, tiny.sumsq, tiny.n]
+        out += [_hip.asian(S, K, T, r, v, 0.0, True, False, 30_000, 64, 5).sum, _hip.barrier(S, K, T, r, v, 0.0, True, 120.0, 0, 30_000, 64, 6).sum,
+                _hip.heston(S, K, T, r, 0.0, True, 2.0, 0.04, 0.3, -0.7, 0.04, 30_000, 32, 7).sum, _hip.european_cv(S, K, T, r, v, 0.0, True, 30_000, 64, 8).value,
+                _hip.american_lsm(S, K, T, r, v, 0.0, False, 20_000, 20, 3, 9).sum]
+        out += [_hip.european(S, K, T, r, v, 0.0, True, n, 64, 10 + i, True).sum for i, n in enumerate((1, 255, 100_000, 65, 300_000, 2))]
+        return out
+
+    polled = everything()
+    _hip.tune(_hip.TUNE_POLL, -1)
+    try:
+        synced = everything()
+    finally:
+        _hip.tune(_hip.TUNE_POLL, 0)
+    assert polled == synced
+    assert polled[2] == 4_000_000 and polled[5] == 14 and polled[3] != polled[0]
+
+
 def test_large_path_offsets_use_the_high_counter_word():
     S, K, T, r, v = ATM
     off = (1 << 32) - 100

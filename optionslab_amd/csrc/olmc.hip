@@ -509,11 +509,16 @@ int sync_or_recover(DeviceCtx* c, hipStream_t s) {
         using clock = std::chrono::steady_clock;
         const auto t0 = clock::now();
         auto next_query = t0 + std::chrono::milliseconds(2);
+        bool queried = false;
         for (uint32_t spins = 0;; ++spins) {
-            if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == want) return OLMC_OK;
+            if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == want) {
+                if (queried) (void)hipGetLastError();                        // a hipErrorNotReady answer must not linger as this thread's last error
+                return OLMC_OK;
+            }
             __builtin_ia32_pause();
             if ((spins & 0xFF) == 0xFF && clock::now() >= next_query) {
                 const hipError_t q = hipStreamQuery(s);
+                queried = true;
                 if (q == hipSuccess) break;                                  // retired: fall through to the runtime's wait
                 if (q != hipErrorNotReady) {
                     ws_recover(c);
@@ -522,6 +527,7 @@ int sync_or_recover(DeviceCtx* c, hipStream_t s) {
                 next_query = clock::now() + std::chrono::microseconds(100);
             }
         }
+        (void)hipGetLastError();
     }
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)); }

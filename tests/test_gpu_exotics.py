@@ -464,3 +464,40 @@ def test_barrier_and_lookback_against_degenerate_closed_forms():
                                     ("fixed", "call", S, atm_call), ("fixed", "put", S, atm_put)):
         p, se = ol.LookbackOption(S, strike, T, r, v, q=q, seed=4).price(N, 1, kind, typ, antithetic=True, return_error=True)
         assert abs(p - want) <= 3.5 * se, (kind, typ, p, want, se)
+
+
+def test_non_positive_barrier_levels_and_negative_maturity_follow_the_reference():
+    """the reference compares barrier LEVELS in price space (exotic_options.py:445-483), so a level <= 0 lies below
+    every price: `S_t >= level` always holds, `S_t <= level` never does.  The device compares logs; log() of a negative
+    level is NaN and every comparison with it false -- so the host maps levels <= 0 to -inf.  And T < 0 makes sqrt(dt) NaN in
+    the reference (gbm_numpy.py:37): every price is NaN, which device fmax() would swallow."""
+    S, T, r, v, q = 100.0, 1.0, 0.05, 0.2, 0.01
+    N, M, f, rate = 50_000, 84, 21, 0.08
+    first = (1 + rate * (1 / (M // f)) * T) * math.exp(-r * f * (T / M))          # everyone is redeemed at the first observation
+    for level in (0.0, -1.0):
+        st = _hip.autocallable(S, T, r, v, q, level, 0.8, rate, 0.6, f, N, M, 3)
+        assert st.price == pytest.approx(first, rel=1e-13) and st.std_error == pytest.approx(0.0, abs=1e-9)
+    # a knock-in level <= 0 is never touched: same sums as a level no path can reach
+    ref = _hip.autocallable(S, T, r, v, q, 1.0, 0.8, rate, 1e-300, f, N, M, 3)
+    for level in (0.0, -0.5):
+        st = _hip.autocallable(S, T, r, v, q, 1.0, 0.8, rate, level, f, N, M, 3)
+        assert (st.sum, st.sumsq) == (ref.sum, ref.sumsq)
+    # a coupon level <= 0 always pays: same as a level every path clears
+    ref = _hip.autocallable(S, T, r, v, q, 1e9, 1e-300, rate, 0.6, f, N, M, 3)
+    st = _hip.autocallable(S, T, r, v, q, 1e9, -2.0, rate, 0.6, f, N, M, 3)
+    assert (st.sum, st.sumsq) == (ref.sum, ref.sumsq)
+    assert math.isnan(_hip.autocallable(S, T, r, v, q, float("nan"), 0.8, rate, 0.6, f, N, M, 3).price)
+    for bad in (_hip.european(100.0, 100.0, -1.0, 0.05, 0.2, 0.0, True, 1000, 8, 1), _hip.asian(100.0, 100.0, -0.5, 0.05, 0.2, 0.0, True, False, 1000, 8, 1),
+                _hip.barrier(100.0, 100.0, -1.0, 0.05, 0.2, 0.0, True, 120.0, 0, 1000, 8, 1), _hip.heston(100.0, 100.0, -1.0, 0.05, 0.0, True, 2.0, 0.04, 0.3, -0.7, 0.04, 1000, 8, 1)):
+        assert math.isnan(bad.price) and math.isnan(bad.sum)
+
+
+def test_jump_rates_beyond_the_inversion_samplers_range_are_refused():
+    """the per-step jump count is drawn by inversion from exp(-lambda dt) with at most 64 jumps; above
+    lambda dt = 20 the truncation would misprice silently (the reference's np.random.poisson has no limit), so such
+    rates are refused with the remedy in the message.  At the edge (lambda dt = 20) the checker still agrees."""
+    with pytest.raises(ol.AccelerationError, match="raise n_steps"):
+        _hip.jump_diffusion(*P, 0.0, True, False, 50.0, -0.1, 0.2, 0.0, 1000, 2, 1)            # lambda dt = 25
+    got = _hip.jump_diffusion(*P, 0.0, True, False, 40.0, -0.1, 0.05, 0.0, 2000, 2, 1)         # lambda dt = 20
+    sx, sxx, n = po.jump_moments(*P, 0.0, True, False, 40.0, -0.1, 0.05, 0.0, 2000, 2, 1)
+    assert got.n == n and got.sum == pytest.approx(sx, rel=1e-5)

@@ -83,6 +83,7 @@ PROTOTYPES = {
     "olmc_multi_gpu_european": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(Stats)]),
     "olmc_combine_stats": (_I, [C.POINTER(Stats), _I32, _D, _D, C.POINTER(Stats)]),
     "olmc_philox_words": (_I, [_U64T, _I64, _I64, _I32, _I32, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "olmc_exp2_probe": (_I, [C.POINTER(_D), _I64, C.POINTER(_D)]),
     "olmc_normal_moments": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(_D)]),
     "olmc_normals": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(C.c_float)]),
     "olmc_clock_probe": (_I, [_I64, _I32, _U64T, C.POINTER(_D)]),
@@ -454,6 +455,14 @@ TUNE_POLL = 8
 
 def tune(knob: int, value: int) -> None:
     _check(load_library().olmc_tune(int(knob), int(value)))
+
+
+def exp2_probe(x: np.ndarray) -> np.ndarray:
+    """2**x by the device's exp2_f64 (validation tap)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.empty_like(x)
+    _check(lib().olmc_exp2_probe(x.ctypes.data_as(C.POINTER(C.c_double)), x.size, y.ctypes.data_as(C.POINTER(C.c_double))))
+    return y
 
 
 def normal_moments(seed: int, n_paths: int, n_steps: int, path_offset: int = 0):

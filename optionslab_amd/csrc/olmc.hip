@@ -1602,6 +1602,26 @@ extern "C" int olmc_philox_words(uint64_t seed, int64_t path_offset, int64_t n_p
     return OLMC_OK;
 }
 
+extern "C" int olmc_exp2_probe(const double* x_host, int64_t n, double* y_host) {
+    if (!x_host || !y_host || n < 1) return fail(OLMC_ERR_ARG, "bad arguments");
+    DeviceCtx* c = nullptr;
+    int rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    const size_t bytes = sizeof(double) * static_cast<size_t>(n);
+    rc = bulk_reserve(c, 2 * bytes);
+    if (rc) return rc;
+    double* d_x = static_cast<double*>(c->d_bulk);
+    double* d_y = d_x + n;
+    HIP_TRY(hipMemcpyAsync(d_x, x_host, bytes, hipMemcpyHostToDevice, c->stream));
+    const int grid = static_cast<int>(std::min<int64_t>((n + 255) / 256, 4096));
+    hipLaunchKernelGGL(exp2_probe_kernel, dim3(grid), dim3(256), 0, c->stream, d_x, n, d_y);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(y_host, d_y, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OLMC_OK;
+}
+
 extern "C" int olmc_normal_moments(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps, double* out4) {
     if (!out4) return fail(OLMC_ERR_ARG, "null pointer");
     olmc_stats dummy;

@@ -727,7 +727,8 @@ __global__ __launch_bounds__(kBlock) void asian_kernel(PathRange pr, AsianContra
 // the exponent already in log2 units).  n = rint(y), r = y - n in [-1/2, 1/2] (exact), 2^r by the degree-11 polynomial
 // interpolating 2^r at the Chebyshev nodes of [-1/2, 1/2] (fitted in 50-digit arithmetic: interpolation error 4e-18,
 // the 1.5 ulp is the Horner chain's rounding, measured against mpmath on 20,001 points), scaled by v_ldexp_f64.
-// Overflow -> inf, underflow -> 0, NaN -> NaN, as exp().
+// Finite overflow -> inf, underflow -> 0, NaN -> NaN, as exp2(); an INFINITE argument answers NaN (inf - rint(inf)) -- a
+// cumulative log-return is infinite only for infinite parameters, and guarding the case would cost 3 of 15 instructions.
 __device__ __forceinline__ double exp2_f64(double y) {
     const double n = __builtin_rint(y);
     const double r = y - n;
@@ -1923,6 +1924,12 @@ __global__ __launch_bounds__(kBlock) void probe_cvt_i32_f64(uint32_t* __restrict
 }
 
 // ------------------------------------------------------- validation taps ----
+// exp2_f64 (the fp64 Asian kernel's exponential) on an array: lets the tests pin it against a reference libm point by point.
+__global__ void exp2_probe_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ y) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+        y[i] = exp2_f64(x[i]);
+}
+
 __global__ void philox_words_kernel(uint64_t first, int64_t n_paths, int32_t block0, int32_t n_blocks,
                                     uint32_t tag, uint32_t k0, uint32_t k1, uint32_t* __restrict__ out) {
     const int64_t total = n_paths * n_blocks;

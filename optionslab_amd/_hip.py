@@ -232,12 +232,14 @@ def european_multi(S, K, T, r, sigma, q, is_call, n_paths: int, n_steps: int, se
 
 
 def european_greeks_fd(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int, seed: int,
-                       second_order: bool) -> Tuple[List[float], List[Stats]]:
+                       second_order: bool, want_evals: bool = True) -> Tuple[List[float], List[Stats]]:
+    """(price, delta, gamma, vega, theta, rho, vanna, charm, vomma) and -- unless want_evals is False, which spares a blocking
+    Greeks call the marshalling of fourteen structs -- the statistics of the bumped contracts in the reference's call order."""
     out9 = (C.c_double * 9)()
-    evals = (Stats * 14)()
+    evals = (Stats * 14)() if want_evals else None
     _check(lib().olmc_european_greeks_fd(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(n_steps), seed64(seed),
                                          int(second_order), out9, evals))
-    return list(out9), list(evals)
+    return list(out9), (list(evals) if want_evals else [])
 
 
 def european_terminal(S, T, r, sigma, q, n_paths: int, n_steps: int, seed: int, antithetic: bool = True) -> np.ndarray:

@@ -190,7 +190,7 @@ class MonteCarloPricer:
             return compute_greeks_unified(self, S, K, T, r, sigma, option_type, q, include_second_order, fused=False, **kw)
         actual_seed = seed if seed is not None else self.seed
         vals, _ = _hip.european_greeks_fd(S, K, T, r, sigma, q, option_type == "call", self.num_simulations,
-                                          self._steps(), actual_seed, include_second_order)
+                                          self._steps(), actual_seed, include_second_order, want_evals=False)
         n = 9 if include_second_order else 6
         return OrderedDict((k, float(v)) for k, v in zip(GREEK_KEYS[:n], vals[:n]))
 

@@ -855,9 +855,7 @@ __device__ __forceinline__ void extrema_block(const float (&z)[4], double drift,
 
 template <bool ANTI>
 __global__ __launch_bounds__(kBlock) void extrema_kernel(PathRange pr, ExtremaContract c, ReduceWs ws) {
-#ifdef OLMC_PIN_EXOTICS
     const RoundKeys rk = pin_round_keys(pr.key0, pr.key1);
-#endif
     double acc[2] = {0.0, 0.0};
     const double vol = c.vol * kZScale;             // applied to RAW normals
     const int32_t full = pr.n_steps >> 2, rem = pr.n_steps & 3;
@@ -868,19 +866,11 @@ __global__ __launch_bounds__(kBlock) void extrema_kernel(PathRange pr, ExtremaCo
         double cum_u = 0.0, mx_u = 0.0, mn_u = 0.0, cum_d = 0.0, mx_d = 0.0, mn_d = 0.0;   // t = 0: ln(S_0/S_0) = 0
         float z[4];
         for (int32_t b = 0; b < full; ++b) {           // branch-free body
-#ifdef OLMC_PIN_EXOTICS
             raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(b), 0u, rk, z);
-#else
-            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1, z);
-#endif
             extrema_block<ANTI, 4>(z, c.drift, vol, cum_u, mx_u, mn_u, cum_d, mx_d, mn_d);
         }
         if (rem) {
-#ifdef OLMC_PIN_EXOTICS
             raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(full), 0u, rk, z);
-#else
-            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(full), 0u, pr.key0, pr.key1, z);
-#endif
             if (rem == 1) extrema_block<ANTI, 1>(z, c.drift, vol, cum_u, mx_u, mn_u, cum_d, mx_d, mn_d);
             else if (rem == 2) extrema_block<ANTI, 2>(z, c.drift, vol, cum_u, mx_u, mn_u, cum_d, mx_d, mn_d);
             else extrema_block<ANTI, 3>(z, c.drift, vol, cum_u, mx_u, mn_u, cum_d, mx_d, mn_d);
@@ -914,9 +904,7 @@ struct AutocallContract {
 
 template <bool ANTI>
 __global__ __launch_bounds__(kBlock) void autocall_kernel(PathRange pr, AutocallContract c, ReduceWs ws) {
-#ifdef OLMC_PIN_EXOTICS
     const RoundKeys rk = pin_round_keys(pr.key0, pr.key1);
-#endif
     double acc[2] = {0.0, 0.0};
     const double vol = c.vol * kZScale;
     constexpr int LEGS = ANTI ? 2 : 1;
@@ -932,11 +920,7 @@ __global__ __launch_bounds__(kBlock) void autocall_kernel(PathRange pr, Autocall
         const int32_t blocks = (pr.n_steps + 3) >> 2;
         for (int32_t b = 0; b < blocks; ++b) {
             float z[4];
-#ifdef OLMC_PIN_EXOTICS
             raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(b), 0u, rk, z);
-#else
-            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1, z);
-#endif
             if (until_obs > 4 && 4 * b + 4 <= pr.n_steps) {
                 // no observation date among these four steps (16 of 21 blocks at monthly observation): only the
                 // cumulative return and its running minimum move -- branch-free, the four dates schedule together
@@ -1002,9 +986,7 @@ struct CliquetContract {
 // normals, fp64 across) and only the blocks with a reset date look at single steps.
 template <bool ANTI>
 __global__ __launch_bounds__(kBlock) void cliquet_kernel(PathRange pr, CliquetContract c, ReduceWs ws) {
-#ifdef OLMC_PIN_EXOTICS
     const RoundKeys rk = pin_round_keys(pr.key0, pr.key1);
-#endif
     double acc[2] = {0.0, 0.0};
     const double vol = c.vol * kZScale;
     constexpr int LEGS = ANTI ? 2 : 1;
@@ -1023,11 +1005,7 @@ __global__ __launch_bounds__(kBlock) void cliquet_kernel(PathRange pr, CliquetCo
         for (int32_t b = 0; b < blocks; ++b) {
             if (until_reset > 4) {                      // no period end among these four steps (and all four are used)
                 until_reset -= 4;
-#ifdef OLMC_PIN_EXOTICS
                 part = raw_block_sum_of_words(part, philox4x32_10_pinned(g_lo, g_hi, static_cast<uint32_t>(b), 0u, rk));
-#else
-                part = raw_block_accumulate(part, g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1);
-#endif
                 if (++part_blocks == kGroup) { psum += static_cast<double>(part); part = 0.0f; part_blocks = 0; }
                 continue;
             }
@@ -1035,11 +1013,7 @@ __global__ __launch_bounds__(kBlock) void cliquet_kernel(PathRange pr, CliquetCo
             part = 0.0f;
             part_blocks = 0;
             float z[4];
-#ifdef OLMC_PIN_EXOTICS
             raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(b), 0u, rk, z);
-#else
-            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1, z);
-#endif
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (4 * b + j < used_steps) {
@@ -1411,9 +1385,7 @@ __device__ __forceinline__ bool heston_start(const HestonContract& c, double& v)
 
 template <bool ANTI>
 __global__ __launch_bounds__(kBlock) void heston_kernel(PathRange pr, HestonContract c, ReduceWs ws) {
-#ifdef OLMC_PIN_EXOTICS
     const RoundKeys rk = pin_round_keys(pr.key0, pr.key1);
-#endif
     double acc[2] = {0.0, 0.0};
     const HestonStep hs(c);
     double v_start;
@@ -1427,11 +1399,7 @@ __global__ __launch_bounds__(kBlock) void heston_kernel(PathRange pr, HestonCont
         const int32_t blocks = (pr.n_steps + 1) >> 1;
         for (int32_t b = 0; b < blocks; ++b) {
             float z[4];
-#ifdef OLMC_PIN_EXOTICS
             raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(b), kTagHeston, rk, z);
-#else
-            raw_normals4(g_lo, g_hi, static_cast<uint32_t>(b), kTagHeston, pr.key0, pr.key1, z);
-#endif
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int32_t t = 2 * b + h;

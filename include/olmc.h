@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define OLMC_ABI_VERSION 1
+#define OLMC_ABI_VERSION 2   /* 2: olmc_asian avg_kind 0 is the fp64-exponent kernel (2 = the fp32 one); probes, tune knobs 5-8 */
 
 enum {
     OLMC_OK = 0,

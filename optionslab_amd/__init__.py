@@ -17,7 +17,7 @@ from .simulation import (hip_available, simulate_gbm_hip, simulate_gbm_hip_fast,
                          simulate_gbm_qmc_antithetic_hip, simulate_gbm_qmc_hip)
 from . import sharding  # noqa: E402  (torch is imported lazily inside)
 
-__version__ = "0.1.0"
+__version__ = "0.2.0"
 
 __all__ = [
     "MonteCarloPricer", "MonteCarloPricerUni", "MCMethod", "MCResult", "NUMBA_AVAILABLE", "compute_greeks_unified", "PricerProtocol",

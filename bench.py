@@ -422,19 +422,21 @@ def main():
             instrumented = len(passes) > len(inst_passes)          # plain, instrumented, plain, ...
             _hip.profile_enable(instrumented)
             base = seed0 + len(passes if not instrumented else inst_passes) * steps     # both kinds walk the same seeds
+            results, stamps, pc = [], [], time.perf_counter
             fence()
-            t0 = time.perf_counter()
-            for k in range(steps):
-                c0 = time.perf_counter()
-                res = step(base + k)
-                if not instrumented:
-                    calls.append(time.perf_counter() - c0)
-                check(res)
-                if not passes:
-                    first.append(res[0])
+            t0 = pc()
+            for k in range(steps):             # the timed region holds the K blocking steps and a clock read each; checks come after
+                results.append(step(base + k))
+                stamps.append(pc())
             torch.cuda.synchronize()
-            dt = max_over_ranks(time.perf_counter() - t0)
+            dt = max_over_ranks(pc() - t0)
             fence()
+            for res in results:
+                check(res)
+            if not instrumented:
+                calls.extend(b - a for a, b in zip([t0] + stamps[:-1], stamps))
+            if not passes and not instrumented:
+                first.extend(res[0] for res in results)
             (inst_passes if instrumented else passes).append(dt)
             if n_pass is None:          # every rank derives the same count from the same max-reduced time
                 n_pass = max(3, min(max_passes, int(math.ceil(min_total_s / max(dt, 1e-9)))))

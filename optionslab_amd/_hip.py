@@ -46,6 +46,7 @@ class DevInfo(C.Structure):
 
 
 _D, _I, _I32, _I64, _U64T, _P = C.c_double, C.c_int, C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
+_byref = C.byref
 _SIX = [_D] * 6
 
 # name -> (restype, argtypes); must list every symbol include/olmc.h declares
@@ -190,8 +191,10 @@ def device_info() -> dict:
 def european(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int, seed: int, antithetic: bool = True,
              path_offset: int = 0) -> Stats:
     out = Stats()
-    _check(lib().olmc_european_shard(S, K, T, r, sigma, q, int(is_call), int(path_offset), int(n_paths), int(n_steps),
-                                     seed64(seed), int(antithetic), C.byref(out)))
+    rc = lib().olmc_european_shard(S, K, T, r, sigma, q, bool(is_call), int(path_offset), int(n_paths), int(n_steps), int(seed) & _U64,
+                                   bool(antithetic), _byref(out))
+    if rc:                              # the hot blocking call of price(): no helper frames on the success path
+        _check(rc)
     return out
 
 

@@ -323,9 +323,6 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws, Epilog
         return;
     }
     if (lane < NV) store_sc1(ws.block_rows + static_cast<size_t>(blockIdx.x) * NV + lane, v);
-#ifdef OLMC_EXPERIMENT_NO_CHAIN
-    return;                                   // timing experiment only: what the ticket / row-sum chain behind the last workgroup costs
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t ticket = 0;
     if (lane == 0) ticket = __hip_atomic_fetch_add(ws.counters + static_cast<size_t>(group) * kCounterStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

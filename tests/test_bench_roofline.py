@@ -1,0 +1,73 @@
+"""bench.py's issue-cycle roofline and its inputs (no GPU needed): the static ISA mix that travels with the build, the
+pricing of a counter set, and the fallbacks."""
+import importlib.util
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec = importlib.util.spec_from_file_location("olmc_bench", os.path.join(ROOT, "bench.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    return mod
+
+
+def test_isa_mix_covers_every_kernel_the_bench_prices(bench):
+    mix = bench.load_isa_mix()
+    assert set(bench.PMC_KERNELS.values()) <= set(mix)
+    for key in bench.PMC_KERNELS.values():
+        m = mix[key]
+        assert m["steps_per_trip"] in (4, 16) and m["loop_valu_instructions"] == sum(m["by_class"].values())
+        assert set(m["by_class"]) <= set(bench.ISSUE_PASSES), key            # every class has a price
+        assert m["by_class"]["v_log_f32"] * 2 == m["steps_per_trip"]        # one Box-Muller log per two normals
+    # the headline loop: 17 multiplies and 19 XOR3 per Philox block, all but two of the XOR3 on three VGPRs (pinned round keys)
+    c2 = mix["c2_european"]["by_class"]
+    assert c2["v_mad_u64_u32"] == 68 and c2["v_bitop3_b32(v,v,v)"] + c2["v_bitop3_b32"] == 76 and c2["v_bitop3_b32"] <= 8
+    # the reference-precision Asian loop carries the fp64 exponential: 12 fma per date (11 polynomial + 1 cumsum), the fp32 one an exp per date
+    assert mix["c4_asian_fp64"]["by_class"]["v_fma_f64"] == 48 and mix["c4_asian_fp64"]["by_class"]["v_ldexp_f64"] == 4
+    assert mix["c4_asian_fp32"]["by_class"]["v_exp_f32"] == 16
+
+
+def test_roofline_pricing_is_bounded_and_uses_the_counters_it_says(bench):
+    mix = bench.load_isa_mix()
+    with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
+        pmc = json.load(f)
+    c = pmc["c2_european"]
+    t = 100.1e-6
+    r = bench.roofline_for(pmc, "c2_european", t, 252, 1_000_000, None, mix, 2.25)
+    loop = 1_000_000 / 64 * 15 * mix["c2_european"]["loop_valu_instructions"]
+    cycles = 1_000_000 / 64 * 15 * sum(n * bench.ISSUE_PASSES[k] for k, n in mix["c2_european"]["by_class"].items()) + (c["SQ_INSTS_VALU"] - loop) * 4
+    assert r["issue_cycles_needed_per_launch"] == pytest.approx(cycles, rel=1e-12)
+    assert r["frac"] == pytest.approx(cycles / t / (1024 * 2.4e9), rel=1e-12) and 0.5 < r["frac"] <= 1.0
+    assert r["peak"] == pytest.approx(2457.6) and r["achieved"] == pytest.approx(r["frac"] * r["peak"])
+    assert r["frac_valu_active_pmc"] == pytest.approx(c["SQ_ACTIVE_INST_VALU"] * 4 / t / (1024 * 2.4e9))
+    assert r["traffic"] == pytest.approx((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024) and r["hbm_frac_of_8TBps"] < 1e-3
+    assert "frac_vs_isolated_rates" not in r                                 # no probe costs were given
+    # a kernel cannot be faster than its own speed of light: at that duration the fraction is exactly 1
+    sol = bench.roofline_for(pmc, "c2_european", r["speed_of_light_kernel_ms"] / 1e3, 252, 1_000_000, None, mix)
+    assert sol["frac"] == pytest.approx(1.0, rel=1e-12)
+    # every committed kernel prices to a fraction in (0, 1] at the duration its own counters were collected next to
+    for key, ms in (("c3_fused8", 0.1152), ("c3_fused14", 0.1313), ("c4_asian_fp64", 0.9408), ("c4_asian_fp64_antithetic", 1.4553),
+                    ("c4_asian_fp32", 0.5433), ("c4_asian_fp32_antithetic", 0.6871)):
+        n_steps = 252 if key.startswith("c3") else 1024
+        rr = bench.roofline_for(pmc, key, ms / 1e3, n_steps, 1_000_000, None, mix)
+        assert 0.6 < rr["frac"] <= 1.0, (key, rr["frac"])
+
+
+def test_roofline_fallbacks(bench):
+    assert bench.roofline_for(None, "c2_european", 1e-4, 252, 1_000_000) is None
+    assert bench.roofline_for({"c2_european": {"SQ_ACTIVE_INST_VALU": 1.0}}, "c2_european", None, 252, 1_000_000) is None
+    r = bench.roofline_for({"c2_european": {"SQ_ACTIVE_INST_VALU": 6.4e7, "SQ_INSTS_VALU": 5.6e7}}, "c2_european", 1e-4, 252, 1_000_000, None, {})
+    assert r["frac"] is None and r["traffic"] is None and r["frac_valu_active_pmc"] > 0      # no mix: only the counter formula
+    committed = bench.committed_pmc()
+    assert committed and committed["source"].startswith("COMMITTED profiles/") and "c2_european" in committed

@@ -374,6 +374,8 @@ int olmc_profile_enable(int on);
  *                          written out of bounds, library usable afterwards) */
 enum { OLMC_TUNE_GRID_CAP = 2, OLMC_TUNE_QMC_BLOCK = 4, OLMC_TUNE_FAULT_SHARD = 5, OLMC_TUNE_FORCE_NV = 6, OLMC_TUNE_SPLIT_TAIL = 7, OLMC_TUNE_POLL = 8 };
 int olmc_tune(int knob, int value);
+/* The two behavioural knobs can also be switched off from the environment, read once by the first olmc_init:
+ * OLMC_POLL=0 (as OLMC_TUNE_POLL = -1) and OLMC_SPLIT_TAIL=0 (as OLMC_TUNE_SPLIT_TAIL = -1). */
 int olmc_profile_reset(void);
 int olmc_kernel_time(int64_t* launches, double* total_ms);
 

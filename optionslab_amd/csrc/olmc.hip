@@ -17,6 +17,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -574,6 +575,16 @@ extern "C" const char* olmc_last_error(void) { return t_error.c_str(); }
 
 extern "C" int olmc_init(int device) {
     std::lock_guard<std::mutex> lock(g_mu);
+    // operational safety valves (no rebuild, no code change in the host): OLMC_POLL=0 makes blocking calls wait with
+    // hipStreamSynchronize, OLMC_SPLIT_TAIL=0 keeps one launch shape throughout -- the same switches olmc_tune offers
+    static const bool env_read = [] {
+        const char* p = std::getenv("OLMC_POLL");
+        if (p && p[0] == '0') g_poll = -1;
+        const char* t = std::getenv("OLMC_SPLIT_TAIL");
+        if (t && t[0] == '0') g_split_tail = -1;
+        return true;
+    }();
+    (void)env_read;
     if (device < 0 || device >= kMaxDevices) return fail(OLMC_ERR_ARG, "device index out of range");
     if (!g_ctx[device]) {
         DeviceCtx* c = nullptr;

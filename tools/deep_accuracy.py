@@ -60,3 +60,12 @@ p, se = m.price_monte_carlo(100.0, 100.0, 1.0, 0.05, 0.2, "call", 0.0, n, 64, 13
 series = m.price(100.0, 100.0, 1.0, 0.05, 0.2, "call")
 rows.append(dict(kind="merton lambda=0.5 2^26 x 64 vs series", price=float(p), series=float(series), std_error=se, z=(float(p) - float(series)) / se))
 print(json.dumps(rows[-1]), flush=True)
+# Round 2: the reference-precision arithmetic Asian (fp64 cumulative log-return + fp64 exp2 per date) against the opt-in
+# fp32-exponent kernel on the SAME normals at 2^24 paths x 1024 dates: their difference is the fp32 exponent's whole
+# effect on a price (stated bound 2e-6 relative); se ~ 2e-3 here, so the statistical error is 1000x larger than it.
+n = 1 << 24
+p64 = _hip.asian(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, True, False, n, 1024, 21, False)
+p32 = _hip.asian(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, True, False, n, 1024, 21, False, fast=True)
+rows.append(dict(kind="arithmetic asian 2^24 x 1024: fp64-exponent kernel vs fp32-exponent kernel, same normals", price_fp64=p64.price, price_fp32=p32.price,
+                 rel_diff=(p32.price - p64.price) / p64.price, std_error=p64.std_error, se_rel_diff=(p32.std_error - p64.std_error) / p64.std_error))
+print(json.dumps(rows[-1]), flush=True)

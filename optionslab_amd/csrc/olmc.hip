@@ -61,7 +61,7 @@ struct DeviceCtx {
     // one launch hides under the head of the next) without sharing rows or counters.  Launches on the library's
     // OWN stream (every blocking entry point) use slot kSlots and no event at all: the stream is in-order, so a
     // launch finds the workspace free by construction -- and a blocking call is spared the two barrier packets
-    // (hipStreamWaitEvent in front of the kernel, hipEventRecord behind it) that cost ~3 us each on the device.
+    // (hipStreamWaitEvent in front of the kernel, hipEventRecord behind it): ~1 us per call, measured.
     struct WsSlot {
         double* block_rows = nullptr;  // [cap] doubles, grown on demand (grid x NV)
         size_t cap = 0;
@@ -189,7 +189,7 @@ int g_qmc_block = 0;         // OLMC_TUNE_QMC_BLOCK: 0 = by size, 1 = always eig
 int g_poll = 0;              // OLMC_TUNE_POLL: 0 = blocking calls poll a host-mapped flag for completion (default), -1 = hipStreamSynchronize
 int g_split_tail = 0;        // OLMC_TUNE_SPLIT_TAIL: 0 = split workgroups for the remainder of a European launch (default), -1 = never
 int g_fault_shard = 0;       // OLMC_TUNE_FAULT_SHARD: k > 0 makes shard k - 1 of olmc_multi_gpu_european fail (tests of the error path)
-int g_force_nv = 0;          // OLMC_TUNE_FORCE_NV: > 0 sizes the next workspaces for this many values per row (test of the device guard)
+int g_force_nv = 0;          // OLMC_TUNE_FORCE_NV: > 0 makes workspaces REPORT room for this many values per row (test of the device guard)
 
 // Launch geometry: one workgroup per 256 paths, handed out by the hardware dispatcher
 // (measured faster than a fixed 8-workgroups-per-CU grid-stride); beyond kMaxGrid

@@ -262,6 +262,17 @@ def cpu_baseline(all_cores=True):
                sample=f"median of 3 x price() at {n} paths x {N_STEPS} steps, NumPy oracle pinned bitwise to the reference "
                       f"(price {res.price:.6f}); host has {os.cpu_count()} logical cores, NumPy's RNG uses 1",
                seconds=dt, seconds_each=times)
+    # BASELINE configs[3] on the same core (scaled from a bounded sample): the reference's AsianOption.price builds the
+    # (n, M) normal, log-return, log-price and price matrices -- 50,000 paths x 1024 dates is 1.6 GB of them
+    try:
+        n_a = 50_000
+        t0 = time.perf_counter()
+        pa = orc.asian_price(WORK["S"], WORK["K"], WORK["T"], WORK["r"], WORK["sigma"], 0.0, SEED, n_a, ASIAN_STEPS, "arithmetic", "call")
+        dta = time.perf_counter() - t0
+        out["c4_asian"] = dict(value=n_a * ASIAN_STEPS / dta, unit="path-steps/s", cores=1, kind="port", seconds=dta,
+                               sample=f"1 x AsianOption.price({n_a} paths, {ASIAN_STEPS} dates, arithmetic call), NumPy oracle (price {float(pa):.4f})")
+    except Exception as e:
+        out["c4_asian"] = {"error": f"{type(e).__name__}: {e}"}
     if all_cores:
         try:
             import concurrent.futures as cf
@@ -580,7 +591,7 @@ def main():
                                                n_global, K_steps, W, bs, first_prices))
         if world == 1 and not use_dist:
             section("c3_greeks", lambda: c3_greeks(ol, _hip, pmc, costs, mixes, clock_ghz))
-            section("c4_asian", lambda: c4_asian(ol, _hip, pmc, costs, mixes, clock_ghz))
+            section("c4_asian", lambda: c4_asian(ol, _hip, pmc, costs, mixes, clock_ghz, cpu))
     dog.cancel()
     emit()
     if use_dist:
@@ -682,7 +693,7 @@ def c3_greeks(ol, _hip, pmc, costs, mixes, clock_ghz):
     return out
 
 
-def c4_asian(ol, _hip, pmc, costs, mixes, clock_ghz):
+def c4_asian(ol, _hip, pmc, costs, mixes, clock_ghz, cpu=None):
     """BASELINE configs[3]: arithmetic Asian call, 1M paths x 1024 dates.  fp64 = the reference's arithmetic (the default);
     fp32 = the opt-in fast kernel, reported beside it, never instead of it."""
     a = ol.AsianOption(*ATM, seed=SEED)
@@ -698,6 +709,9 @@ def c4_asian(ol, _hip, pmc, costs, mixes, clock_ghz):
                              else "f32 normals / f32 exponent + v_exp_f32 per date inside groups of 16 dates, f64 across groups",
                     "roofline": roofline_for(pmc, pk, ks, ASIAN_STEPS, PATHS_PER_GPU, costs, mixes, clock_ghz)}
     out["headline"] = "fp64"
+    if cpu and isinstance(cpu.get("c4_asian"), dict) and cpu["c4_asian"].get("value"):
+        out["cpu_baseline"] = cpu["c4_asian"]
+        out["gpu_over_cpu"] = out["fp64"]["path_steps_per_s"] / cpu["c4_asian"]["value"]
     return out
 
 

@@ -117,7 +117,7 @@ def collect_pmc(keep_dir=None):
         cmd = [exe, "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "--",
                sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child"]
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=90)       # a pass normally takes under a second
         except (OSError, subprocess.TimeoutExpired) as e:
             return {"error": f"pass {name}: {type(e).__name__}: {e}"}
         if r.returncode != 0 or "pmc-child done" not in r.stdout:

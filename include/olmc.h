@@ -318,6 +318,11 @@ int olmc_multi_gpu_european(double S, double K, double T, double r, double sigma
                             int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
                             int n_gpus, olmc_stats* out);
 
+/* Blocking fetch of n (1..33) doubles that work ALREADY QUEUED on hip_stream leaves at d_src -- the triple after the caller's RCCL
+ * all-reduce in the one-process-per-GPU form: a one-wave kernel behind that work hands them over through the library's pinned
+ * buffer and completion word (the hand-over of every blocking pricing), instead of hipMemcpyAsync + hipStreamSynchronize. */
+int olmc_fetch_dev(const double* d_src, int32_t n, void* hip_stream, double* out_host);
+
 /* Host-side finalisation shared by every path: fills price / std_error from
  * (sum, sumsq, n) with discount exp(-rT).  Pure function, no device needed. */
 int olmc_combine_stats(const olmc_stats* parts, int32_t n_parts, double r, double T, olmc_stats* out);

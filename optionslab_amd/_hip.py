@@ -59,6 +59,7 @@ PROTOTYPES = {
     "olmc_european": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_european_shard": (_I, _SIX + [_I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_european_shard_dev": (_I, _SIX + [_I, _I64, _I64, _I32, _U64T, _I, _P, _P]),
+    "olmc_fetch_dev": (_I, [_P, _I32, _P, C.POINTER(_D)]),
     "olmc_european_batch": (_I, [C.POINTER(Option), _I32, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_european_multi": (_I, [C.POINTER(Option), C.POINTER(C.c_uint32), _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_european_greeks_fd": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(_D), C.POINTER(Stats)]),
@@ -203,6 +204,13 @@ def european_shard_dev(S, K, T, r, sigma, q, is_call: bool, path_offset: int, n_
     _check(lib().olmc_european_shard_dev(S, K, T, r, sigma, q, int(is_call), int(path_offset), int(n_local), int(n_steps),
                                          seed64(seed), int(antithetic), C.c_void_p(d_triple_ptr),
                                          C.c_void_p(stream_ptr) if stream_ptr else None))
+
+
+def fetch_dev(d_src_ptr: int, n: int, stream_ptr: int = 0) -> List[float]:
+    """Blocking fetch of n doubles that work queued on the stream leaves at the device pointer (olmc_fetch_dev)."""
+    out = (C.c_double * int(n))()
+    _check(lib().olmc_fetch_dev(C.c_void_p(d_src_ptr), int(n), C.c_void_p(stream_ptr) if stream_ptr else None, out))
+    return list(out)
 
 
 def european_batch(options: Sequence[Tuple[float, float, float, float, float, float, bool]], n_paths: int, n_steps: int,

@@ -56,9 +56,10 @@ struct DeviceCtx {
     int device = -1;
     int cus = 0;
     hipStream_t stream = nullptr;
-    // Reduction workspaces.  Launches on CALLER streams rotate over kSlots of them, each guarded by an event, so
+    // Reduction workspaces.  Each CALLER stream gets one of kSlots of them to itself (stream order guards it), so
     // independent pricings enqueued on DIFFERENT streams may overlap on the device (the tail of
-    // one launch hides under the head of the next) without sharing rows or counters.  Launches on the library's
+    // one launch hides under the head of the next) without sharing rows or counters; a ninth, tenth ... stream shares
+    // slots with the others, rotating and event-guarded.  Launches on the library's
     // OWN stream (every blocking entry point) use slot kSlots and no event at all: the stream is in-order, so a
     // launch finds the workspace free by construction -- and a blocking call is spared the two barrier packets
     // (hipStreamWaitEvent in front of the kernel, hipEventRecord behind it): ~1 us per call, measured.
@@ -67,8 +68,11 @@ struct DeviceCtx {
         size_t cap = 0;
         double* group_rows = nullptr;  // [kMaxGroups][kMaxNV]
         uint32_t* counters = nullptr;  // [(kMaxGroups + 1) * kCounterStride], zero between launches (self-resetting)
-        hipEvent_t done = nullptr;     // recorded after the slot's latest launch
+        hipEvent_t done = nullptr;     // recorded after the slot's latest launch (shared slots only)
         bool used = false;
+        bool claimed = false;          // `owner` (which may be the NULL stream) is the ONE caller stream that has used this slot so far:
+        hipStream_t owner = nullptr;   // its launches need no event (stream order)
+        bool shared = false;           // a second stream had to take the slot: event-guarded from then on
     };
     static constexpr int kSlots = 8;    // = the deepest overlap bench.py's `pipelined` pass asks for (--streams 8)
     WsSlot slots[kSlots + 1];
@@ -228,13 +232,38 @@ int32_t european_launch_shape(const DeviceCtx* c, PathRange* pr) {
 // Workspace of the fused grid reduction for a launch of `grid` workgroups x nv values.
 int make_ws(DeviceCtx* c, hipStream_t stream, int32_t grid, int nv, double* d_out, double tail, ReduceWs* ws) {
     const bool own = stream == c->stream;
-    const int idx = own ? DeviceCtx::kSlots : c->next_slot;
+    int idx = DeviceCtx::kSlots;
+    if (!own) {
+        // a caller stream keeps ONE slot to itself while there are slots to go round (bench.py's 8 streams, a rank's one stream):
+        // its launches are ordered by the stream, no event needed.  Only when more streams than slots show up are slots shared,
+        // rotating and event-guarded as before.
+        idx = -1;
+        for (int i = 0; i < DeviceCtx::kSlots && idx < 0; ++i)
+            if (c->slots[i].claimed && !c->slots[i].shared && c->slots[i].owner == stream) idx = i;
+        for (int i = 0; i < DeviceCtx::kSlots && idx < 0; ++i)
+            if (!c->slots[i].claimed) { c->slots[i].claimed = true; c->slots[i].owner = stream; idx = i; }
+        if (idx < 0) {
+            idx = c->next_slot;
+            c->next_slot = (c->next_slot + 1) % DeviceCtx::kSlots;
+            DeviceCtx::WsSlot& taken = c->slots[idx];
+            if (!taken.shared) {
+                // its owner's launches so far carry no event: drain them once, then guard by events.  (The owner may have been
+                // destroyed by the caller meanwhile; then its work may still be retiring: wait for the device instead.)
+                if (hipStreamSynchronize(taken.owner) != hipSuccess) {
+                    (void)hipGetLastError();
+                    HIP_TRY(hipDeviceSynchronize());
+                }
+                taken.shared = true;
+                taken.used = false;
+            }
+        }
+    }
     DeviceCtx::WsSlot& sl = c->slots[idx];
     c->cur_slot = idx;
-    if (!own) c->next_slot = (c->next_slot + 1) % DeviceCtx::kSlots;
+    const bool guarded = !own && sl.shared;
     const size_t need = static_cast<size_t>(grid) * nv;
     if (need > sl.cap) {
-        if (own) HIP_TRY(hipStreamSynchronize(c->stream));
+        if (!guarded) HIP_TRY(hipStreamSynchronize(stream));
         else if (sl.used) HIP_TRY(hipEventSynchronize(sl.done));
         if (sl.block_rows) HIP_TRY(hipFree(sl.block_rows));
         sl.block_rows = nullptr;
@@ -243,7 +272,7 @@ int make_ws(DeviceCtx* c, hipStream_t stream, int32_t grid, int nv, double* d_ou
         HIP_TRY(hipMalloc(&sl.block_rows, sizeof(double) * cap));
         sl.cap = cap;
     }
-    if (!own && sl.used) HIP_TRY(hipStreamWaitEvent(stream, sl.done, 0));   // previous user of this slot, whatever its stream
+    if (guarded && sl.used) HIP_TRY(hipStreamWaitEvent(stream, sl.done, 0));   // previous user of this shared slot, whatever its stream
     ws->block_rows = sl.block_rows;
     ws->group_rows = sl.group_rows;
     ws->counters = sl.counters;
@@ -273,7 +302,7 @@ void ws_recover(DeviceCtx* c) {
 int after_launch(DeviceCtx* c, hipStream_t stream) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e)); }
-    if (c->cur_slot == DeviceCtx::kSlots) return OLMC_OK;          // the library stream's own slot: stream order is the guard
+    if (c->cur_slot == DeviceCtx::kSlots || !c->slots[c->cur_slot].shared) return OLMC_OK;    // one stream's own slot: stream order is the guard
     DeviceCtx::WsSlot& sl = c->slots[c->cur_slot];
     HIP_TRY(hipEventRecord(sl.done, stream));
     sl.used = true;
@@ -503,8 +532,8 @@ int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32
 // own (it is in-order, so the next launch still starts after this kernel has retired).  Insurance: after 2 ms of spinning
 // the stream is queried every ~100 us -- an error is reported as such, and a stream that reports completion without the
 // flag having shown up falls back to the runtime's own wait.
-int sync_or_recover(DeviceCtx* c, hipStream_t s) {
-    if (c->armed != 0 && s == c->stream) {
+int wait_armed(DeviceCtx* c, hipStream_t s) {
+    if (c->armed != 0) {
         const uint64_t want = c->armed;
         c->armed = 0;
         using clock = std::chrono::steady_clock;
@@ -533,6 +562,11 @@ int sync_or_recover(DeviceCtx* c, hipStream_t s) {
     hipError_t e = hipStreamSynchronize(s);
     if (e != hipSuccess) { ws_recover(c); return fail(OLMC_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e)); }
     return OLMC_OK;
+}
+
+int sync_or_recover(DeviceCtx* c, hipStream_t s) {
+    if (s != c->stream) c->armed = 0;               // only launches on the library's own stream are ever armed
+    return wait_armed(c, s);
 }
 
 int run_batch(const olmc_option* opts, int32_t k, int64_t path_offset, int64_t n_local, int32_t n_steps,
@@ -660,6 +694,33 @@ extern "C" int olmc_european_shard_dev(double S, double K, double T, double r, d
     const double n = static_cast<double>(n_local * (antithetic ? 2 : 1));
     // the path kernel's last workgroup writes {sum, sumsq, n} straight into the caller's buffer
     return run_batch_device(c, s, &o, 1, path_offset, n_local, n_steps, seed, antithetic, d_triple, n, nullptr);
+}
+
+// Blocking fetch of n (<= 33) doubles that work already queued on `hip_stream` leaves at d_src (e.g. the triple after the caller's
+// RCCL all-reduce): a one-wave kernel behind that work copies them into the pinned buffer and raises the completion word, the host
+// polls it -- the same hand-over as a blocking pricing, instead of hipMemcpyAsync + hipStreamSynchronize (8 us -> 3 us per step).
+extern "C" int olmc_fetch_dev(const double* d_src, int32_t n, void* hip_stream, double* out_host) {
+    if (!d_src || !out_host) return fail(OLMC_ERR_ARG, "null pointer");
+    if (n < 1 || n > kMaxNV + 1) return fail(OLMC_ERR_ARG, "n must be in [1, 33]");
+    DeviceCtx* c = nullptr;
+    int rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const uint64_t want = ++c->seq;
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(kWave), 0, s, d_src, n, c->d_result, c->d_flag, want);
+    HIP_TRY(hipGetLastError());
+    if (g_poll >= 0) {
+        c->armed = want;
+        rc = wait_armed(c, s);
+    } else {
+        rc = OLMC_OK;
+        hipError_t e = hipStreamSynchronize(s);
+        if (e != hipSuccess) rc = fail(OLMC_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    }
+    if (rc) return rc;
+    for (int32_t i = 0; i < n; ++i) out_host[i] = c->h_result[i];
+    return OLMC_OK;
 }
 
 extern "C" int olmc_european_batch(const olmc_option* opts, int32_t k, int64_t path_offset, int64_t n_local,

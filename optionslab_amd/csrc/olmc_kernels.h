@@ -1926,6 +1926,15 @@ __global__ __launch_bounds__(kBlock) void probe_cvt_i32_f64(uint32_t* __restrict
     if (acc == 12345) sink[0] = 1u;
 }
 
+// Hands n doubles that earlier work on the stream left in device memory (a shard's all-reduced triple) to the host the way the
+// path kernels hand over their own results: written to the pinned buffer, completion word raised behind them.  One wave.
+__global__ void publish_kernel(const double* __restrict__ src, int32_t n, double* __restrict__ host_dst, uint64_t* __restrict__ done_flag,
+                               uint64_t done_value) {
+    if (static_cast<int32_t>(threadIdx.x) < n) host_dst[threadIdx.x] = src[threadIdx.x];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (threadIdx.x == 0) __hip_atomic_store(done_flag, done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ------------------------------------------------------- validation taps ----
 // exp2_f64 (the fp64 Asian kernel's exponential) on an array: lets the tests pin it against a reference libm point by point.
 __global__ void exp2_probe_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ y) {

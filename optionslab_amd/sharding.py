@@ -65,7 +65,12 @@ def price_european_sharded(S, K, T, r, sigma, option_type, q, n_paths_global: in
     _hip.european_shard_dev(S, K, T, r, sigma, q, option_type == "call", lo, hi - lo, n_steps, seed, antithetic,
                             buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
     allreduce_triple(buf, group)
-    s, ss, n = buf.cpu().tolist()
+    if buf.is_cuda and (not dist.is_initialized() or dist.get_backend(group) == "nccl"):
+        # behind the RCCL all-reduce on the caller's stream: hand the triple over through the library's pinned buffer and
+        # completion word instead of a D2H copy + stream synchronise
+        s, ss, n = _hip.fetch_dev(buf.data_ptr(), 3, torch.cuda.current_stream().cuda_stream)
+    else:
+        s, ss, n = buf.cpu().tolist()
     price, se = finalize(s, ss, int(n), r, T)
     return price, se, int(n)
 

@@ -812,3 +812,48 @@ def test_qmc_eight_point_blocks_give_the_same_points():
         assert abs(big.price - BS_CALL) < 2e-3
     finally:
         _hip.tune(_hip.TUNE_QMC_BLOCK, 0)
+
+
+def test_fetch_dev_hands_over_what_earlier_work_on_the_stream_left():
+    """olmc_fetch_dev: the blocking hand-over of a shard's (all-reduced) triple from a device buffer -- queued behind the
+    caller's work on the caller's stream, polled like a blocking pricing.  Checked with a torch stream and buffer as in
+    bench.py / sharding.price_european_sharded, against the same triple fetched by a plain D2H copy, polled and not."""
+    torch = pytest.importorskip("torch")
+    S, K, T, r, v = ATM
+    st = torch.cuda.Stream()
+    buf = torch.zeros(3, dtype=torch.float64, device="cuda")
+    for poll in (0, -1):
+        _hip.tune(_hip.TUNE_POLL, poll)
+        try:
+            with torch.cuda.stream(st):
+                for k in range(4):
+                    _hip.european_shard_dev(S, K, T, r, v, 0.0, True, 1000 * k, 300_000, 32, 5 + k, True, buf.data_ptr(), st.cuda_stream)
+                    got = _hip.fetch_dev(buf.data_ptr(), 3, st.cuda_stream)
+                    assert got == buf.cpu().tolist() and got[2] == 600_000.0
+                    want = _hip.european(S, K, T, r, v, 0.0, True, 300_000, 32, 5 + k, True, path_offset=1000 * k)
+                    assert (got[0], got[1]) == (want.sum, want.sumsq)
+        finally:
+            _hip.tune(_hip.TUNE_POLL, 0)
+    with pytest.raises(ol.AccelerationError):
+        _hip.fetch_dev(buf.data_ptr(), 64, st.cuda_stream)
+
+
+def test_caller_streams_get_their_own_workspace_and_more_streams_than_slots_share_safely():
+    """Launches on caller streams (olmc_european_shard_dev) take a reduction workspace per stream -- no event needed, the stream
+    orders its own launches -- for up to eight streams; a ninth and later streams share slots, event-guarded.  Twelve streams
+    (the NULL stream among them) with several launches in flight each must all deliver the blocking call's triple."""
+    torch = pytest.importorskip("torch")
+    S, K, T, r, v = ATM
+    streams = [torch.cuda.Stream() for _ in range(11)]
+    ptrs = [st.cuda_stream for st in streams] + [0]                  # 0 = the NULL stream
+    rounds, n = 5, 200_000
+    out = torch.zeros((rounds, len(ptrs), 3), dtype=torch.float64, device="cuda")
+    for k in range(rounds):
+        for j, ptr in enumerate(ptrs):
+            _hip.european_shard_dev(S, K, T, r, v, 0.0, True, 0, n + 257 * j, 48, 100 * k + j, True, out[k, j].data_ptr(), ptr)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    for k in range(rounds):
+        for j in range(len(ptrs)):
+            want = _hip.european(S, K, T, r, v, 0.0, True, n + 257 * j, 48, 100 * k + j, True)
+            assert (got[k, j, 0], got[k, j, 1], got[k, j, 2]) == (want.sum, want.sumsq, float(want.n)), (k, j)

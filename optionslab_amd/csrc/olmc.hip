@@ -90,8 +90,12 @@ struct DeviceCtx {
     double* d_triple = nullptr;      // {sum, sumsq, n} of this device's shard in olmc_multi_gpu_european (never reallocated)
     size_t bulk_bytes = 0;
     // independent-contract batches (european_multi_kernel)
-    void* d_multi = nullptr;         // [opts | out | rows | counters]
-    size_t multi_bytes = 0;
+    void* d_multi = nullptr;         // device [ticket counters | done counter | contracts | rows], see olmc_european_multi
+    void* h_multi = nullptr;         // pinned + mapped [contracts | sums]
+    void* d_h_multi = nullptr;       // device alias of h_multi
+    int64_t multi_cap = 0;           // capacity in contracts
+    size_t multi_bpo = 0;            // workgroups per contract the rows are sized for
+    size_t multi_off_done = 0, multi_off_opts = 0, multi_off_rows = 0, multi_hoff_out = 0;
     std::mutex mu;
     // profiling
     std::vector<EventPair> ev_free, ev_pending;
@@ -129,6 +133,7 @@ void ctx_release(DeviceCtx* c) {
     if (c->d_bulk) (void)hipFree(c->d_bulk);
     if (c->d_triple) (void)hipFree(c->d_triple);
     if (c->d_multi) (void)hipFree(c->d_multi);
+    if (c->h_multi) (void)hipHostFree(c->h_multi);
     for (auto& sl : c->slots) {
         if (sl.block_rows) (void)hipFree(sl.block_rows);
         if (sl.group_rows) (void)hipFree(sl.group_rows);
@@ -296,6 +301,14 @@ void ws_recover(DeviceCtx* c) {
     (void)hipDeviceSynchronize();
     (void)hipGetLastError();
     for (auto& sl : c->slots) (void)hipMemset(sl.counters, 0, sizeof(uint32_t) * (kMaxGroups + 1) * kCounterStride);
+}
+
+// The same for the batch workspace (self-resetting ticket counters and the batch's done counter).
+void multi_recover(DeviceCtx* c) {
+    c->armed = 0;
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    if (c->d_multi) (void)hipMemset(c->d_multi, 0, c->multi_off_opts);
 }
 
 // Call right after launching a kernel that uses the workspace handed out by make_ws.
@@ -747,6 +760,7 @@ extern "C" int olmc_european_multi(const olmc_option* opts, const uint32_t* tags
                                    int32_t n_steps, uint64_t seed, int antithetic, olmc_stats* out) {
     if (!opts || !out) return fail(OLMC_ERR_ARG, "null pointer");
     if (n_options < 1) return fail(OLMC_ERR_ARG, "n_options must be >= 1");
+    if (n_options > (int64_t(1) << 31) - 2) return fail(OLMC_ERR_ARG, "too many contracts in one call");
     int rc = check_paths(0, n_paths, n_steps);
     if (rc) return rc;
     DeviceCtx* c = nullptr;
@@ -755,47 +769,73 @@ extern "C" int olmc_european_multi(const olmc_option* opts, const uint32_t* tags
     std::lock_guard<std::mutex> lock(c->mu);
     const int32_t bpo = static_cast<int32_t>(std::min<int64_t>((n_paths + kBlock - 1) / kBlock, 1024));   // workgroups per contract
     auto align = [](size_t b) { return (b + 255) / 256 * 256; };
-    const size_t b_opts = align(sizeof(MultiOption) * n_options), b_out = align(sizeof(double) * 2 * n_options);
-    const size_t b_rows = align(sizeof(double) * 2 * bpo * n_options), b_cnt = align(sizeof(uint32_t) * n_options * kMultiCounterStride);
-    const size_t need = b_opts + b_out + b_rows + b_cnt;
-    if (need > c->multi_bytes) {
+    // Device workspace [counters | done counter | contracts | rows]: the ticket counters sit FIRST and are sized by the capacity in
+    // contracts, so their place does not move with the batch size and they are zeroed once per (re)allocation -- every finisher
+    // re-zeroes the counter it consumed.  Pinned host staging [contracts | sums]: contracts go up by one asynchronous DMA from
+    // pinned memory, the sums are written into pinned memory by the kernel itself, completion is the polled word of the context.
+    if (n_options > c->multi_cap || static_cast<size_t>(bpo) > c->multi_bpo) {
+        const int64_t cap = std::max<int64_t>(n_options, std::max<int64_t>(2 * c->multi_cap, 64));
+        const size_t bpo_cap = std::max<size_t>(bpo, c->multi_bpo);
+        const size_t b_cnt = align(sizeof(uint32_t) * cap * kMultiCounterStride), b_done = 256, b_opts = align(sizeof(MultiOption) * cap);
+        const size_t b_rows = align(sizeof(double) * 2 * bpo_cap * cap);
+        HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->d_multi) HIP_TRY(hipFree(c->d_multi));
-        c->d_multi = nullptr;
-        c->multi_bytes = 0;
-        HIP_TRY(hipMalloc(&c->d_multi, need));
-        c->multi_bytes = need;
+        if (c->h_multi) HIP_TRY(hipHostFree(c->h_multi));
+        c->d_multi = nullptr; c->h_multi = nullptr; c->multi_cap = 0; c->multi_bpo = 0;
+        HIP_TRY(hipMalloc(&c->d_multi, b_cnt + b_done + b_opts + b_rows));
+        HIP_TRY(hipMemsetAsync(c->d_multi, 0, b_cnt + b_done, c->stream));
+        HIP_TRY(hipHostMalloc(&c->h_multi, b_opts + align(sizeof(double) * 2 * cap), hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(&c->d_h_multi, c->h_multi, 0));
+        c->multi_cap = cap;
+        c->multi_bpo = bpo_cap;
+        c->multi_off_done = b_cnt; c->multi_off_opts = b_cnt + b_done; c->multi_off_rows = b_cnt + b_done + b_opts; c->multi_hoff_out = b_opts;
     }
     char* base = static_cast<char*>(c->d_multi);
-    MultiOption* d_opts = reinterpret_cast<MultiOption*>(base);
-    double* d_out = reinterpret_cast<double*>(base + b_opts);
-    double* d_rows = reinterpret_cast<double*>(base + b_opts + b_out);
-    uint32_t* d_cnt = reinterpret_cast<uint32_t*>(base + b_opts + b_out + b_rows);
-    std::vector<MultiOption> h(static_cast<size_t>(n_options));
+    uint32_t* d_cnt = reinterpret_cast<uint32_t*>(base);
+    uint32_t* d_done = reinterpret_cast<uint32_t*>(base + c->multi_off_done);
+    MultiOption* d_opts = reinterpret_cast<MultiOption*>(base + c->multi_off_opts);
+    double* d_rows = reinterpret_cast<double*>(base + c->multi_off_rows);
+    MultiOption* h = reinterpret_cast<MultiOption*>(c->h_multi);
+    const double* h_out = reinterpret_cast<const double*>(static_cast<char*>(c->h_multi) + c->multi_hoff_out);
+    double* d_out = reinterpret_cast<double*>(static_cast<char*>(c->d_h_multi) + c->multi_hoff_out);
     for (int64_t j = 0; j < n_options; ++j) {
         const Contract ct = make_contract(opts[j], n_steps);
         h[j].a = ct.a; h[j].vol = ct.vol; h[j].strike = ct.strike; h[j].sign = ct.sign;
         h[j].tag = tags ? tags[j] : static_cast<uint32_t>(j);
         h[j].pad = 0;
     }
-    HIP_TRY(hipMemcpyAsync(d_opts, h.data(), sizeof(MultiOption) * n_options, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(uint32_t) * n_options * kMultiCounterStride, c->stream));   // layout moves with n_options
+    HIP_TRY(hipMemcpyAsync(d_opts, h, sizeof(MultiOption) * n_options, hipMemcpyHostToDevice, c->stream));
+    MultiDone md;
+    md.done_count = d_done;
+    md.n_total = static_cast<uint32_t>(n_options);
+    md.done_flag = nullptr;
+    md.done_value = 0;
+    c->armed = 0;
+    if (g_poll >= 0) {
+        c->armed = ++c->seq;
+        md.done_flag = c->d_flag;
+        md.done_value = c->armed;
+    }
     const PathRange pr = make_range(0, n_paths, n_steps, seed);
     EventPair ep{};
     if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
     for (int64_t base_opt = 0; base_opt < n_options; base_opt += 65535) {
         const unsigned ny = static_cast<unsigned>(std::min<int64_t>(65535, n_options - base_opt));
-        if (antithetic) hipLaunchKernelGGL((european_multi_kernel<true>), dim3(bpo, ny), dim3(kBlock), 0, c->stream, pr, d_opts, base_opt, d_rows, d_cnt, d_out);
-        else hipLaunchKernelGGL((european_multi_kernel<false>), dim3(bpo, ny), dim3(kBlock), 0, c->stream, pr, d_opts, base_opt, d_rows, d_cnt, d_out);
-        HIP_TRY(hipGetLastError());
+        if (antithetic) hipLaunchKernelGGL((european_multi_kernel<true>), dim3(bpo, ny), dim3(kBlock), 0, c->stream, pr, d_opts, base_opt, d_rows, d_cnt, d_out, md);
+        else hipLaunchKernelGGL((european_multi_kernel<false>), dim3(bpo, ny), dim3(kBlock), 0, c->stream, pr, d_opts, base_opt, d_rows, d_cnt, d_out, md);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            multi_recover(c);
+            return fail(OLMC_ERR_HIP, std::string("kernel launch: ") + hipGetErrorString(e));
+        }
     }
-    if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) return rc; }
-    std::vector<double> res(static_cast<size_t>(2 * n_options));
-    HIP_TRY(hipMemcpyAsync(res.data(), d_out, sizeof(double) * 2 * n_options, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (g_profile) { rc = prof_end(c, c->stream, ep); if (rc) { multi_recover(c); return rc; } }
+    rc = wait_armed(c, c->stream);
+    if (rc) { multi_recover(c); return rc; }
     const int64_t n = n_paths * (antithetic ? 2 : 1);
     for (int64_t j = 0; j < n_options; ++j) {
         if (poisoned(opts[j].S, opts[j].K, opts[j].T, opts[j].r, opts[j].sigma, opts[j].q)) nan_stats(n, &out[j]);
-        else finish_stats(res[2 * j], res[2 * j + 1], n, opts[j].r, opts[j].T, &out[j]);
+        else finish_stats(h_out[2 * j], h_out[2 * j + 1], n, opts[j].r, opts[j].T, &out[j]);
     }
     return OLMC_OK;
 }

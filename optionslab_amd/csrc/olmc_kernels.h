@@ -579,10 +579,20 @@ struct MultiOption {
     uint32_t pad;
 };
 
+// Completion of a whole batch: out[] is pinned host memory; the finisher of every contract makes its two sums visible
+// system-wide and takes a ticket on `done_count`; the finisher that takes the LAST ticket of the batch (n_total contracts, over
+// all launches of the call) re-zeroes the counter and raises the host's completion word.
+struct MultiDone {
+    uint32_t* done_count;
+    uint64_t* done_flag;     // NULL: the host waits for the stream instead
+    uint64_t done_value;
+    uint32_t n_total;
+};
+
 template <bool ANTI>
 __global__ __launch_bounds__(kBlock) void european_multi_kernel(PathRange pr, const MultiOption* __restrict__ opts,
                                                                 int64_t opt_base, double* __restrict__ block_rows,
-                                                                uint32_t* __restrict__ counters, double* __restrict__ out) {
+                                                                uint32_t* __restrict__ counters, double* __restrict__ out, MultiDone md) {
     __shared__ double stage[kWavesPerBlock][2];
     const int64_t opt = opt_base + blockIdx.y;
     const MultiOption o = opts[opt];
@@ -619,6 +629,16 @@ __global__ __launch_bounds__(kBlock) void european_multi_kernel(PathRange pr, co
     const double total = wave_rows_sum<2>(rows, static_cast<int32_t>(gridDim.x));
     if (lane < 2) out[opt * 2 + lane] = total;
     if (lane == 0) __hip_atomic_store(counters + static_cast<size_t>(opt) * kMultiCounterStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (md.done_flag == nullptr) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: this contract's sums are in host memory before its ticket
+    uint32_t fin = 0;
+    if (lane == 0) fin = __hip_atomic_fetch_add(md.done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    fin = __builtin_amdgcn_readfirstlane(fin);
+    if (fin != md.n_total - 1u) return;
+    if (lane == 0) {
+        __hip_atomic_store(md.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(md.done_flag, md.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Asian option: running arithmetic sum of S_t (or sum of ln S_t) over t = 1..M kept in

@@ -48,6 +48,8 @@ def report(name, path_steps, fn, extra=None, reps=20):
 
 def main():
     print(json.dumps(dict(device=_hip.device_info())), flush=True)
+    for k in range(2500):                                   # ~0.3 s of load: an idle MI355X needs tens of ms to reach its sustained clocks
+        _hip.european(*ATM, 0.0, True, 1_000_000, 252, k)
     N, M = 1_000_000, 252
     p = ol.MonteCarloPricer(N, M, 42)
     report("C2 european call 1M x 252 antithetic, price(return_error=True)", N * M,

@@ -16,8 +16,11 @@ BS = ol.black_scholes(*ATM, "call")
 
 
 def timeit(fn, reps=20, warm=3):
-    for _ in range(warm):
+    t_end = time.perf_counter() + 0.08          # >= 80 ms of THIS workload first: the clock sags within milliseconds of idling
+    n = 0                                       # (a D2H-heavy config before a compute-heavy one made the latter read 10-15 % slow)
+    while n < warm or time.perf_counter() < t_end:
         fn()
+        n += 1
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter()

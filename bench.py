@@ -1,30 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: GBM path-steps/s, European call, 1M paths x 252 steps per GPU
-(BASELINE.json configs[1]), antithetic on, on-device reduction.
+"""bench.py -- headline benchmark: GBM path-steps/s, European call, antithetic on, on-device reduction.
 
     python bench.py --gpus N --steps K --warmup W
+
+N = 1: BASELINE.json configs[1] -- 1M paths x 252 steps on one GPU.  N > 1: configs[4] -- 8M paths x 252 steps per GPU,
+contiguous global path ranges, ONE RCCL all-reduce of the (sum, sumsq, n) triple per pricing (weak scaling); the 1M-per-GPU
+figure and the one-GPU basis of the same 8M workload travel as secondary keys of the same line.
 
 ONE pass defines the line: a "step" is one complete BLOCKING pricing --
 `MonteCarloPricer.price(S, K, T, r, sigma, "call", seed=..., return_error=True)` at N = 1 (one path kernel with its
 fused reduction, result on the host), and at N > 1 the same thing sharded: this rank's kernel on its block of the
-global paths -> ONE all-reduce of the 24-byte (sum, sumsq, n) triple over RCCL/xGMI -> result on the host of every
-rank.  After W untimed warm-up steps a pass times EXACTLY K steps between barrier + synchronise fences (max over
-ranks); the pass is repeated so that short passes (K = 20 is 2.5 ms) are not a one-shot sample, and
+global paths -> the all-reduce -> result on the host of every rank.  After W untimed warm-up steps a pass times EXACTLY
+K steps between barrier + synchronise fences (max over ranks); passes repeat until >= 0.5 s are covered, and
 
     value                  = global paths x 252 x K / median pass time
     ms_per_step            = median pass time / K
     roofline.avg_kernel_ms = HIP events attached to the dispatches of those very calls
 
-so `avg_kernel_ms <= ms_per_step` by construction.  `roofline.frac` is an issue-cycle fraction: VALU-active
-SIMD-cycles per launch (rocprofv3 PMC, collected LIVE by a child pass of this script before the parent touches the
-GPU) over the SIMD-cycles of the measured kernel time at the 2.4 GHz peak clock -- <= 1 by construction.  Secondary
-keys: `pipelined` (the same K pricings dealt over --streams HIP streams, tails overlapping), `c3_greeks`, `c4_asian`
-(BASELINE configs[2], [3]; N = 1 only), `c5_weak` / `c5_strong` (configs[4]: 8M paths per GPU, and 64M paths split
-over the ranks), `clock` (shader clock held under the kernel's load, s_memtime / s_memrealtime), `cpu_baseline`.
+so `avg_kernel_ms <= ms_per_step` by construction.  `roofline.frac` is an issue-cycle fraction: VALU issue cycles the
+kernel's instruction stream needs per launch (rocprofv3 PMC, collected LIVE by a child pass of this script before the
+parent touches the GPU) over the SIMD-cycles of the measured kernel time at the 2.4 GHz peak clock -- <= 1 by construction.
+
+stdout carries ONE JSON line of <= 3 KB (`compact_line`): the contract keys, `roofline`, `cpu_baseline` and
+{value, ms, frac} entries for configs[2] (`c3`), [3] (`c4`), [4] (`c5`).  Everything else -- issue tables, instruction
+mixes, per-pass seconds, probes -- goes to the sidecar file the line names in `detail` (bench_detail.json next to this
+script; copies of record live under profiles/).
 
 torch is plumbing here (device result slots, stream handle, process group); the compute is libolmc.so through its
-C ABI.  With N > 1 launch as
-`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N`.
+C ABI.  With N > 1 and no launcher in the environment (WORLD_SIZE unset) this script starts its own N ranks as a child
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...` BEFORE
+anything touches a GPU and relays rank 0's line and the exit code; under an external torch.distributed.run it is a rank.
 """
 import argparse
 import csv
@@ -34,6 +39,7 @@ import json
 import math
 import os
 import shutil
+import socket
 import statistics
 import subprocess
 import sys
@@ -88,6 +94,9 @@ def pmc_child():
     p = ol.MonteCarloPricer(PATHS_PER_GPU, N_STEPS, SEED)
     for i in range(12):
         p.price(*ATM, "call", seed=SEED + i, return_error=True)
+    p8 = ol.MonteCarloPricer(C5_PATHS_PER_GPU, N_STEPS, SEED)       # configs[4]'s shard: the same kernel, another launch shape
+    for i in range(4):
+        p8.price(*ATM, "call", seed=SEED + i, return_error=True)
     for second in (False, True):
         for _ in range(4):
             p.greeks(*ATM, "call", include_second_order=second)
@@ -97,6 +106,14 @@ def pmc_child():
             for _ in range(3):
                 a.price(PATHS_PER_GPU, ASIAN_STEPS, "arithmetic", "call", antithetic=anti, precision=precision)
     print("pmc-child done", flush=True)
+
+
+def _row_threads(row):
+    """Threads of a dispatch row of rocprofv3's counter_collection.csv (Grid_Size = total work-items)."""
+    try:
+        return int(float(row.get("Grid_Size") or row.get("Grid_Size_X") or 0))
+    except ValueError:
+        return 0
 
 
 def collect_pmc(keep_dir=None):
@@ -130,6 +147,8 @@ def collect_pmc(keep_dir=None):
             with open(f) as fh:
                 for row in csv.DictReader(fh):
                     key = next((k for pat, k in PMC_KERNELS.items() if pat in row["Kernel_Name"]), None)
+                    if key == "c2_european" and _row_threads(row) > 4 * PATHS_PER_GPU:
+                        key = "c5_shard"                  # the 8M-path launches of the same kernel (configs[4]'s per-GPU shard)
                     if key:
                         agg.setdefault((key, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
         for (key, ctr), vals in agg.items():
@@ -292,6 +311,146 @@ def cpu_baseline(all_cores=True):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ the line
+LINE_BUDGET = 3072            # bytes of the ONE stdout line (the driver keeps an 8 KB tail of stdout; r02's 29 KB line left parsed = null)
+DETAIL_FILE = os.environ.get("OLMC_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")
+
+
+def _num(x, digits=6):
+    """Floats to `digits` significant digits (the line is read by machines; 17 digits of a timing are noise)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def _entry(value=None, ms=None, frac=None, **more):
+    e = {"value": _num(value), "ms": _num(ms, 5)}
+    if frac is not None:
+        e["frac"] = _num(frac, 4)
+    e.update({k: _num(v) for k, v in more.items() if v is not None})
+    return e
+
+
+def compact_line(full, detail_name=None):
+    """The ONE stdout line, from the full record (pure: no I/O, no clocks -- tests/test_bench_line.py feeds it canned records).
+    Contract keys verbatim; roofline and cpu_baseline as the task defines them; c3 / c4 / c5 as {value, ms, frac}; nothing else.
+    Stays under LINE_BUDGET bytes for any record: free-text fields are clipped, error lists truncated."""
+    def clip(sv, n):
+        sv = str(sv)
+        return sv if len(sv) <= n else sv[: n - 1] + "~"
+
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                     "vs_baseline", "dtype", "data")}
+    line["value"], line["ms_per_step"] = _num(line["value"], 7), _num(line["ms_per_step"], 6)
+    cfg = full.get("config") or {}
+    line["config"] = {"workload": clip(cfg.get("workload", ""), 300), "paths_per_gpu": cfg.get("paths_per_gpu"), "n_steps": cfg.get("n_steps"),
+                      "global_paths": cfg.get("global_paths"), "parallelism": clip(cfg.get("parallelism", ""), 120)}
+    line["ranks_seen"] = full.get("ranks_seen")
+    line["timed_s"] = _num(sum((full.get("passes") or {}).get("seconds") or []), 4)
+    acc = full.get("accuracy") or {}
+    line["accuracy"] = {"max_abs_err_over_sigma": _num(acc.get("max_abs_err_over_sigma"), 4), "steps_checked": acc.get("steps_checked")}
+    r = full.get("roofline") or {}
+    line["roofline"] = {"bound": r.get("bound", "valu"), "achieved": _num(r.get("achieved")), "peak": _num(r.get("peak")),
+                        "unit": "G VALU issue-cycles/s", "frac": _num(r.get("frac"), 4), "traffic": _num(r.get("traffic")),
+                        "avg_kernel_ms": _num(r.get("avg_kernel_ms"), 5), "kernel": clip(r.get("kernel", ""), 60),
+                        "pmc_source": clip(r.get("pmc_source") or r.get("why_null") or "", 90),
+                        "clock_ghz_under_load": _num(r.get("clock_ghz_under_load"), 4), "hbm_gbps": _num(r.get("hbm_gbps"), 4)}
+    cpu = full.get("cpu_baseline")
+    if cpu:
+        line["cpu_baseline"] = {"value": _num(cpu.get("value")), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
+                                "seconds": _num(cpu.get("seconds"), 4), "sample": clip(cpu.get("sample", ""), 160)}
+        if isinstance(cpu.get("all_cores"), dict) and cpu["all_cores"].get("value"):
+            line["cpu_baseline"]["all_cores"] = {"value": _num(cpu["all_cores"]["value"]), "cores": cpu["all_cores"].get("cores")}
+        line["gpu_over_cpu"] = _num(full.get("gpu_over_cpu"), 5)
+
+    def roof_frac(d):
+        return ((d or {}).get("roofline") or {}).get("frac")
+
+    g = full.get("c3_greeks")
+    if isinstance(g, dict) and "error" not in g:
+        line["c3"] = {k: _entry(v.get("path_steps_per_s"), v.get("ms_per_call"), roof_frac(v), kernel_ms=v.get("avg_kernel_ms"))
+                      for k, v in g.items() if isinstance(v, dict) and "ms_per_call" in v}
+    a = full.get("c4_asian")
+    if isinstance(a, dict) and "error" not in a:
+        line["c4"] = {k: _entry(v.get("path_steps_per_s"), v.get("ms_per_call"), roof_frac(v), kernel_ms=v.get("avg_kernel_ms"))
+                      for k, v in a.items() if isinstance(v, dict) and "ms_per_call" in v}
+        if a.get("gpu_over_cpu"):
+            line["c4"]["gpu_over_cpu"] = _num(a["gpu_over_cpu"], 5)
+    c5 = {}
+    for k in ("c5_weak", "c5_strong", "c2_1m_per_gpu", "n1_basis", "pipelined"):
+        v = full.get(k)
+        if isinstance(v, dict) and "error" not in v:
+            c5[k] = _entry(v.get("value"), v.get("ms_per_step"), roof_frac(v), paths_per_gpu=v.get("paths_per_gpu"), kernel_ms=v.get("avg_kernel_ms"))
+    for k in ("c5_weak", "c5_strong"):
+        if k in c5:
+            line.setdefault("c5", {})[k[3:]] = c5.pop(k)
+    line.update(c5)
+    errs = []
+    for k in ("c3_greeks", "c4_asian", "c5_weak", "c5_strong", "c2_1m_per_gpu", "n1_basis", "pipelined"):
+        if isinstance(full.get(k), dict) and "error" in full[k]:
+            errs.append(f"{k}: {full[k]['error']}")
+    errs += list(full.get("errors") or [])
+    if errs:
+        line["errors"] = [clip(e, 120) for e in errs[:4]]
+    if detail_name:
+        line["detail"] = detail_name
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > LINE_BUDGET:                      # belt and braces: shed the secondary entries, never the contract keys
+        for k in ("pipelined", "c4", "c3", "c5", "errors"):
+            line.pop(k, None)
+            if len(json.dumps(line, separators=(",", ":"))) <= LINE_BUDGET:
+                break
+    return line
+
+
+def write_detail(full):
+    """The full record next to this script (and wherever $OLMC_BENCH_DETAIL points); returns the name the line carries."""
+    try:
+        with open(DETAIL_FILE, "w") as f:
+            json.dump(full, f, indent=1)
+        return os.path.relpath(DETAIL_FILE, ROOT) if DETAIL_FILE.startswith(ROOT) else DETAIL_FILE
+    except OSError as e:
+        print(f"[bench] cannot write {DETAIL_FILE}: {e}", file=sys.stderr)
+        return None
+
+
+# ------------------------------------------------------------------------------------------------ launcher (N > 1, no torchrun around)
+def launch_ranks(args):
+    """`python3 bench.py --gpus N` on its own: this process never touches a GPU; it starts the N ranks as ONE child process
+    tree (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1), relays rank 0's JSON line and the exit code."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["OLMC_BENCH_SPAWNED"] = "1"
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {' '.join(cmd[1:8])} ...", file=sys.stderr)
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, timeout=1500)
+    except subprocess.TimeoutExpired as e:
+        sys.stderr.write(f"[bench] the ranks did not finish within {e.timeout:.0f} s\n")
+        return 5
+    line = None
+    for raw in (r.stdout or b"").decode("utf-8", "replace").splitlines():
+        raw = raw.strip()
+        if raw.startswith("{") and '"metric"' in raw:
+            line = raw
+    if line is not None:
+        sys.stdout.write(line + "\n")
+        sys.stdout.flush()
+    if r.returncode == 0 and line is None:
+        sys.stderr.write("[bench] the ranks exited 0 without printing a line\n")
+        return 4
+    return r.returncode
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     faulthandler.enable()             # a crash in native code (HIP, RCCL) leaves a Python traceback on stderr instead of nothing
@@ -305,14 +464,20 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip pipelined / C3 / C4 / C5 (profiling runs)")
     ap.add_argument("--pmc-keep", default=None, help="directory to keep the rocprofv3 CSVs of the live passes in")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--paths-per-gpu", type=int, default=PATHS_PER_GPU,
-                    help="default 1,000,000 (BASELINE configs[1]); 8000000 reproduces configs[4]'s 8M-per-GPU shards")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="timed passes repeat until this much wall time is covered")
+    ap.add_argument("--paths-per-gpu", type=int, default=0,
+                    help="default: 1,000,000 at --gpus 1 (BASELINE configs[1]), 8,000,000 at --gpus N > 1 (configs[4]'s per-GPU shard)")
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child()
-    if args.steps < 1 or args.warmup < 0:
-        raise SystemExit("--steps must be >= 1 and --warmup >= 0")
+    if args.steps < 1 or args.warmup < 0 or args.gpus < 1:
+        raise SystemExit("--gpus and --steps must be >= 1 and --warmup >= 0")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
+    return worker(args)
 
+
+def worker(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # Rehearsal of the N > 1 control flow on a ONE-GPU box (never the driver's mode): OLMC_BENCH_REHEARSAL=1 puts every
@@ -325,6 +490,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     os.environ["OLMC_DEVICE"] = str(local_rank)
     use_dist = world > 1 or os.environ.get("OLMC_BENCH_FORCE_DIST") == "1"
+    paths_per_gpu = args.paths_per_gpu or (PATHS_PER_GPU if world == 1 else C5_PATHS_PER_GPU)
+    pmc_key = {PATHS_PER_GPU: "c2_european", C5_PATHS_PER_GPU: "c5_shard"}.get(paths_per_gpu)
 
     # Child-process work first, while this process has not touched the GPU: the live PMC passes and the CPU baseline's pool.
     pmc, cpu = None, None
@@ -383,9 +550,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def make_step(n_global):
-        """step(k) -> (price, std_error, n): ONE blocking pricing of n_global paths x 252 steps, result on the host."""
-        if not use_dist:
+    def make_step(n_global, sharded=None):
+        """step(k) -> (price, std_error, n): ONE blocking pricing of n_global paths x 252 steps, result on the host.
+        sharded=False prices all n_global paths on THIS rank without any collective (the one-GPU basis of a workload)."""
+        if not (use_dist if sharded is None else sharded):
             pricer = ol.MonteCarloPricer(n_global, N_STEPS, SEED)
 
             def step(k):
@@ -409,14 +577,15 @@ def main():
             return price, se, int(n)
         return step
 
-    def timed_passes(step, n_global, steps, warm, min_total_s=0.05, max_passes=25, seed0=0):
+    def timed_passes(step, n_global, steps, warm, min_total_s=0.5, max_passes=400, seed0=0):
         """warm untimed steps, then passes of EXACTLY `steps` blocking steps, each between fences; max over ranks per pass.
         Passes ALTERNATE plain / instrumented: an instrumented pass is the same loop with a HIP event pair attached to
         every dispatch (the kernel's own begin / end timestamps).  Attaching the pair puts a marker packet in front of the
         kernel, which costs a blocking call several microseconds, so the events ride on every other pass instead of
         on all of them: `value` comes from the plain passes, the kernel duration from the instrumented ones, and both
-        pass times are reported.  Returns (plain pass times, instrumented pass times, per-call times of the plain passes
-        on this rank, avg kernel seconds, launches timed, worst |price - BS| / se, prices of the first pass)."""
+        pass times are reported.  The number of passes is chosen so that the plain ones alone cover `min_total_s` (every rank
+        derives it from the same max-reduced first pass).  Returns (plain pass times, instrumented pass times, per-call times of
+        the plain passes on this rank, avg kernel seconds, launches timed, worst |price - BS| / se, prices of the first pass)."""
         worst, calls, first = 0.0, [], []
 
         def check(res):
@@ -433,7 +602,7 @@ def main():
         while n_pass is None or len(inst_passes) < n_pass:
             instrumented = len(passes) > len(inst_passes)          # plain, instrumented, plain, ...
             _hip.profile_enable(instrumented)
-            base = seed0 + len(passes if not instrumented else inst_passes) * steps     # both kinds walk the same seeds
+            base = seed0 + (len(passes if not instrumented else inst_passes) * steps) % 1_000_000     # both kinds walk the same seeds
             results, stamps, pc = [], [], time.perf_counter
             fence()
             t0 = pc()
@@ -452,6 +621,8 @@ def main():
             (inst_passes if instrumented else passes).append(dt)
             if n_pass is None:          # every rank derives the same count from the same max-reduced time
                 n_pass = max(3, min(max_passes, int(math.ceil(min_total_s / max(dt, 1e-9)))))
+            if instrumented and len(inst_passes) % 16 == 0:
+                _hip.kernel_time()      # drain the event pool as the passes go (4096 pairs)
         launches, kernel_ms = _hip.kernel_time()
         _hip.profile_enable(False)
         avg_kernel_s = kernel_ms / 1e3 / launches if launches else None
@@ -460,9 +631,11 @@ def main():
     # Before anything is timed the device gets ~150 ms of the same work (untimed, `pre_warm_ms`): an idle MI355X needs tens
     # of milliseconds of load to reach its sustained clocks.  A FIXED count, not a clock: every rank enters the same
     # collectives the same number of times.
-    step_main = make_step(args.paths_per_gpu * world)
+    n_global = paths_per_gpu * world
+    step_main = make_step(n_global)
+    pre_warm = max(64, PRE_WARM_PASSES * 32 * PATHS_PER_GPU // paths_per_gpu)
     t_pre = time.perf_counter()
-    for k in range(PRE_WARM_PASSES * 32):
+    for k in range(pre_warm):
         step_main(500_000 + k)
     pre_warm_ms = (time.perf_counter() - t_pre) * 1e3
 
@@ -474,9 +647,9 @@ def main():
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         ranks_seen = int(ones.item())
 
-    n_global = args.paths_per_gpu * world
-    passes, inst_passes, calls, avg_kernel_s, launches, worst, first_prices = timed_passes(step_main, n_global, K_steps, W)     # THE measured passes
-    assert worst <= 5.0, f"a step's price is {worst:.2f} sigma from Black-Scholes"     # max of up to ~2,500 draws of |N(0,1)|: P(> 5) ~ 1e-3
+    passes, inst_passes, calls, avg_kernel_s, launches, worst, first_prices = timed_passes(step_main, n_global, K_steps, W,
+                                                                                           min_total_s=args.min_seconds)     # THE measured passes
+    assert worst <= 5.5, f"a step's price is {worst:.2f} sigma from Black-Scholes"     # max of up to ~50,000 draws of |N(0,1)|: P(> 5.5) ~ 2e-3
     pass_s = statistics.median(passes)
     path_steps = n_global * N_STEPS
     value = path_steps * K_steps / pass_s
@@ -484,7 +657,7 @@ def main():
     clock = None
     try:
         for _ in range(3):
-            clock = _hip.clock_probe(args.paths_per_gpu, N_STEPS, SEED)
+            clock = _hip.clock_probe(PATHS_PER_GPU, N_STEPS, SEED)
     except Exception as e:
         clock = {"error": f"{type(e).__name__}: {e}"}
     clock_ghz = clock.get("ghz") if clock else None
@@ -493,15 +666,17 @@ def main():
         costs = _hip.issue_probe(8)         # ns per wave64 instruction per SIMD, per class, on this device, now
     except Exception as e:
         print(f"[bench] issue probes unavailable: {type(e).__name__}: {e}", file=sys.stderr)
+    if "c5_shard" not in mixes and "c2_european" in mixes:
+        mixes = dict(mixes, c5_shard=mixes["c2_european"])          # the same kernel, another launch shape
 
     out = None
     if rank == 0:
         local_paths = sharding.shard_bounds(n_global, 0, world)[1]
-        roof = roofline_for(pmc, "c2_european", avg_kernel_s, N_STEPS, args.paths_per_gpu, costs, mixes, clock_ghz) if args.paths_per_gpu == PATHS_PER_GPU else None
+        roof = roofline_for(pmc, pmc_key, avg_kernel_s, N_STEPS, paths_per_gpu, costs, mixes, clock_ghz) if pmc_key else None
         if roof is None:
             roof = {"bound": "valu", "achieved": None, "peak": N_SIMD * PEAK_GHZ, "unit": "G VALU issue-cycles/s (peak = 1024 SIMDs x 2.4 GHz)", "frac": None,
                     "traffic": None, "avg_kernel_ms": avg_kernel_s * 1e3 if avg_kernel_s else None,
-                    "why_null": (pmc or {}).get("error", "no PMC counters for this launch size (non-default sizes do not run the rocprofv3 passes)")}
+                    "why_null": (pmc or {}).get("error", "no PMC counters for this launch size (only 1M and 8M paths per launch are profiled)")}
         roof.update({
             "kernel": "european_path_kernel<1,true,kReduce,false>", "launches_timed": launches,
             "pmc_source": (pmc or {}).get("source"), "issue_costs_ns": costs,
@@ -516,15 +691,16 @@ def main():
                               "what": "SURVEY 8(d)'s algorithmic count (32 lane-ops per path-step) over 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T "
                                       "(the guide's 157.3 TF fp32 / 2; SURVEY's own 39.3 T assumed SIMD-16). A MODEL, not a bound: the kernel "
                                       "issues 14.5 instructions per path-step, so this ratio can exceed 1"}})
+        which = "configs[1]" if (world == 1 and paths_per_gpu == PATHS_PER_GPU) else ("configs[4]" if paths_per_gpu == C5_PATHS_PER_GPU else "non-default size")
         out = {
             "metric": "MC path-steps/sec (1M paths × 252 steps Euro call); price vs BS |err|/σ",      # BASELINE.json, verbatim
             "value": value, "unit": "path-steps/s", "n_gpus": world, "steps": K_steps, "warmup": W,
             "ms_per_step": pass_s / K_steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 normals / f64 prices", "data": "synthetic",
-            "config": {"workload": f"European call S0=100 K=100 sigma=0.2 r=0.05 T=1, {args.paths_per_gpu:,} paths x 252 steps per GPU, "
-                                   "antithetic on (two payoffs per path), Philox4x32-10 + Box-Muller in registers, on-device reduction; "
-                                   "a step = one blocking price(return_error=True) call, result on the host",
-                       "paths_per_gpu": args.paths_per_gpu, "n_steps": N_STEPS, "global_paths": n_global,
+            "config": {"workload": f"BASELINE {which}: European call S0=100 K=100 sigma=0.2 r=0.05 T=1, {paths_per_gpu:,} paths x 252 steps per GPU, "
+                                   "antithetic on, Philox4x32-10 + Box-Muller in registers, on-device reduction; "
+                                   "step = one blocking price(return_error=True), result on the host",
+                       "paths_per_gpu": paths_per_gpu, "n_steps": N_STEPS, "global_paths": n_global,
                        "parallelism": f"path-sharded x{world}" + (", 1 RCCL all-reduce of (sum,sumsq,n) per step" if world > 1 else "")
                                       + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")},
             "passes": {"n": len(passes), "seconds": passes, "what": f"each = exactly {K_steps} blocking steps between fences, max over ranks; "
@@ -535,38 +711,44 @@ def main():
                                             "the difference to ms_per_step is its price, which is why `value` is not taken from these passes"},
             "per_call": {"median_ms": statistics.median(calls) * 1e3, "min_ms": min(calls) * 1e3, "p90_ms": sorted(calls)[int(0.9 * (len(calls) - 1))] * 1e3,
                          "n": len(calls), "what": "wall of the individual blocking calls of the timed passes (rank 0)"},
-            "pre_warm_ms": pre_warm_ms, "pre_warm_pricings": PRE_WARM_PASSES * 32,
+            "pre_warm_ms": pre_warm_ms, "pre_warm_pricings": pre_warm,
             "ranks_seen": ranks_seen,
             "payoff_samples_per_s": 2 * n_global * K_steps / pass_s,      # the antithetic mirror doubles the payoff samples, not the path-steps
-            "accuracy": {"bs_price": bs, "max_abs_err_over_sigma": worst, "payoffs_per_step": 2 * n_global, "steps_checked": len(calls) + W},
+            "accuracy": {"bs_price": bs, "max_abs_err_over_sigma": worst, "payoffs_per_step": 2 * n_global, "steps_checked": len(calls) + len(inst_passes) * K_steps + W},
             "roofline": roof,
             "clock": clock,
             "device": info,
+            "isa_mix": {k: mixes.get(k) for k in set(PMC_KERNELS.values()) if k in mixes},
+            "issue_passes": ISSUE_PASSES,
         }
         if cpu:
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = value / cpu["value"]
 
-    # ---- everything below is secondary: it must never cost the line.  A watchdog prints what exists if a section hangs.
+    # ---- everything below is secondary: it must never cost the line.  A watchdog prints what exists if a section hangs --
+    # and then exits NON-ZERO, naming the section, so a stuck GPU section is not reported as success.
     printed = threading.Event()
+    current = {"section": None}
 
     def emit():
         if rank == 0 and not printed.is_set():
             printed.set()
             sys.stdout.flush()
-            os.write(json_fd, (json.dumps(out) + "\n").encode())
+            detail = write_detail(out)
+            os.write(json_fd, (json.dumps(compact_line(out, detail), separators=(",", ":")) + "\n").encode())
 
     def watchdog_fire():
         if rank == 0 and out is not None:
-            out.setdefault("errors", []).append("a secondary section did not finish within its time limit; line printed by the watchdog")
+            out.setdefault("errors", []).append(f"section `{current['section']}` did not finish within its time limit; line printed by the watchdog, exit 3")
         emit()
-        os._exit(0)
+        os._exit(3)
 
-    dog = threading.Timer(600.0 if world == 1 else 240.0, watchdog_fire)
+    dog = threading.Timer(600.0 if world == 1 else 300.0, watchdog_fire)
     dog.daemon = True
     dog.start()
 
     def section(name, fn):
+        current["section"] = name
         try:
             res = fn()
         except Exception as e:          # recorded, not raised
@@ -574,20 +756,33 @@ def main():
         if rank == 0 and res is not None:
             out[name] = res
 
-    def c5(n_glob, steps, what):
-        step = make_step(n_glob)
-        ps, _ips, cs, ks, ln, wst, _first = timed_passes(step, n_glob, steps, 2, min_total_s=0.03, max_passes=5, seed0=7_000_000)
+    def side(n_glob, steps, what, sharded=None, key=None, min_total_s=0.1):
+        """A secondary workload through the same timed_passes: {value, ms_per_step, avg_kernel_ms, roofline, ...}."""
+        step = make_step(n_glob, sharded)
+        ps, _ips, cs, ks, ln, wst, _first = timed_passes(step, n_glob, steps, 2, min_total_s=min_total_s, max_passes=12, seed0=7_000_000)
         med = statistics.median(ps)
-        return {"value": n_glob * N_STEPS * steps / med, "unit": "path-steps/s", "ms_per_step": med / steps * 1e3, "steps": steps, "passes": len(ps),
-                "global_paths": n_glob, "paths_per_gpu": n_glob // world, "n_gpus": world, "avg_kernel_ms": ks * 1e3 if ks else None,
-                "max_abs_err_over_sigma": wst, "dtype": "f32 normals / f64 prices", "workload": what}
+        per_gpu = n_glob // world if (use_dist if sharded is None else sharded) else n_glob
+        d = {"value": n_glob * N_STEPS * steps / med, "unit": "path-steps/s", "ms_per_step": med / steps * 1e3, "steps": steps, "passes": len(ps),
+             "global_paths": n_glob, "paths_per_gpu": per_gpu, "n_gpus": world, "avg_kernel_ms": ks * 1e3 if ks else None,
+             "max_abs_err_over_sigma": wst, "dtype": "f32 normals / f64 prices", "workload": what}
+        if rank == 0 and key:
+            d["roofline"] = roofline_for(pmc, key, ks, N_STEPS, per_gpu, costs, mixes, clock_ghz)
+        return d
 
     if not args.no_extras:
-        # BASELINE configs[4] -- so that a scaling run lands on it at every N: 8M paths per GPU (weak), 64M paths in total (strong)
-        section("c5_weak", lambda: c5(C5_PATHS_PER_GPU * world, 5,
-                                      f"configs[4] weak: European call, {C5_PATHS_PER_GPU:,} paths x 252 steps per GPU x {world} GPU(s), blocking sharded price(), one all-reduce of the triple per step"))
-        section("c5_strong", lambda: c5(C5_TOTAL, 3,
-                                        f"configs[4] strong: European call, {C5_TOTAL:,} paths x 252 steps in total split over {world} GPU(s), blocking sharded price(), one all-reduce of the triple per step"))
+        if world > 1:
+            # the same 8M-path workload on ONE GPU with no collective, measured by every rank in this very run: the N = 1 basis the
+            # scaling efficiency of `value` is computable from (value / (N x n1_basis.value)) out of one record
+            section("n1_basis", lambda: side(paths_per_gpu, 10, f"one-GPU basis of the headline workload: European call, {paths_per_gpu:,} paths x 252 steps on this "
+                                             "rank alone, blocking price(), no collective; max over ranks", sharded=False, key=pmc_key))
+            section("c2_1m_per_gpu", lambda: side(PATHS_PER_GPU * world, 50, f"configs[1] sharded: {PATHS_PER_GPU:,} paths x 252 steps per GPU x {world} GPUs, blocking "
+                                                  "sharded price(), one all-reduce of the triple per step", key="c2_european"))
+        else:
+            # BASELINE configs[4] on one GPU: its per-GPU shard (8M paths), and all 64M paths on this one device
+            section("c5_weak", lambda: side(C5_PATHS_PER_GPU, 10, f"configs[4] weak: European call, {C5_PATHS_PER_GPU:,} paths x 252 steps per GPU x {world} GPU(s), "
+                                            "blocking price()", key="c5_shard"))
+        section("c5_strong", lambda: side(C5_TOTAL, 3, f"configs[4] strong: European call, {C5_TOTAL:,} paths x 252 steps in total split over {world} GPU(s), "
+                                          "blocking sharded price(), one all-reduce of the triple per step", min_total_s=0.05))
         section("pipelined", lambda: pipelined(args, torch, dist, _hip, sharding, use_dist, rehearsal, world, rank, main_stream, fence, max_over_ranks,
                                                n_global, K_steps, W, bs, first_prices))
         if world == 1 and not use_dist:

@@ -339,6 +339,15 @@ int olmc_normal_moments(uint64_t seed, int64_t path_offset, int64_t n_paths, int
 int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps,
                  float* out_host);
 
+/* Where one launch of the headline kernel (European call, antithetic, n_paths x n_steps, production launch shape) spends its
+ * time: wave 0 of every workgroup stamps the device-wide 100 MHz counter (s_memrealtime) at entry, after the step loop, after
+ * the workgroup sums and on return from the grid reduction, and notes where it ran (HW_ID | XCC_ID << 32); the wave that writes
+ * the totals stamps once more.  stamps_host (caller-owned, `capacity` words >= 5 * workgroups + 1) receives [workgroup][5] then
+ * the final stamp; info3 = {workgroups,
+ * index of the first split workgroup (= workgroups when none), duration of the dispatch in ns by its own begin / end
+ * timestamps}.  Measurement only (tools/phase_stamps.py); prices nothing. */
+int olmc_phase_stamps(int64_t n_paths, int32_t n_steps, uint64_t seed, uint64_t* stamps_host, int64_t capacity, int64_t* info3);
+
 /* Shader clock the device holds while every SIMD runs the headline kernel's step loop (n_paths x n_steps, one
  * workgroup per 256 paths): out3 = {median shader cycles of a workgroup's loop (s_memtime), median 100 MHz ticks of
  * the same interval (s_memrealtime), median of their quotient in GHz}.  Feeds bench.py's roofline; prices nothing. */
@@ -372,12 +381,15 @@ int olmc_profile_enable(int on);
  *                        (default), -1 = hipStreamSynchronize
  *   OLMC_TUNE_SPLIT_TAIL European launches: 0 = the paths beyond a whole number of workgroups per compute unit go to split
  *                        workgroups (64 paths, each wave a quarter of the steps; default), -1 = never (one shape throughout)
+ *   OLMC_TUNE_SPLIT_SAT  k in [1, 16]: when the whole workgroups per compute unit leave a last round (of `occupancy` resident
+ *                        workgroups) with fewer than k of them, that round is handed to the split workgroups too; 0 = never
+ *                        (default: measured at 1M x 252, no gain at any k)
  * and two fault-injection knobs for the tests of the error paths (0 = off, the default):
  *   OLMC_TUNE_FAULT_SHARD  k > 0: shard k - 1 of olmc_multi_gpu_european fails before it launches
  *   OLMC_TUNE_FORCE_NV     v > 0: reduction workspaces REPORT a capacity of v values per workgroup row, so a kernel
  *                          that reduces more than v values trips its device-side bound check (result NaN, nothing
  *                          written out of bounds, library usable afterwards) */
-enum { OLMC_TUNE_GRID_CAP = 2, OLMC_TUNE_QMC_BLOCK = 4, OLMC_TUNE_FAULT_SHARD = 5, OLMC_TUNE_FORCE_NV = 6, OLMC_TUNE_SPLIT_TAIL = 7, OLMC_TUNE_POLL = 8 };
+enum { OLMC_TUNE_GRID_CAP = 2, OLMC_TUNE_QMC_BLOCK = 4, OLMC_TUNE_FAULT_SHARD = 5, OLMC_TUNE_FORCE_NV = 6, OLMC_TUNE_SPLIT_TAIL = 7, OLMC_TUNE_POLL = 8, OLMC_TUNE_SPLIT_SAT = 9 };
 int olmc_tune(int knob, int value);
 /* The two behavioural knobs can also be switched off from the environment, read once by the first olmc_init:
  * OLMC_POLL=0 (as OLMC_TUNE_POLL = -1) and OLMC_SPLIT_TAIL=0 (as OLMC_TUNE_SPLIT_TAIL = -1). */

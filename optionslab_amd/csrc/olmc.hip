@@ -202,6 +202,8 @@ int g_grid_cap = 0;          // OLMC_TUNE_GRID_CAP: max workgroups per launch (0
 int g_qmc_block = 0;         // OLMC_TUNE_QMC_BLOCK: 0 = by size, 1 = always eight points per thread, -1 = never
 int g_poll = 0;              // OLMC_TUNE_POLL: 0 = blocking calls poll a host-mapped flag for completion (default), -1 = hipStreamSynchronize
 int g_split_tail = 0;        // OLMC_TUNE_SPLIT_TAIL: 0 = split workgroups for the remainder of a European launch (default), -1 = never
+int g_split_sat = 0;         // OLMC_TUNE_SPLIT_SAT: k > 0: a last round of fewer than k whole workgroups per CU is split too; 0 = never (default:
+                             // measured, no gain -- see european_launch_shape)
 int g_fault_shard = 0;       // OLMC_TUNE_FAULT_SHARD: k > 0 makes shard k - 1 of olmc_multi_gpu_european fail (tests of the error path)
 int g_force_nv = 0;          // OLMC_TUNE_FORCE_NV: > 0 makes workspaces REPORT room for this many values per row (test of the device guard)
 
@@ -220,23 +222,61 @@ int32_t grid_for(int64_t n_paths, int32_t n_steps = INT32_MAX) {
     return static_cast<int32_t>(std::min<int64_t>((n_paths + kBlock - 1) / kBlock, cap));
 }
 
+// Resident workgroups per compute unit of one kernel instantiation (register / LDS limited), asked of the runtime once.
+template <typename Kernel>
+int resident_workgroups(Kernel kernel) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> cache;
+    const void* key = reinterpret_cast<const void*>(kernel);
+    std::lock_guard<std::mutex> lock(mu);
+    for (const auto& e : cache)
+        if (e.first == key) return e.second;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, 0) != hipSuccess || nb < 1) {
+        (void)hipGetLastError();
+        nb = 1;
+    }
+    cache.emplace_back(key, nb);
+    return nb;
+}
+
 // Launch shape of european_path_kernel for pr.count paths: returns the grid and sets pr->split_from.  When one workgroup
-// per 256 paths covers the launch (no grid-striding) the first F = floor(whole workgroups / CUs) * CUs workgroups own 256
-// paths each and the remaining paths go to split workgroups of 64 paths (four waves x a quarter of the steps each; see
-// the kernel) -- unless the paths have fewer than four full fp32 groups (64 steps) to hand out.
-int32_t european_launch_shape(const DeviceCtx* c, PathRange* pr) {
+// per 256 paths covers the launch (no grid-striding) the first F workgroups own 256 paths each and the remaining paths go to
+// split workgroups of 64 paths (four waves x a quarter of the steps each; see the kernel) -- unless the paths have fewer than
+// four full fp32 groups (64 steps) to hand out.
+//
+// F = floor(W / C) C: every CU gets the same number of whole workgroups, the remainder is spread in quarter-length units.
+// Round 3 asked whether a THIN last round of whole workgroups (1M paths = 15 per CU = 7 + 7 + 1 at 7 resident per CU) should be
+// split too, on the theory that a lone wave per SIMD issues slowly.  It does not: exactly k C whole workgroups take
+// 9.4 + 6.03 k us for every k from 1 to 28 (tools/occupancy_probe.py, profiles/r03_occupancy_probe.jsonl) -- one wave per SIMD
+// already issues at the full rate (four interleaved Philox blocks are enough ILP), the SIMD serves its waves oldest-first
+// rather than in rounds (first workgroup of a 7-per-CU launch done after 9 us, last after 48: profiles/r03_phase_stamps.jsonl),
+// and OLMC_TUNE_SPLIT_SAT at 2 / 5 / 7 left the 1M x 252 kernel at 100.35 us +- 0.1 (profiles/r03_ab_kernels.txt).  The knob
+// stays for measurements; the default is off.
+int32_t european_launch_shape(const DeviceCtx* c, PathRange* pr, int occ) {
     pr->split_from = INT32_MAX;
     const int32_t grid = grid_for(pr->count, pr->n_steps);
     const int64_t wgs = (pr->count + kBlock - 1) / kBlock;
     if (g_split_tail < 0 || g_grid_cap != 0 || wgs != grid) return grid;           // tuned or grid-striding launches keep their shape
     if ((pr->n_steps >> 2) / kGroup < 4 || c->cus < 1) return grid;
-    const int64_t full = (pr->count / kBlock) / c->cus * c->cus;                    // whole 256-path workgroups, a multiple of the CU count
+    int64_t per_cu = (pr->count / kBlock) / c->cus;                                 // whole 256-path workgroups per CU
+    if (occ >= 1 && g_split_sat > 0) {
+        const int64_t r = per_cu % occ;
+        if (r > 0 && r < std::min(g_split_sat, occ)) per_cu -= r;
+    }
+    const int64_t full = per_cu * c->cus;
     const int64_t rest = pr->count - full * kBlock;
     if (rest == 0) return grid;
     const int64_t split = (rest + kWave - 1) / kWave;
     if (full + split > kMaxGrid) return grid;
     pr->split_from = static_cast<int32_t>(full);
     return static_cast<int32_t>(full + split);
+}
+
+// The kernel launch_european<NSETS, MODE> will pick for a launch that covers every path (the only shape that splits).
+template <int NSETS, int MODE>
+int european_occupancy(bool anti) {
+    return anti ? resident_workgroups(european_path_kernel<NSETS, true, MODE, false>) : resident_workgroups(european_path_kernel<NSETS, false, MODE, false>);
 }
 
 // Workspace of the fused grid reduction for a launch of `grid` workgroups x nv values.
@@ -387,35 +427,49 @@ Contract make_contract(const olmc_option& o, int32_t n_steps) {
     c.vol = vol;
     c.strike = o.K;
     c.sign = o.is_call ? 1.0 : -1.0;
-    c.scale = 0.0;
+    c.scale = 1.0;                                   // a base until group_contracts says otherwise
+    c.neg_sign_strike = -c.sign * o.K;
     return c;
 }
 
 // Orders k contracts so that those with bit-identical vol are contiguous, the first of each group being its
-// base (scale 0) and the others carrying scale = exp(a - a_base); fills `set` (padded to nsets with scale-1
-// copies of the last contract) and pos[i] = slot of contract i.
+// base (its bit in base_mask, scale 1) and the others carrying scale = exp(a - a_base); fills `set` (padded to nsets with
+// scale-1 copies of the last contract) and pos[i] = slot of contract i.  The kernel walks the two halves of the set as two
+// streams, each with its own "latest base" (european_payoffs_folded), so slot NSETS / 2 is ALWAYS a base: a group that
+// straddles the middle gets a second base there (one more pair of exponentials per path; the first-order Greeks set
+// {mid, S+, S-, r+, r-} + 3 pays it, the second-order set of 14 does not).
 template <int NSETS>
 void group_contracts(const olmc_option* opts, int32_t k, int32_t n_steps, ContractSet<NSETS>* set, int* pos) {
     Contract all[OLMC_MAX_BATCH];
     bool placed[OLMC_MAX_BATCH] = {};
     for (int i = 0; i < k; ++i) all[i] = make_contract(opts[i], n_steps);
     int slot = 0;
+    set->base_mask = 0;
+    set->pad = 0;
+    auto put = [&](int j, int base_slot) -> int {   // returns the slot of the base the NEXT member of the group should refer to
+        set->c[slot] = all[j];
+        if (base_slot < 0 || slot == NSETS / 2) {
+            set->c[slot].scale = 1.0;
+            set->base_mask |= 1u << slot;
+            base_slot = slot;
+        } else {
+            set->c[slot].scale = std::exp(all[j].a - set->c[base_slot].a);
+        }
+        pos[j] = slot++;
+        placed[j] = true;
+        return base_slot;
+    };
     for (int i = 0; i < k; ++i) {
         if (placed[i]) continue;
-        set->c[slot] = all[i];                       // base of a new group
-        pos[i] = slot++;
-        placed[i] = true;
+        int base = put(i, -1);                       // base of a new group
         for (int j = i + 1; j < k; ++j)
-            if (!placed[j] && std::memcmp(&all[j].vol, &all[i].vol, sizeof(double)) == 0 && std::isfinite(all[j].a - all[i].a)) {
-                set->c[slot] = all[j];
-                set->c[slot].scale = std::exp(all[j].a - all[i].a);
-                pos[j] = slot++;
-                placed[j] = true;
-            }
+            if (!placed[j] && std::memcmp(&all[j].vol, &all[i].vol, sizeof(double)) == 0 && std::isfinite(all[j].a - all[i].a))
+                base = put(j, base);
     }
-    for (; slot < NSETS; ++slot) {                   // padding: cheap non-base copies
+    for (; slot < NSETS; ++slot) {                   // padding: cheap non-base copies (a base of its own if it opens the second half)
         set->c[slot] = set->c[slot - 1];
         set->c[slot].scale = 1.0;
+        if (slot == NSETS / 2) set->base_mask |= 1u << slot;
     }
 }
 
@@ -516,9 +570,10 @@ int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32
                      int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic, double* d_out, double tail,
                      int* pos /* [k]: slot of contract i in d_out, may be NULL when k == 1 */) {
     PathRange pr = make_range(path_offset, n_local, n_steps, seed);
-    const int32_t grid = european_launch_shape(c, &pr);
     const bool anti = antithetic != 0;
     const int nsets = k == 1 ? 1 : (k <= 8 ? 8 : 16);
+    const int occ = nsets == 1 ? european_occupancy<1, kReduce>(anti) : (nsets == 8 ? european_occupancy<8, kReduce>(anti) : european_occupancy<16, kReduce>(anti));
+    const int32_t grid = european_launch_shape(c, &pr, occ);
     ReduceWs ws;
     int rc = make_ws(c, s, grid, 2 * nsets, d_out, tail, &ws);
     if (rc) return rc;
@@ -529,6 +584,7 @@ int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32
     if (nsets == 1) {
         ContractSet<1> cs;
         cs.c[0] = make_contract(opts[0], n_steps);
+        cs.base_mask = 1u; cs.pad = 0;
         if (pos) pos[0] = 0;
         launch_european<1, kReduce>(anti, grid, s, pr, cs, ws, nullptr, timed);
     } else if (nsets == 8) {
@@ -910,9 +966,10 @@ extern "C" int olmc_european_terminal(double S, double T, double r, double sigma
     rc = bulk_reserve(c, bytes);
     if (rc) return rc;
     PathRange pr = make_range(0, n_paths, n_steps, seed);
-    const int32_t grid = european_launch_shape(c, &pr);
+    const int32_t grid = european_launch_shape(c, &pr, european_occupancy<1, kTerminal>(antithetic != 0));
     ContractSet<1> cs;
     cs.c[0] = make_contract(make_option(S, 0.0, T, r, sigma, q, 1), n_steps);
+    cs.base_mask = 1u; cs.pad = 0;
     ReduceWs ws{};   // unused in kTerminal mode
     launch_european<1, kTerminal>(antithetic != 0, grid, c->stream, pr, cs, ws, static_cast<double*>(c->d_bulk));
     HIP_TRY(hipGetLastError());
@@ -947,9 +1004,10 @@ extern "C" int olmc_european_cv_shard(double S, double K, double T, double r, do
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(c->mu);
     PathRange pr = make_range(path_offset, n_local, n_steps, seed);
-    const int32_t grid = european_launch_shape(c, &pr);
+    const int32_t grid = european_launch_shape(c, &pr, european_occupancy<1, kControlVariate>(antithetic != 0));
     ContractSet<1> cs;
     cs.c[0] = make_contract(make_option(S, K, T, r, sigma, q, is_call), n_steps);
+    cs.base_mask = 1u; cs.pad = 0;
     ReduceWs ws;
     rc = make_ws(c, c->stream, grid, 5, c->d_result, -1.0, &ws);
     if (rc) return rc;
@@ -1516,7 +1574,8 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
     ct.a = mirror ? std::log(S) + (r - q - 0.5 * sigma * sigma) * T : std::log(S) + drift * dims;
     ct.strike = K;
     ct.sign = is_call ? 1.0 : -1.0;
-    ct.scale = 0.0;
+    ct.scale = 1.0;
+    ct.neg_sign_strike = -ct.sign * K;
     QmcRange qr;
     qr.first = static_cast<uint64_t>(point_offset);
     qr.count = n_paths;
@@ -1824,6 +1883,50 @@ extern "C" int olmc_clock_probe(int64_t n_paths, int32_t n_steps, uint64_t seed,
     return OLMC_OK;
 }
 
+// Where a launch of the headline kernel spends its time (see european_stamp_kernel): one blocking launch of n_paths x n_steps in
+// the production launch shape; stamps_host receives 5 words per workgroup (4 stamps in 100 MHz ticks + where it ran) + the final stamp, info3 = {workgroups,
+// split_from (or workgroups when nothing is split), the dispatch's own duration in nanoseconds (begin / end timestamps)}.
+extern "C" int olmc_phase_stamps(int64_t n_paths, int32_t n_steps, uint64_t seed, uint64_t* stamps_host, int64_t capacity, int64_t* info3) {
+    if (!stamps_host || !info3) return fail(OLMC_ERR_ARG, "null pointer");
+    int rc = check_paths(0, n_paths, n_steps);
+    if (rc) return rc;
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    PathRange pr = make_range(0, n_paths, n_steps, seed);
+    const int32_t grid = european_launch_shape(c, &pr, european_occupancy<1, kReduce>(true));
+    if (static_cast<int64_t>(grid) * kBlock < n_paths) return fail(OLMC_ERR_ARG, "grid-striding launches are not instrumented");
+    const int64_t words = kStampWords * static_cast<int64_t>(grid) + 1;
+    if (capacity < words) return fail(OLMC_ERR_ARG, "stamp buffer too small: need 5 * workgroups + 1 words");
+    rc = bulk_reserve(c, sizeof(uint64_t) * static_cast<size_t>(words));
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_bulk, 0, sizeof(uint64_t) * static_cast<size_t>(words), c->stream));
+    ContractSet<1> cs;
+    cs.c[0] = make_contract(make_option(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, 1), n_steps);
+    cs.base_mask = 1u; cs.pad = 0;
+    ReduceWs ws;
+    rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
+    if (rc) return rc;
+    EventPair ep{};
+    rc = prof_acquire(c, &ep);
+    if (rc) return rc;
+    hipExtLaunchKernelGGL(european_stamp_kernel, dim3(grid), dim3(kBlock), 0, c->stream, ep.start, ep.stop, 0, pr, cs, ws, static_cast<uint64_t*>(c->d_bulk));
+    rc = after_launch(c, c->stream);
+    if (rc) return rc;
+    rc = sync_or_recover(c, c->stream);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(stamps_host, c->d_bulk, sizeof(uint64_t) * static_cast<size_t>(words), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ep.start, ep.stop));
+    c->ev_free.push_back(ep);
+    info3[0] = grid;
+    info3[1] = pr.split_from == INT32_MAX ? grid : pr.split_from;
+    info3[2] = static_cast<int64_t>(static_cast<double>(ms) * 1e6);
+    return OLMC_OK;
+}
+
 // Issue cost of one instruction class on this device (see the probe kernels): nanoseconds one SIMD needs per wave64
 // instruction of the class with `waves_per_simd` waves resident.
 extern "C" int olmc_issue_probe(int op, int waves_per_simd, double* ns_per_instr) {
@@ -1866,6 +1969,7 @@ extern "C" int olmc_tune(int knob, int value) {
     if (knob == OLMC_TUNE_QMC_BLOCK && value >= -1 && value <= 1) { g_qmc_block = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_POLL && value >= -1 && value <= 0) { g_poll = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_SPLIT_TAIL && value >= -1 && value <= 0) { g_split_tail = value; return OLMC_OK; }
+    if (knob == OLMC_TUNE_SPLIT_SAT && value >= 0 && value <= 16) { g_split_sat = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_FAULT_SHARD && value >= 0 && value <= kMaxDevices) { g_fault_shard = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_FORCE_NV && value >= 0 && value <= kMaxNV) { g_force_nv = value; return OLMC_OK; }
     return fail(OLMC_ERR_ARG, "unknown tuning knob or value");

@@ -361,27 +361,63 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws, Epilog
     signal_done(ws);
 }
 
-// Wave-wide sums of P (a power of two) per-lane values in P-1 + (6 - log2 P) shuffle-adds instead of
+// Wave-wide sums of P (a power of two) per-lane values in P-1 + (6 - log2 P) exchange-adds instead of
 // 6 P: at every halving step a lane trades half of its values with the lane `off` away and keeps the
 // sums of the other half, so after log2 P steps each lane holds ONE value's sum over a lane subset;
 // the remaining steps finish that single value.  On return v[0] of every lane holds the total of value
 // index  lane >> (6 - log2 P).  Fixed exchange pattern => deterministic.
+//
+// The two widest exchanges (lane ^ 32, lane ^ 16) are gfx950's v_permlane32_swap / v_permlane16_swap: ONE VALU
+// instruction per dword that swaps the upper half-wave (odd rows of 16 lanes) of register A with the lower half-wave
+// (even rows) of register B -- with A = v[k], B = v[k + H] that IS the trade of this step, so a kept value costs two swaps
+// and an add where the generic form (select what to send, select what to keep, two ds_bpermute through the LDS crossbar,
+// add) cost ten instructions and an LDS round trip.  Same operands per addition as the generic form (a + b vs b + a in the
+// upper lanes), hence the same bits.  Three quarters of the exchanges of a 32-value reduction happen at these two levels.
+__device__ __forceinline__ uint32_t dbl_lo(double x) { return static_cast<uint32_t>(__double_as_longlong(x)); }
+__device__ __forceinline__ uint32_t dbl_hi(double x) { return static_cast<uint32_t>(static_cast<uint64_t>(__double_as_longlong(x)) >> 32); }
+__device__ __forceinline__ double dbl_of(uint32_t lo, uint32_t hi) {
+    return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | lo));
+}
+
+// a' + b' after swapping the upper (OFF = 32: lanes 32..63; OFF = 16: rows 1 and 3) part of a with the lower part of b:
+// lanes with bit OFF clear get a(own) + a(partner), lanes with it set get b(partner) + b(own).
+template <int OFF>
+__device__ __forceinline__ double swap_add(double a, double b) {
+    static_assert(OFF == 32 || OFF == 16, "permlane swaps exist for half-waves and rows");
+    if constexpr (OFF == 32) {
+        const auto lo = __builtin_amdgcn_permlane32_swap(dbl_lo(a), dbl_lo(b), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(dbl_hi(a), dbl_hi(b), false, false);
+        return dbl_of(lo[0], hi[0]) + dbl_of(lo[1], hi[1]);
+    } else {
+        const auto lo = __builtin_amdgcn_permlane16_swap(dbl_lo(a), dbl_lo(b), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(dbl_hi(a), dbl_hi(b), false, false);
+        return dbl_of(lo[0], hi[0]) + dbl_of(lo[1], hi[1]);
+    }
+}
+
 template <int P, int OFF = kWave / 2>
 __device__ __forceinline__ void wave_transpose_reduce(double (&v)[P]) {
     if constexpr (P > 1) {
         constexpr int H = P / 2;
-        const bool upper = (threadIdx.x & OFF) != 0;
         double kept[H];
+        if constexpr (OFF >= 16) {
 #pragma unroll
-        for (int k = 0; k < H; ++k) {
-            const double send = upper ? v[k] : v[k + H];
-            const double mine = upper ? v[k + H] : v[k];
-            kept[k] = mine + __shfl_xor(send, OFF, kWave);
+            for (int k = 0; k < H; ++k) kept[k] = swap_add<OFF>(v[k], v[k + H]);
+        } else {
+            const bool upper = (threadIdx.x & OFF) != 0;
+#pragma unroll
+            for (int k = 0; k < H; ++k) {
+                const double send = upper ? v[k] : v[k + H];
+                const double mine = upper ? v[k + H] : v[k];
+                kept[k] = mine + __shfl_xor(send, OFF, kWave);
+            }
         }
         wave_transpose_reduce<H, OFF / 2>(kept);
         v[0] = kept[0];
     } else if constexpr (OFF >= 1) {
-        double one[1] = {v[0] + __shfl_xor(v[0], OFF, kWave)};
+        double one[1];
+        if constexpr (OFF >= 16) one[0] = swap_add<OFF>(v[0], v[0]);        // own + partner in every lane
+        else one[0] = v[0] + __shfl_xor(v[0], OFF, kWave);
         wave_transpose_reduce<1, OFF / 2>(one);
         v[0] = one[0];
     }
@@ -392,17 +428,19 @@ constexpr int log2_of(int p) { return p <= 1 ? 0 : 1 + log2_of(p / 2); }
 
 // One-thread-per-path kernels: fold NV per-thread values over the workgroup (fixed order,
 // LDS-staged across the four waves), then into the grid reduction.
-template <int NV, typename Epilogue = NoEpilogue>
-__device__ __forceinline__ void block_then_grid_reduce(const double (&v)[NV], const ReduceWs& ws, Epilogue done = Epilogue()) {
+//
+// `w` holds the values after the FIRST `DONE` halving steps of wave_transpose_reduce<P> (DONE = 0: the P padded values
+// themselves; DONE = 1: the P / 2 sums the lane ^ 32 exchange leaves -- a producer that makes its values two at a time can
+// fold that step into its own loop and never hold all P of them, see european_payoffs_folded).
+template <int NV, int DONE = 0, typename Epilogue = NoEpilogue>
+__device__ __forceinline__ void block_then_grid_reduce_from(double (&w)[pow2_ceil(NV) >> DONE], const ReduceWs& ws, Epilogue done = Epilogue()) {
     constexpr int P = pow2_ceil(NV);
     constexpr int SHIFT = 6 - log2_of(P);           // lanes sharing one value after the transpose-reduce: 2^SHIFT
+    static_assert(DONE == 0 || (DONE == 1 && P >= 2), "only the widest exchange can be folded into the producer");
     __shared__ double stage[kWavesPerBlock][P];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
-    double w[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) w[i] = i < NV ? v[i] : 0.0;
-    wave_transpose_reduce<P>(w);
+    wave_transpose_reduce<(P >> DONE), ((kWave / 2) >> DONE)>(w);
     if ((lane & ((1 << SHIFT) - 1)) == 0) stage[wave][lane >> SHIFT] = w[0];
     __syncthreads();
     if (wave != 0) return;
@@ -413,6 +451,15 @@ __device__ __forceinline__ void block_then_grid_reduce(const double (&v)[NV], co
         for (int k = 1; k < kWavesPerBlock; ++k) s += stage[k][threadIdx.x];
     }
     grid_reduce<NV, Epilogue>(s, ws, done);
+}
+
+template <int NV, typename Epilogue = NoEpilogue>
+__device__ __forceinline__ void block_then_grid_reduce(const double (&v)[NV], const ReduceWs& ws, Epilogue done = Epilogue()) {
+    constexpr int P = pow2_ceil(NV);
+    double w[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) w[i] = i < NV ? v[i] : 0.0;
+    block_then_grid_reduce_from<NV, 0, Epilogue>(w, ws, done);
 }
 
 // 2^y in fp64, |error| <= 1.5 ulp (the library exp() is ~25 instructions + its argument scaling; this is 15 and takes
@@ -447,14 +494,18 @@ struct Contract {
     double vol;      // sigma * sqrt(dt)
     double strike;
     double sign;     // +1 call, -1 put : payoff = max(sign * (S_T - K), 0)
-    double scale;    // 0: evaluates its own exp(a +- vol z).  > 0: shares vol with the nearest base contract
-                     // before it in the set and S_T = scale * S_T(base), scale = exp(a - a_base): the S- and
-                     // r-bumped contracts of a Greeks batch cost a multiply instead of two fp64 exps
+    double scale;    // a BASE contract (ContractSet::base_mask) evaluates its own exp(a +- vol z) and carries scale = 1.  Any other
+                     // shares vol with the nearest base before it in its half of the set and S_T = scale * S_T(base), scale =
+                     // exp(a - a_base): the S- and r-bumped contracts of a Greeks batch cost a multiply instead of two fp64 exps
+    double neg_sign_strike;   // -sign * K: payoff = max(fma(sign, S_T, -sign K), 0) -- the same bits as sign * (S_T - K) for sign = +-1
+                              // (one rounding of +-(S_T - K) either way), one instruction fewer per sample
 };
 
 template <int NSETS>
 struct ContractSet {
     Contract c[NSETS];
+    uint32_t base_mask;   // bit s set <=> contract s is a base: it evaluates its own exponentials.  An integer test on the scalar
+    uint32_t pad;         // unit (s_bitcmp) where round 2 compared Contract::scale with 0.0 on the vector unit, once per contract
 };
 
 struct PathRange {
@@ -500,12 +551,19 @@ template <int NSETS, bool ANTI, int MODE>
 __device__ __forceinline__ void european_payoffs(const ContractSet<NSETS>& cs, double zsum, bool live, int64_t i, int64_t count,
                                                  double* __restrict__ terminal, double (&acc)[(MODE == kControlVariate) ? 5 : 2 * NSETS]) {
     constexpr int NC = (MODE == kControlVariate) ? 5 : 2;
+    // kReduce: a dead lane (the ragged end of the last workgroup) carries a NaN normal sum: every S_T of the lane is NaN and
+    // fmax(NaN, 0) = 0 (IEEE maxnum), so its payoffs and their squares are exact zeros without a select per sample (64
+    // v_cndmask for 16 contracts).  Contract parameters that are themselves NaN are answered on the host (olmc.hip, poisoned()).
+    if constexpr (MODE == kReduce) zsum = live ? zsum : __builtin_nan("");
     double base_st[2] = {0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < NSETS; ++s) {
         const Contract c = cs.c[s];
-        const bool is_base = NSETS == 1 || c.scale == 0.0;          // wave-uniform
+        const bool is_base = NSETS == 1 || ((cs.base_mask >> s) & 1u) != 0u;          // wave-uniform, on the scalar unit
         if (is_base) {
+            // a real, wave-uniform branch around the two exponentials (the empty volatile asm keeps the block from being
+            // speculated into selects): the 14 contracts of second-order Greeks have 4 distinct vols = 8 exps per path, not 28
+            if constexpr (NSETS > 1) asm volatile("");
             const double dz = c.vol * zsum;
             // the library exp() (the reference's np.exp); the 15-instruction exp2_f64 here was measured at -0.4 % (1 contract) ... -1.3 %
             // (8 contracts) and not adopted: not worth moving the terminal prices 2-3 ulp away from libm
@@ -514,15 +572,58 @@ __device__ __forceinline__ void european_payoffs(const ContractSet<NSETS>& cs, d
         }
 #pragma unroll
         for (int leg = 0; leg < (ANTI ? 2 : 1); ++leg) {
-            const double st = is_base ? base_st[leg] : c.scale * base_st[leg];
+            const double st = NSETS == 1 ? base_st[leg] : c.scale * base_st[leg];      // scale = 1 exactly for a base
             if constexpr (MODE == kTerminal) {
                 if (live) terminal[leg * count + i] = st;
             } else {
                 const double x = fmax(c.sign * (st - c.strike), 0.0);
                 double (&slot)[NC] = *reinterpret_cast<double (*)[NC]>(&acc[(MODE == kControlVariate) ? 0 : 2 * s]);
-                add_sample<MODE>(slot, live ? x : 0.0, live ? st : 0.0);
+                if constexpr (MODE == kReduce) add_sample<MODE>(slot, x, st);
+                else add_sample<MODE>(slot, live ? x : 0.0, live ? st : 0.0);
             }
         }
+    }
+}
+
+// The two sums (x_u + x_d, x_u^2 + x_d^2) of ONE contract for this lane's path.  `base_st` is the pair of terminal prices of the
+// latest base contract of the stream the caller walks (a base refreshes it, the others scale it).
+template <bool ANTI>
+__device__ __forceinline__ void contract_sums(const Contract& c, bool is_base, double zsum, double (&base_st)[2], double& sum, double& sumsq) {
+    if (is_base) {                                   // wave-uniform scalar branch, kept real (see european_payoffs)
+        asm volatile("");
+        const double dz = c.vol * zsum;
+        base_st[0] = exp(c.a + dz);
+        if constexpr (ANTI) base_st[1] = exp(c.a - dz);
+    }
+    // scale = 1 exactly for a base: one multiply for every contract, no select between "own" and "scaled" prices
+    const double xu = fmax(__builtin_fma(c.sign, c.scale * base_st[0], c.neg_sign_strike), 0.0);
+    sum = xu;                                        // the additions of add_sample<kReduce> on accumulators born at zero, term by term
+    sumsq = xu * xu;
+    if constexpr (ANTI) {
+        const double xd = fmax(__builtin_fma(c.sign, c.scale * base_st[1], c.neg_sign_strike), 0.0);
+        sum += xd;
+        sumsq += xd * xd;
+    }
+}
+
+// kReduce with 8 / 16 contracts on a launch that covers every path (one path per thread): the 2 NSETS per-lane sums are made
+// two CONTRACTS at a time -- s and s + NSETS/2, i.e. values k and k + P/2 of the wave reduction -- and traded across the
+// half-waves at once (swap_add<32>, the first step of wave_transpose_reduce), so a lane never holds more than NSETS sums:
+// 32 instead of 64 VGPRs of accumulators for second-order Greeks, and the kernel keeps the step loop's own occupancy
+// (round 2: 84 VGPRs, 5 waves per SIMD; the loop alone needs 66 = 7 waves).  The two half-sets are walked as two streams,
+// each with its own latest base: the host lays the set out so that slot NSETS/2 is a base (group_contracts).
+// `zsum` is NaN in dead lanes (all their payoffs are then exact zeros, see european_payoffs).
+template <int NSETS, bool ANTI>
+__device__ __forceinline__ void european_payoffs_folded(const ContractSet<NSETS>& cs, double zsum, double (&kept)[NSETS]) {
+    constexpr int H = NSETS / 2;
+    double base_lo[2] = {0.0, 0.0}, base_hi[2] = {0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < H; ++s) {
+        double a0, a1, b0, b1;
+        contract_sums<ANTI>(cs.c[s], ((cs.base_mask >> s) & 1u) != 0u, zsum, base_lo, a0, a1);
+        contract_sums<ANTI>(cs.c[s + H], ((cs.base_mask >> (s + H)) & 1u) != 0u, zsum, base_hi, b0, b1);
+        kept[2 * s] = swap_add<32>(a0, b0);
+        kept[2 * s + 1] = swap_add<32>(a1, b1);
     }
 }
 
@@ -530,8 +631,8 @@ template <int NSETS, bool ANTI, int MODE, bool STRIDED>
 __global__ __launch_bounds__(kBlock) void european_path_kernel(PathRange pr, ContractSet<NSETS> cs, ReduceWs ws,
                                                                double* __restrict__ terminal) {
     constexpr int NV = (MODE == kControlVariate) ? 5 : 2 * NSETS;
-    double acc[NV];
     if constexpr (STRIDED) {
+        double acc[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) acc[k] = 0.0;
         const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
@@ -540,6 +641,7 @@ __global__ __launch_bounds__(kBlock) void european_path_kernel(PathRange pr, Con
             const double zsum = path_normal_sum(static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32), pr.n_steps, pr.key0, pr.key1);
             european_payoffs<NSETS, ANTI, MODE>(cs, zsum, true, i, pr.count, terminal, acc);
         }
+        if constexpr (MODE != kTerminal) block_then_grid_reduce<NV>(acc, ws);
     } else {
         __shared__ double quarter_sum[kWavesPerBlock][kWave];
         // readfirstlane: the wave index is uniform, and the compiler must KNOW it -- the Philox block counter derives from it in
@@ -558,12 +660,21 @@ __global__ __launch_bounds__(kBlock) void european_path_kernel(PathRange pr, Con
             zsum = ((quarter_sum[0][lane] + quarter_sum[1][lane]) + quarter_sum[2][lane]) + quarter_sum[3][lane];
         }
         zsum *= kZScale;
+        const bool payer = !split || wave == 0;         // waves 1..3 of a split workgroup carry no path through the payoffs (wave-uniform)
+        if constexpr (MODE == kReduce && NSETS > 1) {
+            double kept[NSETS];                         // born after the step loop, and only NSETS of them (folded first exchange)
 #pragma unroll
-        for (int k = 0; k < NV; ++k) acc[k] = 0.0;      // born after the step loop
-        // waves 1..3 of a split workgroup carry no path through the payoffs (wave-uniform branch)
-        if (!split || wave == 0) european_payoffs<NSETS, ANTI, MODE>(cs, zsum, i < pr.count, i, pr.count, terminal, acc);
+            for (int k = 0; k < NSETS; ++k) kept[k] = 0.0;
+            if (payer) european_payoffs_folded<NSETS, ANTI>(cs, i < pr.count ? zsum : __builtin_nan(""), kept);
+            block_then_grid_reduce_from<NV, 1>(kept, ws);
+        } else {
+            double acc[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) acc[k] = 0.0;      // born after the step loop
+            if (payer) european_payoffs<NSETS, ANTI, MODE>(cs, zsum, i < pr.count, i, pr.count, terminal, acc);
+            if constexpr (MODE != kTerminal) block_then_grid_reduce<NV>(acc, ws);
+        }
     }
-    if constexpr (MODE != kTerminal) block_then_grid_reduce<NV>(acc, ws);
 }
 
 // Many INDEPENDENT contracts in one launch (MonteCarloPricerUni.price_batch,
@@ -1795,6 +1906,61 @@ __global__ __launch_bounds__(kBlock) void clock_probe_kernel(PathRange pr, uint6
     if (threadIdx.x == 0) {
         stamps[2 * static_cast<size_t>(blockIdx.x)] = t1 - t0;
         stamps[2 * static_cast<size_t>(blockIdx.x) + 1] = r1 - r0;
+    }
+}
+
+// Measurement tap (tools/phase_stamps.py; never on a pricing path): WHERE a launch of the headline kernel spends its time.
+// The body is european_path_kernel<1, true, kReduce, false> call for call (same device functions, same launch shape, same
+// reduction); wave 0 of every workgroup additionally leaves four s_memrealtime stamps (a constant 100 MHz counter shared by
+// the whole device): [0] entry, [1] step loop done, [2] payoffs + workgroup sums done (about to enter the grid reduction),
+// [3] back from the grid reduction (ticket taken; for the workgroup that took the LAST ticket of the launch: totals written),
+// and [4] where it ran: HW_REG_HW_ID in the low word (cu_id bits 11:8, sh_id 12, se_id 15:13), HW_REG_XCC_ID in the high word.
+// The wave that writes the totals also stamps slot kStampWords * gridDim.x: the end of the launch's useful work.
+constexpr int kStampWords = 5;
+struct StampEpilogue {
+    uint64_t* final_stamp;
+    __device__ __forceinline__ void operator()(double) const {
+        if (threadIdx.x == 0) *final_stamp = __builtin_amdgcn_s_memrealtime();
+    }
+};
+
+__global__ __launch_bounds__(kBlock) void european_stamp_kernel(PathRange pr, ContractSet<1> cs, ReduceWs ws, uint64_t* __restrict__ stamps) {
+    __shared__ double quarter_sum[kWavesPerBlock][kWave];
+    const uint64_t t_entry = __builtin_amdgcn_s_memrealtime();
+    const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / kWave), lane = threadIdx.x & (kWave - 1);
+    const bool split = static_cast<int32_t>(blockIdx.x) >= pr.split_from;
+    const int64_t i = split ? static_cast<int64_t>(pr.split_from) * kBlock + (static_cast<int64_t>(blockIdx.x) - pr.split_from) * kWave + lane
+                            : static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const uint64_t g = pr.first + static_cast<uint64_t>(i);
+    double zsum = path_normal_quarters(static_cast<uint32_t>(g), static_cast<uint32_t>(g >> 32), pr.n_steps, split ? wave : 0,
+                                       split ? wave + 1 : 4, pr.key0, pr.key1);
+    if (split) {
+        quarter_sum[wave][lane] = zsum;
+        __syncthreads();
+        zsum = ((quarter_sum[0][lane] + quarter_sum[1][lane]) + quarter_sum[2][lane]) + quarter_sum[3][lane];
+    }
+    zsum *= kZScale;
+    asm volatile("s_nop 0" ::"v"(zsum));                 // the stamp below must follow the loop's last result
+    const uint64_t t_loop = __builtin_amdgcn_s_memrealtime();
+    double acc[2] = {0.0, 0.0};
+    if (!split || wave == 0) european_payoffs<1, true, kReduce>(cs, zsum, i < pr.count, i, pr.count, nullptr, acc);
+    constexpr int P = 2;
+    __shared__ double stage[kWavesPerBlock][P];
+    double w[P] = {acc[0], acc[1]};
+    wave_transpose_reduce<P>(w);
+    if ((lane & 31) == 0) stage[wave][lane >> 5] = w[0];
+    __syncthreads();
+    if (wave != 0) return;
+    double v = 0.0;
+    if (threadIdx.x < 2) v = ((stage[0][threadIdx.x] + stage[1][threadIdx.x]) + stage[2][threadIdx.x]) + stage[3][threadIdx.x];
+    asm volatile("s_nop 0" ::"v"(v));
+    const uint64_t t_sums = __builtin_amdgcn_s_memrealtime();
+    grid_reduce<2, StampEpilogue>(v, ws, StampEpilogue{stamps + kStampWords * static_cast<size_t>(gridDim.x)});
+    if (threadIdx.x == 0) {
+        uint64_t* mine = stamps + kStampWords * static_cast<size_t>(blockIdx.x);
+        const uint32_t hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        mine[0] = t_entry; mine[1] = t_loop; mine[2] = t_sums; mine[3] = __builtin_amdgcn_s_memrealtime();
+        mine[4] = (static_cast<uint64_t>(xcc_id) << 32) | hw_id;
     }
 }
 

@@ -70,7 +70,9 @@ for r in range(a.rounds):
         env = dict(os.environ, OLMC_LIBRARY=os.path.abspath(path))
         if tune:
             env["OLMC_AB_TUNE"] = tune
-        out = subprocess.run([sys.executable, "-c", CHILD, str(a.n), str(a.m), a.case], env=env, capture_output=True, text=True, check=True)
+        out = subprocess.run([sys.executable, "-c", CHILD, str(a.n), str(a.m), a.case], env=env, capture_output=True, text=True)
+        if out.returncode != 0:
+            raise SystemExit(f"{l}: child failed (rc {out.returncode}): {out.stderr[-600:]}")
         d = json.loads(out.stdout.strip().splitlines()[-1])
         res[l].append(d["us"])
         wall[l].append(d["wall_us"])

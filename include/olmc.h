@@ -304,6 +304,17 @@ int olmc_european_qmc_cv(double S, double K, double T, double r, double sigma, d
                          int64_t point_offset, int64_t n_paths, int32_t dims,
                          const uint32_t* sv, const uint32_t* shift, int32_t bits, olmc_cv_moments* out);
 
+/* k <= OLMC_MAX_BATCH contracts on the SAME Sobol points in ONE launch: the points, their uniforms and the inverse normals are
+ * formed once, each contract adds its exponential (contracts whose sigma sqrt(T / dims) agrees bit for bit share it) and its
+ * payoff.  out[i] = what olmc_european_qmc answers for opts[i] alone, to the last few ulp.  And the finite-difference Greeks of
+ * compute_greeks_unified (unified_greeks.py:280-358) over it -- bumps, evaluation order and out9 / evals exactly as
+ * olmc_european_greeks_fd -- for a MCMethod.QMC pricer: one launch where the literal form makes 8 or 14. */
+int olmc_european_qmc_batch(const olmc_option* opts, int32_t k, int64_t point_offset, int64_t n_paths, int32_t dims,
+                            const uint32_t* sv, const uint32_t* shift, int32_t bits, olmc_stats* out /* [k] */);
+int olmc_european_qmc_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
+                                int second_order, double* out9, olmc_stats* evals /* [14] or NULL */);
+
 /* antithetic != 0: simulate_gbm_qmc_antithetic (gbm_qmc.py:49-76), 2 * n_paths values [pos | neg]. */
 int olmc_european_qmc_terminal(double S, double T, double r, double sigma, double q,
                                int64_t point_offset, int64_t n_paths, int32_t dims,

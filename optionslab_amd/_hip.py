@@ -70,6 +70,8 @@ PROTOTYPES = {
     "olmc_combine_cv": (_I, [C.POINTER(CvMoments), _I32, _D, _D, _D, _D, C.POINTER(CvMoments)]),
     "olmc_european_qmc": (_I, _SIX + [_I, _I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, C.POINTER(Stats)]),
     "olmc_european_qmc_cv": (_I, _SIX + [_I, _I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, C.POINTER(CvMoments)]),
+    "olmc_european_qmc_batch": (_I, [C.POINTER(Option), _I32, _I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, C.POINTER(Stats)]),
+    "olmc_european_qmc_greeks_fd": (_I, _SIX + [_I, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, _I, C.POINTER(_D), C.POINTER(Stats)]),
     "olmc_european_qmc_terminal": (_I, [_D] * 5 + [_I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, _I, C.POINTER(_D)]),
     "olmc_asian": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_barrier": (_I, _SIX + [_I, _D, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
@@ -359,6 +361,30 @@ def european_qmc_cv(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv: np.nd
     _check(lib().olmc_european_qmc_cv(S, K, T, r, sigma, q, int(is_call), int(point_offset), int(n_paths), int(sv.shape[0]), psv, psh,
                                       int(sv.shape[1]), C.byref(out)))
     return out
+
+
+def european_qmc_batch(options: Sequence[Tuple[float, float, float, float, float, float, bool]], n_paths: int, sv: np.ndarray, shift: np.ndarray,
+                       point_offset: int = 0) -> List[Stats]:
+    """k <= 16 contracts (S, K, T, r, sigma, q, is_call) on the same Sobol points, one launch (olmc_european_qmc_batch)."""
+    sv, psv = _u32(sv)
+    shift, psh = _u32(shift)
+    k = len(options)
+    arr = (Option * k)(*[Option(S, K, T, r, v, q, int(c), 0) for (S, K, T, r, v, q, c) in options])
+    out = (Stats * k)()
+    _check(lib().olmc_european_qmc_batch(arr, k, int(point_offset), int(n_paths), int(sv.shape[0]), psv, psh, int(sv.shape[1]), out))
+    return list(out)
+
+
+def european_qmc_greeks_fd(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv: np.ndarray, shift: np.ndarray, second_order: bool,
+                           want_evals: bool = True) -> Tuple[List[float], List[Stats]]:
+    """As european_greeks_fd, on the Sobol points of a MCMethod.QMC pricer: the 8 / 14 bumped contracts in ONE launch."""
+    sv, psv = _u32(sv)
+    shift, psh = _u32(shift)
+    out9 = (C.c_double * 9)()
+    evals = (Stats * 14)() if want_evals else None
+    _check(lib().olmc_european_qmc_greeks_fd(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(sv.shape[0]), psv, psh, int(sv.shape[1]),
+                                             int(second_order), out9, evals))
+    return list(out9), (list(evals) if want_evals else [])
 
 
 def european_qmc_terminal(S, T, r, sigma, q, n_paths: int, sv: np.ndarray, shift: np.ndarray,

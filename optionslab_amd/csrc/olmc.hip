@@ -902,53 +902,69 @@ extern "C" int olmc_european_multi(const olmc_option* opts, const uint32_t* tags
 }
 
 // ================================================== finite-difference Greeks ====
+namespace {
+// The evaluations of compute_greeks_unified (unified_greeks.py:274-277, 295-358) in the reference's get_price() call order, and
+// the finite differences over their prices.  Shared by the pseudo-random and the Sobol form: only the pricing of the set differs.
+struct GreeksSet {
+    olmc_option o[OLMC_MAX_BATCH];
+    int k = 0;
+    double h_S, h_v, h_r, h_T;
+    bool has_T, second;
+    int i_mid, i_su, i_sd, i_vu, i_vd, i_td, i_ru, i_rd, i_uu = -1, i_ud = -1, i_du = -1, i_dd = -1, i_ut = -1, i_dt = -1;
+
+    GreeksSet(double S, double K, double T, double r, double sigma, double q, int is_call, int second_order) {
+        h_S = std::max(1e-4, 0.01 * S);                             // :274-277
+        h_v = std::max(1e-4, 0.01);
+        h_r = 1e-4;
+        h_T = 1 / 365.0;
+        has_T = T > h_T;                                            // :310
+        second = second_order != 0;
+        auto add = [&](double S_, double T_, double r_, double v_) { o[k] = make_option(S_, K, T_, r_, v_, q, is_call); return k++; };
+        i_mid = add(S, T, r, sigma);
+        i_su = add(S + h_S, T, r, sigma); i_sd = add(S - h_S, T, r, sigma);
+        i_vu = add(S, T, r, sigma + h_v); i_vd = add(S, T, r, sigma - h_v);
+        i_td = has_T ? add(S, T - h_T, r, sigma) : -1;
+        i_ru = add(S, T, r + h_r, sigma); i_rd = add(S, T, r - h_r, sigma);
+        if (second) {
+            i_uu = add(S + h_S, T, r, sigma + h_v); i_ud = add(S + h_S, T, r, sigma - h_v);
+            i_du = add(S - h_S, T, r, sigma + h_v); i_dd = add(S - h_S, T, r, sigma - h_v);
+            if (has_T) { i_ut = add(S + h_S, T - h_T, r, sigma); i_dt = add(S - h_S, T - h_T, r, sigma); }
+        }
+    }
+
+    void finish(const olmc_stats* st, double T, double* out9, olmc_stats* evals) const {
+        auto P = [&](int i) { return st[i].price; };
+        const double mid = P(i_mid);
+        const double delta = (P(i_su) - P(i_sd)) / (2 * h_S);                       // :301
+        out9[0] = mid;
+        out9[1] = delta;
+        out9[2] = (P(i_su) - 2 * mid + P(i_sd)) / (h_S * h_S);                       // :302
+        out9[3] = (P(i_vu) - P(i_vd)) / (2 * h_v);                                   // :307
+        out9[4] = has_T ? (P(i_td) - mid) / h_T : -mid / std::max(T, 1e-6);          // :310-314
+        out9[5] = (P(i_ru) - P(i_rd)) / (2 * h_r);                                   // :319
+        if (second) {
+            out9[6] = (P(i_uu) - P(i_ud) - P(i_du) + P(i_dd)) / (4 * h_S * h_v);    // :343-345
+            out9[7] = has_T ? ((P(i_ut) - P(i_dt)) / (2 * h_S) - delta) / h_T : 0.0; // :348-354
+            out9[8] = (P(i_vu) - 2 * mid + P(i_vd)) / (h_v * h_v);                   // :357
+        }
+        if (evals) {
+            for (int i = 0; i < k; ++i) evals[i] = st[i];
+            for (int i = k; i < 14; ++i) std::memset(&evals[i], 0, sizeof(olmc_stats));
+        }
+    }
+};
+}  // namespace
+
 extern "C" int olmc_european_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call,
                                        int64_t n_paths, int32_t n_steps, uint64_t seed, int second_order,
                                        double* out9, olmc_stats* evals) {
     if (!out9) return fail(OLMC_ERR_ARG, "null pointer");
     if (!(T > 0.0)) return fail(OLMC_ERR_ARG, "T must be > 0 (price() returns intrinsic value without simulating)");
-    // unified_greeks.py:274-277
-    const double h_S = std::max(1e-4, 0.01 * S);
-    const double h_v = std::max(1e-4, 0.01);
-    const double h_r = 1e-4;
-    const double h_T = 1 / 365.0;
-    const bool has_T = T > h_T;                                  // :310
-    olmc_option o[OLMC_MAX_BATCH];
-    int k = 0;
-    auto add = [&](double S_, double T_, double r_, double v_) { o[k] = make_option(S_, K, T_, r_, v_, q, is_call); return k++; };
-    // evaluation order = the reference's get_price() call order (:295-358)
-    const int i_mid = add(S, T, r, sigma);
-    const int i_su = add(S + h_S, T, r, sigma), i_sd = add(S - h_S, T, r, sigma);
-    const int i_vu = add(S, T, r, sigma + h_v), i_vd = add(S, T, r, sigma - h_v);
-    const int i_td = has_T ? add(S, T - h_T, r, sigma) : -1;
-    const int i_ru = add(S, T, r + h_r, sigma), i_rd = add(S, T, r - h_r, sigma);
-    int i_uu = -1, i_ud = -1, i_du = -1, i_dd = -1, i_ut = -1, i_dt = -1;
-    if (second_order) {
-        i_uu = add(S + h_S, T, r, sigma + h_v); i_ud = add(S + h_S, T, r, sigma - h_v);
-        i_du = add(S - h_S, T, r, sigma + h_v); i_dd = add(S - h_S, T, r, sigma - h_v);
-        if (has_T) { i_ut = add(S + h_S, T - h_T, r, sigma); i_dt = add(S - h_S, T - h_T, r, sigma); }
-    }
+    const GreeksSet gs(S, K, T, r, sigma, q, is_call, second_order);
     olmc_stats st[OLMC_MAX_BATCH];
-    int rc = run_batch(o, k, 0, n_paths, n_steps, seed, 1, st);
+    int rc = run_batch(gs.o, gs.k, 0, n_paths, n_steps, seed, 1, st);
     if (rc) return rc;
-    auto P = [&](int i) { return st[i].price; };
-    const double mid = P(i_mid);
-    const double delta = (P(i_su) - P(i_sd)) / (2 * h_S);                       // :301
-    out9[0] = mid;
-    out9[1] = delta;
-    out9[2] = (P(i_su) - 2 * mid + P(i_sd)) / (h_S * h_S);                       // :302
-    out9[3] = (P(i_vu) - P(i_vd)) / (2 * h_v);                                   // :307
-    out9[4] = has_T ? (P(i_td) - mid) / h_T : -mid / std::max(T, 1e-6);          // :310-314
-    out9[5] = (P(i_ru) - P(i_rd)) / (2 * h_r);                                   // :319
-    if (second_order) {
-        out9[6] = (P(i_uu) - P(i_ud) - P(i_du) + P(i_dd)) / (4 * h_S * h_v);    // :343-345
-        out9[7] = has_T ? ((P(i_ut) - P(i_dt)) / (2 * h_S) - delta) / h_T : 0.0; // :348-354
-        out9[8] = (P(i_vu) - 2 * mid + P(i_vd)) / (h_v * h_v);                   // :357
-    }
-    if (evals) {
-        for (int i = 0; i < k; ++i) evals[i] = st[i];
-        for (int i = k; i < 14; ++i) std::memset(&evals[i], 0, sizeof(olmc_stats));
-    }
+    gs.finish(st, T, out9, evals);
     return OLMC_OK;
 }
 
@@ -1524,44 +1540,58 @@ extern "C" int olmc_jump_paths(double S, double T, double r, double sigma, doubl
 
 // ======================================================================= QMC ====
 namespace {
-int run_qmc(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t point_offset,
-            int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
-            olmc_stats* out, double* terminal_host, int mirror = 0, olmc_cv_moments* cv = nullptr) {
+// The scrambled direction matrix and digital shift on the device: [dims x 30 | dims] words.  The table travels only when it
+// differs from the one already there (compared word for word: 31 KB at 252 dims, ~1 us, against two pageable uploads): the
+// 8 / 14 pricings of literal FD Greeks and every repeated pricing share one upload.  Call under c->mu.
+int qmc_table(DeviceCtx* c, const uint32_t* sv, const uint32_t* shift, int32_t dims) {
+    const size_t sv_words = static_cast<size_t>(dims) * kSobolBits, table_words = sv_words + dims;
+    const bool same = c->sobol_host.size() == table_words && std::memcmp(c->sobol_host.data(), sv, sizeof(uint32_t) * sv_words) == 0 &&
+                      std::memcmp(c->sobol_host.data() + sv_words, shift, sizeof(uint32_t) * dims) == 0;
+    if (same) return OLMC_OK;
+    c->sobol_host.clear();                       // whatever happens below, the device copy is no longer described by it
+    if (table_words > c->sobol_words) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_sobol) HIP_TRY(hipFree(c->d_sobol));
+        c->d_sobol = nullptr;
+        c->sobol_words = 0;
+        HIP_TRY(hipMalloc(&c->d_sobol, sizeof(uint32_t) * table_words));
+        c->sobol_words = table_words;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_sobol, sv, sizeof(uint32_t) * sv_words, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_sobol + sv_words, shift, sizeof(uint32_t) * dims, hipMemcpyHostToDevice, c->stream));
+    c->sobol_host.assign(sv, sv + sv_words);
+    c->sobol_host.insert(c->sobol_host.end(), shift, shift + dims);
+    return OLMC_OK;
+}
+
+int qmc_check(const uint32_t* sv, const uint32_t* shift, int32_t bits, int32_t dims, int64_t point_offset, int64_t n_paths) {
     if (!sv || !shift) return fail(OLMC_ERR_ARG, "null pointer");
     if (bits != kSobolBits) return fail(OLMC_ERR_ARG, "only 30-bit Sobol tables (SciPy's default) are supported");
     if (dims < 1 || dims > 21201) return fail(OLMC_ERR_ARG, "dims must be in [1, 21201]");
     int rc = check_paths(point_offset, n_paths, dims);
     if (rc) return rc;
     if (point_offset + n_paths > (int64_t(1) << kSobolBits)) return fail(OLMC_ERR_ARG, "at most 2**30 Sobol points");
+    return OLMC_OK;
+}
+
+// gbm_qmc.py:38-44 as an olmc_option -> Contract: dt = T / dims, a = ln S + drift dims, vol = sigma sqrt(dt) = make_contract(o, dims)
+int run_qmc(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t point_offset,
+            int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
+            olmc_stats* out, double* terminal_host, int mirror = 0, olmc_cv_moments* cv = nullptr) {
+    int rc = qmc_check(sv, shift, bits, dims, point_offset, n_paths);
+    if (rc) return rc;
     DeviceCtx* c = nullptr;
     rc = ctx_get(&c);
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(c->mu);
-    const size_t sv_words = static_cast<size_t>(dims) * kSobolBits, table_words = sv_words + dims;
+    const size_t sv_words = static_cast<size_t>(dims) * kSobolBits;
     const size_t term_bytes = terminal_host ? sizeof(double) * static_cast<size_t>(n_paths) * (mirror ? 2 : 1) : 0;
     if (term_bytes) {
         rc = bulk_reserve(c, term_bytes);
         if (rc) return rc;
     }
-    // the table travels only when it differs from the one already on the device (compared word for word: 31 KB at 252 dims,
-    // ~1 us, against two pageable uploads): the 8 / 14 pricings of FD Greeks and every repeated pricing share one upload
-    const bool same = c->sobol_host.size() == table_words && std::memcmp(c->sobol_host.data(), sv, sizeof(uint32_t) * sv_words) == 0 &&
-                      std::memcmp(c->sobol_host.data() + sv_words, shift, sizeof(uint32_t) * dims) == 0;
-    if (!same) {
-        c->sobol_host.clear();                       // whatever happens below, the device copy is no longer described by it
-        if (table_words > c->sobol_words) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            if (c->d_sobol) HIP_TRY(hipFree(c->d_sobol));
-            c->d_sobol = nullptr;
-            c->sobol_words = 0;
-            HIP_TRY(hipMalloc(&c->d_sobol, sizeof(uint32_t) * table_words));
-            c->sobol_words = table_words;
-        }
-        HIP_TRY(hipMemcpyAsync(c->d_sobol, sv, sizeof(uint32_t) * sv_words, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_sobol + sv_words, shift, sizeof(uint32_t) * dims, hipMemcpyHostToDevice, c->stream));
-        c->sobol_host.assign(sv, sv + sv_words);
-        c->sobol_host.insert(c->sobol_host.end(), shift, shift + dims);
-    }
+    rc = qmc_table(c, sv, shift, dims);
+    if (rc) return rc;
     uint32_t* d_sv = c->d_sobol;
     uint32_t* d_shift = d_sv + sv_words;
     double* d_term = terminal_host ? static_cast<double*>(c->d_bulk) : nullptr;
@@ -1647,6 +1677,91 @@ extern "C" int olmc_european_qmc_terminal(double S, double T, double r, double s
                                           int32_t bits, int antithetic, double* out_host) {
     if (!out_host) return fail(OLMC_ERR_ARG, "null pointer");
     return run_qmc(S, 0.0, T, r, sigma, q, 1, point_offset, n_paths, dims, sv, shift, bits, nullptr, out_host, antithetic);
+}
+
+namespace {
+// k contracts on the same Sobol points, ONE launch (european_qmc_batch_kernel); falls back to k launches beyond the size one
+// grid covers.  out[i] = stats of opts[i].
+int run_qmc_batch(const olmc_option* opts, int32_t k, int64_t point_offset, int64_t n_paths, int32_t dims, const uint32_t* sv,
+                  const uint32_t* shift, int32_t bits, olmc_stats* out) {
+    if (!opts || !out) return fail(OLMC_ERR_ARG, "null pointer");
+    if (k < 1 || k > OLMC_MAX_BATCH) return fail(OLMC_ERR_ARG, "batch size must be in [1, OLMC_MAX_BATCH]");
+    int rc = qmc_check(sv, shift, bits, dims, point_offset, n_paths);
+    if (rc) return rc;
+    const bool blocks = g_qmc_block > 0 ? true : (g_qmc_block < 0 ? false : n_paths >= (int64_t(1) << 20));
+    const int64_t units = blocks ? (point_offset + n_paths + kQmcBlock - 1) / kQmcBlock - point_offset / kQmcBlock : n_paths;
+    if (k == 1 || (units + kBlock - 1) / kBlock > kMaxGrid) {             // one contract, or more points than a grid covers: literal launches
+        for (int i = 0; i < k; ++i) {
+            rc = run_qmc(opts[i].S, opts[i].K, opts[i].T, opts[i].r, opts[i].sigma, opts[i].q, opts[i].is_call, point_offset, n_paths, dims, sv, shift,
+                         bits, &out[i], nullptr);
+            if (rc) return rc;
+        }
+        return OLMC_OK;
+    }
+    DeviceCtx* c = nullptr;
+    rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    rc = qmc_table(c, sv, shift, dims);
+    if (rc) return rc;
+    const size_t sv_words = static_cast<size_t>(dims) * kSobolBits;
+    uint32_t* d_sv = c->d_sobol;
+    uint32_t* d_shift = d_sv + sv_words;
+    QmcRange qr;
+    qr.first = static_cast<uint64_t>(point_offset);
+    qr.count = n_paths;
+    qr.dims = dims;
+    qr.mirror = 0;
+    const int32_t grid = static_cast<int32_t>((units + kBlock - 1) / kBlock);
+    const int nsets = k <= 8 ? 8 : 16;
+    ReduceWs ws;
+    rc = make_ws(c, c->stream, grid, 2 * nsets, c->d_result, -1.0, &ws);
+    if (rc) return rc;
+    EventPair ep{};
+    const EventPair* timed = nullptr;
+    rc = prof_pair(c, &ep, &timed);
+    if (rc) return rc;
+    int pos[OLMC_MAX_BATCH];
+    // make_contract(o, dims) IS gbm_qmc.py:38-44: dt = T / dims, drift * dims, sigma sqrt(dt)
+    if (nsets == 8) {
+        ContractSet<8> cs;
+        group_contracts<8>(opts, k, dims, &cs, pos);
+        if (blocks) launch_timed(european_qmc_batch_kernel<8, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+        else launch_timed(european_qmc_batch_kernel<8, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+    } else {
+        ContractSet<16> cs;
+        group_contracts<16>(opts, k, dims, &cs, pos);
+        if (blocks) launch_timed(european_qmc_batch_kernel<16, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+        else launch_timed(european_qmc_batch_kernel<16, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+    }
+    rc = after_launch(c, c->stream);
+    if (rc) return rc;
+    rc = sync_or_recover(c, c->stream);
+    if (rc) return rc;
+    for (int i = 0; i < k; ++i) {
+        if (poisoned(opts[i].S, opts[i].K, opts[i].T, opts[i].r, opts[i].sigma, opts[i].q)) nan_stats(n_paths, &out[i]);
+        else finish_stats(c->h_result[2 * pos[i]], c->h_result[2 * pos[i] + 1], n_paths, opts[i].r, opts[i].T, &out[i]);
+    }
+    return OLMC_OK;
+}
+}  // namespace
+
+extern "C" int olmc_european_qmc_batch(const olmc_option* opts, int32_t k, int64_t point_offset, int64_t n_paths, int32_t dims,
+                                       const uint32_t* sv, const uint32_t* shift, int32_t bits, olmc_stats* out) {
+    return run_qmc_batch(opts, k, point_offset, n_paths, dims, sv, shift, bits, out);
+}
+
+extern "C" int olmc_european_qmc_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t n_paths,
+                                           int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits, int second_order,
+                                           double* out9, olmc_stats* evals) {
+    if (!out9) return fail(OLMC_ERR_ARG, "null pointer");
+    if (!(T > 0.0)) return fail(OLMC_ERR_ARG, "T must be > 0 (price() returns intrinsic value without simulating)");
+    const GreeksSet gs(S, K, T, r, sigma, q, is_call, second_order);
+    olmc_stats st[OLMC_MAX_BATCH];
+    int rc = run_qmc_batch(gs.o, gs.k, 0, n_paths, dims, sv, shift, bits, st);
+    if (rc) return rc;
+    gs.finish(st, T, out9, evals);
+    return OLMC_OK;
 }
 
 // ======================================================== multi-GPU (RCCL) ====

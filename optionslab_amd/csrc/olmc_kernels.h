@@ -1868,6 +1868,58 @@ __global__ __launch_bounds__(kBlock) void european_qmc_block_kernel(QmcRange qr,
     if constexpr (MODE != kTerminal) block_then_grid_reduce<NV>(acc, ws);
 }
 
+// k contracts on the SAME Sobol points in one launch (the 8 / 14 bumped contracts of compute_greeks_unified on a
+// MCMethod.QMC pricer, unified_greeks.py:295-358; round 2 priced them by 8 / 14 launches): the points, their uniforms and
+// the inverse normals do not depend on the contract (every bump keeps dims = min(n_steps, 21201) and the seed), so sum z is
+// formed once per point and each contract costs its exp (or, with the base's vol, one multiply) and a payoff -- the
+// ContractSet machinery of the pseudo-random kernel.  Contract c prices exp(c.a + c.vol sum z) exactly as european_qmc_kernel
+// does for it alone; a contract that shares its vol with a base takes scale * S_T(base) (2-3 ulp from its own exp).
+// BLOCK8 = the eight-points-per-thread expansion of european_qmc_block_kernel.  The grid covers every point / block (host
+// guarantee), so the 2 NSETS sums are born after the dimension loop.
+template <int NSETS, bool BLOCK8>
+__global__ __launch_bounds__(kBlock) void european_qmc_batch_kernel(QmcRange qr, ContractSet<NSETS> cs, const uint32_t* __restrict__ sv,
+                                                                    const uint32_t* __restrict__ shift, ReduceWs ws) {
+    constexpr int NV = 2 * NSETS;
+    constexpr int NP = BLOCK8 ? kQmcBlock : 1;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const uint64_t base = BLOCK8 ? qr.first / kQmcBlock : qr.first;
+    const uint64_t last = qr.first + static_cast<uint64_t>(qr.count);
+    const int64_t n_units = BLOCK8 ? static_cast<int64_t>((last + kQmcBlock - 1) / kQmcBlock - base) : qr.count;
+    const bool unit_live = i < n_units;
+    const uint64_t k0 = BLOCK8 ? (base + static_cast<uint64_t>(unit_live ? i : 0)) * kQmcBlock : qr.first + static_cast<uint64_t>(unit_live ? i : 0);
+    const uint32_t gray = static_cast<uint32_t>(k0 ^ (k0 >> 1));
+    constexpr int B0 = BLOCK8 ? 2 : 0;                   // an aligned block of eight starts with gray bits 0 and 1 clear
+    uint32_t mask[kSobolBits];
+#pragma unroll
+    for (int b = B0; b < kSobolBits; ++b) mask[b] = 0u - ((gray >> b) & 1u);
+    double zsum[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) zsum[p] = 0.0;
+    for (int32_t t = 0; t < qr.dims; ++t) {
+        const uint32_t* __restrict__ row = sv + static_cast<size_t>(t) * kSobolBits;
+        uint32_t x = shift[t];
+#pragma unroll
+        for (int b = B0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (p) x ^= row[__builtin_ctz(static_cast<unsigned>(p))];
+            double u = static_cast<double>(x) * 9.313225746154785e-10;      // 2^-30
+            u = fmin(fmax(u, 1e-10), 1.0 - 1e-10);
+            zsum[p] += ndtri_w(u);
+        }
+    }
+    double acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const uint64_t k = k0 + static_cast<uint64_t>(p);
+        const bool live = unit_live && k >= qr.first && k < last;           // the ragged ends of the range
+        european_payoffs<NSETS, false, kReduce>(cs, zsum[p], live, 0, 0, nullptr, acc);
+    }
+    block_then_grid_reduce<NV>(acc, ws);
+}
+
 // Power sums of the normal stream (validation tap): out[m-1] = sum over paths and steps of z^m, m = 1..4,
 // z = kZScale * z' in fp64.  At 2^36 normals the second moment is resolved to 5e-6: a bias hunt.
 __global__ __launch_bounds__(kBlock) void normal_moments_kernel(PathRange pr, ReduceWs ws) {

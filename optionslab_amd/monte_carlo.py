@@ -184,13 +184,14 @@ class MonteCarloPricer:
         return compute_greeks_unified(self, S, K, T, r, sigma, option_type, q, include_second_order, **kw)
 
     def _fused_greeks(self, S, K, T, r, sigma, option_type, q, include_second_order, seed=None):
-        if self.method == MCMethod.QMC:   # no fused QMC kernel: literal bump-and-reprice (same Sobol points each call)
-            from .greeks import compute_greeks_unified
-            kw = {} if seed is None else {"seed": seed}
-            return compute_greeks_unified(self, S, K, T, r, sigma, option_type, q, include_second_order, fused=False, **kw)
         actual_seed = seed if seed is not None else self.seed
-        vals, _ = _hip.european_greeks_fd(S, K, T, r, sigma, q, option_type == "call", self.num_simulations,
-                                          self._steps(), actual_seed, include_second_order, want_evals=False)
+        if self.method == MCMethod.QMC:   # the bumped contracts share the Sobol points (same dims, same seed): one launch prices them all
+            sv, shift = sobol_tables(self._steps(), actual_seed)
+            vals, _ = _hip.european_qmc_greeks_fd(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift,
+                                                  include_second_order, want_evals=False)
+        else:
+            vals, _ = _hip.european_greeks_fd(S, K, T, r, sigma, q, option_type == "call", self.num_simulations,
+                                              self._steps(), actual_seed, include_second_order, want_evals=False)
         n = 9 if include_second_order else 6
         return OrderedDict((k, float(v)) for k, v in zip(GREEK_KEYS[:n], vals[:n]))
 

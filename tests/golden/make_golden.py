@@ -136,6 +136,15 @@ def main():
     doc["greeks"].append(dict(ctor=[20000, 4, 42, "numpy"], args=[100.0, 100.0, 0.002, 0.05, 0.2, "call", 0.0],
                               include_second_order=True, keys=list(g.keys()), values={k: float(x) for k, x in g.items()}))
 
+    # -- FD Greeks of a MCMethod.QMC pricer: every bumped contract on the same scrambled-Sobol points (gbm_qmc.py:14-46 under
+    #    unified_greeks.py:280-358) -- the reference values of the device's one-launch form (olmc_european_qmc_greeks_fd)
+    doc["qmc_greeks"] = []
+    for N, M, seed, typ, q, second in [(2**14, 16, 42, "call", 0.0, False), (2**14, 16, 42, "call", 0.0, True),
+                                       (2**12, 252, 7, "put", 0.02, True), (1000, 5, 3, "call", 0.0, True)]:
+        g = cgu(MCP(N, M, seed, MCMethod.QMC), 100.0, 100.0, 1.0, 0.05, 0.2, typ, q, include_second_order=second)
+        doc["qmc_greeks"].append(dict(ctor=[N, M, seed, "qmc"], args=[100.0, 100.0, 1.0, 0.05, 0.2, typ, q],
+                                      include_second_order=second, keys=list(g.keys()), values={k: float(x) for k, x in g.items()}))
+
     # -- Asian (G11/G12) ----------------------------------------------------
     doc["asian"] = []
     A = ref["AsianOption"]

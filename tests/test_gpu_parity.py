@@ -206,6 +206,51 @@ def test_qmc_greeks_and_control_variate_run_on_the_same_points():
         _hip.european_qmc(*ATM, 0.0, True, 10, np.zeros((4, 31), np.uint32), np.zeros(4, np.uint32))   # bits != 30
 
 
+# Finite-difference steps the Greeks are quotients over (unified_greeks.py:274-277): an error eps on every price shows as about
+# eps x this factor in the Greek (sum of |coefficients| / step)
+def _fd_amplification(S=100.0):
+    h_S, h_v, h_r, h_T = max(1e-4, 0.01 * S), 0.01, 1e-4, 1 / 365.0
+    return dict(price=1.0, delta=1 / h_S, gamma=4 / h_S**2, vega=1 / h_v, theta=2 / h_T, rho=1 / h_r, vanna=1 / (h_S * h_v),
+                charm=2 / (h_S * h_T), vomma=4 / h_v**2)
+
+
+def test_qmc_fused_greeks_equal_the_reference_and_the_literal_form(golden):
+    """olmc_european_qmc_greeks_fd: the 8 / 14 bumped contracts of compute_greeks_unified on the Sobol points in ONE launch.
+    Against the reference's own numbers (golden qmc_greeks: every device QMC price is within 1e-10 relative of the reference's,
+    test_qmc_matches_reference_sobol, so each Greek is within that error times its finite-difference amplification) and against
+    the literal 8 / 14 single-contract launches on the device (contracts that share a vol take scale x S_T(base): a few ulp)."""
+    amp = _fd_amplification()
+    for c in golden["qmc_greeks"]:
+        N, M, seed, _ = c["ctor"]
+        S, K, T, r, v, typ, q = c["args"]
+        p = ol.MonteCarloPricer(N, M, seed, ol.MCMethod.QMC)
+        fused = p.greeks(S, K, T, r, v, typ, q, include_second_order=c["include_second_order"])
+        literal = ol.compute_greeks_unified(p, S, K, T, r, v, typ, q, include_second_order=c["include_second_order"], fused=False)
+        assert list(fused) == list(literal) == c["keys"]
+        price = c["values"]["price"]
+        for k in c["keys"]:
+            assert fused[k] == pytest.approx(c["values"][k], abs=2e-10 * price * amp[k]), (c["ctor"], k, "vs the reference")
+            assert fused[k] == pytest.approx(literal[k], abs=1e-13 * price * amp[k] + 1e-12), (c["ctor"], k, "vs literal launches")
+        assert fused == ol.compute_greeks_unified(p, S, K, T, r, v, typ, q, include_second_order=c["include_second_order"])
+
+
+def test_qmc_batch_prices_each_contract_as_its_own_launch_does():
+    """olmc_european_qmc_batch: arbitrary contracts (nothing shared but the points), both launch shapes, ragged ranges."""
+    rng = np.random.default_rng(11)
+    for N, M, off, k in [(5000, 12, 0, 16), (777, 33, 1234, 3), (4096, 64, 0, 9), (2**20 + 5, 4, 3, 5)]:
+        tables = ol.monte_carlo.sobol_tables(M, 9)
+        opts = [(float(rng.uniform(80, 120)), float(rng.uniform(80, 120)), float(rng.uniform(0.3, 2.0)), float(rng.uniform(0.0, 0.08)),
+                 float(rng.uniform(0.1, 0.5)), float(rng.uniform(0.0, 0.03)), bool(i % 2)) for i in range(k)]
+        opts[1] = opts[0][:3] + (opts[0][3] + 1e-3,) + opts[0][4:]            # an r-bump of contract 0: same vol, takes the scaled price
+        got = _hip.european_qmc_batch(opts, N, *tables, point_offset=off)
+        for o, g in zip(opts, got):
+            one = _hip.european_qmc(*o[:6], o[6], N, *tables, point_offset=off)
+            assert g.n == one.n == N
+            assert g.price == pytest.approx(one.price, rel=1e-13, abs=1e-13) and g.std_error == pytest.approx(one.std_error, rel=1e-10)
+    with pytest.raises(ol.AccelerationError):
+        _hip.european_qmc_batch([opts[0]] * 17, 100, *tables)
+
+
 # ------------------------------------------------------------------ terminal array (backend contract)
 @pytest.mark.parametrize("N,M", [(1000, 12), (257, 1), (5000, 6)])
 def test_terminal_array_layout_and_values(N, M):

@@ -76,6 +76,18 @@ def test_fd_greeks(golden):
             assert float(g[k]) == c["values"][k], (c["ctor"], k)
 
 
+def test_fd_greeks_of_the_qmc_pricer(golden):
+    """unified_greeks.py:280-358 over MCMethod.QMC (gbm_qmc.py:14-46): every bumped contract on the same scrambled-Sobol points."""
+    assert len(golden["qmc_greeks"]) == 4
+    for c in golden["qmc_greeks"]:
+        N, M, seed, method = c["ctor"]
+        S, K, T, r, v, typ, q = c["args"]
+        g = orc.fd_greeks(orc.OraclePricer(N, M, seed, method).price, S, K, T, r, v, typ, q, include_second_order=c["include_second_order"])
+        assert list(g.keys()) == c["keys"]
+        for k in c["keys"]:
+            assert float(g[k]) == c["values"][k], (c["ctor"], k)
+
+
 def test_asian(golden):
     for c in golden["asian"]:
         S, K, T, r, v, q = c["params"]

@@ -149,6 +149,10 @@ int olmc_european_multi(const olmc_option* opts, const uint32_t* tags, int64_t n
                         int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
                         olmc_stats* out /* [n_options] */);
 
+/* Capacity of the library-owned workspace behind olmc_european_multi as it stands: out2 = {contracts, workgroups per contract}.
+ * The two grow independently (more contracts doubles the first, more paths per contract only widens the rows). */
+int olmc_multi_capacity(int64_t* out2);
+
 /* Finite-difference Greeks, bumps exactly as unified_greeks.py:274-277, 295-362.
  * out9 = {price, delta, gamma, vega, theta, rho, vanna, charm, vomma}; the last
  * three are written only when second_order != 0.  `evals` (nullable) receives
@@ -322,9 +326,11 @@ int olmc_european_qmc_terminal(double S, double T, double r, double sigma, doubl
                                int antithetic, double* out_host /* [n_paths * (1 + antithetic)] */);
 
 /* ---- multi-GPU, single process ------------------------------------------
- * n_paths split into n_gpus contiguous global path ranges, one host thread and
- * one stream per device, ONE RCCL all-reduce of {sum, sumsq, n} (3 x fp64)
- * over xGMI, identical finalisation on every rank. */
+ * n_paths split into n_gpus contiguous global path ranges (devices 0 .. n_gpus - 1), one stream per device.  ONE host
+ * thread -- the caller's -- queues every device's path kernel and then ONE grouped RCCL all-reduce of {sum, sumsq, n}
+ * (3 x fp64) over xGMI before it waits for anything; the triple is handed to the host by device 0's polled completion word
+ * (as olmc_fetch_dev), the other devices are drained before the call returns.  Identical finalisation on every rank
+ * (SURVEY §8e).  On any error return the thread's device and the streams already launched on are restored / drained. */
 int olmc_multi_gpu_european(double S, double K, double T, double r, double sigma, double q, int is_call,
                             int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
                             int n_gpus, olmc_stats* out);

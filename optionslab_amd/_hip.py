@@ -62,6 +62,7 @@ PROTOTYPES = {
     "olmc_fetch_dev": (_I, [_P, _I32, _P, C.POINTER(_D)]),
     "olmc_european_batch": (_I, [C.POINTER(Option), _I32, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_european_multi": (_I, [C.POINTER(Option), C.POINTER(C.c_uint32), _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
+    "olmc_multi_capacity": (_I, [C.POINTER(_I64)]),
     "olmc_european_greeks_fd": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(_D), C.POINTER(Stats)]),
     "olmc_european_terminal": (_I, [_D] * 5 + [_I64, _I32, _U64T, _I, C.POINTER(_D)]),
     "olmc_gbm_paths": (_I, [_D] * 5 + [_I64, _I32, _U64T, _I, C.POINTER(_D)]),
@@ -256,6 +257,13 @@ def european_multi(S, K, T, r, sigma, q, is_call, n_paths: int, n_steps: int, se
     _check(lib().olmc_european_multi(C.cast(opts.ctypes.data, _P_OPTION), ptags, n, int(n_paths), int(n_steps), int(seed) & _U64,
                                      bool(antithetic), C.cast(out.ctypes.data, _P_STATS)))
     return out.view(_STATS_DT).reshape(n)
+
+
+def multi_capacity() -> Tuple[int, int]:
+    """(contracts, workgroups per contract) the batch workspace of european_multi is sized for right now."""
+    out = (C.c_int64 * 2)()
+    _check(lib().olmc_multi_capacity(out))
+    return int(out[0]), int(out[1])
 
 
 def european_greeks_fd(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int, seed: int,

@@ -2,6 +2,7 @@
 import os
 import shutil
 import subprocess
+import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
@@ -34,9 +35,15 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    # the static instruction mix of the step loops (bench.py's issue-cycle roofline) belongs to this very build
-    subprocess.run([os.environ.get("PYTHON", "python3"), os.path.join(ROOT, "tools", "isa_mix.py")], check=True,
-                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    # the static instruction mix of the step loops (bench.py's issue-cycle roofline) belongs to this very build.  It is a
+    # by-product: the library above is complete without it, so a failure here (tools/ absent in a packaged copy, a symbol
+    # pattern that no longer matches after a kernel was renamed) is reported and leaves the previous isa_mix.json in place
+    mix = os.path.join(ROOT, "tools", "isa_mix.py")
+    if os.path.exists(mix):
+        r = subprocess.run([sys.executable, mix], env=dict(os.environ, HIPCC=_hipcc()), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            print(f"[optionslab_amd.build] warning: tools/isa_mix.py failed (rc {r.returncode}); optionslab_amd/isa_mix.json left as it was:\n"
+                  f"{r.stderr[-1500:]}", file=sys.stderr)
     return LIBRARY
 
 

@@ -9,6 +9,8 @@
 #include "olmc_kernels.h"
 
 #include <dlfcn.h>
+#include <sched.h>
+#include <time.h>
 #include <hip/hip_ext.h>
 #include <rccl/rccl.h>      // types and enum values only: the library itself is dlopen()ed on first multi-GPU use
 
@@ -601,26 +603,42 @@ int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32
     return OLMC_OK;
 }
 
-// Waits for the launch just made on stream s.  If it was armed (make_ws), the host spins on the flag word in pinned memory:
+// Waits for the launch just made on stream s.  If it was armed (make_ws), the host polls the flag word in pinned memory:
 // the results are there as soon as the flag shows the launch's sequence number.  The stream itself is left to drain on its
-// own (it is in-order, so the next launch still starts after this kernel has retired).  Insurance: after 2 ms of spinning
-// the stream is queried every ~100 us -- an error is reported as such, and a stream that reports completion without the
-// flag having shown up falls back to the runtime's own wait.
+// own (it is in-order, so the next launch still starts after this kernel has retired).
+// The poll is a spin only for as long as a spin is cheap: the first kSpinUs (200 us: every interactive size, the 1M x 252
+// headline at 100 us) spin with `pause`; from then on every poll is followed by sched_yield(), so a host thread waiting for a
+// 6 ms pricing of 64M paths hands its core to any other runnable thread (Streamlit runs one thread per session) instead of
+// burning it; after kYieldUs (2 ms) the polls are kSleepUs apart (nanosleep: < 3 % on anything that long; the calling thread's
+// CPU share over a 6 ms pricing falls from 1.0 to 0.34, profiles/r03_call_overhead.jsonl).  Insurance: from 2 ms on the stream
+// is queried as well, about once a millisecond -- an error is reported as such, and a stream that reports completion without
+// the flag having shown up falls back to the runtime's own wait.
+constexpr int64_t kSpinUs = 200, kYieldUs = 2000, kSleepUs = 50;
+
 int wait_armed(DeviceCtx* c, hipStream_t s) {
     if (c->armed != 0) {
         const uint64_t want = c->armed;
         c->armed = 0;
         using clock = std::chrono::steady_clock;
         const auto t0 = clock::now();
-        auto next_query = t0 + std::chrono::milliseconds(2);
         bool queried = false;
+        int phase = 0;                                                           // 0 spin, 1 yield, 2 sleep + query
         for (uint32_t spins = 0;; ++spins) {
             if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == want) {
                 if (queried) (void)hipGetLastError();                        // a hipErrorNotReady answer must not linger as this thread's last error
                 return OLMC_OK;
             }
-            __builtin_ia32_pause();
-            if ((spins & 0xFF) == 0xFF && clock::now() >= next_query) {
+            if (phase == 0) {
+                __builtin_ia32_pause();
+                if ((spins & 0x3F) == 0x3F && clock::now() - t0 >= std::chrono::microseconds(kSpinUs)) phase = 1;
+                continue;
+            }
+            if (phase == 1) {
+                sched_yield();
+                if ((spins & 0xF) == 0xF && clock::now() - t0 >= std::chrono::microseconds(kYieldUs)) phase = 2;
+                continue;
+            }
+            if ((spins & 0xF) == 0) {                                        // the stream is asked every 16th nap (~1 ms), the word every time
                 const hipError_t q = hipStreamQuery(s);
                 queried = true;
                 if (q == hipSuccess) break;                                  // retired: fall through to the runtime's wait
@@ -628,8 +646,9 @@ int wait_armed(DeviceCtx* c, hipStream_t s) {
                     ws_recover(c);
                     return fail(OLMC_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
                 }
-                next_query = clock::now() + std::chrono::microseconds(100);
             }
+            const timespec nap{0, kSleepUs * 1000};
+            nanosleep(&nap, nullptr);
         }
         (void)hipGetLastError();
     }
@@ -835,7 +854,9 @@ extern "C" int olmc_european_multi(const olmc_option* opts, const uint32_t* tags
     // re-zeroes the counter it consumed.  Pinned host staging [contracts | sums]: contracts go up by one asynchronous DMA from
     // pinned memory, the sums are written into pinned memory by the kernel itself, completion is the polled word of the context.
     if (n_options > c->multi_cap || static_cast<size_t>(bpo) > c->multi_bpo) {
-        const int64_t cap = std::max<int64_t>(n_options, std::max<int64_t>(2 * c->multi_cap, 64));
+        // the two capacities grow independently: more contracts doubles the contract capacity, more workgroups per contract (a
+        // larger n_paths on the same batch) only widens the rows -- a convergence sweep over n_paths must not double `cap` each time
+        const int64_t cap = n_options > c->multi_cap ? std::max<int64_t>(n_options, std::max<int64_t>(2 * c->multi_cap, 64)) : c->multi_cap;
         const size_t bpo_cap = std::max<size_t>(bpo, c->multi_bpo);
         const size_t b_cnt = align(sizeof(uint32_t) * cap * kMultiCounterStride), b_done = 256, b_opts = align(sizeof(MultiOption) * cap);
         const size_t b_rows = align(sizeof(double) * 2 * bpo_cap * cap);
@@ -898,6 +919,18 @@ extern "C" int olmc_european_multi(const olmc_option* opts, const uint32_t* tags
         if (poisoned(opts[j].S, opts[j].K, opts[j].T, opts[j].r, opts[j].sigma, opts[j].q)) nan_stats(n, &out[j]);
         else finish_stats(h_out[2 * j], h_out[2 * j + 1], n, opts[j].r, opts[j].T, &out[j]);
     }
+    return OLMC_OK;
+}
+
+// Capacity of the batch workspace as it stands: {contracts, workgroups per contract} (0, 0 before the first batch).
+extern "C" int olmc_multi_capacity(int64_t* out2) {
+    if (!out2) return fail(OLMC_ERR_ARG, "null pointer");
+    DeviceCtx* c = nullptr;
+    int rc = ctx_get(&c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    out2[0] = c->multi_cap;
+    out2[1] = static_cast<int64_t>(c->multi_bpo);
     return OLMC_OK;
 }
 
@@ -1857,13 +1890,20 @@ int multi_gpu_body(MultiGpuScope& scope, double S, double K, double T, double r,
     for (int d = 0; d < n_gpus; ++d)
         RCCL_TRY(g_rccl.AllReduce(triples[d], triples[d], 3, ncclFloat64, ncclSum, g_rccl.comms[d], g_ctx[d]->stream));
     RCCL_TRY(g_rccl.GroupEnd());
+    // Every launch and the collective are queued on every device before the first wait (one host thread drives all devices: the
+    // calls above only enqueue).  The triple comes home the way every blocking pricing's result does: a one-wave kernel behind
+    // the all-reduce on device 0 writes it into that device's pinned buffer and raises the completion word the host polls
+    // (olmc_fetch_dev); the other devices hold the same triple and are drained afterwards -- they finish with the same collective.
     double host[3] = {0, 0, 0};
-    for (int d = n_gpus - 1; d >= 0; --d) {
+    HIP_TRY(hipSetDevice(0));
+    t_device = 0;
+    rc = olmc_fetch_dev(triples[0], 3, g_ctx[0]->stream, host);
+    if (rc) return rc;
+    for (int d = n_gpus - 1; d >= 1; --d) {
         HIP_TRY(hipSetDevice(d));
-        if (d == 0) HIP_TRY(hipMemcpyAsync(host, triples[0], sizeof(host), hipMemcpyDeviceToHost, g_ctx[0]->stream));
         HIP_TRY(hipStreamSynchronize(g_ctx[d]->stream));
     }
-    scope.launched.clear();                        // everything drained: nothing left for the guard to wait for
+    scope.launched.clear();                        // device 0 handed over by its completion word, the others drained: nothing left for the guard
     finish_stats(host[0], host[1], static_cast<int64_t>(host[2]), r, T, out);
     if (poisoned(S, K, T, r, sigma, q)) nan_stats(out->n, out);
     return OLMC_OK;

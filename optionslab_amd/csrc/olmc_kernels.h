@@ -361,6 +361,110 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws, Epilog
     signal_done(ws);
 }
 
+// The same reduction for WIDE rows (NV > 2), with the whole workgroup summing.  grid_reduce lets one wave sum a group's rows:
+// with NV = 2 that is 8 rows per lane, one batch of loads in flight, but a row of 32 sums (second-order Greeks) leaves only two
+// lanes per column -- 128 rows each, sixteen dependent batches of ~1 us behind the LAST workgroup of the launch (round 3 found the
+// fused 14-contract kernel paying 21 us over the one-contract kernel for 450 instructions per wave that should cost 8; and the
+// American option's per-date launches, NV = 16, spending 8 of their 11 us here).  Here all 256 threads of the workgroup that took
+// the last ticket load: thread t sums rows == t / NVP (mod 256 / NVP) of column t % NVP in row order, the 256 / NVP partial
+// sums of a column meet in LDS and are added in index order -- 32 rows per lane for NV = 32, four batches.  Call with ALL waves
+// of the workgroup; `v` is this workgroup's sum of component threadIdx.x (wave 0, lanes < NV).
+template <int NV>
+__device__ __forceinline__ double workgroup_rows_sum(const double* src, int32_t rows, double* part /* LDS [kBlock] */) {
+    constexpr int NVP = NV <= 8 ? 8 : NV <= 16 ? 16 : 32;
+    constexpr int SUBS = kBlock / NVP;
+    const int c = threadIdx.x % NVP, sub = threadIdx.x / NVP;
+    double v = 0.0;
+    if (c < NV) {
+        constexpr int kBatch = 8;
+        for (int32_t row = sub; row < rows; row += SUBS * kBatch) {
+            double t[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const int32_t rj = row + j * SUBS;
+                t[j] = rj < rows ? load_sc1(src + static_cast<size_t>(rj) * NV + c) : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) v += t[j];
+        }
+    }
+    part[threadIdx.x] = v;                       // part[sub * NVP + c]
+    __syncthreads();
+    double total = 0.0;
+    if (threadIdx.x < NV) {
+#pragma unroll
+        for (int k = 0; k < SUBS; ++k) total += part[k * NVP + threadIdx.x];
+    }
+    __syncthreads();                             // `part` is free again
+    return total;                                // valid in threads < NV
+}
+
+template <int NV, typename Epilogue = NoEpilogue>
+__device__ __forceinline__ void grid_reduce_workgroup(double v, const ReduceWs& ws, Epilogue done = Epilogue()) {
+    __shared__ double part[kBlock];
+    __shared__ uint32_t last;                    // did this workgroup take the last ticket (of its group / of the launch)?
+    const int t = threadIdx.x;
+    const bool wave0 = t < kWave;
+    const int32_t n_blocks = static_cast<int32_t>(gridDim.x);
+    const int32_t n_groups = (n_blocks + kGroupBlocks - 1) / kGroupBlocks;
+    const int32_t group = static_cast<int32_t>(blockIdx.x) / kGroupBlocks;
+    const int32_t group_size = min(kGroupBlocks, n_blocks - group * kGroupBlocks);
+
+    if (static_cast<uint64_t>(n_blocks) * NV > ws.row_capacity || n_groups * NV > kGroupRowsCapacity) {   // host/kernel NV mismatch
+        if (blockIdx.x == 0 && wave0) {
+            if (t < NV) ws.out[t] = __builtin_nan("");
+            signal_done(ws);
+        }
+        return;
+    }
+    if (wave0) {
+        if (t < NV) store_sc1(ws.block_rows + static_cast<size_t>(blockIdx.x) * NV + t, v);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t == 0) last = __hip_atomic_fetch_add(ws.counters + static_cast<size_t>(group) * kCounterStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                           static_cast<uint32_t>(group_size - 1);
+    }
+    __syncthreads();
+    if (!last) return;                           // workgroup-uniform
+
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const double g = workgroup_rows_sum<NV>(ws.block_rows + static_cast<size_t>(group) * kGroupBlocks * NV, group_size, part);
+    if (n_groups == 1) {                         // the only group IS the total
+        if (wave0) {
+            if (t < NV) ws.out[t] = g;
+            if (t == 0) {
+                if (ws.tail >= 0.0) ws.out[NV] = ws.tail;
+                __hip_atomic_store(ws.counters, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            done(g);
+            signal_done(ws);
+        }
+        return;
+    }
+    if (wave0) {
+        if (t < NV) store_sc1(ws.group_rows + static_cast<size_t>(group) * NV + t, g);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (t == 0) {
+            __hip_atomic_store(ws.counters + static_cast<size_t>(group) * kCounterStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = __hip_atomic_fetch_add(ws.counters + static_cast<size_t>(n_groups) * kCounterStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                   static_cast<uint32_t>(n_groups - 1);
+        }
+    }
+    __syncthreads();
+    if (!last) return;
+
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const double total = workgroup_rows_sum<NV>(ws.group_rows, n_groups, part);
+    if (wave0) {
+        if (t < NV) ws.out[t] = total;
+        if (t == 0) {
+            if (ws.tail >= 0.0) ws.out[NV] = ws.tail;
+            __hip_atomic_store(ws.counters + static_cast<size_t>(n_groups) * kCounterStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        done(total);
+        signal_done(ws);
+    }
+}
+
 // Wave-wide sums of P (a power of two) per-lane values in P-1 + (6 - log2 P) exchange-adds instead of
 // 6 P: at every halving step a lane trades half of its values with the lane `off` away and keeps the
 // sums of the other half, so after log2 P steps each lane holds ONE value's sum over a lane subset;
@@ -443,14 +547,17 @@ __device__ __forceinline__ void block_then_grid_reduce_from(double (&w)[pow2_cei
     wave_transpose_reduce<(P >> DONE), ((kWave / 2) >> DONE)>(w);
     if ((lane & ((1 << SHIFT) - 1)) == 0) stage[wave][lane >> SHIFT] = w[0];
     __syncthreads();
-    if (wave != 0) return;
+    if constexpr (NV <= 2) {
+        if (wave != 0) return;
+    }
     double s = 0.0;
     if (threadIdx.x < NV) {
         s = stage[0][threadIdx.x];
 #pragma unroll
         for (int k = 1; k < kWavesPerBlock; ++k) s += stage[k][threadIdx.x];
     }
-    grid_reduce<NV, Epilogue>(s, ws, done);
+    if constexpr (NV <= 2) grid_reduce<NV, Epilogue>(s, ws, done);                 // narrow rows: one wave is plenty
+    else grid_reduce_workgroup<NV, Epilogue>(s, ws, done);                         // wide rows: the whole workgroup sums them
 }
 
 template <int NV, typename Epilogue = NoEpilogue>
@@ -691,8 +798,8 @@ struct MultiOption {
 };
 
 // Completion of a whole batch: out[] is pinned host memory; the finisher of every contract makes its two sums visible
-// system-wide and takes a ticket on `done_count`; the finisher that takes the LAST ticket of the batch (n_total contracts, over
-// all launches of the call) re-zeroes the counter and raises the host's completion word.
+// system-wide and takes an acquire-release ticket on `done_count`; the finisher that takes the LAST ticket of the batch (n_total
+// contracts, over all launches of the call) re-zeroes the counter, releases at system scope and raises the host's completion word.
 struct MultiDone {
     uint32_t* done_count;
     uint64_t* done_flag;     // NULL: the host waits for the stream instead
@@ -741,15 +848,20 @@ __global__ __launch_bounds__(kBlock) void european_multi_kernel(PathRange pr, co
     if (lane < 2) out[opt * 2 + lane] = total;
     if (lane == 0) __hip_atomic_store(counters + static_cast<size_t>(opt) * kMultiCounterStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (md.done_flag == nullptr) return;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope: this contract's sums are in host memory before its ticket
+    // Completion of the batch, by the memory model and not by what a fence happens to drain on gfx950: every contract's finisher
+    //   (1) releases its two sums at SYSTEM scope (they are in host memory before anything ordered after the fence),
+    //   (2) takes its ticket with an ACQUIRE-RELEASE add at agent scope -- the tickets form a release sequence on done_count, so the
+    //       finisher that takes the last one synchronises with every earlier finisher and with all that they released,
+    //   (3) the last finisher releases again at system scope and only then raises the host's word: the host's acquire load of the
+    //       word therefore sees the sums of ALL contracts, whichever workgroup wrote them.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     uint32_t fin = 0;
-    if (lane == 0) fin = __hip_atomic_fetch_add(md.done_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) fin = __hip_atomic_fetch_add(md.done_count, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
     fin = __builtin_amdgcn_readfirstlane(fin);
     if (fin != md.n_total - 1u) return;
-    if (lane == 0) {
-        __hip_atomic_store(md.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(md.done_flag, md.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (lane == 0) __hip_atomic_store(md.done_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");          // system scope, as signal_done(): one fence, paid by the last workgroup only
+    if (lane == 0) __hip_atomic_store(md.done_flag, md.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Asian option: running arithmetic sum of S_t (or sum of ln S_t) over t = 1..M kept in

@@ -49,7 +49,7 @@ def device_asm():
     hipcc = os.environ.get("HIPCC") or "/opt/rocm/bin/hipcc"
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
                     "-I" + os.path.join(PKG, "csrc"), "-S", "--cuda-device-only", "-o", out, os.path.join(PKG, "csrc", "olmc.hip")],
-                   check=True, stderr=subprocess.DEVNULL, cwd=tmp)
+                   check=True, stderr=subprocess.PIPE, cwd=tmp)
     with open(out) as f:
         return f.read().splitlines()
 

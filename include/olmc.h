@@ -350,6 +350,9 @@ int olmc_philox_words(uint64_t seed, int64_t path_offset, int64_t n_paths,
                       int32_t block0, int32_t n_blocks, uint32_t stream_tag, uint32_t* out_host);
 /* The device's fp64 base-2 exponential (the per-date exponential of OLMC_AVG_ARITHMETIC): y[i] = 2^x[i], host arrays. */
 int olmc_exp2_probe(const double* x_host, int64_t n, double* y_host);
+/* The same for either form of it the library carries: form 0 = rint + degree-11 polynomial, 1 = 64-entry table + degree-5
+ * polynomial (the one OLMC_AVG_ARITHMETIC uses). */
+int olmc_exp2_probe_form(const double* x_host, int64_t n, double* y_host, int form);
 /* Power sums of the normal stream: out4[m-1] = sum over paths and steps of z^m, m = 1..4 (fp64). */
 int olmc_normal_moments(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps, double* out4);
 /* The fp32 normal stream: out[p*n_steps + t]. */

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "olmc_combine_stats": (_I, [C.POINTER(Stats), _I32, _D, _D, C.POINTER(Stats)]),
     "olmc_philox_words": (_I, [_U64T, _I64, _I64, _I32, _I32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "olmc_exp2_probe": (_I, [C.POINTER(_D), _I64, C.POINTER(_D)]),
+    "olmc_exp2_probe_form": (_I, [C.POINTER(_D), _I64, C.POINTER(_D), _I]),
     "olmc_normal_moments": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(_D)]),
     "olmc_normals": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(C.c_float)]),
     "olmc_phase_stamps": (_I, [_I64, _I32, _U64T, C.POINTER(C.c_uint64), _I64, C.POINTER(_I64)]),
@@ -519,11 +520,16 @@ def tune(knob: int, value: int) -> None:
     _check(load_library().olmc_tune(int(knob), int(value)))
 
 
-def exp2_probe(x: np.ndarray) -> np.ndarray:
-    """2**x by the device's exp2_f64 (validation tap)."""
+def exp2_probe(x: np.ndarray, form: Optional[int] = None) -> np.ndarray:
+    """2**x by the device's fp64 exponential (validation tap): the form the Asian kernel uses, or form 0 (degree-11 polynomial) /
+    1 (64-entry table) explicitly."""
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.empty_like(x)
-    _check(lib().olmc_exp2_probe(x.ctypes.data_as(C.POINTER(C.c_double)), x.size, y.ctypes.data_as(C.POINTER(C.c_double))))
+    px, py = x.ctypes.data_as(C.POINTER(C.c_double)), y.ctypes.data_as(C.POINTER(C.c_double))
+    if form is None:
+        _check(lib().olmc_exp2_probe(px, x.size, py))
+    else:
+        _check(lib().olmc_exp2_probe_form(px, x.size, py, int(form)))
     return y
 
 

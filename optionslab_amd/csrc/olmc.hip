@@ -1951,8 +1951,9 @@ extern "C" int olmc_philox_words(uint64_t seed, int64_t path_offset, int64_t n_p
     return OLMC_OK;
 }
 
-extern "C" int olmc_exp2_probe(const double* x_host, int64_t n, double* y_host) {
+extern "C" int olmc_exp2_probe_form(const double* x_host, int64_t n, double* y_host, int form) {
     if (!x_host || !y_host || n < 1) return fail(OLMC_ERR_ARG, "bad arguments");
+    if (form != 0 && form != 1) return fail(OLMC_ERR_ARG, "form must be 0 (polynomial) or 1 (table)");
     DeviceCtx* c = nullptr;
     int rc = ctx_get(&c);
     if (rc) return rc;
@@ -1964,11 +1965,16 @@ extern "C" int olmc_exp2_probe(const double* x_host, int64_t n, double* y_host) 
     double* d_y = d_x + n;
     HIP_TRY(hipMemcpyAsync(d_x, x_host, bytes, hipMemcpyHostToDevice, c->stream));
     const int grid = static_cast<int>(std::min<int64_t>((n + 255) / 256, 4096));
-    hipLaunchKernelGGL(exp2_probe_kernel, dim3(grid), dim3(256), 0, c->stream, d_x, n, d_y);
+    hipLaunchKernelGGL(exp2_probe_kernel, dim3(grid), dim3(256), 0, c->stream, d_x, n, d_y, form);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(y_host, d_y, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return OLMC_OK;
+}
+
+// the form the arithmetic Asian kernel is built with
+extern "C" int olmc_exp2_probe(const double* x_host, int64_t n, double* y_host) {
+    return olmc_exp2_probe_form(x_host, n, y_host, OLMC_EXP2_TABLE ? 1 : 0);
 }
 
 extern "C" int olmc_normal_moments(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps, double* out4) {

@@ -593,6 +593,56 @@ __device__ __forceinline__ double exp2_f64(double y) {
     return __builtin_ldexp(p, static_cast<int>(n));
 }
 
+// The same function by a 64-entry table: with c = 64 y,  j = rint(c),  r = c - j in [-1/2, 1/2] (exact),
+//     2^y = 2^(j div 64) * T[j mod 64] * 2^(r / 64),      T[k] = 2^(k / 64) rounded to fp64 (512 bytes of LDS),
+// and 2^(r / 64) - 1 = r q(r) with q of degree 4 (|r ln 2 / 64| <= 0.0054: interpolation error 0.02 ulp; tools/fit_exp2_table.py),
+// so the result is fma(T, r q(r), T) scaled by v_ldexp_f64.  13 VALU instructions -- rndne, sub, cvt, three 2-cycle integer ops for
+// the table index and the exponent, 4 fma + 1 mul + 1 fma, ldexp -- about 46 issue cycles against the 60 of the degree-11 form,
+// plus one ds_read_b64 per call (64 entries = every LDS bank twice: at most 2-way conflicts between lanes k and k + 32).
+// Error: half an ulp of T, half an ulp of the final fma, the polynomial's 0.02: <= 1.1 ulp.  Takes 64 y, so a caller that carries
+// its exponent in units of 1/64 (asian_exp64_kernel scales drift and vol once) pays no multiply.  Limits as exp2_f64.
+constexpr double kExp2Q[5] = {0.010830424696249145, 5.864904955051792e-05, 2.1173137155458003e-07, 5.732858693358711e-10, 1.2417854539440544e-12};
+__constant__ double kExp2Tab[64] = {
+    1.0, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
+    1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
+    1.0905077326652577, 1.102382583307841, 1.1143867425958924, 1.1265216186082418,
+    1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
+    1.189207115002721, 1.202156731452703, 1.215247359980469, 1.22848053610687,
+    1.241857812073484, 1.255380757024691, 1.2690509571917332, 1.2828700160787783,
+    1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.339667524053303,
+    1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
+    1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647,
+    1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384,
+    1.5422108254079407, 1.559004400237837, 1.5759808451078865, 1.593142151342267,
+    1.6104903319492543, 1.6280274218573478, 1.645755478153965, 1.6636765803267364,
+    1.681792830507429, 1.7001063537185235, 1.718619298122478, 1.7373338352737062,
+    1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989,
+    1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656,
+    1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.978456026387951,
+};
+
+__device__ __forceinline__ void exp2_table_to_lds(double* tab /* LDS [64] */) {
+    if (threadIdx.x < 64) tab[threadIdx.x] = kExp2Tab[threadIdx.x];
+    __syncthreads();
+}
+
+__device__ __forceinline__ double exp2_f64_tab(double c64, const double* tab /* LDS [64] */) {
+    const double n = __builtin_rint(c64);
+    const double r = c64 - n;
+    const int j = static_cast<int>(n);
+    const double t = tab[j & 63];
+    double q = kExp2Q[4];
+    q = __builtin_fma(q, r, kExp2Q[3]);
+    q = __builtin_fma(q, r, kExp2Q[2]);
+    q = __builtin_fma(q, r, kExp2Q[1]);
+    q = __builtin_fma(q, r, kExp2Q[0]);
+    return __builtin_ldexp(__builtin_fma(t, q * r, t), j >> 6);
+}
+
+#ifndef OLMC_EXP2_TABLE
+#define OLMC_EXP2_TABLE 1           // 0 builds the degree-11 polynomial into asian_exp64_kernel (A/B measurements)
+#endif
+
 // ------------------------------------------------------------- contracts ----
 // Host-precomputed per-contract constants, in the reference's own arithmetic
 // order (gbm_numpy.py:35-39): a = ln S + (r - q - sigma^2/2) dt * M, vol = sigma sqrt(dt).
@@ -997,15 +1047,17 @@ __global__ __launch_bounds__(kBlock) void asian_kernel(PathRange pr, AsianContra
 // add (running sum), + one v_cvt_f64_f32 shared by the legs.
 template <bool ANTI, int LIVE>
 __device__ __forceinline__ void asian_exp64_block(const float (&z)[4], double drift, double vol, double& cum_u, double& run_u,
-                                                  double& cum_d, double& run_d) {
+                                                  double& cum_d, double& run_d, const double* tab) {
 #pragma unroll
     for (int j = 0; j < LIVE; ++j) {
         const double zj = static_cast<double>(z[j]);
         cum_u += __builtin_fma(vol, zj, drift);
-        run_u += exp2_f64(cum_u);
+        if constexpr (OLMC_EXP2_TABLE) run_u += exp2_f64_tab(cum_u, tab);
+        else run_u += exp2_f64(cum_u);
         if constexpr (ANTI) {
             cum_d += __builtin_fma(-vol, zj, drift);
-            run_d += exp2_f64(cum_d);
+            if constexpr (OLMC_EXP2_TABLE) run_d += exp2_f64_tab(cum_d, tab);
+            else run_d += exp2_f64(cum_d);
         }
     }
 }
@@ -1013,9 +1065,12 @@ __device__ __forceinline__ void asian_exp64_block(const float (&z)[4], double dr
 template <bool ANTI>
 __global__ __launch_bounds__(kBlock) void asian_exp64_kernel(PathRange pr, AsianContract c, ReduceWs ws) {
     constexpr double kLog2e = 1.4426950408889634;
+    constexpr double kUnit = OLMC_EXP2_TABLE ? 64.0 * kLog2e : kLog2e;     // the exponent is carried in the units the exponential takes: 1/64 log2 (table) or log2
+    __shared__ double tab[64];
+    if constexpr (OLMC_EXP2_TABLE) exp2_table_to_lds(tab);
     double acc[2] = {0.0, 0.0};
-    const double drift = c.drift * kLog2e;              // log2 units: exp2_f64 needs no argument scaling
-    const double vol = c.vol * kZScale * kLog2e;        // applied to RAW normals
+    const double drift = c.drift * kUnit;               // no argument scaling per date
+    const double vol = c.vol * kZScale * kUnit;         // applied to RAW normals
     const int32_t full = pr.n_steps >> 2, rem = pr.n_steps & 3;
     const RoundKeys rk = pin_round_keys(pr.key0, pr.key1);       // A/B at 1M x 1024: 965 -> 940 us (antithetic 1478 -> 1467)
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
@@ -1026,13 +1081,13 @@ __global__ __launch_bounds__(kBlock) void asian_exp64_kernel(PathRange pr, Asian
         float z[4];
         for (int32_t b = 0; b < full; ++b) {            // branch-free body
             raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(b), 0u, rk, z);
-            asian_exp64_block<ANTI, 4>(z, drift, vol, cum_u, run_u, cum_d, run_d);
+            asian_exp64_block<ANTI, 4>(z, drift, vol, cum_u, run_u, cum_d, run_d, tab);
         }
         if (rem) {
             raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(full), 0u, rk, z);
-            if (rem == 1) asian_exp64_block<ANTI, 1>(z, drift, vol, cum_u, run_u, cum_d, run_d);
-            else if (rem == 2) asian_exp64_block<ANTI, 2>(z, drift, vol, cum_u, run_u, cum_d, run_d);
-            else asian_exp64_block<ANTI, 3>(z, drift, vol, cum_u, run_u, cum_d, run_d);
+            if (rem == 1) asian_exp64_block<ANTI, 1>(z, drift, vol, cum_u, run_u, cum_d, run_d, tab);
+            else if (rem == 2) asian_exp64_block<ANTI, 2>(z, drift, vol, cum_u, run_u, cum_d, run_d, tab);
+            else asian_exp64_block<ANTI, 3>(z, drift, vol, cum_u, run_u, cum_d, run_d, tab);
         }
 #pragma unroll
         for (int leg = 0; leg < (ANTI ? 2 : 1); ++leg) {
@@ -2287,9 +2342,12 @@ __global__ void publish_kernel(const double* __restrict__ src, int32_t n, double
 
 // ------------------------------------------------------- validation taps ----
 // exp2_f64 (the fp64 Asian kernel's exponential) on an array: lets the tests pin it against a reference libm point by point.
-__global__ void exp2_probe_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ y) {
+// which = 0: exp2_f64 (degree-11 polynomial); 1: exp2_f64_tab (table; the argument is scaled by 64 here, exactly)
+__global__ void exp2_probe_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ y, int which) {
+    __shared__ double tab[64];
+    exp2_table_to_lds(tab);
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x)
-        y[i] = exp2_f64(x[i]);
+        y[i] = which ? exp2_f64_tab(64.0 * x[i], tab) : exp2_f64(x[i]);
 }
 
 __global__ void philox_words_kernel(uint64_t first, int64_t n_paths, int32_t block0, int32_t n_blocks,

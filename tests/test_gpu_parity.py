@@ -519,19 +519,23 @@ def test_asian_matches_same_stream_checker(geometric, typ, anti, N, M):
         assert st.sum == pytest.approx(sx, rel=REL_STREAM_TOL) and st.sumsq == pytest.approx(sxx, rel=4 * REL_STREAM_TOL)
 
 
-def test_device_exp2_f64_is_within_two_ulp_of_libm_everywhere():
-    """exp2_f64 (olmc_kernels.h: rint + degree-11 polynomial on [-1/2, 1/2] + v_ldexp_f64) is the per-date exponential of the
-    reference-precision Asian kernel.  Against the host libm (numpy.exp2, < 1 ulp): <= 2 ulp on a dense sweep of the range
-    a cumulative log-return can take, on the reduction's seams (half-integers), and correct limits (0, inf, NaN)."""
+@pytest.mark.parametrize("form", [None, 0, 1])
+def test_device_exp2_f64_is_within_two_ulp_of_libm_everywhere(form):
+    """The per-date exponential of the reference-precision Asian kernel (olmc_kernels.h), in both forms the library carries:
+    exp2_f64 (rint + degree-11 polynomial on [-1/2, 1/2] + v_ldexp_f64) and exp2_f64_tab (64-entry table + degree-5 polynomial;
+    form None = whichever the kernel is built with).  Against the host libm (numpy.exp2, < 1 ulp): <= 2 ulp on a dense sweep of
+    the range a cumulative log-return can take, on the reduction's seams (half-integers and, for the table, the 128ths where the
+    table index rounds), and correct limits (0, inf, NaN)."""
     rng = np.random.default_rng(7)
     x = np.concatenate([rng.uniform(-60.0, 60.0, 400_000), rng.uniform(-1.0, 1.0, 400_000), rng.normal(0.0, 1e-3, 100_000),
                         np.arange(-80, 81) + 0.5, np.nextafter(np.arange(-80, 81) + 0.5, np.inf), np.nextafter(np.arange(-80, 81) + 0.5, -np.inf),
-                        np.arange(-1000, 1001, 7.0), [0.0, -0.0, 1.0, -1.0, 1e-300, -1e-300, 1023.999, -1021.5]])
-    y, want = _hip.exp2_probe(x), np.exp2(x)
+                        np.arange(-1000, 1001, 7.0), [0.0, -0.0, 1.0, -1.0, 1e-300, -1e-300, 1023.999, -1021.5],
+                        (np.arange(-4096, 4097) + 0.5) / 64.0, np.nextafter((np.arange(-4096, 4097) + 0.5) / 64.0, np.inf)])
+    y, want = _hip.exp2_probe(x, form), np.exp2(x)
     ulp = np.abs(y - want) / np.spacing(want)
     assert np.isfinite(y).all() and ulp.max() <= 2.0, (ulp.max(), x[np.argmax(ulp)])
     assert (y[np.isin(x, np.arange(-1000, 1001, 7.0))] == want[np.isin(x, np.arange(-1000, 1001, 7.0))]).all()     # exact powers of two
-    special = _hip.exp2_probe(np.array([np.nan, 1025.0, 5000.0, 1e300, -1100.0, -5000.0, -1e300, np.inf, -np.inf]))
+    special = _hip.exp2_probe(np.array([np.nan, 1025.0, 5000.0, 1e300, -1100.0, -5000.0, -1e300, np.inf, -np.inf]), form)
     assert np.isnan(special[0]) and (special[1:4] == np.inf).all()          # overflow like exp2()
     assert (special[4:7] == 0.0).all()                                       # below the subnormal range: zero like exp2()
     # documented limit of the domain: an INFINITE argument answers NaN (inf - rint(inf)), where exp2() says inf / 0.  A

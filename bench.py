@@ -583,8 +583,8 @@ def worker(args):
         every dispatch (the kernel's own begin / end timestamps).  Attaching the pair puts a marker packet in front of the
         kernel, which costs a blocking call several microseconds, so the events ride on every other pass instead of
         on all of them: `value` comes from the plain passes, the kernel duration from the instrumented ones, and both
-        pass times are reported.  The number of passes is chosen so that the plain ones alone cover `min_total_s` (every rank
-        derives it from the same max-reduced first pass).  Returns (plain pass times, instrumented pass times, per-call times of
+        pass times are reported.  Passes repeat until the plain ones alone cover `min_total_s` (at least 3, at most `max_passes`
+        of each kind).  Returns (plain pass times, instrumented pass times, per-call times of
         the plain passes on this rank, avg kernel seconds, launches timed, worst |price - BS| / se, prices of the first pass)."""
         worst, calls, first = 0.0, [], []
 
@@ -598,8 +598,9 @@ def worker(args):
             check(step(seed0 + 100_000 + k))
         _hip.profile_enable(True)       # pre-creates the event pool outside the timed region
         _hip.profile_reset()
-        passes, inst_passes, n_pass = [], [], None
-        while n_pass is None or len(inst_passes) < n_pass:
+        passes, inst_passes = [], []
+        # every rank sees the same max-reduced pass times, so every rank stops after the same pass
+        while len(inst_passes) < len(passes) or len(passes) < 3 or (sum(passes) < min_total_s and len(passes) < max_passes):
             instrumented = len(passes) > len(inst_passes)          # plain, instrumented, plain, ...
             _hip.profile_enable(instrumented)
             base = seed0 + (len(passes if not instrumented else inst_passes) * steps) % 1_000_000     # both kinds walk the same seeds
@@ -619,8 +620,6 @@ def worker(args):
             if not passes and not instrumented:
                 first.extend(res[0] for res in results)
             (inst_passes if instrumented else passes).append(dt)
-            if n_pass is None:          # every rank derives the same count from the same max-reduced time
-                n_pass = max(3, min(max_passes, int(math.ceil(min_total_s / max(dt, 1e-9)))))
             if instrumented and len(inst_passes) % 16 == 0:
                 _hip.kernel_time()      # drain the event pool as the passes go (4096 pairs)
         launches, kernel_ms = _hip.kernel_time()
@@ -675,7 +674,7 @@ def worker(args):
         roof = roofline_for(pmc, pmc_key, avg_kernel_s, N_STEPS, paths_per_gpu, costs, mixes, clock_ghz) if pmc_key else None
         if roof is None:
             roof = {"bound": "valu", "achieved": None, "peak": N_SIMD * PEAK_GHZ, "unit": "G VALU issue-cycles/s (peak = 1024 SIMDs x 2.4 GHz)", "frac": None,
-                    "traffic": None, "avg_kernel_ms": avg_kernel_s * 1e3 if avg_kernel_s else None,
+                    "traffic": None, "avg_kernel_ms": avg_kernel_s * 1e3 if avg_kernel_s else None, "clock_ghz_under_load": clock_ghz,
                     "why_null": (pmc or {}).get("error", "no PMC counters for this launch size (only 1M and 8M paths per launch are profiled)")}
         roof.update({
             "kernel": "european_path_kernel<1,true,kReduce,false>", "launches_timed": launches,

@@ -365,8 +365,10 @@ int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_
  * the totals stamps once more.  stamps_host (caller-owned, `capacity` words >= 5 * workgroups + 1) receives [workgroup][5] then
  * the final stamp; info3 = {workgroups,
  * index of the first split workgroup (= workgroups when none), duration of the dispatch in ns by its own begin / end
- * timestamps}.  Measurement only (tools/phase_stamps.py); prices nothing. */
-int olmc_phase_stamps(int64_t n_paths, int32_t n_steps, uint64_t seed, uint64_t* stamps_host, int64_t capacity, int64_t* info3);
+ * timestamps}.  `lead_launches` identical launches are queued back to back in front of the recorded one, so that it runs at the
+ * clock the device holds under this load.  Measurement only (tools/phase_stamps.py); prices nothing. */
+int olmc_phase_stamps(int64_t n_paths, int32_t n_steps, uint64_t seed, int32_t lead_launches, uint64_t* stamps_host, int64_t capacity,
+                      int64_t* info3);
 
 /* Shader clock the device holds while every SIMD runs the headline kernel's step loop (n_paths x n_steps, one
  * workgroup per 256 paths): out3 = {median shader cycles of a workgroup's loop (s_memtime), median 100 MHz ticks of

@@ -92,7 +92,7 @@ PROTOTYPES = {
     "olmc_exp2_probe_form": (_I, [C.POINTER(_D), _I64, C.POINTER(_D), _I]),
     "olmc_normal_moments": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(_D)]),
     "olmc_normals": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(C.c_float)]),
-    "olmc_phase_stamps": (_I, [_I64, _I32, _U64T, C.POINTER(C.c_uint64), _I64, C.POINTER(_I64)]),
+    "olmc_phase_stamps": (_I, [_I64, _I32, _U64T, _I32, C.POINTER(C.c_uint64), _I64, C.POINTER(_I64)]),
     "olmc_clock_probe": (_I, [_I64, _I32, _U64T, C.POINTER(_D)]),
     "olmc_issue_probe": (_I, [_I, _I, C.POINTER(_D)]),
     "olmc_profile_enable": (_I, [_I]),
@@ -540,13 +540,13 @@ def normal_moments(seed: int, n_paths: int, n_steps: int, path_offset: int = 0):
     return tuple(out)
 
 
-def phase_stamps(n_paths: int = 1_000_000, n_steps: int = 252, seed: int = 42):
+def phase_stamps(n_paths: int = 1_000_000, n_steps: int = 252, seed: int = 42, lead_launches: int = 20):
     """(stamps[workgroups, 5]: four stamps in 100 MHz ticks + HW_ID | XCC_ID << 32, final stamp, first split workgroup, dispatch ns) of
     one instrumented launch (olmc_phase_stamps)."""
     cap = 5 * ((int(n_paths) + 63) // 64 + 1024) + 1
     buf = np.zeros(cap, dtype=np.uint64)
     info = (C.c_int64 * 3)()
-    _check(lib().olmc_phase_stamps(int(n_paths), int(n_steps), seed64(seed), buf.ctypes.data_as(C.POINTER(C.c_uint64)), cap, info))
+    _check(lib().olmc_phase_stamps(int(n_paths), int(n_steps), seed64(seed), int(lead_launches), buf.ctypes.data_as(C.POINTER(C.c_uint64)), cap, info))
     grid = int(info[0])
     return buf[:5 * grid].reshape(grid, 5).astype(np.int64), int(buf[5 * grid]), int(info[1]), int(info[2])
 

@@ -21,9 +21,8 @@ TICK_US = 0.01          # s_memrealtime: 100 MHz
 
 
 def one(n, m, seed):
-    for k in range(20):             # load in front of every instrumented launch: it is timed at the clock the production kernel runs at
-        _hip.european(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, True, n, m, k, True)
-    st, final, split_from, disp_ns = _hip.phase_stamps(n, m, seed)
+    # 30 identical launches queued back to back in front of the recorded one: it runs at the clock the production kernel runs at
+    st, final, split_from, disp_ns = _hip.phase_stamps(n, m, seed, lead_launches=30)
     where = st[:, 4]
     st = st[:, :4]
     t0 = int(st[:, 0].min())

@@ -20,6 +20,14 @@ def newest(pattern):
 
 
 def bench_line(path):
+    """The record of a bench.py pass: the full one (<pass>.detail.json, written next to the one-line JSON) when it is there,
+    else the stdout line."""
+    stem = path[:-len(".log")] if path.endswith(".log") else path[:-len(".json")]
+    try:
+        with open(stem + ".detail.json") as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        pass
     try:
         for l in open(path):
             if l.startswith('{"metric"'):
@@ -41,7 +49,7 @@ def main(root):
         if line:
             r = line["roofline"]
             print(f"bench.py of that (profiled) run: value {line['value']:.4g} {line['unit']}, ms_per_step {line['ms_per_step']:.4f}, "
-                  f"roofline.avg_kernel_ms {r['avg_kernel_ms']:.4f} (HIP events attached to {r['launches_timed']} dispatches)")
+                  f"roofline.avg_kernel_ms {r['avg_kernel_ms']:.4f} (HIP events attached to {r.get('launches_timed')} dispatches)")
         # the headline kernel's dispatches by bench.py phase: pre-warm / warm-up / timed passes
         for f in newest(os.path.join(root, sub, "**", "*_kernel_trace.csv")):
             rows = sorted((r for r in csv.DictReader(open(f)) if "european_path_kernel<1, true, 0, false>" in r["Kernel_Name"]), key=lambda r: int(r["Dispatch_Id"]))

@@ -117,3 +117,32 @@ def test_qmc_terminal_equals_the_scipy_based_oracle(N, M, seed, S, v, r, q, T, o
         want = orc.terminal_sobol(S, T, r, v, q, N + off, M, seed)[off:]
     got = _hip.european_qmc_terminal(S, T, r, v, q, N, *ol.monte_carlo.sobol_tables(M, seed), point_offset=off)
     assert got.shape == want.shape and np.allclose(got, want, rtol=1e-11, atol=0)
+
+
+# ---- sets of contracts on common normals (the fused Greeks machinery) ----------------------------------------------------------
+# A set is laid out by the host (group_contracts): contracts with bit-identical sigma * sqrt(dt) form a group behind one base (a
+# pair of exps), the others take scale * S_T(base); slot NSETS / 2 is always a base because the kernel walks the two halves as two
+# streams.  Random group structures probe every such layout: groups that straddle the middle, sets of 2..16 contracts (8- and
+# 16-slot kernels with padding), with and without antithetic legs, ragged path counts (dead lanes carry a NaN normal sum), split
+# workgroups (M >= 64), many workgroups (wide rows summed by the whole workgroup, one and two reduction levels).
+contracts = st.lists(st.tuples(st.integers(0, 5), st.floats(60.0, 140.0), st.floats(-5.0, 5.0), st.floats(-0.02, 0.02), st.booleans()),
+                     min_size=2, max_size=16)
+batch_paths = st.one_of(st.integers(1, 600), st.sampled_from([255, 256, 257, 70_000, 131_073]))
+batch_steps = st.one_of(st.integers(1, 20), st.sampled_from([63, 64, 65, 130]))
+
+
+@settings(max_examples=40 * SCALE, **COMMON)
+@given(cs=contracts, N=batch_paths, M=batch_steps, seed=seeds, off=offsets, S=spot, r=rate, q=div, T=mat, anti=st.booleans())
+def test_european_batch_prices_every_contract_as_its_own_launch_does(cs, N, M, seed, off, S, r, q, T, anti):
+    """olmc_european_batch (one launch, one set of normals) against one olmc_european_shard launch per contract on the same
+    stream.  A base contract evaluates the very same expressions as the single launch; a contract that shares its vol with a
+    base takes scale * S_T(base) with scale = exp(a - a_base) -- a few ulp of S_T, i.e. ~1e-15 relative on a sum of prices;
+    the reduction orders differ (1e-16 per addition).  Tolerance 1e-11 relative on sum and sum of squares."""
+    vols = [0.1 + 0.07 * g for g in range(6)]
+    opts = [(S + dS, K, T, r + dr, vols[g], q, call) for (g, K, dS, dr, call) in cs]        # same g => same vol bits: S- and r-bumps of one another
+    got = _hip.european_batch(opts, N, M, seed, anti, path_offset=off)
+    for o, g in zip(opts, got):
+        one = _hip.european(*o[:6], o[6], N, M, seed, anti, path_offset=off)
+        assert g.n == one.n
+        assert g.sum == pytest.approx(one.sum, rel=1e-11, abs=1e-9) and g.sumsq == pytest.approx(one.sumsq, rel=1e-11, abs=1e-7)
+        assert g.price == pytest.approx(one.price, rel=1e-11, abs=1e-12)

@@ -57,7 +57,7 @@ def device_asm():
 def function_body(lines, pattern):
     rx = re.compile(pattern)
     start = next(i for i, l in enumerate(lines) if rx.match(l) and l.rstrip().split(";")[0].strip().endswith(":"))
-    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))      # a kernel may hold several s_endpgm (early exits)
     return lines[start:end + 1]
 
 

@@ -76,6 +76,10 @@ def one(n, m, seed):
 
 def main():
     _hip.lib()
+    if os.environ.get("OLMC_AB_TUNE"):                      # "knob=value,knob=value", as tools/ab_libs.py
+        for kv in os.environ["OLMC_AB_TUNE"].split(","):
+            k, v = kv.split("=")
+            _hip.tune(int(k), int(v))
     for k in range(2500):
         _hip.european(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, True, 1_000_000, 252, k, True)
     print(json.dumps({"device": _hip.device_info(), "what": "medians over launches of olmc_phase_stamps; microseconds from the first wave's entry stamp"}), flush=True)

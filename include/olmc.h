@@ -40,7 +40,9 @@
 extern "C" {
 #endif
 
-#define OLMC_ABI_VERSION 2   /* 2: olmc_asian avg_kind 0 is the fp64-exponent kernel (2 = the fp32 one); probes, tune knobs 5-8 */
+#define OLMC_ABI_VERSION 3   /* 2: olmc_asian avg_kind 0 is the fp64-exponent kernel (2 = the fp32 one); probes, tune knobs 5-8
+                              * 3: additions only -- olmc_european_qmc_batch, olmc_european_qmc_greeks_fd, olmc_multi_capacity,
+                              *    olmc_exp2_probe_form, olmc_phase_stamps, tune knob 9; every v2 entry point keeps its signature and meaning */
 
 enum {
     OLMC_OK = 0,

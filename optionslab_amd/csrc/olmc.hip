@@ -278,6 +278,7 @@ int32_t european_launch_shape(const DeviceCtx* c, PathRange* pr, int occ) {
 // The kernel launch_european<NSETS, MODE> will pick for a launch that covers every path (the only shape that splits).
 template <int NSETS, int MODE>
 int european_occupancy(bool anti) {
+    if (g_split_sat <= 0) return 0;              // only the measurement knob needs it: nothing on the path of an ordinary call
     return anti ? resident_workgroups(european_path_kernel<NSETS, true, MODE, false>) : resident_workgroups(european_path_kernel<NSETS, false, MODE, false>);
 }
 

@@ -76,8 +76,8 @@ def load_isa_mix():
 
 PMC_KERNELS = {         # substring of the demangled kernel name -> key in the JSON
     "european_path_kernel<1, true, 0, false>": "c2_european",
-    "european_path_kernel<8, true, 0, false>": "c3_fused8",
-    "european_path_kernel<16, true, 0, false>": "c3_fused14",
+    "european_path_kernel<8, true, 3, false>": "c3_fused8",        # MODE 3 = kSumOnly: what MonteCarloPricer.greeks() launches (prices only)
+    "european_path_kernel<16, true, 3, false>": "c3_fused14",
     "asian_exp64_kernel<false>": "c4_asian_fp64",
     "asian_exp64_kernel<true>": "c4_asian_fp64_antithetic",
     "asian_kernel<false, false>": "c4_asian_fp32",
@@ -855,15 +855,19 @@ def pipelined(args, torch, dist, _hip, sharding, use_dist, rehearsal, world, ran
 
 
 def _timed_calls(_hip, fn, reps, warm=3):
+    """(median wall of a call, kernel seconds per launch, launches per call).  Two loops: the wall is taken with the dispatch events
+    OFF (an event pair puts a marker packet in front of the kernel: +9 us on a blocking call), the kernel time with them on."""
     for _ in range(warm):
         fn()
-    _hip.profile_enable(True)
-    _hip.profile_reset()
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter()
         fn()
         ts.append(time.perf_counter() - t0)
+    _hip.profile_enable(True)
+    _hip.profile_reset()
+    for _ in range(reps):
+        fn()
     launches, kernel_ms = _hip.kernel_time()
     _hip.profile_enable(False)
     return statistics.median(ts), (kernel_ms / 1e3 / launches if launches else None), launches // reps

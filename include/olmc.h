@@ -158,7 +158,9 @@ int olmc_multi_capacity(int64_t* out2);
 /* Finite-difference Greeks, bumps exactly as unified_greeks.py:274-277, 295-362.
  * out9 = {price, delta, gamma, vega, theta, rho, vanna, charm, vomma}; the last
  * three are written only when second_order != 0.  `evals` (nullable) receives
- * the 8 or 14 per-evaluation stats in the reference's call order. */
+ * the 8 or 14 per-evaluation stats in the reference's call order; with evals == NULL
+ * the launch reduces the prices only (no sums of squares: nobody would read the
+ * standard errors), which is the faster form. */
 int olmc_european_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call,
                             int64_t n_paths, int32_t n_steps, uint64_t seed, int second_order,
                             double* out9, olmc_stats* evals /* [14] or NULL */);

@@ -47,6 +47,7 @@ class DevInfo(C.Structure):
 
 _D, _I, _I32, _I64, _U64T, _P = C.c_double, C.c_int, C.c_int32, C.c_int64, C.c_uint64, C.c_void_p
 _byref = C.byref
+_Out9 = C.c_double * 9
 _SIX = [_D] * 6
 
 # name -> (restype, argtypes); must list every symbol include/olmc.h declares
@@ -270,12 +271,18 @@ def multi_capacity() -> Tuple[int, int]:
 def european_greeks_fd(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int, seed: int,
                        second_order: bool, want_evals: bool = True) -> Tuple[List[float], List[Stats]]:
     """(price, delta, gamma, vega, theta, rho, vanna, charm, vomma) and -- unless want_evals is False, which spares a blocking
-    Greeks call the marshalling of fourteen structs -- the statistics of the bumped contracts in the reference's call order."""
-    out9 = (C.c_double * 9)()
-    evals = (Stats * 14)() if want_evals else None
-    _check(lib().olmc_european_greeks_fd(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(n_steps), seed64(seed),
-                                         int(second_order), out9, evals))
-    return list(out9), (list(evals) if want_evals else [])
+    Greeks call the marshalling of fourteen structs AND lets the library launch its prices-only kernel -- the statistics of the
+    bumped contracts in the reference's call order."""
+    out9 = _Out9()
+    if want_evals:
+        evals = (Stats * 14)()
+        _check(lib().olmc_european_greeks_fd(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(n_steps), seed64(seed),
+                                             int(second_order), out9, evals))
+        return list(out9), list(evals)
+    rc = lib().olmc_european_greeks_fd(S, K, T, r, sigma, q, bool(is_call), int(n_paths), int(n_steps), int(seed) & _U64, bool(second_order), out9, None)
+    if rc:                              # the hot blocking call of greeks(): no helper frames on the success path
+        _check(rc)
+    return out9[:], []
 
 
 def european_terminal(S, T, r, sigma, q, n_paths: int, n_steps: int, seed: int, antithetic: bool = True) -> np.ndarray:

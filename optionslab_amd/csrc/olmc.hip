@@ -432,6 +432,7 @@ Contract make_contract(const olmc_option& o, int32_t n_steps) {
     c.sign = o.is_call ? 1.0 : -1.0;
     c.scale = 1.0;                                   // a base until group_contracts says otherwise
     c.neg_sign_strike = -c.sign * o.K;
+    c.sign_scale = c.sign;
     return c;
 }
 
@@ -458,6 +459,7 @@ void group_contracts(const olmc_option* opts, int32_t k, int32_t n_steps, Contra
         } else {
             set->c[slot].scale = std::exp(all[j].a - set->c[base_slot].a);
         }
+        set->c[slot].sign_scale = set->c[slot].sign * set->c[slot].scale;
         pos[j] = slot++;
         placed[j] = true;
         return base_slot;
@@ -472,6 +474,7 @@ void group_contracts(const olmc_option* opts, int32_t k, int32_t n_steps, Contra
     for (; slot < NSETS; ++slot) {                   // padding: cheap non-base copies (a base of its own if it opens the second half)
         set->c[slot] = set->c[slot - 1];
         set->c[slot].scale = 1.0;
+        set->c[slot].sign_scale = set->c[slot].sign;
         if (slot == NSETS / 2) set->base_mask |= 1u << slot;
     }
 }
@@ -571,14 +574,19 @@ void launch_european(bool anti, int32_t grid, hipStream_t s, const PathRange& pr
 // (padded to the kernel's NSETS) and, when tail >= 0, `tail` in d_out[2 * nsets].
 int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32_t k, int64_t path_offset,
                      int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic, double* d_out, double tail,
-                     int* pos /* [k]: slot of contract i in d_out, may be NULL when k == 1 */) {
+                     int* pos /* [k]: slot of contract i in d_out, may be NULL when k == 1 */, bool* sums_only = nullptr
+                     /* in: the caller needs no sums of squares; out: the launch made left ONE sum per slot (d_out[slot]) */) {
     PathRange pr = make_range(path_offset, n_local, n_steps, seed);
     const bool anti = antithetic != 0;
     const int nsets = k == 1 ? 1 : (k <= 8 ? 8 : 16);
     const int occ = nsets == 1 ? european_occupancy<1, kReduce>(anti) : (nsets == 8 ? european_occupancy<8, kReduce>(anti) : european_occupancy<16, kReduce>(anti));
     const int32_t grid = european_launch_shape(c, &pr, occ);
+    // prices only (finite-difference Greeks without their evaluations' standard errors): the sum-only form of the fused kernels,
+    // where the launch covers every path
+    const bool lean = sums_only && *sums_only && nsets > 1 && static_cast<int64_t>(grid) * kBlock >= n_local;
+    if (sums_only) *sums_only = lean;
     ReduceWs ws;
-    int rc = make_ws(c, s, grid, 2 * nsets, d_out, tail, &ws);
+    int rc = make_ws(c, s, grid, lean ? nsets : 2 * nsets, d_out, tail, &ws);
     if (rc) return rc;
     EventPair ep{};
     const EventPair* timed = nullptr;
@@ -593,11 +601,15 @@ int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32
     } else if (nsets == 8) {
         ContractSet<8> cs;
         group_contracts<8>(opts, k, n_steps, &cs, pos);
-        launch_european<8, kReduce>(anti, grid, s, pr, cs, ws, nullptr, timed);
+        if (!lean) launch_european<8, kReduce>(anti, grid, s, pr, cs, ws, nullptr, timed);
+        else if (anti) launch_one(european_path_kernel<8, true, kSumOnly, false>, grid, s, timed, pr, cs, ws, nullptr);
+        else launch_one(european_path_kernel<8, false, kSumOnly, false>, grid, s, timed, pr, cs, ws, nullptr);
     } else {
         ContractSet<16> cs;
         group_contracts<16>(opts, k, n_steps, &cs, pos);
-        launch_european<16, kReduce>(anti, grid, s, pr, cs, ws, nullptr, timed);
+        if (!lean) launch_european<16, kReduce>(anti, grid, s, pr, cs, ws, nullptr, timed);
+        else if (anti) launch_one(european_path_kernel<16, true, kSumOnly, false>, grid, s, timed, pr, cs, ws, nullptr);
+        else launch_one(european_path_kernel<16, false, kSumOnly, false>, grid, s, timed, pr, cs, ws, nullptr);
     }
     rc = after_launch(c, s);
     if (rc) return rc;
@@ -664,7 +676,7 @@ int sync_or_recover(DeviceCtx* c, hipStream_t s) {
 }
 
 int run_batch(const olmc_option* opts, int32_t k, int64_t path_offset, int64_t n_local, int32_t n_steps,
-              uint64_t seed, int antithetic, olmc_stats* out) {
+              uint64_t seed, int antithetic, olmc_stats* out, bool prices_only = false) {
     if (!opts || !out) return fail(OLMC_ERR_ARG, "null pointer");
     if (k < 1 || k > OLMC_MAX_BATCH) return fail(OLMC_ERR_ARG, "batch size must be in [1, OLMC_MAX_BATCH]");
     int rc = check_paths(path_offset, n_local, n_steps);
@@ -674,14 +686,20 @@ int run_batch(const olmc_option* opts, int32_t k, int64_t path_offset, int64_t n
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(c->mu);
     int pos[OLMC_MAX_BATCH];
-    rc = run_batch_device(c, c->stream, opts, k, path_offset, n_local, n_steps, seed, antithetic, c->d_result, -1.0, pos);
+    bool lean = prices_only;
+    rc = run_batch_device(c, c->stream, opts, k, path_offset, n_local, n_steps, seed, antithetic, c->d_result, -1.0, pos, &lean);
     if (rc) return rc;
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     const int64_t n = n_local * (antithetic ? 2 : 1);
     for (int i = 0; i < k; ++i) {
-        if (poisoned(opts[i].S, opts[i].K, opts[i].T, opts[i].r, opts[i].sigma, opts[i].q)) nan_stats(n, &out[i]);
-        else finish_stats(c->h_result[2 * pos[i]], c->h_result[2 * pos[i] + 1], n, opts[i].r, opts[i].T, &out[i]);
+        if (poisoned(opts[i].S, opts[i].K, opts[i].T, opts[i].r, opts[i].sigma, opts[i].q)) {
+            nan_stats(n, &out[i]);
+        } else if (lean) {                           // one sum per slot: the price is exact, the standard error was not asked for
+            finish_stats(c->h_result[pos[i]], std::nan(""), n, opts[i].r, opts[i].T, &out[i]);
+        } else {
+            finish_stats(c->h_result[2 * pos[i]], c->h_result[2 * pos[i] + 1], n, opts[i].r, opts[i].T, &out[i]);
+        }
     }
     return OLMC_OK;
 }
@@ -996,7 +1014,7 @@ extern "C" int olmc_european_greeks_fd(double S, double K, double T, double r, d
     if (!(T > 0.0)) return fail(OLMC_ERR_ARG, "T must be > 0 (price() returns intrinsic value without simulating)");
     const GreeksSet gs(S, K, T, r, sigma, q, is_call, second_order);
     olmc_stats st[OLMC_MAX_BATCH];
-    int rc = run_batch(gs.o, gs.k, 0, n_paths, n_steps, seed, 1, st);
+    int rc = run_batch(gs.o, gs.k, 0, n_paths, n_steps, seed, 1, st, /*prices_only=*/evals == nullptr);     // no evaluations asked for: no sums of squares
     if (rc) return rc;
     gs.finish(st, T, out9, evals);
     return OLMC_OK;
@@ -1640,6 +1658,7 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
     ct.sign = is_call ? 1.0 : -1.0;
     ct.scale = 1.0;
     ct.neg_sign_strike = -ct.sign * K;
+    ct.sign_scale = ct.sign;
     QmcRange qr;
     qr.first = static_cast<uint64_t>(point_offset);
     qr.count = n_paths;

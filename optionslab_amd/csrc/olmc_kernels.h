@@ -656,6 +656,8 @@ struct Contract {
                      // exp(a - a_base): the S- and r-bumped contracts of a Greeks batch cost a multiply instead of two fp64 exps
     double neg_sign_strike;   // -sign * K: payoff = max(fma(sign, S_T, -sign K), 0) -- the same bits as sign * (S_T - K) for sign = +-1
                               // (one rounding of +-(S_T - K) either way), one instruction fewer per sample
+    double sign_scale;        // sign * scale (exact): the fused-Greeks epilogue forms max(fma(sign_scale, S_T(base), -sign K), 0) -- for a
+                              // base (scale 1) the very same bits as above, for a scaled contract one rounding fewer and one multiply fewer
 };
 
 template <int NSETS>
@@ -674,7 +676,7 @@ struct PathRange {
                           // there); INT32_MAX = none.  Other kernels ignore it.
 };
 
-enum Mode : int { kReduce = 0, kTerminal = 1, kControlVariate = 2 };
+enum Mode : int { kReduce = 0, kTerminal = 1, kControlVariate = 2, kSumOnly = 3 };   // kSumOnly: sum x per contract, no sum x^2 (prices only)
 
 template <int MODE>
 __device__ __forceinline__ void add_sample(double (&acc)[MODE == kControlVariate ? 5 : 2], double x, double st) {
@@ -744,7 +746,7 @@ __device__ __forceinline__ void european_payoffs(const ContractSet<NSETS>& cs, d
 
 // The two sums (x_u + x_d, x_u^2 + x_d^2) of ONE contract for this lane's path.  `base_st` is the pair of terminal prices of the
 // latest base contract of the stream the caller walks (a base refreshes it, the others scale it).
-template <bool ANTI>
+template <bool ANTI, bool SQUARES = true>
 __device__ __forceinline__ void contract_sums(const Contract& c, bool is_base, double zsum, double (&base_st)[2], double& sum, double& sumsq) {
     if (is_base) {                                   // wave-uniform scalar branch, kept real (see european_payoffs)
         asm volatile("");
@@ -752,14 +754,14 @@ __device__ __forceinline__ void contract_sums(const Contract& c, bool is_base, d
         base_st[0] = exp(c.a + dz);
         if constexpr (ANTI) base_st[1] = exp(c.a - dz);
     }
-    // scale = 1 exactly for a base: one multiply for every contract, no select between "own" and "scaled" prices
-    const double xu = fmax(__builtin_fma(c.sign, c.scale * base_st[0], c.neg_sign_strike), 0.0);
-    sum = xu;                                        // the additions of add_sample<kReduce> on accumulators born at zero, term by term
-    sumsq = xu * xu;
+    // sign_scale = +-1 exactly for a base: one fma for every contract, no select between "own" and "scaled" prices
+    const double xu = fmax(__builtin_fma(c.sign_scale, base_st[0], c.neg_sign_strike), 0.0);
+    sum = xu;                                        // add_sample<kReduce> on accumulators born at zero
+    if constexpr (SQUARES) sumsq = xu * xu;
     if constexpr (ANTI) {
-        const double xd = fmax(__builtin_fma(c.sign, c.scale * base_st[1], c.neg_sign_strike), 0.0);
+        const double xd = fmax(__builtin_fma(c.sign_scale, base_st[1], c.neg_sign_strike), 0.0);
         sum += xd;
-        sumsq += xd * xd;
+        if constexpr (SQUARES) sumsq = __builtin_fma(xd, xd, sumsq);      // one rounding fewer than x_d^2 rounded, then added: the squares feed the standard error only
     }
 }
 
@@ -770,24 +772,32 @@ __device__ __forceinline__ void contract_sums(const Contract& c, bool is_base, d
 // (round 2: 84 VGPRs, 5 waves per SIMD; the loop alone needs 66 = 7 waves).  The two half-sets are walked as two streams,
 // each with its own latest base: the host lays the set out so that slot NSETS/2 is a base (group_contracts).
 // `zsum` is NaN in dead lanes (all their payoffs are then exact zeros, see european_payoffs).
-template <int NSETS, bool ANTI>
-__device__ __forceinline__ void european_payoffs_folded(const ContractSet<NSETS>& cs, double zsum, double (&kept)[NSETS]) {
+//
+// SQUARES = false (kSumOnly): only sum x per contract -- what finite-difference Greeks need (prices, no standard errors): NSETS
+// values per lane, NSETS / 2 after the fold, two of the seven fp64 operations per contract and half of every exchange gone.
+template <int NSETS, bool ANTI, bool SQUARES = true>
+__device__ __forceinline__ void european_payoffs_folded(const ContractSet<NSETS>& cs, double zsum, double (&kept)[SQUARES ? NSETS : NSETS / 2]) {
     constexpr int H = NSETS / 2;
     double base_lo[2] = {0.0, 0.0}, base_hi[2] = {0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < H; ++s) {
-        double a0, a1, b0, b1;
-        contract_sums<ANTI>(cs.c[s], ((cs.base_mask >> s) & 1u) != 0u, zsum, base_lo, a0, a1);
-        contract_sums<ANTI>(cs.c[s + H], ((cs.base_mask >> (s + H)) & 1u) != 0u, zsum, base_hi, b0, b1);
-        kept[2 * s] = swap_add<32>(a0, b0);
-        kept[2 * s + 1] = swap_add<32>(a1, b1);
+        double a0, a1 = 0.0, b0, b1 = 0.0;
+        contract_sums<ANTI, SQUARES>(cs.c[s], ((cs.base_mask >> s) & 1u) != 0u, zsum, base_lo, a0, a1);
+        contract_sums<ANTI, SQUARES>(cs.c[s + H], ((cs.base_mask >> (s + H)) & 1u) != 0u, zsum, base_hi, b0, b1);
+        if constexpr (SQUARES) {
+            kept[2 * s] = swap_add<32>(a0, b0);
+            kept[2 * s + 1] = swap_add<32>(a1, b1);
+        } else {
+            kept[s] = swap_add<32>(a0, b0);          // value s of NSETS meets value s + NSETS / 2
+        }
     }
 }
 
 template <int NSETS, bool ANTI, int MODE, bool STRIDED>
 __global__ __launch_bounds__(kBlock) void european_path_kernel(PathRange pr, ContractSet<NSETS> cs, ReduceWs ws,
                                                                double* __restrict__ terminal) {
-    constexpr int NV = (MODE == kControlVariate) ? 5 : 2 * NSETS;
+    constexpr int NV = (MODE == kControlVariate) ? 5 : (MODE == kSumOnly ? NSETS : 2 * NSETS);
+    static_assert(MODE != kSumOnly || (!STRIDED && NSETS > 1), "kSumOnly exists for the fused sets on launches that cover every path");
     if constexpr (STRIDED) {
         double acc[NV];
 #pragma unroll
@@ -818,11 +828,12 @@ __global__ __launch_bounds__(kBlock) void european_path_kernel(PathRange pr, Con
         }
         zsum *= kZScale;
         const bool payer = !split || wave == 0;         // waves 1..3 of a split workgroup carry no path through the payoffs (wave-uniform)
-        if constexpr (MODE == kReduce && NSETS > 1) {
-            double kept[NSETS];                         // born after the step loop, and only NSETS of them (folded first exchange)
+        if constexpr ((MODE == kReduce || MODE == kSumOnly) && NSETS > 1) {
+            constexpr int KEPT = NV / 2;                // born after the step loop, and only half of the NV sums (folded first exchange)
+            double kept[KEPT];
 #pragma unroll
-            for (int k = 0; k < NSETS; ++k) kept[k] = 0.0;
-            if (payer) european_payoffs_folded<NSETS, ANTI>(cs, i < pr.count ? zsum : __builtin_nan(""), kept);
+            for (int k = 0; k < KEPT; ++k) kept[k] = 0.0;
+            if (payer) european_payoffs_folded<NSETS, ANTI, MODE == kReduce>(cs, i < pr.count ? zsum : __builtin_nan(""), kept);
             block_then_grid_reduce_from<NV, 1>(kept, ws);
         } else {
             double acc[NV];

@@ -88,6 +88,7 @@ def _check_sobol_tables(val, eng, d: int) -> None:
 
 NUMBA_AVAILABLE = False          # kept for `from ...monte_carlo import NUMBA_AVAILABLE` (monte_carlo.py:189)
 GREEK_KEYS = ("price", "delta", "gamma", "vega", "theta", "rho", "vanna", "charm", "vomma")
+_GREEK_KEYS6 = GREEK_KEYS[:6]
 
 
 class MCMethod(Enum):
@@ -178,6 +179,12 @@ class MonteCarloPricer:
         """Additive convenience: the OrderedDict compute_greeks_unified(self, ...)
         returns (src/greeks/unified_greeks.py:235-367), from ONE fused launch that
         draws the normals once and evaluates all 8 / 14 bumped contracts per path."""
+        if T > 0:                   # what compute_greeks_unified(self, ...) does for this pricer, minus its dispatch (T <= 0 takes its branch there)
+            try:
+                return self._fused_greeks(S, K, T, r, sigma, option_type, q, include_second_order, seed)
+            except Exception as e:  # unified_greeks.py:366-367
+                from .exceptions import GreeksError
+                raise GreeksError(f"Failed to compute unified Greeks: {str(e)}") from e
         from .greeks import compute_greeks_unified
 
         kw = {} if seed is None else {"seed": seed}
@@ -192,8 +199,7 @@ class MonteCarloPricer:
         else:
             vals, _ = _hip.european_greeks_fd(S, K, T, r, sigma, q, option_type == "call", self.num_simulations,
                                               self._steps(), actual_seed, include_second_order, want_evals=False)
-        n = 9 if include_second_order else 6
-        return OrderedDict((k, float(v)) for k, v in zip(GREEK_KEYS[:n], vals[:n]))
+        return OrderedDict(zip(GREEK_KEYS if include_second_order else _GREEK_KEYS6, vals))      # zip stops at the shorter: 6 or 9 floats
 
 
 __all__ = ["MonteCarloPricer", "MCMethod", "MCResult", "NUMBA_AVAILABLE"]

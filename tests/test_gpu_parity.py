@@ -460,6 +460,23 @@ def test_fused_greeks_equal_literal_bump_and_reprice(second):
     assert fused == p.greeks(*ATM, "call", 0.0, include_second_order=second)
 
 
+@pytest.mark.parametrize("second", [False, True])
+@pytest.mark.parametrize("N,M", [(200_000, 52), (777, 7), (1_000_000, 252)])
+def test_prices_only_greeks_equal_the_greeks_with_their_evaluations(second, N, M):
+    """olmc_european_greeks_fd with evals == NULL (what MonteCarloPricer.greeks() calls) launches the sum-only form of the fused kernel
+    (kSumOnly: no sums of squares, half the exchanges); with evals it launches the full one.  Same paths, same payoffs, another
+    association of the lane sums: every Greek within 1e-13 x price x its finite-difference amplification of the other form's, and
+    the evaluations the full form returns carry the standard errors the lean form never computed."""
+    amp = _fd_amplification()
+    lean, none = _hip.european_greeks_fd(*ATM, 0.0, True, N, M, 42, second, want_evals=False)
+    full, evals = _hip.european_greeks_fd(*ATM, 0.0, True, N, M, 42, second, want_evals=True)
+    assert none == [] and len(evals) == 14 and evals[0].std_error > 0 and evals[0].n == 2 * N
+    keys = ol.monte_carlo.GREEK_KEYS[:9 if second else 6]
+    for k, a, b in zip(keys, lean, full):
+        assert a == pytest.approx(b, abs=1e-13 * full[0] * amp[k] + 1e-13), k
+    assert lean[0] == pytest.approx(evals[0].price, rel=1e-13)
+
+
 def test_greeks_against_reference_golden_and_black_scholes(golden):
     exact = orc.bs_greeks(*ATM, "call")
     g7 = next(c for c in golden["greeks"] if c["ctor"][:2] == [100000, 252] and not c["include_second_order"])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of whole libolmc builds: one subprocess per (library, round), each timing the
 European path kernel with HIP events (olmc_kernel_time).  Usage (GPU box):
-    python tools/ab_libs.py libA.so libB.so ... [--n 1000000] [--m 252] [--rounds 7] [--case european|greeks8|greeks14|asian|asian_fast|asian_fast_anti|asian_anti|asian_geo|barrier|heston|merton|kou|autocall[_anti]|cliquet[_anti]]"""
+    python tools/ab_libs.py libA.so libB.so ... [--n 1000000] [--m 252] [--rounds 7] [--case european|greeks8|greeks14|greeks8_lean|greeks14_lean|asian|asian_fast|asian_fast_anti|asian_anti|asian_geo|barrier|heston|merton|kou|autocall[_anti]|cliquet[_anti]]"""
 import argparse
 import json
 import os
@@ -21,6 +21,9 @@ CASES = {
     "european": lambda s: _hip.european(*P, True, N, M, s, True),
     "greeks8": lambda s: _hip.european_greeks_fd(*P, True, N, M, s, False)[1][0],
     "greeks14": lambda s: _hip.european_greeks_fd(*P, True, N, M, s, True)[1][0],
+    # the call MonteCarloPricer.greeks() makes: no per-evaluation statistics asked for (prices-only kernel from round 3 on)
+    "greeks8_lean": lambda s: type("R", (), dict(zip(("price", "sum"), (lambda v: (v[0], v[1]))(_hip.european_greeks_fd(*P, True, N, M, s, False, want_evals=False)[0]))))(),
+    "greeks14_lean": lambda s: type("R", (), dict(zip(("price", "sum"), (lambda v: (v[0], v[8]))(_hip.european_greeks_fd(*P, True, N, M, s, True, want_evals=False)[0]))))(),
     "asian": lambda s: _hip.asian(*P, True, False, N, M, s, False),
     "asian_fast": lambda s: _hip.asian(*P, True, False, N, M, s, False, fast=True),
     "asian_fast_anti": lambda s: _hip.asian(*P, True, False, N, M, s, True, fast=True),

@@ -22,8 +22,8 @@ OUT = os.path.join(PKG, "isa_mix.json")
 
 KERNELS = {      # key in bench.py's JSON -> mangled-name regex
     "c2_european": r"^_ZN4olmc20european_path_kernelILi1ELb1ELi0ELb0EEE",
-    "c3_fused8": r"^_ZN4olmc20european_path_kernelILi8ELb1ELi0ELb0EEE",
-    "c3_fused14": r"^_ZN4olmc20european_path_kernelILi16ELb1ELi0ELb0EEE",
+    "c3_fused8": r"^_ZN4olmc20european_path_kernelILi8ELb1ELi3ELb0EEE",          # MODE 3 = kSumOnly, the form MonteCarloPricer.greeks() launches
+    "c3_fused14": r"^_ZN4olmc20european_path_kernelILi16ELb1ELi3ELb0EEE",
     "c4_asian_fp64": r"^_ZN4olmc18asian_exp64_kernelILb0EEE",
     "c4_asian_fp64_antithetic": r"^_ZN4olmc18asian_exp64_kernelILb1EEE",
     "c4_asian_fp32": r"^_ZN4olmc12asian_kernelILb0ELb0EEE",

@@ -449,10 +449,14 @@ void group_contracts(const olmc_option* opts, int32_t k, int32_t n_steps, Contra
     for (int i = 0; i < k; ++i) all[i] = make_contract(opts[i], n_steps);
     int slot = 0;
     set->base_mask = 0;
-    set->pad = 0;
+    set->upper_continues_slot0 = 0;
     auto put = [&](int j, int base_slot) -> int {   // returns the slot of the base the NEXT member of the group should refer to
         set->c[slot] = all[j];
-        if (base_slot < 0 || slot == NSETS / 2) {
+        // the second stream (slots >= NSETS / 2) starts without a base of its own -- unless the group that straddles the middle is slot
+        // 0's, whose prices the kernel hands over to it (one pair of exponentials saved for first-order Greeks)
+        const bool needs_own_base = slot == NSETS / 2 && base_slot != 0;
+        if (slot == NSETS / 2 && base_slot == 0) set->upper_continues_slot0 = 1;
+        if (base_slot < 0 || needs_own_base) {
             set->c[slot].scale = 1.0;
             set->base_mask |= 1u << slot;
             base_slot = slot;
@@ -595,7 +599,7 @@ int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32
     if (nsets == 1) {
         ContractSet<1> cs;
         cs.c[0] = make_contract(opts[0], n_steps);
-        cs.base_mask = 1u; cs.pad = 0;
+        cs.base_mask = 1u; cs.upper_continues_slot0 = 0;
         if (pos) pos[0] = 0;
         launch_european<1, kReduce>(anti, grid, s, pr, cs, ws, nullptr, timed);
     } else if (nsets == 8) {
@@ -1037,7 +1041,7 @@ extern "C" int olmc_european_terminal(double S, double T, double r, double sigma
     const int32_t grid = european_launch_shape(c, &pr, european_occupancy<1, kTerminal>(antithetic != 0));
     ContractSet<1> cs;
     cs.c[0] = make_contract(make_option(S, 0.0, T, r, sigma, q, 1), n_steps);
-    cs.base_mask = 1u; cs.pad = 0;
+    cs.base_mask = 1u; cs.upper_continues_slot0 = 0;
     ReduceWs ws{};   // unused in kTerminal mode
     launch_european<1, kTerminal>(antithetic != 0, grid, c->stream, pr, cs, ws, static_cast<double*>(c->d_bulk));
     HIP_TRY(hipGetLastError());
@@ -1075,7 +1079,7 @@ extern "C" int olmc_european_cv_shard(double S, double K, double T, double r, do
     const int32_t grid = european_launch_shape(c, &pr, european_occupancy<1, kControlVariate>(antithetic != 0));
     ContractSet<1> cs;
     cs.c[0] = make_contract(make_option(S, K, T, r, sigma, q, is_call), n_steps);
-    cs.base_mask = 1u; cs.pad = 0;
+    cs.base_mask = 1u; cs.upper_continues_slot0 = 0;
     ReduceWs ws;
     rc = make_ws(c, c->stream, grid, 5, c->d_result, -1.0, &ws);
     if (rc) return rc;
@@ -2086,7 +2090,7 @@ extern "C" int olmc_phase_stamps(int64_t n_paths, int32_t n_steps, uint64_t seed
     HIP_TRY(hipMemsetAsync(c->d_bulk, 0, sizeof(uint64_t) * static_cast<size_t>(words), c->stream));
     ContractSet<1> cs;
     cs.c[0] = make_contract(make_option(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, 1), n_steps);
-    cs.base_mask = 1u; cs.pad = 0;
+    cs.base_mask = 1u; cs.upper_continues_slot0 = 0;
     ReduceWs ws;
     rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
     if (rc) return rc;

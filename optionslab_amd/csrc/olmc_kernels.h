@@ -664,7 +664,9 @@ template <int NSETS>
 struct ContractSet {
     Contract c[NSETS];
     uint32_t base_mask;   // bit s set <=> contract s is a base: it evaluates its own exponentials.  An integer test on the scalar
-    uint32_t pad;         // unit (s_bitcmp) where round 2 compared Contract::scale with 0.0 on the vector unit, once per contract
+                          // unit (s_bitcmp) where round 2 compared Contract::scale with 0.0 on the vector unit, once per contract
+    uint32_t upper_continues_slot0;   // != 0: slot NSETS/2 is not a base -- it and the non-base slots behind it belong to the group of
+                                      // slot 0 (the group straddles the middle: first-order Greeks' {mid, S+, S-, r+, r-}); see european_payoffs_folded
 };
 
 struct PathRange {
@@ -770,7 +772,8 @@ __device__ __forceinline__ void contract_sums(const Contract& c, bool is_base, d
 // half-waves at once (swap_add<32>, the first step of wave_transpose_reduce), so a lane never holds more than NSETS sums:
 // 32 instead of 64 VGPRs of accumulators for second-order Greeks, and the kernel keeps the step loop's own occupancy
 // (round 2: 84 VGPRs, 5 waves per SIMD; the loop alone needs 66 = 7 waves).  The two half-sets are walked as two streams,
-// each with its own latest base: the host lays the set out so that slot NSETS/2 is a base (group_contracts).
+// each with its own latest base: the host lays the set out so that slot NSETS/2 is a base, or -- when the group that straddles
+// the middle is the one of slot 0 -- tells the second stream to start from slot 0's prices (group_contracts).
 // `zsum` is NaN in dead lanes (all their payoffs are then exact zeros, see european_payoffs).
 //
 // SQUARES = false (kSumOnly): only sum x per contract -- what finite-difference Greeks need (prices, no standard errors): NSETS
@@ -783,6 +786,10 @@ __device__ __forceinline__ void european_payoffs_folded(const ContractSet<NSETS>
     for (int s = 0; s < H; ++s) {
         double a0, a1 = 0.0, b0, b1 = 0.0;
         contract_sums<ANTI, SQUARES>(cs.c[s], ((cs.base_mask >> s) & 1u) != 0u, zsum, base_lo, a0, a1);
+        if (s == 0 && cs.upper_continues_slot0 != 0u) {         // launch-uniform: the second stream starts inside slot 0's group
+            base_hi[0] = base_lo[0];
+            base_hi[1] = base_lo[1];
+        }
         contract_sums<ANTI, SQUARES>(cs.c[s + H], ((cs.base_mask >> (s + H)) & 1u) != 0u, zsum, base_hi, b0, b1);
         if constexpr (SQUARES) {
             kept[2 * s] = swap_add<32>(a0, b0);

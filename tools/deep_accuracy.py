@@ -69,3 +69,29 @@ p32 = _hip.asian(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, True, False, n, 1024, 21, Fa
 rows.append(dict(kind="arithmetic asian 2^24 x 1024: fp64-exponent kernel vs fp32-exponent kernel, same normals", price_fp64=p64.price, price_fp32=p32.price,
                  rel_diff=(p32.price - p64.price) / p64.price, std_error=p64.std_error, se_rel_diff=(p32.std_error - p64.std_error) / p64.std_error))
 print(json.dumps(rows[-1]), flush=True)
+# Round 3: (a) sixteen times deeper on the headline contract: 2^36 paths x 16 steps (se ~ 3e-5, 3e-6 of the price) -- the antithetic
+# naive se overstates the error, so |z| stays conservative; (b) the fused finite-difference Greeks (sum-only kernel, folded
+# exchanges, workgroup-wide row sums) at 2^30 paths x 16 steps against the analytic Black-Scholes Greeks: what is left is the
+# finite-difference truncation of unified_greeks.py's steps (h_S = 1, h_sigma = 0.01, h_r = 1e-4, h_T = 1/365), listed beside it from
+# the closed form itself; (c) the arithmetic Asian with the table-driven exp2 against the degree-11 form is a pointwise matter
+# (tests: <= 2 ulp) -- here its price at 2^26 x 252 next to the geometric one as a sanity bracket (arithmetic >= geometric).
+st = _hip.european(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, True, 1 << 36, 16, 77, True)
+bs = ol.black_scholes(100.0, 100.0, 1.0, 0.05, 0.2, "call", 0.0)
+rows.append(dict(kind="european ATM call 2^36 paths x 16 steps", n_paths=1 << 36, price=st.price, bs=float(bs), std_error=st.std_error,
+                 z=(st.price - bs) / st.std_error, rel_err=(st.price - bs) / bs))
+print(json.dumps(rows[-1]), flush=True)
+from oracle import numpy_reference as orc  # noqa: E402  (closed-form Greeks only; nothing is priced on the CPU)
+g = ol.MonteCarloPricer(1 << 30, 16, 5).greeks(100.0, 100.0, 1.0, 0.05, 0.2, "call", include_second_order=True)
+exact = orc.bs_greeks(100.0, 100.0, 1.0, 0.05, 0.2, "call")
+fd_of_bs = orc.fd_greeks(lambda S, K, T, r, v, typ, q=0.0: float(ol.black_scholes(S, K, T, r, v, typ, q)), 100.0, 100.0, 1.0, 0.05, 0.2, "call", 0.0,
+                         include_second_order=True)
+rows.append(dict(kind="fused FD Greeks 2^30 paths x 16 steps vs analytic / vs the same finite differences of the closed form",
+                 greeks={k: g[k] for k in g}, analytic={k: exact[k] for k in exact if k in g},
+                 fd_of_closed_form={k: fd_of_bs[k] for k in g}, abs_diff_vs_fd_of_closed_form={k: g[k] - fd_of_bs[k] for k in g}))
+print(json.dumps(rows[-1]), flush=True)
+a = ol.AsianOption(100.0, 100.0, 1.0, 0.05, 0.2, seed=31)
+pa, sea = a.price(1 << 26, 252, "arithmetic", "call", return_error=True)
+pg, seg = a.price(1 << 26, 252, "geometric", "call", return_error=True)
+rows.append(dict(kind="arithmetic (table exp2) vs geometric Asian 2^26 x 252, same seed", arithmetic=float(pa), geometric=float(pg), se=sea,
+                 geometric_closed_form=discrete_geometric_call(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, 252)))
+print(json.dumps(rows[-1]), flush=True)

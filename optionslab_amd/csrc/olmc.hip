@@ -2105,7 +2105,8 @@ extern "C" int olmc_phase_stamps(int64_t n_paths, int32_t n_steps, uint64_t seed
     quiet.done_flag = nullptr;
     for (int32_t k = 0; k < lead_launches; ++k) {
         hipLaunchKernelGGL(european_stamp_kernel, dim3(grid), dim3(kBlock), 0, c->stream, pr, cs, quiet, static_cast<uint64_t*>(c->d_bulk));
-        HIP_TRY(hipGetLastError());
+        rc = after_launch(c, c->stream);             // a failed launch leaves the self-resetting counters to ws_recover()
+        if (rc) return rc;
     }
     hipExtLaunchKernelGGL(european_stamp_kernel, dim3(grid), dim3(kBlock), 0, c->stream, ep.start, ep.stop, 0, pr, cs, ws, static_cast<uint64_t*>(c->d_bulk));
     rc = after_launch(c, c->stream);

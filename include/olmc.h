@@ -42,7 +42,7 @@ extern "C" {
 
 #define OLMC_ABI_VERSION 3   /* 2: olmc_asian avg_kind 0 is the fp64-exponent kernel (2 = the fp32 one); probes, tune knobs 5-8
                               * 3: additions only -- olmc_european_qmc_batch, olmc_european_qmc_greeks_fd, olmc_multi_capacity,
-                              *    olmc_exp2_probe_form, olmc_phase_stamps, tune knob 9; every v2 entry point keeps its signature and meaning */
+                              *    olmc_exp2_probe_form, olmc_phase_stamps, olmc_contract_layout, tune knob 9; every v2 entry point keeps its signature and meaning */
 
 enum {
     OLMC_OK = 0,
@@ -150,6 +150,14 @@ int olmc_european_batch(const olmc_option* opts, int32_t k,
 int olmc_european_multi(const olmc_option* opts, const uint32_t* tags, int64_t n_options,
                         int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
                         olmc_stats* out /* [n_options] */);
+
+/* How a set of k (2 .. OLMC_MAX_BATCH) contracts is laid out for the fused kernels (host arithmetic only; no device needed):
+ * nsets = 8 or 16 slots; pos[i] = slot of contract i; bit s of base_mask = slot s evaluates its own exponentials (its
+ * sigma * sqrt(dt) differs bit-wise from every earlier base's, or it opens the second half of the set); scale16[s] = 1 for a base,
+ * else exp(a_s - a_base), a = ln S + (r - q - sigma^2 / 2) dt n_steps; upper_continues_slot0 != 0: slot nsets / 2 is not a base
+ * but belongs to slot 0's group.  For tests of the layout logic. */
+int olmc_contract_layout(const olmc_option* opts, int32_t k, int32_t n_steps, int32_t* nsets, int32_t* pos /* [k] */,
+                         uint32_t* base_mask, int32_t* upper_continues_slot0, double* scale16 /* [16] */);
 
 /* Capacity of the library-owned workspace behind olmc_european_multi as it stands: out2 = {contracts, workgroups per contract}.
  * The two grow independently (more contracts doubles the first, more paths per contract only widens the rows). */

@@ -64,6 +64,7 @@ PROTOTYPES = {
     "olmc_european_batch": (_I, [C.POINTER(Option), _I32, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_european_multi": (_I, [C.POINTER(Option), C.POINTER(C.c_uint32), _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_multi_capacity": (_I, [C.POINTER(_I64)]),
+    "olmc_contract_layout": (_I, [C.POINTER(Option), _I32, _I32, C.POINTER(_I32), C.POINTER(_I32), C.POINTER(C.c_uint32), C.POINTER(_I32), C.POINTER(_D)]),
     "olmc_european_greeks_fd": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, C.POINTER(_D), C.POINTER(Stats)]),
     "olmc_european_terminal": (_I, [_D] * 5 + [_I64, _I32, _U64T, _I, C.POINTER(_D)]),
     "olmc_gbm_paths": (_I, [_D] * 5 + [_I64, _I32, _U64T, _I, C.POINTER(_D)]),
@@ -259,6 +260,16 @@ def european_multi(S, K, T, r, sigma, q, is_call, n_paths: int, n_steps: int, se
     _check(lib().olmc_european_multi(C.cast(opts.ctypes.data, _P_OPTION), ptags, n, int(n_paths), int(n_steps), int(seed) & _U64,
                                      bool(antithetic), C.cast(out.ctypes.data, _P_STATS)))
     return out.view(_STATS_DT).reshape(n)
+
+
+def contract_layout(options: Sequence[Tuple[float, float, float, float, float, float, bool]], n_steps: int):
+    """(nsets, pos[k], base_mask, upper_continues_slot0, scale[nsets]) of a set of contracts for the fused kernels (olmc_contract_layout;
+    pure host function: loads the library, not the GPU)."""
+    k = len(options)
+    arr = (Option * k)(*[Option(S, K, T, r, v, q, int(c), 0) for (S, K, T, r, v, q, c) in options])
+    nsets, pos, mask, cont, scale = C.c_int32(0), (C.c_int32 * k)(), C.c_uint32(0), C.c_int32(0), (C.c_double * 16)()
+    _check(load_library().olmc_contract_layout(arr, k, int(n_steps), C.byref(nsets), pos, C.byref(mask), C.byref(cont), scale))
+    return nsets.value, list(pos), mask.value, bool(cont.value), list(scale)[:nsets.value]
 
 
 def multi_capacity() -> Tuple[int, int]:

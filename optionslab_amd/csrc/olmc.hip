@@ -945,6 +945,29 @@ extern "C" int olmc_european_multi(const olmc_option* opts, const uint32_t* tags
     return OLMC_OK;
 }
 
+// The layout olmc_european_batch / olmc_european_greeks_fd give a set of k contracts (pure host arithmetic: needs no device).
+extern "C" int olmc_contract_layout(const olmc_option* opts, int32_t k, int32_t n_steps, int32_t* nsets_out, int32_t* pos, uint32_t* base_mask,
+                                    int32_t* upper_continues_slot0, double* scale16) {
+    if (!opts || !nsets_out || !pos || !base_mask || !upper_continues_slot0 || !scale16) return fail(OLMC_ERR_ARG, "null pointer");
+    if (k < 2 || k > OLMC_MAX_BATCH) return fail(OLMC_ERR_ARG, "a set has 2 .. OLMC_MAX_BATCH contracts");
+    if (n_steps < 1) return fail(OLMC_ERR_ARG, "n_steps must be >= 1");
+    int p[OLMC_MAX_BATCH];
+    for (int i = 0; i < OLMC_MAX_BATCH; ++i) scale16[i] = 0.0;
+    if (k <= 8) {
+        ContractSet<8> cs;
+        group_contracts<8>(opts, k, n_steps, &cs, p);
+        *nsets_out = 8; *base_mask = cs.base_mask; *upper_continues_slot0 = static_cast<int32_t>(cs.upper_continues_slot0);
+        for (int i = 0; i < 8; ++i) scale16[i] = cs.c[i].scale;
+    } else {
+        ContractSet<16> cs;
+        group_contracts<16>(opts, k, n_steps, &cs, p);
+        *nsets_out = 16; *base_mask = cs.base_mask; *upper_continues_slot0 = static_cast<int32_t>(cs.upper_continues_slot0);
+        for (int i = 0; i < 16; ++i) scale16[i] = cs.c[i].scale;
+    }
+    for (int i = 0; i < k; ++i) pos[i] = p[i];
+    return OLMC_OK;
+}
+
 // Capacity of the batch workspace as it stands: {contracts, workgroups per contract} (0, 0 before the first batch).
 extern "C" int olmc_multi_capacity(int64_t* out2) {
     if (!out2) return fail(OLMC_ERR_ARG, "null pointer");

@@ -251,3 +251,69 @@ def test_sobol_guard_refuses_an_engine_whose_private_tables_changed(monkeypatch,
     assert not mc._sobol_cache                               # nothing bad was cached
     monkeypatch.setattr(qmc, "Sobol", real)
     assert mc.sobol_tables(12, 5)[0].shape == (12, 30)       # and the real engine still works afterwards
+
+
+# ---- layout of a contract set for the fused kernels (host arithmetic of libolmc, no device) ---------------------------------------
+def _layout_invariants(opts, n_steps):
+    import math
+    from optionslab_amd import _hip
+    nsets, pos, mask, cont, scale = _hip.contract_layout(opts, n_steps)
+    k, H = len(opts), (8 if len(opts) <= 8 else 16) // 2
+    assert nsets == 2 * H and sorted(pos) == sorted(set(pos)) and all(0 <= p < nsets for p in pos)          # distinct slots
+    assert mask & 1, "slot 0 is always a base"
+    slot_of = {p: i for i, p in enumerate(pos)}
+
+    def consts(o):
+        S, K, T, r, v, q, _c = o
+        dt = T / n_steps
+        return math.log(S) + (r - q - 0.5 * v * v) * dt * n_steps, v * math.sqrt(dt)
+
+    # the second half starts with a base, or continues slot 0's group -- and then no other base sits between slot 0 and the middle
+    if cont:
+        assert not (mask >> H) & 1 and not any((mask >> s) & 1 for s in range(1, H))
+    else:
+        assert (mask >> H) & 1
+    for half in (range(0, H), range(H, nsets)):
+        base = 0 if (cont and half[0] == H) else None
+        for s in half:
+            if (mask >> s) & 1:
+                base = s
+                assert scale[s] == 1.0
+            elif s in slot_of:                      # a real (not padding) contract that takes scale * S_T(base)
+                assert base is not None and base in slot_of or base == 0
+                a, vol = consts(opts[slot_of[s]])
+                a_b, vol_b = consts(opts[slot_of[base]])
+                assert vol == vol_b, "a scaled contract shares its base's vol bit for bit"
+                assert scale[s] == pytest.approx(math.exp(a - a_b), rel=1e-15)
+    # contracts with one vol sit in consecutive slots (a group), up to the forced split at the middle
+    groups = {}
+    for i, o in enumerate(opts):
+        groups.setdefault(consts(o)[1], []).append(pos[i])
+    for slots in groups.values():
+        assert sorted(slots) == list(range(min(slots), min(slots) + len(slots)))
+    return nsets, pos, mask, cont
+
+
+def test_contract_set_layout_of_the_greeks_sets_and_of_random_sets():
+    """group_contracts (olmc.hip): what the fused kernels' two-stream walk relies on.  First-order Greeks: {mid, S+, S-, r+, r-} is
+    slot 0's group and straddles the middle of the 8-slot set -> the second stream continues it (no base of its own there); second
+    order: 14 contracts, 4 groups, slot 8 is a natural base."""
+    S, K, T, r, v, q = 100.0, 100.0, 1.0, 0.05, 0.2, 0.0
+    h_S, h_v, h_r, h_T = 1.0, 0.01, 1e-4, 1 / 365.0
+    first = [(S, K, T, r, v, q, True), (S + h_S, K, T, r, v, q, True), (S - h_S, K, T, r, v, q, True), (S, K, T, r, v + h_v, q, True),
+             (S, K, T, r, v - h_v, q, True), (S, K, T - h_T, r, v, q, True), (S, K, T, r + h_r, v, q, True), (S, K, T, r - h_r, v, q, True)]
+    nsets, pos, mask, cont = _layout_invariants(first, 252)
+    assert nsets == 8 and cont and pos[:3] == [0, 1, 2] and sorted(pos[i] for i in (0, 1, 2, 6, 7)) == [0, 1, 2, 3, 4]
+    assert bin(mask).count("1") == 4                                              # mid, sigma+, sigma-, T-: four pairs of exponentials
+    second = first + [(S + h_S, K, T, r, v + h_v, q, True), (S + h_S, K, T, r, v - h_v, q, True), (S - h_S, K, T, r, v + h_v, q, True),
+                      (S - h_S, K, T, r, v - h_v, q, True), (S + h_S, K, T - h_T, r, v, q, True), (S - h_S, K, T - h_T, r, v, q, True)]
+    nsets, pos, mask, cont = _layout_invariants(second, 252)
+    assert nsets == 16 and not cont and bin(mask & ((1 << 14) - 1)).count("1") == 4
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for _ in range(300):
+        k = int(rng.integers(2, 17))
+        vols = [0.1 + 0.05 * g for g in range(int(rng.integers(1, 7)))]
+        opts = [(100.0 + float(rng.normal(0, 3)), float(rng.uniform(80, 120)), 1.0, 0.05 + float(rng.normal(0, 0.01)), vols[int(rng.integers(0, len(vols)))], 0.0,
+                 bool(rng.integers(0, 2))) for _ in range(k)]
+        _layout_invariants(opts, int(rng.integers(1, 300)))

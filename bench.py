@@ -11,7 +11,7 @@ ONE pass defines the line: a "step" is one complete BLOCKING pricing
 `MonteCarloPricer.price(S, K, T, r, sigma, "call", seed=..., return_error=True)` at N = 1 (one path kernel with its
 fused reduction, result on the host), and at N > 1 the same thing sharded: this rank's kernel on its block of the
 global paths -> the all-reduce -> result on the host of every rank.  After W untimed warm-up steps a pass times EXACTLY
-K steps between barrier + synchronise fences (max over ranks); passes repeat until >= 0.5 s are covered, and
+K steps between barrier + synchronise fences (max over ranks); passes repeat until >= 1.5 s are covered, and
 
     value                  = global paths x 252 x K / median pass time
     ms_per_step            = median pass time / K
@@ -464,7 +464,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip pipelined / C3 / C4 / C5 (profiling runs)")
     ap.add_argument("--pmc-keep", default=None, help="directory to keep the rocprofv3 CSVs of the live passes in")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--min-seconds", type=float, default=0.5, help="timed passes repeat until this much wall time is covered")
+    ap.add_argument("--min-seconds", type=float, default=1.5,
+                    help="timed passes repeat until the plain ones alone cover this much wall time (as many instrumented ones ride along: the GPU "
+                         "is busy for about twice this, which an outside utilisation sampler can see)")
     ap.add_argument("--paths-per-gpu", type=int, default=0,
                     help="default: 1,000,000 at --gpus 1 (BASELINE configs[1]), 8,000,000 at --gpus N > 1 (configs[4]'s per-GPU shard)")
     args = ap.parse_args()
@@ -577,7 +579,7 @@ def worker(args):
             return price, se, int(n)
         return step
 
-    def timed_passes(step, n_global, steps, warm, min_total_s=0.5, max_passes=400, seed0=0):
+    def timed_passes(step, n_global, steps, warm, min_total_s=1.5, max_passes=1000, seed0=0):
         """warm untimed steps, then passes of EXACTLY `steps` blocking steps, each between fences; max over ranks per pass.
         Passes ALTERNATE plain / instrumented: an instrumented pass is the same loop with a HIP event pair attached to
         every dispatch (the kernel's own begin / end timestamps).  Attaching the pair puts a marker packet in front of the

@@ -547,7 +547,8 @@ def test_device_exp2_f64_is_within_two_ulp_of_libm_everywhere(form):
     x = np.concatenate([rng.uniform(-60.0, 60.0, 400_000), rng.uniform(-1.0, 1.0, 400_000), rng.normal(0.0, 1e-3, 100_000),
                         np.arange(-80, 81) + 0.5, np.nextafter(np.arange(-80, 81) + 0.5, np.inf), np.nextafter(np.arange(-80, 81) + 0.5, -np.inf),
                         np.arange(-1000, 1001, 7.0), [0.0, -0.0, 1.0, -1.0, 1e-300, -1e-300, 1023.999, -1021.5],
-                        (np.arange(-4096, 4097) + 0.5) / 64.0, np.nextafter((np.arange(-4096, 4097) + 0.5) / 64.0, np.inf)])
+                        (np.arange(-4096, 4097) + 0.5) / 64.0, np.nextafter((np.arange(-4096, 4097) + 0.5) / 64.0, np.inf),
+                        (np.arange(-8192, 8193) + 0.5) / 256.0, np.nextafter((np.arange(-8192, 8193) + 0.5) / 256.0, -np.inf)])
     y, want = _hip.exp2_probe(x, form), np.exp2(x)
     ulp = np.abs(y - want) / np.spacing(want)
     assert np.isfinite(y).all() and ulp.max() <= 2.0, (ulp.max(), x[np.argmax(ulp)])

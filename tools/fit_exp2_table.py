@@ -5,10 +5,10 @@
 import mpmath as mp
 
 mp.mp.dps = 50
-N_TAB, DEG = 64, 4                 # q has DEG + 1 coefficients: 2^(r/64) - 1 = r (c1 + c2 r + ... + c5 r^4)
+N_TAB, DEG = 256, 3                # q has DEG + 1 coefficients: 2^(r/256) - 1 = r (c1 + c2 r + c3 r^2 + c4 r^3)
 
 
-def target(r):                     # (2^(r/64) - 1) / r, analytic at 0
+def target(r):                     # (2^(r/N_TAB) - 1) / r, analytic at 0
     r = mp.mpf(r)
     if abs(r) < mp.mpf(10) ** -20:
         return mp.log(2) / N_TAB
@@ -28,7 +28,7 @@ for i in range(-2000, 2001):
     r = mp.mpf(i) / 4000
     approx = 1 + r * sum(c[j] * r ** j for j in range(DEG + 1))
     worst = max(worst, abs(approx / mp.power(2, r / N_TAB) - 1))
-print(f"// interpolation error of 1 + r q(r) against 2^(r/64): {mp.nstr(worst, 3)} relative ({mp.nstr(worst / mp.mpf(2) ** -53, 3)} ulp)")
+print(f"// interpolation error of 1 + r q(r) against 2^(r/N_TAB): {mp.nstr(worst, 3)} relative ({mp.nstr(worst / mp.mpf(2) ** -53, 3)} ulp)")
 print("constexpr double kExp2Q[%d] = {%s};" % (DEG + 1, ", ".join(repr(float(c[j])) for j in range(DEG + 1))))
 print("__constant__ double kExp2Tab[%d] = {" % N_TAB)
 for k in range(0, N_TAB, 4):

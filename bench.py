@@ -903,7 +903,7 @@ def c4_asian(ol, _hip, pmc, costs, mixes, clock_ghz, cpu=None):
     for key, precision, anti, pk in (("fp64", "fp64", False, "c4_asian_fp64"), ("fp64_antithetic", "fp64", True, "c4_asian_fp64_antithetic"),
                                      ("fp32_fast", "fp32", False, "c4_asian_fp32"), ("fp32_fast_antithetic", "fp32", True, "c4_asian_fp32_antithetic")):
         fn = lambda: a.price(PATHS_PER_GPU, ASIAN_STEPS, "arithmetic", "call", antithetic=anti, return_error=True, precision=precision)
-        med, ks, per = _timed_calls(_hip, fn, 8, warm=2)
+        med, ks, per = _timed_calls(_hip, fn, 16, warm=6)
         price, se = fn()
         out[key] = {"ms_per_call": med * 1e3, "path_steps_per_s": ps / med, "avg_kernel_ms": ks * 1e3 if ks else None, "price": float(price), "std_error": se,
                     "dtype": "f32 normals / f64 cumulative log-return, f64 exp per date, f64 sums" if precision == "fp64"

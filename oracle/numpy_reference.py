@@ -254,15 +254,20 @@ def asian_paths(S, T, r, sigma, q, n_paths, n_steps, seed: Optional[int]):
 
 
 def asian_price(S, K, T, r, sigma, q=0.0, seed=None, n_paths=100000, n_steps=252,
-                avg_type="arithmetic", option_type="call"):
-    """exotic_options.py:97-131 -- average over t=1..M (t=0 excluded)."""
+                avg_type="arithmetic", option_type="call", return_error=False):
+    """exotic_options.py:97-131 -- average over t=1..M (t=0 excluded).  `return_error=True` adds what the reference does not
+    return: the standard error of the SAME payoffs, disc * std(x, ddof=0) / sqrt(n) as monte_carlo.py:147-149 takes it."""
     paths = asian_paths(S, T, r, sigma, q, n_paths, n_steps, seed)
     if avg_type == "arithmetic":  # :119-120
         avg = np.mean(paths[:, 1:], axis=1)
     else:  # :121-122
         avg = np.exp(np.mean(np.log(paths[:, 1:]), axis=1))
+    del paths
     x = np.maximum(avg - K, 0) if option_type == "call" else np.maximum(K - avg, 0)  # :125-128
-    return np.exp(-r * T) * np.mean(x)  # :131  (np.float64)
+    price = np.exp(-r * T) * np.mean(x)  # :131  (np.float64)
+    if return_error:
+        return price, np.exp(-r * T) * np.std(x) / np.sqrt(n_paths)
+    return price
 
 
 def barrier_price(S, K, T, r, sigma, barrier, q=0.0, seed=None, n_paths=100000, n_steps=252,

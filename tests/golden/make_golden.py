@@ -155,6 +155,25 @@ def main():
         doc["asian"].append(dict(params=[100.0, 100.0, 1.0, 0.05, 0.2, q], seed=seed, n_paths=n, n_steps=m, avg_type=avg,
                                  option_type=typ, price=float(o.price(n, m, avg, typ)),
                                  geometric_closed_form=float(o.price_geometric_closed_form(typ))))
+    # -- BASELINE configs[3]'s own shape: 1024 monitoring dates (the device's 1,000,000 x 1024 run is compared with THESE, not with
+    #    a 252-date cousin).  100,000 x 1024 is what fits here: Z, log-returns, log S and exp are 0.82 GB each (exotic_options.py:59-67).
+    #    The reference returns no standard error for an Asian, so one is recorded from the reference's OWN paths (`_generate_paths`
+    #    re-seeds, so the second call walks the paths `price` just used -- asserted): disc * std(payoffs) / sqrt(n), ddof = 0 as
+    #    monte_carlo.py:147-149 takes it.
+    doc["asian_c4_shape"] = []
+    for n, m, seed, avg, typ in [(100000, 1024, 42, "arithmetic", "call"), (100000, 1024, 42, "arithmetic", "put"),
+                                 (100000, 1024, 42, "geometric", "call")]:
+        o = A(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, q=0.0, seed=seed)
+        price = float(o.price(n, m, avg, typ))
+        paths = o._generate_paths(n, m)
+        avg_price = np.mean(paths[:, 1:], axis=1) if avg == "arithmetic" else np.exp(np.mean(np.log(paths[:, 1:]), axis=1))
+        del paths
+        payoffs = np.maximum(avg_price - 100.0, 0) if typ == "call" else np.maximum(100.0 - avg_price, 0)
+        assert float(np.exp(-0.05 * 1.0) * np.mean(payoffs)) == price
+        doc["asian_c4_shape"].append(dict(params=[100.0, 100.0, 1.0, 0.05, 0.2, 0.0], seed=seed, n_paths=n, n_steps=m, avg_type=avg,
+                                          option_type=typ, price=price,
+                                          std_error_from_reference_paths=float(np.exp(-0.05 * 1.0) * np.std(payoffs) / np.sqrt(n)),
+                                          geometric_closed_form=float(o.price_geometric_closed_form(typ))))
     doc["price_asian_helper"] = dict(args=[100.0, 100.0, 1.0, 0.05, 0.2, "arithmetic", "call", 20000, 42],
                                      value=float(ref["price_asian"](100.0, 100.0, 1.0, 0.05, 0.2, "arithmetic", "call", 20000, 42)))
     # ExoticAdapter Greeks on an Asian (unified_greeks.py:177-227)

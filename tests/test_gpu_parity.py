@@ -626,6 +626,51 @@ def test_asian_against_reference_golden_and_reference_tests(golden):
     assert ol.price_asian(100, 100, 1.0, 0.05, 0.2, n_paths=1000, seed=42) == a.price(n_paths=1000)
 
 
+def test_asian_1m_x_1024_against_the_reference_run_at_that_shape(golden):
+    """BASELINE configs[3] at its own shape: the default (fp64-exponent) kernel at 1,000,000 x 1024 against the reference's run of
+    exotic_options.py:97-131 at 100,000 x 1024 (`asian_c4_shape` in the fixture; its standard error was taken from the reference's
+    own paths).  3 sigma of the two independent errors, the tolerance north_star states.  The geometric average goes through
+    `asian_kernel<., true>`, the arithmetic ones through `asian_exp64_kernel`."""
+    for c in golden["asian_c4_shape"]:
+        S, K, T, r, v, q = c["params"]
+        o = ol.AsianOption(S, K, T, r, v, q, seed=c["seed"])
+        price, se = o.price(1_000_000, c["n_steps"], c["avg_type"], c["option_type"], return_error=True)
+        se_ref = c["std_error_from_reference_paths"]
+        assert isinstance(price, np.float64)
+        assert se == pytest.approx(se_ref / math.sqrt(10.0), rel=0.02), c          # ten times the paths, no antithetic in either
+        assert abs(price - c["price"]) <= 3 * math.sqrt(se * se + se_ref * se_ref), (c, price, se)
+        # the opt-in fp32-exponent form prices the same paths: 2e-6 of the default, so it sits inside the same bound
+        if c["avg_type"] == "arithmetic":
+            fast = _hip.asian(S, K, T, r, v, q, c["option_type"] == "call", False, 1_000_000, c["n_steps"], c["seed"], False, fast=True)
+            assert fast.price == pytest.approx(float(price), rel=2e-6)
+    call, put = (next(c for c in golden["asian_c4_shape"] if c["avg_type"] == "arithmetic" and c["option_type"] == t) for t in ("call", "put"))
+    # arithmetic put-call parity at 1024 dates on the device's own paths: C - P = disc * (mean(A) - K), mean(A) known in closed form
+    S, K, T, r, v, q = call["params"]
+    o = ol.AsianOption(S, K, T, r, v, q, seed=42)
+    c1, e1 = o.price(1_000_000, 1024, "arithmetic", "call", return_error=True)
+    p1, e2 = o.price(1_000_000, 1024, "arithmetic", "put", return_error=True)
+    dt, g = T / 1024, (r - q) * T / 1024
+    mean_avg = S * math.exp(g) * (1 - math.exp(g * 1024)) / (1 - math.exp(g)) / 1024
+    # a path pays the call or the put, never both: cov(x_c, x_p) = -E[x_c] E[x_p], so var(C - P) = var C + var P + 2 C P / n
+    se_cp = math.sqrt(e1 * e1 + e2 * e2 + 2.0 * float(c1) * float(p1) / 1_000_000)
+    assert abs((c1 - p1) - math.exp(-r * T) * (mean_avg - K)) <= 3.5 * se_cp
+
+
+def test_literal_eight_launch_greeks_equal_the_fused_kernel_at_1m_x_252():
+    """BASELINE configs[2] in its literal form -- the 8 (14) `price()` calls of unified_greeks.py:295-358, each its own launch of
+    the one-contract kernel -- against the fused kernel at the size the config names.  Same normals, same payoffs, another
+    association of the sums: 1e-8 on every Greek."""
+    p = ol.MonteCarloPricer(1_000_000, 252, 42)
+    for second in (False, True):
+        fused = ol.compute_greeks_unified(p, *ATM, "call", 0.0, include_second_order=second)
+        literal = ol.compute_greeks_unified(p, *ATM, "call", 0.0, include_second_order=second, fused=False)
+        assert list(fused) == list(literal)
+        for k in fused:
+            assert fused[k] == pytest.approx(literal[k], rel=1e-8, abs=1e-8), (second, k)
+    exact = orc.bs_greeks(*ATM, "call")
+    assert abs(literal["delta"] - exact["delta"]) < 1e-3 and abs(literal["vega"] - exact["vega"]) < 0.2
+
+
 def test_asian_greeks_through_exotic_adapter(golden):
     c = golden["asian_greeks"]
     ad = ol.ExoticAdapter(ol.AsianOption(100.0, 100.0, 1.0, 0.05, 0.2, seed=42), n_paths=200_000, n_steps=64, avg_type="arithmetic")

@@ -99,6 +99,20 @@ def test_asian(golden):
     assert float(orc.asian_price(S, K, T, r, v, 0.0, seed, n, 252, avg, typ)) == h["value"]
 
 
+def test_asian_at_the_shape_of_baseline_config_3(golden):
+    """BASELINE configs[3] has 1024 monitoring dates; the reference was run at 100,000 x 1024 (what fits in this container: four
+    0.82 GB arrays, exotic_options.py:59-67) and the restatement must return its bits.  The standard error in the fixture comes
+    from the reference's own paths (tests/golden/make_golden.py) -- the 1,000,000 x 1024 device run is bounded with it."""
+    assert len(golden["asian_c4_shape"]) == 3
+    for c in golden["asian_c4_shape"]:
+        assert (c["n_paths"], c["n_steps"]) == (100000, 1024)
+        S, K, T, r, v, q = c["params"]
+        got, se = orc.asian_price(S, K, T, r, v, q, c["seed"], c["n_paths"], c["n_steps"], c["avg_type"], c["option_type"], return_error=True)
+        assert float(got) == c["price"]
+        assert float(se) == c["std_error_from_reference_paths"]
+        assert float(orc.asian_geometric_closed_form(S, K, T, r, v, q, c["option_type"])) == c["geometric_closed_form"]
+
+
 def test_asian_greeks_via_adapter(golden):
     c = golden["asian_greeks"]
 

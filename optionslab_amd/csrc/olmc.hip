@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <chrono>
 #include <climits>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -102,15 +103,31 @@ struct DeviceCtx {
     uint32_t* d_sobol = nullptr;     // [dims x 30 direction numbers | dims shifts]
     size_t sobol_words = 0;          // capacity
     std::vector<uint32_t> sobol_host;   // what d_sobol holds (compared word for word with the caller's table)
-    std::mutex mu;
+    bool busy = false;                  // leased (guarded by the pool's mutex)
     // profiling
     std::vector<EventPair> ev_free, ev_pending;
     int64_t prof_launches = 0;
     double prof_ms = 0.0;
 };
 
-std::mutex g_mu;
-DeviceCtx* g_ctx[kMaxDevices] = {};
+// Contexts of one device.  A call LEASES a context for its whole duration (CtxLease): it picks the first idle one under the pool's
+// mutex -- a single-threaded caller therefore always works on context 0, exactly round 3's one-context library -- and everything
+// after that (argument staging, launches, the wait for the result) runs outside any lock, on the context's own stream, workspace,
+// pinned landing buffer and completion word.  Concurrent callers (Streamlit runs one thread per session, SURVEY §8b "Threading")
+// get a context each, up to kMaxContexts per device (created on demand, never destroyed before olmc_shutdown); a further caller
+// waits for a lease to come back.  Round 3 held ONE mutex around launch AND wait, so N sessions' pricings ran strictly one after
+// the other, host launch overhead and device ramp / drain included.
+constexpr int kMaxContexts = 8;
+
+struct DevicePool {
+    std::mutex mu;
+    std::condition_variable idle;       // a lease came back
+    std::vector<DeviceCtx*> all;        // grows to kMaxContexts, first idle first
+    int device = -1;
+};
+
+std::mutex g_mu;                        // guards g_pool[] slots, g_default_device (olmc_init / olmc_shutdown)
+DevicePool* g_pool[kMaxDevices] = {};
 int g_default_device = -1;
 bool g_profile = false;
 
@@ -174,7 +191,53 @@ int ctx_create(int device, DeviceCtx** out) {
     return OLMC_OK;
 }
 
-int ctx_get(DeviceCtx** out) {
+// RAII lease of one context of the calling thread's device (see DevicePool).
+struct CtxLease {
+    DeviceCtx* c = nullptr;
+    DevicePool* pool = nullptr;
+    CtxLease() = default;
+    CtxLease(const CtxLease&) = delete;
+    CtxLease& operator=(const CtxLease&) = delete;
+    ~CtxLease() { release(); }
+    void release() {
+        if (!c) return;
+        {
+            std::lock_guard<std::mutex> lock(pool->mu);
+            c->busy = false;
+        }
+        pool->idle.notify_one();
+        c = nullptr;
+    }
+};
+
+int ctx_lease_on(int dev, CtxLease* out) {
+    DevicePool* pool = g_pool[dev];
+    if (!pool) return fail(OLMC_ERR_STATE, "device not initialised (call olmc_init)");
+    HIP_TRY(hipSetDevice(dev));
+    std::unique_lock<std::mutex> lock(pool->mu);
+    for (;;) {
+        for (DeviceCtx* c : pool->all)
+            if (!c->busy) {
+                c->busy = true;
+                out->c = c;
+                out->pool = pool;
+                return OLMC_OK;
+            }
+        if (static_cast<int>(pool->all.size()) < kMaxContexts) {
+            DeviceCtx* c = nullptr;
+            const int rc = ctx_create(dev, &c);
+            if (rc) return rc;
+            c->busy = true;
+            pool->all.push_back(c);
+            out->c = c;
+            out->pool = pool;
+            return OLMC_OK;
+        }
+        pool->idle.wait(lock);
+    }
+}
+
+int ctx_lease(CtxLease* out) {
     int dev = t_device >= 0 ? t_device : g_default_device;
     if (dev < 0) {
         // lazy init on device 0 so a bare compute call still works (or fails loudly)
@@ -182,11 +245,7 @@ int ctx_get(DeviceCtx** out) {
         if (rc) return rc;
         dev = t_device;
     }
-    DeviceCtx* c = g_ctx[dev];
-    if (!c) return fail(OLMC_ERR_STATE, "device not initialised (call olmc_init)");
-    HIP_TRY(hipSetDevice(dev));
-    *out = c;
-    return OLMC_OK;
+    return ctx_lease_on(dev, out);
 }
 
 int bulk_reserve(DeviceCtx* c, size_t bytes) {
@@ -685,10 +744,10 @@ int run_batch(const olmc_option* opts, int32_t k, int64_t path_offset, int64_t n
     if (k < 1 || k > OLMC_MAX_BATCH) return fail(OLMC_ERR_ARG, "batch size must be in [1, OLMC_MAX_BATCH]");
     int rc = check_paths(path_offset, n_local, n_steps);
     if (rc) return rc;
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     int pos[OLMC_MAX_BATCH];
     bool lean = prices_only;
     rc = run_batch_device(c, c->stream, opts, k, path_offset, n_local, n_steps, seed, antithetic, c->d_result, -1.0, pos, &lean);
@@ -718,6 +777,8 @@ olmc_option make_option(double S, double K, double T, double r, double sigma, do
 
 }  // namespace
 
+namespace { void multi_gpu_release(); }      // the multi-GPU engine's streams, buffers and communicators (defined with it)
+
 // =============================================================== lifetime ====
 extern "C" int olmc_abi_version(void) { return OLMC_ABI_VERSION; }
 
@@ -736,11 +797,14 @@ extern "C" int olmc_init(int device) {
     }();
     (void)env_read;
     if (device < 0 || device >= kMaxDevices) return fail(OLMC_ERR_ARG, "device index out of range");
-    if (!g_ctx[device]) {
+    if (!g_pool[device]) {
         DeviceCtx* c = nullptr;
-        int rc = ctx_create(device, &c);
+        int rc = ctx_create(device, &c);            // the first context of the device: a device that cannot be used fails HERE, loudly
         if (rc) return rc;
-        g_ctx[device] = c;
+        DevicePool* pool = new DevicePool();
+        pool->device = device;
+        pool->all.push_back(c);
+        g_pool[device] = pool;
     } else {
         HIP_TRY(hipSetDevice(device));
     }
@@ -751,12 +815,17 @@ extern "C" int olmc_init(int device) {
 
 extern "C" int olmc_shutdown(void) {
     std::lock_guard<std::mutex> lock(g_mu);
-    for (int d = 0; d < kMaxDevices; ++d) {
-        DeviceCtx* c = g_ctx[d];
-        if (!c) continue;
-        if (hipSetDevice(d) == hipSuccess) ctx_release(c);
-        else delete c;
-        g_ctx[d] = nullptr;
+    multi_gpu_release();
+    for (int d = 0; d < kMaxDevices; ++d) {         // the caller's contract: no call is in flight on any thread
+        DevicePool* pool = g_pool[d];
+        if (!pool) continue;
+        const bool usable = hipSetDevice(d) == hipSuccess;
+        for (DeviceCtx* c : pool->all) {
+            if (usable) ctx_release(c);
+            else delete c;
+        }
+        delete pool;
+        g_pool[d] = nullptr;
     }
     g_default_device = -1;
     t_device = -1;
@@ -765,9 +834,10 @@ extern "C" int olmc_shutdown(void) {
 
 extern "C" int olmc_device_info(olmc_devinfo* out) {
     if (!out) return fail(OLMC_ERR_ARG, "null pointer");
-    DeviceCtx* c = nullptr;
-    int rc = ctx_get(&c);
+    CtxLease lease;
+    int rc = ctx_lease(&lease);
     if (rc) return rc;
+    DeviceCtx* const c = lease.c;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, c->device));
     std::memset(out, 0, sizeof(*out));
@@ -801,10 +871,10 @@ extern "C" int olmc_european_shard_dev(double S, double K, double T, double r, d
     if (!d_triple) return fail(OLMC_ERR_ARG, "null pointer");
     int rc = check_paths(path_offset, n_local, n_steps);
     if (rc) return rc;
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);   // used as given: NULL is the HIP null stream
     const olmc_option o = make_option(S, K, T, r, sigma, q, is_call);
     const double n = static_cast<double>(n_local * (antithetic ? 2 : 1));
@@ -818,10 +888,10 @@ extern "C" int olmc_european_shard_dev(double S, double K, double T, double r, d
 extern "C" int olmc_fetch_dev(const double* d_src, int32_t n, void* hip_stream, double* out_host) {
     if (!d_src || !out_host) return fail(OLMC_ERR_ARG, "null pointer");
     if (n < 1 || n > kMaxNV + 1) return fail(OLMC_ERR_ARG, "n must be in [1, 33]");
-    DeviceCtx* c = nullptr;
-    int rc = ctx_get(&c);
+    CtxLease lease;
+    int rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const uint64_t want = ++c->seq;
     hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(kWave), 0, s, d_src, n, c->d_result, c->d_flag, want);
@@ -866,10 +936,10 @@ extern "C" int olmc_european_multi(const olmc_option* opts, const uint32_t* tags
     if (n_options > (int64_t(1) << 31) - 2) return fail(OLMC_ERR_ARG, "too many contracts in one call");
     int rc = check_paths(0, n_paths, n_steps);
     if (rc) return rc;
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     const int32_t bpo = static_cast<int32_t>(std::min<int64_t>((n_paths + kBlock - 1) / kBlock, 1024));   // workgroups per contract
     auto align = [](size_t b) { return (b + 255) / 256 * 256; };
     // Device workspace [counters | done counter | contracts | rows]: the ticket counters sit FIRST and are sized by the capacity in
@@ -971,10 +1041,10 @@ extern "C" int olmc_contract_layout(const olmc_option* opts, int32_t k, int32_t 
 // Capacity of the batch workspace as it stands: {contracts, workgroups per contract} (0, 0 before the first batch).
 extern "C" int olmc_multi_capacity(int64_t* out2) {
     if (!out2) return fail(OLMC_ERR_ARG, "null pointer");
-    DeviceCtx* c = nullptr;
-    int rc = ctx_get(&c);
+    CtxLease lease;
+    int rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     out2[0] = c->multi_cap;
     out2[1] = static_cast<int64_t>(c->multi_bpo);
     return OLMC_OK;
@@ -1053,10 +1123,10 @@ extern "C" int olmc_european_terminal(double S, double T, double r, double sigma
     if (!out_host) return fail(OLMC_ERR_ARG, "null pointer");
     int rc = check_paths(0, n_paths, n_steps);
     if (rc) return rc;
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     const size_t bytes = sizeof(double) * static_cast<size_t>(n_paths) * (antithetic ? 2 : 1);
     rc = bulk_reserve(c, bytes);
     if (rc) return rc;
@@ -1094,10 +1164,10 @@ extern "C" int olmc_european_cv_shard(double S, double K, double T, double r, do
     if (!out) return fail(OLMC_ERR_ARG, "null pointer");
     int rc = check_paths(path_offset, n_local, n_steps);
     if (rc) return rc;
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     PathRange pr = make_range(path_offset, n_local, n_steps, seed);
     const int32_t grid = european_launch_shape(c, &pr, european_occupancy<1, kControlVariate>(antithetic != 0));
     ContractSet<1> cs;
@@ -1154,10 +1224,10 @@ extern "C" int olmc_asian(double S, double K, double T, double r, double sigma, 
         return fail(OLMC_ERR_ARG, "bad avg_kind");
     int rc = check_paths(path_offset, n_local, n_steps);
     if (rc) return rc;
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
     const int32_t grid = grid_for(n_local);
     AsianContract ac;
@@ -1199,10 +1269,10 @@ int run_extrema(double S, double K, double T, double r, double sigma, double q, 
     if (!out) return fail(OLMC_ERR_ARG, "null pointer");
     int rc = check_paths(path_offset, n_local, n_steps);
     if (rc) return rc;
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
     const int32_t grid = grid_for(n_local);
     ExtremaContract ec;
@@ -1257,10 +1327,10 @@ int run_structured(int64_t path_offset, int64_t n_local, int32_t n_steps, uint64
     if (!out) return fail(OLMC_ERR_ARG, "null pointer");
     int rc = check_paths(path_offset, n_local, n_steps);
     if (rc) return rc;
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
     const int32_t grid = grid_for(n_local);
     ReduceWs ws;
@@ -1276,7 +1346,7 @@ int run_structured(int64_t path_offset, int64_t n_local, int32_t n_steps, uint64
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     finish_stats(c->h_result[0], c->h_result[1], n_local * (antithetic ? 2 : 1), r_for_discount, T, out);
-    if (raw_sums) for (int m = 0; m < nv; ++m) raw_sums[m] = c->h_result[m];     // still under c->mu
+    if (raw_sums) for (int m = 0; m < nv; ++m) raw_sums[m] = c->h_result[m];     // the context is still leased
     if (poisoned_inputs) nan_stats(out->n, out);
     return OLMC_OK;
 }
@@ -1338,10 +1408,10 @@ extern "C" int olmc_gbm_paths(double S, double T, double r, double sigma, double
     if (rc) return rc;
     const double bytes = 8.0 * static_cast<double>(n_paths) * (n_steps + 1.0);
     if (bytes > 64e9) return fail(OLMC_ERR_ARG, "path matrix would exceed 64 GB");
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     rc = bulk_reserve(c, static_cast<size_t>(bytes));
     if (rc) return rc;
     LsmContract lc{};
@@ -1367,10 +1437,10 @@ extern "C" int olmc_exercise_boundary(double S, double K, double T, double r, do
     if (rc) return rc;
     const double bytes = 8.0 * static_cast<double>(n_paths) * (n_steps + 1.0);
     if (bytes > 64e9) return fail(OLMC_ERR_ARG, "path matrix would exceed 64 GB");
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     const size_t rows = static_cast<size_t>(n_steps) + 1;
     const size_t path_bytes = (static_cast<size_t>(bytes) + 255) / 256 * 256;
     rc = bulk_reserve(c, path_bytes + rows * sizeof(double));
@@ -1405,10 +1475,10 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
     if (rc) return rc;
     const double path_bytes = 8.0 * static_cast<double>(n_paths) * (n_steps + 2.0) + 256.0;
     if (path_bytes > 64e9) return fail(OLMC_ERR_ARG, "path matrix would exceed 64 GB: lower n_paths or n_steps");
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     rc = bulk_reserve(c, static_cast<size_t>(path_bytes));
     if (rc) return rc;
     double* d_paths = static_cast<double*>(c->d_bulk);                                  // [n_steps + 1][n_paths]
@@ -1428,8 +1498,15 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
     lc.n_steps = n_steps;
     const PathRange pr = make_range(0, n_paths, n_steps, seed);
     const int32_t path_grid = grid_for(n_paths);
-    // the per-date launches do ~30 flops per path and then reduce 16 sums per wave: few, fat workgroups
-    const int32_t grid = std::min<int32_t>(path_grid, 2 * c->cus);
+    // The per-date launches move 32 bytes per path and reduce 16 sums per workgroup: at most ONE workgroup per compute unit (a single
+    // group of the grid reduction: one ticket round, <= 256 rows for the last workgroup to sum), each thread taking its paths U at a
+    // time with all 3 U loads in flight.  Measured per call, 51 launches (profiles/r04_lsm_ab.jsonl): 1M x 50 -- 959 us at U = 1,
+    // 816 at 4, 804 at 8 (two workgroups per CU: 887 / 841 / 867; eight: 921 / 980 / 1081); 50k x 50, where a thread has one path --
+    // 429 at U = 1, 441 at 4, 459 at 8 (the unrolled trip's dead slots).  Round 3's kernel (130 VGPRs, 256 B scratch, one path per
+    // trip, two workgroups per CU, serial solve in one lane) took 1,123 / 490 us.
+    const int32_t grid = std::min<int32_t>(path_grid, c->cus);
+    const int64_t per_thread = (n_paths + static_cast<int64_t>(grid) * kBlock - 1) / (static_cast<int64_t>(grid) * kBlock);
+    const int lsm_unroll = per_thread <= 1 ? 1 : per_thread <= 2 ? 2 : per_thread <= 4 ? 4 : 8;
     EventPair ep{};
     if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
     hipLaunchKernelGGL((lsm_paths_kernel<false>), dim3(path_grid), dim3(kBlock), 0, c->stream, pr, lc, d_paths);
@@ -1443,7 +1520,19 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
         if (rc) return rc;
         ws.done_flag = nullptr;                       // one call = many launches sharing d_result: the call waits for the stream itself
         c->armed = 0;
-        hipLaunchKernelGGL(lsm_step_kernel, dim3(grid), dim3(kBlock), 0, c->stream, n_paths, lc, d_coef, t_fit, init, d_paths, d_cash, ws);
+        const bool first = init != 0, final_date = t_fit == 0;
+        auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, c->stream, n_paths, lc, d_coef, t_fit, d_paths, d_cash, ws); };
+        auto pick = [&](auto u) {
+            constexpr int U = decltype(u)::value;
+            if (first && final_date) go(lsm_step_kernel<U, true, true>);
+            else if (first) go(lsm_step_kernel<U, true, false>);
+            else if (final_date) go(lsm_step_kernel<U, false, true>);
+            else go(lsm_step_kernel<U, false, false>);
+        };
+        if (lsm_unroll == 1) pick(std::integral_constant<int, 1>{});
+        else if (lsm_unroll == 2) pick(std::integral_constant<int, 2>{});
+        else if (lsm_unroll == 8) pick(std::integral_constant<int, 8>{});
+        else pick(std::integral_constant<int, 4>{});
         rc = after_launch(c, c->stream);
         if (rc) return rc;
         init = 0;
@@ -1488,10 +1577,10 @@ extern "C" int olmc_heston_paths(double S, double T, double r, double q, double 
     if (rc) return rc;
     const double bytes = 8.0 * static_cast<double>(n_paths) * (n_steps + 1.0);
     if (2 * bytes > 64e9) return fail(OLMC_ERR_ARG, "path matrices would exceed 64 GB");
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     rc = bulk_reserve(c, 2 * static_cast<size_t>(bytes));
     if (rc) return rc;
     double* d_spot = static_cast<double*>(c->d_bulk);
@@ -1514,10 +1603,10 @@ extern "C" int olmc_heston(double S, double K, double T, double r, double q, int
     if (!(rho >= -1.0 && rho <= 1.0)) return fail(OLMC_ERR_ARG, "rho must be in [-1, 1]");
     int rc = check_paths(path_offset, n_local, n_steps);
     if (rc) return rc;
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     const PathRange pr = make_range(path_offset, n_local, n_steps, seed);
     const int32_t grid = grid_for(n_local);
     const HestonContract hc = make_heston(S, K, T, r, q, is_call, kappa, theta, sigma_v, rho, v0, n_steps);
@@ -1600,10 +1689,10 @@ extern "C" int olmc_jump_paths(double S, double T, double r, double sigma, doubl
     if (rc) return rc;
     const double bytes = 8.0 * static_cast<double>(n_paths) * (n_steps + 1.0);
     if (bytes > 64e9) return fail(OLMC_ERR_ARG, "path matrix would exceed 64 GB");
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     rc = bulk_reserve(c, static_cast<size_t>(bytes));
     if (rc) return rc;
     const PathRange pr = make_range(0, n_paths, n_steps, seed);
@@ -1621,7 +1710,7 @@ extern "C" int olmc_jump_paths(double S, double T, double r, double sigma, doubl
 namespace {
 // The scrambled direction matrix and digital shift on the device: [dims x 30 | dims] words.  The table travels only when it
 // differs from the one already there (compared word for word: 31 KB at 252 dims, ~1 us, against two pageable uploads): the
-// 8 / 14 pricings of literal FD Greeks and every repeated pricing share one upload.  Call under c->mu.
+// 8 / 14 pricings of literal FD Greeks and every repeated pricing share one upload.  The caller holds the context's lease.
 int qmc_table(DeviceCtx* c, const uint32_t* sv, const uint32_t* shift, int32_t dims) {
     const size_t sv_words = static_cast<size_t>(dims) * kSobolBits, table_words = sv_words + dims;
     const bool same = c->sobol_host.size() == table_words && std::memcmp(c->sobol_host.data(), sv, sizeof(uint32_t) * sv_words) == 0 &&
@@ -1659,10 +1748,10 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
             olmc_stats* out, double* terminal_host, int mirror = 0, olmc_cv_moments* cv = nullptr) {
     int rc = qmc_check(sv, shift, bits, dims, point_offset, n_paths);
     if (rc) return rc;
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     const size_t sv_words = static_cast<size_t>(dims) * kSobolBits;
     const size_t term_bytes = terminal_host ? sizeof(double) * static_cast<size_t>(n_paths) * (mirror ? 2 : 1) : 0;
     if (term_bytes) {
@@ -1778,10 +1867,10 @@ int run_qmc_batch(const olmc_option* opts, int32_t k, int64_t point_offset, int6
         }
         return OLMC_OK;
     }
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     rc = qmc_table(c, sv, shift, dims);
     if (rc) return rc;
     const size_t sv_words = static_cast<size_t>(dims) * kSobolBits;
@@ -1980,10 +2069,10 @@ extern "C" int olmc_multi_gpu_european(double S, double K, double T, double r, d
 extern "C" int olmc_philox_words(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t block0, int32_t n_blocks,
                                  uint32_t stream_tag, uint32_t* out_host) {
     if (!out_host || n_paths < 1 || n_blocks < 1 || block0 < 0 || path_offset < 0) return fail(OLMC_ERR_ARG, "bad arguments");
-    DeviceCtx* c = nullptr;
-    int rc = ctx_get(&c);
+    CtxLease lease;
+    int rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     const size_t bytes = sizeof(uint32_t) * 4 * static_cast<size_t>(n_paths) * n_blocks;
     rc = bulk_reserve(c, bytes);
     if (rc) return rc;
@@ -2001,10 +2090,10 @@ extern "C" int olmc_philox_words(uint64_t seed, int64_t path_offset, int64_t n_p
 extern "C" int olmc_exp2_probe_form(const double* x_host, int64_t n, double* y_host, int form) {
     if (!x_host || !y_host || n < 1) return fail(OLMC_ERR_ARG, "bad arguments");
     if (form != 0 && form != 1) return fail(OLMC_ERR_ARG, "form must be 0 (polynomial) or 1 (table)");
-    DeviceCtx* c = nullptr;
-    int rc = ctx_get(&c);
+    CtxLease lease;
+    int rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     const size_t bytes = sizeof(double) * static_cast<size_t>(n);
     rc = bulk_reserve(c, 2 * bytes);
     if (rc) return rc;
@@ -2035,10 +2124,10 @@ extern "C" int olmc_normal_moments(uint64_t seed, int64_t path_offset, int64_t n
 
 extern "C" int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps, float* out_host) {
     if (!out_host || n_paths < 1 || n_steps < 1 || path_offset < 0) return fail(OLMC_ERR_ARG, "bad arguments");
-    DeviceCtx* c = nullptr;
-    int rc = ctx_get(&c);
+    CtxLease lease;
+    int rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     const size_t bytes = sizeof(float) * static_cast<size_t>(n_paths) * n_steps;
     rc = bulk_reserve(c, bytes);
     if (rc) return rc;
@@ -2058,10 +2147,10 @@ extern "C" int olmc_clock_probe(int64_t n_paths, int32_t n_steps, uint64_t seed,
     if (!out3) return fail(OLMC_ERR_ARG, "null pointer");
     int rc = check_paths(0, n_paths, n_steps);
     if (rc) return rc;
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     const int32_t grid = static_cast<int32_t>(std::min<int64_t>((n_paths + kBlock - 1) / kBlock, kMaxGrid));
     const size_t bytes = sizeof(uint64_t) * 2 * static_cast<size_t>(grid) + 256;
     rc = bulk_reserve(c, bytes);
@@ -2099,10 +2188,10 @@ extern "C" int olmc_phase_stamps(int64_t n_paths, int32_t n_steps, uint64_t seed
     if (!stamps_host || !info3) return fail(OLMC_ERR_ARG, "null pointer");
     int rc = check_paths(0, n_paths, n_steps);
     if (rc) return rc;
-    DeviceCtx* c = nullptr;
-    rc = ctx_get(&c);
+    CtxLease lease;
+    rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     PathRange pr = make_range(0, n_paths, n_steps, seed);
     const int32_t grid = european_launch_shape(c, &pr, european_occupancy<1, kReduce>(true));
     if (static_cast<int64_t>(grid) * kBlock < n_paths) return fail(OLMC_ERR_ARG, "grid-striding launches are not instrumented");
@@ -2161,10 +2250,10 @@ extern "C" int olmc_issue_probe(int op, int waves_per_simd, double* ns_per_instr
     if (!ns_per_instr) return fail(OLMC_ERR_ARG, "null pointer");
     if (op < 0 || op >= kOps) return fail(OLMC_ERR_ARG, "unknown probe class");
     if (waves_per_simd < 1 || waves_per_simd > 8) return fail(OLMC_ERR_ARG, "waves_per_simd must be in [1, 8]");
-    DeviceCtx* c = nullptr;
-    int rc = ctx_get(&c);
+    CtxLease lease;
+    int rc = ctx_lease(&lease);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    DeviceCtx* const c = lease.c;
     rc = bulk_reserve(c, 256);
     if (rc) return rc;
     const dim3 grid(static_cast<uint32_t>(c->cus * waves_per_simd)), block(kBlock);    // one 4-wave workgroup per (CU, resident wave slot)
@@ -2195,14 +2284,49 @@ extern "C" int olmc_tune(int knob, int value) {
     return fail(OLMC_ERR_ARG, "unknown tuning knob or value");
 }
 
+namespace {
+// Runs fn on EVERY context of the calling thread's device, each taken out of circulation first (waits for the calls in flight).
+template <typename Fn>
+int with_all_contexts(Fn fn) {
+    int dev = t_device >= 0 ? t_device : g_default_device;
+    if (dev < 0) {
+        int rc = olmc_init(0);
+        if (rc) return rc;
+        dev = t_device;
+    }
+    DevicePool* pool = g_pool[dev];
+    if (!pool) return fail(OLMC_ERR_STATE, "device not initialised (call olmc_init)");
+    HIP_TRY(hipSetDevice(dev));
+    std::vector<DeviceCtx*> mine;
+    {
+        std::unique_lock<std::mutex> lock(pool->mu);
+        pool->idle.wait(lock, [&] { return std::none_of(pool->all.begin(), pool->all.end(), [](const DeviceCtx* c) { return c->busy; }); });
+        mine = pool->all;
+        for (DeviceCtx* c : mine) c->busy = true;
+    }
+    int rc = OLMC_OK;
+    for (DeviceCtx* c : mine) {
+        const int r = fn(c);
+        if (r && !rc) rc = r;
+    }
+    {
+        std::lock_guard<std::mutex> lock(pool->mu);
+        for (DeviceCtx* c : mine) c->busy = false;
+    }
+    pool->idle.notify_all();
+    return rc;
+}
+}  // namespace
+
 extern "C" int olmc_profile_enable(int on) {
     g_profile = on != 0;
     if (g_profile && (t_device >= 0 || g_default_device >= 0)) {
         // pre-create the event pairs a measurement pass will consume, so that no hipEventCreate lands inside a timed call
-        DeviceCtx* c = nullptr;
-        int rc = ctx_get(&c);
+        // (context 0 is the one a single-threaded measurement runs on; the others create theirs on demand)
+        CtxLease lease;
+        int rc = ctx_lease(&lease);
         if (rc) return rc;
-        std::lock_guard<std::mutex> lock(c->mu);
+        DeviceCtx* const c = lease.c;
         constexpr size_t kPool = 4096;
         while (c->ev_free.size() + c->ev_pending.size() < kPool) {
             EventPair ep{};
@@ -2215,25 +2339,26 @@ extern "C" int olmc_profile_enable(int on) {
 }
 
 extern "C" int olmc_profile_reset(void) {
-    DeviceCtx* c = nullptr;
-    int rc = ctx_get(&c);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
-    rc = prof_drain(c);
-    c->prof_launches = 0;
-    c->prof_ms = 0.0;
-    return rc;
+    return with_all_contexts([](DeviceCtx* c) {
+        const int rc = prof_drain(c);
+        c->prof_launches = 0;
+        c->prof_ms = 0.0;
+        return rc;
+    });
 }
 
 extern "C" int olmc_kernel_time(int64_t* launches, double* total_ms) {
     if (!launches || !total_ms) return fail(OLMC_ERR_ARG, "null pointer");
-    DeviceCtx* c = nullptr;
-    int rc = ctx_get(&c);
+    int64_t n = 0;
+    double ms = 0.0;
+    const int rc = with_all_contexts([&](DeviceCtx* c) {
+        const int r = prof_drain(c);
+        n += c->prof_launches;
+        ms += c->prof_ms;
+        return r;
+    });
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
-    rc = prof_drain(c);
-    if (rc) return rc;
-    *launches = c->prof_launches;
-    *total_ms = c->prof_ms;
+    *launches = n;
+    *total_ms = ms;
     return OLMC_OK;
 }

@@ -1563,133 +1563,158 @@ struct LsmCoeffs {
 
 __device__ __forceinline__ double lsm_intrinsic(const LsmContract& c, double s) { return fmax(c.sign * (s - c.strike), 0.0); }
 
-// Runs in the wave that holds the grid totals of one exercise date: lane m < 2d+1 has sum x^m,
-// lane 9+k has sum x^k cf, lane 14 the in-the-money count.  Lane 0 gathers them, solves the
-// (d+1)x(d+1) normal equations (Gaussian elimination, partial pivoting, fp64 -- the moments of
-// x = S/K in (0, ~2) are benign) and publishes the coefficients for the NEXT launch, which is
-// ordered behind this one on the stream: no host round trip per exercise date.
+// Runs in the wave that holds the grid totals of one exercise date (all 64 lanes active): lane m < 2d+1 has sum x^m,
+// lane 9+k has sum x^k cf, lane 14 the in-the-money count.  The wave solves the (d+1)x(d+1) normal equations (Gaussian
+// elimination, partial pivoting, fp64 -- the moments of x = S/K in (0, ~2) are benign) and publishes the coefficients for
+// the NEXT launch, which is ordered behind this one on the stream: no host round trip per exercise date.
+//
+// Round 4: the augmented 5 x 6 matrix lives ONE ELEMENT PER LANE (lane = 8 row + column) instead of thirty doubles in lane 0.
+// Round 3's form indexed its private array with the run-time pivot row (`a[piv][col]`), which put the whole matrix into a
+// 256-byte private segment (the only scratch in the library) and ran ~1,200 dependent fp64 instructions in one lane behind the
+// LAST workgroup of each of the per-date launches.  Here an elimination step is two broadcasts from compile-time lanes
+// (v_readlane: the pivot candidates, the pivot), one run-time row exchange and two gathers (ds_bpermute) and ONE multiply-subtract
+// per lane; back-substitution runs on broadcast (wave-uniform) values.  Every element sees the operations of the serial form in
+// the serial form's order (same pivot choice: first maximum; `f = a[row][col] * inv`, `a -= f * a[col][l]`; the same
+// back-substitution chain), so the coefficients -- and with them every exercise decision -- are the bits round 3 produced.
+__device__ __forceinline__ double lane_bcast(double v, int src_lane /* compile-time constant */) {
+    const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(dbl_lo(v)), src_lane));
+    const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(dbl_hi(v)), src_lane));
+    return dbl_of(lo, hi);
+}
+
 struct LsmFit {
     LsmCoeffs* coef;
     int32_t degree;
     __device__ __forceinline__ void operator()(double total) const {
-        double sums[kLsmNV];
-#pragma unroll
-        for (int k = 0; k < kLsmNV; ++k) sums[k] = __shfl(total, k, kWave);
-        if (threadIdx.x != 0) return;
+        constexpr int D = kLsmMaxDegree;               // rows 0..D, columns 0..D + the right-hand side in column D + 1
+        const int lane = threadIdx.x & (kWave - 1);
+        const int row = lane >> 3, l = lane & 7;
+        const bool live = row <= D && l <= D + 1;
         const int n = degree + 1;
-        double a[kLsmMaxDegree + 1][kLsmMaxDegree + 2];
+        // a[row][l] = sum x^(row + l)  (l <= D),  a[row][D + 1] = sum x^row cf
+        double e = __shfl(total, live ? (l <= D ? row + l : 2 * D + 1 + row) : 0, kWave);
+        bool ok = lane_bcast(total, kLsmNV - 2) > static_cast<double>(degree + 1);       // np.sum(itm) > poly_degree + 1 (:279)
+        // unknowns beyond `degree` are pinned to 0 by turning their rows / columns into the identity
+        if (row >= n || (l <= D && l >= n)) e = row == l ? 1.0 : 0.0;
+        if (!live) e = 0.0;
 #pragma unroll
-        for (int k = 0; k <= kLsmMaxDegree; ++k) {
-#pragma unroll
-            for (int l = 0; l <= kLsmMaxDegree; ++l) a[k][l] = sums[k + l];
-            a[k][kLsmMaxDegree + 1] = sums[2 * kLsmMaxDegree + 1 + k];
-        }
-        bool ok = sums[kLsmNV - 2] > static_cast<double>(degree + 1);       // np.sum(itm) > poly_degree + 1 (:279)
-        // unknowns beyond `degree` are pinned to 0 by turning their rows/columns into the identity
-#pragma unroll
-        for (int k = 0; k <= kLsmMaxDegree; ++k)
-            if (k >= n) {
-#pragma unroll
-                for (int l = 0; l <= kLsmMaxDegree + 1; ++l) a[k][l] = 0.0;
-#pragma unroll
-                for (int l = 0; l <= kLsmMaxDegree; ++l) a[l][k] = 0.0;
-                a[k][k] = 1.0;
-            }
-#pragma unroll
-        for (int col = 0; col <= kLsmMaxDegree; ++col) {
+        for (int col = 0; col <= D; ++col) {
             int piv = col;
+            double best = fabs(lane_bcast(e, col * 8 + col));
 #pragma unroll
-            for (int row = 0; row <= kLsmMaxDegree; ++row)
-                if (row > col && fabs(a[row][col]) > fabs(a[piv][col])) piv = row;
-#pragma unroll
-            for (int row = 0; row <= kLsmMaxDegree; ++row)            // swap rows piv <-> col without dynamic indexing
-                if (row > col && row == piv) {
-#pragma unroll
-                    for (int l = 0; l <= kLsmMaxDegree + 1; ++l) { const double tmp = a[row][l]; a[row][l] = a[col][l]; a[col][l] = tmp; }
-                }
-            if (!(fabs(a[col][col]) > 1e-280)) ok = false;
-            const double inv = 1.0 / a[col][col];
-#pragma unroll
-            for (int row = 0; row <= kLsmMaxDegree; ++row)
-                if (row > col) {
-                    const double f = a[row][col] * inv;
-#pragma unroll
-                    for (int l = 0; l <= kLsmMaxDegree + 1; ++l)
-                        if (l >= col) a[row][l] -= f * a[col][l];
-                }
+            for (int r = col + 1; r <= D; ++r) {
+                const double cand = fabs(lane_bcast(e, r * 8 + col));
+                if (cand > best) { best = cand; piv = r; }
+            }
+            // rows piv <-> col trade places (a no-op gather when piv == col)
+            const int from = row == col ? piv : (row == piv ? col : row);
+            e = __shfl(e, from * 8 + l, kWave);
+            const double p = lane_bcast(e, col * 8 + col);
+            if (!(fabs(p) > 1e-280)) ok = false;
+            const double inv = 1.0 / p;
+            const double f = __shfl(e, row * 8 + col, kWave) * inv;
+            const double pr = __shfl(e, col * 8 + l, kWave);
+            if (live && row > col && l >= col) e -= f * pr;
         }
-        double beta[kLsmMaxDegree + 1];
+        double beta[D + 1];
 #pragma unroll
-        for (int k = kLsmMaxDegree; k >= 0; --k) {
-            double v = a[k][kLsmMaxDegree + 1];
+        for (int k = D; k >= 0; --k) {
+            double v = lane_bcast(e, k * 8 + D + 1);
 #pragma unroll
-            for (int l = 0; l <= kLsmMaxDegree; ++l)
-                if (l > k) v -= a[k][l] * beta[l];
-            beta[k] = v / a[k][k];
+            for (int j = 0; j <= D; ++j)
+                if (j > k) v -= lane_bcast(e, k * 8 + j) * beta[j];
+            beta[k] = v / lane_bcast(e, k * 8 + k);
         }
+        if (lane == 0) {
 #pragma unroll
-        for (int k = 0; k <= kLsmMaxDegree; ++k) coef->beta[k] = ok ? beta[k] : 0.0;
-        coef->valid = ok ? 1 : 0;
+            for (int k = 0; k <= D; ++k) coef->beta[k] = ok ? beta[k] : 0.0;
+            coef->valid = ok ? 1 : 0;
+        }
     }
 };
 
 // One exercise date for this thread's paths.  t_fit: the date whose moments are accumulated (>= 1);
 // the date finished first is t_fit + 1 (skipped when init: the terminal payoff needs no regression).
 // init != 0: cash flow starts as the terminal intrinsic value.  `prev` = fit of date t_fit + 1.
-__device__ __forceinline__ void lsm_date(int64_t n, const LsmContract& c, const LsmCoeffs& prev, int32_t t_fit, int32_t init,
+//
+// A date is 24 bytes read and 8 written per path and ~40 flops: the loop is bounded by how many loads the few resident waves
+// keep in flight, so a thread issues the loads of U of its paths (3 U doubles) before it touches any of them (round 4; round 3
+// walked one path at a time: three dependent load round trips per path, eight paths per thread at 1M paths).  The paths of a
+// thread are still consumed in ascending order, so the sixteen per-thread sums -- and the bits of the price -- do not depend on U.
+template <int U, bool INIT, bool FINAL>
+__device__ __forceinline__ void lsm_date(int64_t n, const LsmContract& c, const LsmCoeffs& prev, int32_t t_fit,
                                          const double* __restrict__ paths, double* __restrict__ cash, double (&acc)[kLsmNV]) {
 #pragma unroll
     for (int k = 0; k < kLsmNV; ++k) acc[k] = 0.0;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n; i += stride) {
-        double cf;
-        if (init) {
-            cf = lsm_intrinsic(c, paths[static_cast<size_t>(c.n_steps) * n + i]);
-        } else {
-            cf = cash[i];
-            const double s1 = paths[static_cast<size_t>(t_fit + 1) * n + i];
-            const double iv = lsm_intrinsic(c, s1);
-            if (prev.valid && iv > 0.0) {
-                const double x = s1 * c.inv_strike;
-                double cont = prev.beta[kLsmMaxDegree];
+    const double* __restrict__ row1 = paths + static_cast<size_t>(INIT ? c.n_steps : t_fit + 1) * n;     // the later date
+    const double* __restrict__ row0 = paths + static_cast<size_t>(t_fit) * n;                            // the date being fitted
+    for (int64_t i0 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i0 < n; i0 += stride * U) {
+        double cfv[U], s1v[U], s0v[U];
 #pragma unroll
-                for (int k = kLsmMaxDegree - 1; k >= 0; --k) cont = cont * x + prev.beta[k];
-                if (iv > cont) cf = iv;
-            }
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            const bool in = i < n;
+            s1v[u] = in ? row1[i] : 0.0;
+            cfv[u] = (in && !INIT) ? cash[i] : 0.0;
+            s0v[u] = (in && !FINAL) ? row0[i] : 0.0;
         }
-        cf *= c.discount;
-        cash[i] = cf;
-        if (t_fit >= 1) {
-            const double s0 = paths[static_cast<size_t>(t_fit) * n + i];
-            if (lsm_intrinsic(c, s0) > 0.0) {
-                const double x = s0 * c.inv_strike;
-                double p = 1.0;
 #pragma unroll
-                for (int m = 0; m <= 2 * kLsmMaxDegree; ++m) {
-                    if (m <= 2 * c.degree) acc[m] += p;
-                    if (m <= c.degree) acc[2 * kLsmMaxDegree + 1 + m] += p * cf;
-                    p *= x;
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n) {
+                double cf;
+                if constexpr (INIT) {
+                    cf = lsm_intrinsic(c, s1v[u]);
+                } else {
+                    cf = cfv[u];
+                    const double iv = lsm_intrinsic(c, s1v[u]);
+                    if (prev.valid && iv > 0.0) {
+                        const double x = s1v[u] * c.inv_strike;
+                        double cont = prev.beta[kLsmMaxDegree];
+#pragma unroll
+                        for (int k = kLsmMaxDegree - 1; k >= 0; --k) cont = cont * x + prev.beta[k];
+                        if (iv > cont) cf = iv;
+                    }
                 }
-                acc[kLsmNV - 2] += 1.0;       // in-the-money count
+                cf *= c.discount;
+                cash[i] = cf;
+                if constexpr (!FINAL) {
+                    // every power up to 2 kLsmMaxDegree is summed whatever the degree: LsmFit replaces the rows and columns beyond
+                    // `degree` by the identity, so the surplus sums are never read (and a sum that IS read is the same chain of adds)
+                    const bool itm = lsm_intrinsic(c, s0v[u]) > 0.0;
+                    const double x = s0v[u] * c.inv_strike;
+                    double p = itm ? 1.0 : 0.0;                 // out-of-the-money paths add exact zeros (x is finite)
+                    const double w = itm ? cf : 0.0;
+#pragma unroll
+                    for (int m = 0; m <= 2 * kLsmMaxDegree; ++m) {
+                        acc[m] += p;
+                        if (m <= kLsmMaxDegree) acc[2 * kLsmMaxDegree + 1 + m] += p * w;
+                        p *= x;
+                    }
+                    acc[kLsmNV - 2] += itm ? 1.0 : 0.0;       // in-the-money count
+                } else {
+                    acc[0] += cf;                     // final date (t_fit == 0): moments of the time-0 cash flow
+                    acc[1] += cf * cf;
+                }
             }
-        } else {
-            acc[0] += cf;                     // final date (t_fit == 0): moments of the time-0 cash flow
-            acc[1] += cf * cf;
         }
     }
 }
 
 // One launch per exercise date: `coef` is read at entry (fit of date t_fit + 1, written by the previous
 // launch) and overwritten at the very end by this launch's fit; stream order is the synchronisation.
+// INIT: the cash flow starts as the terminal intrinsic value (first launch); FINAL: t_fit == 0, the launch that leaves the
+// moments of the time-0 cash flow instead of a regression.
+template <int U, bool INIT, bool FINAL>
 __global__ __launch_bounds__(kBlock) void lsm_step_kernel(int64_t n, LsmContract c, LsmCoeffs* __restrict__ coef, int32_t t_fit,
-                                                          int32_t init, const double* __restrict__ paths,
-                                                          double* __restrict__ cash, ReduceWs ws) {
+                                                          const double* __restrict__ paths, double* __restrict__ cash, ReduceWs ws) {
     double acc[kLsmNV];
     LsmCoeffs prev;
     prev.valid = 0;
-    if (!init) prev = *coef;
-    lsm_date(n, c, prev, t_fit, init, paths, cash, acc);
-    if (t_fit >= 1) block_then_grid_reduce<kLsmNV>(acc, ws, LsmFit{coef, c.degree});
+    if constexpr (!INIT) prev = *coef;
+    lsm_date<U, INIT, FINAL>(n, c, prev, t_fit, paths, cash, acc);
+    if constexpr (!FINAL) block_then_grid_reduce<kLsmNV>(acc, ws, LsmFit{coef, c.degree});
     else block_then_grid_reduce<kLsmNV>(acc, ws);
 }
 
@@ -1968,6 +1993,16 @@ __constant__ double kNdtriB[23] = {
 // residual correction, e ln 2 in two pieces: ~33 instructions where the library's correctly rounded log spends ~75.
 __constant__ double kLogQ[7] = {0.666666666666667, 0.39999999999886615, 0.28571428631764334, 0.2222221019926421, 0.18182956608063458, 0.15329500754204178, 0.14643628601909797};
 
+// A zero the optimiser cannot see through (see ndtri_lockstep): a table indexed [k + opaque_zero()] is loaded where it is used.
+__device__ __forceinline__ int opaque_zero() {
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
+}
+
+// The one-point-per-thread kernels (european_qmc_kernel, european_qmc_batch_kernel<., false>) call ndtri_w once per dimension: the
+// compiler keeps the 55 coefficients in scalar registers across the dimension loop (what does not fit next to the dimension's 30
+// direction numbers comes back through a few v_readlane_b32).
 __device__ __forceinline__ double neg_log_unit(double t) {
     double m = __builtin_amdgcn_frexp_mant(t);          // t = m 2^e, m in [0.5, 1)
     int e = __builtin_amdgcn_frexp_exp(t);
@@ -1989,7 +2024,16 @@ __device__ __forceinline__ double neg_log_unit(double t) {
     return -__builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, ln_m));
 }
 
-__device__ __forceinline__ double ndtri_w(double p) {
+// The rare side of the inverse normal (w >= 6.25, 0.1 % of the points): degree 22 in sqrt(w) - 3.6.
+__device__ __forceinline__ double ndtri_tail(double w, int z = 0 /* see ndtri_lockstep */) {
+    const double t = sqrt(w) - kNdtriCentreB;
+    double f = kNdtriB[22 + z];
+#pragma unroll
+    for (int k = 21; k >= 0; --k) f = __builtin_fma(f, t, kNdtriB[k + z]);
+    return f;
+}
+
+__device__ __forceinline__ double ndtri_w(double p, int z_tail = 0) {
     const double x = 2.0 * p - 1.0;                    // exact for p = k 2^-30
     const double w = neg_log_unit(4.0 * p * (1.0 - p));        // p (1 - p) straight from p: no cancellation at either end
     double f;
@@ -2003,12 +2047,60 @@ __device__ __forceinline__ double ndtri_w(double p) {
         // skip (s_cbranch_execz) -- without it hipcc flattened both sides into selects in european_qmc_batch_kernel (58 instead of
         // 34 fp64 fma per dimension and the sqrt expansion for every point: 229 vs 160 us at 2^17 x 252)
         asm volatile("");
-        const double t = sqrt(w) - kNdtriCentreB;
-        f = kNdtriB[22];
-#pragma unroll
-        for (int k = 21; k >= 0; --k) f = __builtin_fma(f, t, kNdtriB[k]);
+        f = ndtri_tail(w, z_tail);
     }
     return 1.4142135623730951 * x * f;
+}
+
+// fma(a, b, c) with the addend taken straight from a scalar register pair (VOP3).  Left to itself hipcc copies a freshly s_load-ed
+// coefficient into a VGPR pair (two v_mov_b32) so that it can use the two-address v_fmac_f64.
+__device__ __forceinline__ double fma_scalar_addend(double a, double b, double c_uniform) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+    return d;
+}
+
+// EIGHT inverse normals per thread, in lockstep (round 4; the eight-points-per-thread kernels).  Round 3 called ndtri_w eight times
+// per dimension: eight basic blocks (each point has its own main / tail branch), so nothing of one point overlapped anything of
+// another -- a wave ran eight serial chains of ~45 dependent fp64 operations per dimension -- and the 55 coefficients, hoisted in
+// front of the dimension loop, overflowed the scalar registers next to the 28 direction numbers of the dimension: 511 v_readlane_b32
+// per trip of european_qmc_block_kernel's loop brought them back one by one (the 16-contract batch kernel's spill lanes and
+// accumulation registers took its VGPR count to 270).  Here
+//   * the eight logarithms run as one basic block (eight independent chains for the scheduler to interleave);
+//   * the main polynomial (99.9 % of the points) is evaluated for ALL eight points, coefficient by coefficient: one scalar load
+//     serves eight fma, the chains cover each other's latency;
+//   * a point in the tail (w >= 6.25) is repaired afterwards behind a branch the wave almost always skips;
+//   * the tables are indexed [k + z] with z an OPAQUE ZERO the caller redefines once per dimension (opaque_zero()): the address is
+//     then not invariant in the dimension loop, so the coefficients are s_load-ed where they are used (440 bytes per trip from
+//     the scalar data cache) and occupy scalar registers only then.
+// Every point sees exactly the operations of ndtri_w: the same bits.
+template <int NP>
+__device__ __forceinline__ void ndtri_lockstep(const double (&p)[NP], double (&out)[NP], int z) {
+    double w[NP], f[NP], t[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        w[j] = neg_log_unit(4.0 * p[j] * (1.0 - p[j]));
+        t[j] = w[j] - kNdtriCentreA;
+    }
+    {
+        const double c = kNdtriA[24 + z];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) f[j] = c;
+    }
+#pragma unroll
+    for (int k = 23; k >= 0; --k) {
+        const double c = kNdtriA[k + z];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) f[j] = fma_scalar_addend(f[j], t[j], c);
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        if (!(w[j] < kNdtriSplit)) {
+            asm volatile("");                           // a real branch (see ndtri_w)
+            f[j] = ndtri_tail(w[j], z);
+        }
+        out[j] = 1.4142135623730951 * (2.0 * p[j] - 1.0) * f[j];
+    }
 }
 
 struct QmcRange {
@@ -2040,7 +2132,7 @@ __global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contr
             for (int b = 0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);   // x ^ (row & mask), one v_bitop3_b32
             double u = static_cast<double>(x) * 9.313225746154785e-10;      // 2^-30
             u = fmin(fmax(u, 1e-10), 1.0 - 1e-10);
-            zsum += ndtri_w(u);
+            zsum += ndtri_w(u, opaque_zero());
         }
         const double st = exp(c.a + c.vol * zsum);
         if constexpr (MODE == kTerminal) {
@@ -2082,25 +2174,35 @@ __global__ __launch_bounds__(kBlock) void european_qmc_block_kernel(QmcRange qr,
         for (int32_t t = 0; t < qr.dims; ++t) {
             const uint32_t* __restrict__ row = sv + static_cast<size_t>(t) * kSobolBits;
             uint32_t x = shift[t];
+            const int z0 = opaque_zero();
 #pragma unroll
             for (int b = 2; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);
+            double u[kQmcBlock], z[kQmcBlock];
 #pragma unroll
             for (int p = 0; p < kQmcBlock; ++p) {
                 if (p) x ^= row[__builtin_ctz(static_cast<unsigned>(p))];          // gray(k + 1) = gray(k) ^ (1 << ctz(k + 1))
-                double u = static_cast<double>(x) * 9.313225746154785e-10;      // 2^-30
-                u = fmin(fmax(u, 1e-10), 1.0 - 1e-10);
-                zsum[p] += ndtri_w(u);
+                u[p] = static_cast<double>(x) * 9.313225746154785e-10;          // 2^-30
+                u[p] = fmin(fmax(u[p], 1e-10), 1.0 - 1e-10);
             }
-        }
+            ndtri_lockstep<kQmcBlock>(u, z, z0);
 #pragma unroll
+            for (int p = 0; p < kQmcBlock; ++p) zsum[p] += z[p];
+        }
+        // the eight exponentials one after the other (a real loop over LDS-staged sums, as in european_qmc_batch_kernel): unrolled,
+        // their interleaving set the kernel's register count
+        __shared__ double zs[kQmcBlock][kBlock];
+#pragma unroll
+        for (int p = 0; p < kQmcBlock; ++p) zs[p][threadIdx.x] = zsum[p];
+#pragma unroll 1
         for (int p = 0; p < kQmcBlock; ++p) {
             const uint64_t k = k0 + static_cast<uint64_t>(p);
             if (k < qr.first || k >= last) continue;                            // the ragged ends of the range
-            const double st = exp(c.a + c.vol * zsum[p]);
+            const double zp = zs[p][threadIdx.x];
+            const double st = exp(c.a + c.vol * zp);
             if constexpr (MODE == kTerminal) {
                 const int64_t at = static_cast<int64_t>(k - qr.first);
                 terminal[at] = st;
-                if (qr.mirror) terminal[qr.count + at] = exp(c.a - c.vol * zsum[p]);
+                if (qr.mirror) terminal[qr.count + at] = exp(c.a - c.vol * zp);
             } else {
                 add_sample<MODE>(acc, fmax(c.sign * (st - c.strike), 0.0), st);
             }
@@ -2139,24 +2241,47 @@ __global__ __launch_bounds__(kBlock) void european_qmc_batch_kernel(QmcRange qr,
     for (int32_t t = 0; t < qr.dims; ++t) {
         const uint32_t* __restrict__ row = sv + static_cast<size_t>(t) * kSobolBits;
         uint32_t x = shift[t];
+        [[maybe_unused]] const int z0 = BLOCK8 ? opaque_zero() : 0;
 #pragma unroll
         for (int b = B0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);
+        double u[NP];
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             if (p) x ^= row[__builtin_ctz(static_cast<unsigned>(p))];
-            double u = static_cast<double>(x) * 9.313225746154785e-10;      // 2^-30
-            u = fmin(fmax(u, 1e-10), 1.0 - 1e-10);
-            zsum[p] += ndtri_w(u);
+            u[p] = static_cast<double>(x) * 9.313225746154785e-10;          // 2^-30
+            u[p] = fmin(fmax(u[p], 1e-10), 1.0 - 1e-10);
+        }
+        if constexpr (BLOCK8) {
+            double z[NP];
+            ndtri_lockstep<NP>(u, z, z0);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) zsum[p] += z[p];
+        } else {
+            zsum[0] += ndtri_w(u[0], opaque_zero());
         }
     }
     double acc[NV];
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = 0.0;
+    if constexpr (BLOCK8) {
+        // The eight points of the thread are priced ONE AFTER THE OTHER by a real loop (round 4).  Unrolled, the compiler interleaved
+        // eight times NSETS payoffs with up to five library exponentials each: 12,600 instructions and 270 VGPRs for 14 contracts
+        // (one wave per SIMD in a kernel whose dimension loop needs 127).  A loop needs the normal sums addressable by a run-time
+        // index, which registers are not, so they pass through LDS: 16 KB per workgroup, each thread reads back only what it wrote
+        // itself (no barrier).  The payoffs of a thread's points are still added in ascending order: same bits.
+        __shared__ double zs[kQmcBlock][kBlock];
+        uint32_t live_points = 0u;                                          // bit p: point k0 + p lies in the range (its ragged ends)
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const uint64_t k = k0 + static_cast<uint64_t>(p);
-        const bool live = unit_live && k >= qr.first && k < last;           // the ragged ends of the range
-        european_payoffs<NSETS, false, kReduce>(cs, zsum[p], live, 0, 0, nullptr, acc);
+        for (int p = 0; p < NP; ++p) {
+            const uint64_t k = k0 + static_cast<uint64_t>(p);
+            live_points |= (unit_live && k >= qr.first && k < last) ? (1u << p) : 0u;
+            zs[p][threadIdx.x] = zsum[p];
+        }
+#pragma unroll 1
+        for (int p = 0; p < NP; ++p)
+            european_payoffs<NSETS, false, kReduce>(cs, zs[p][threadIdx.x], ((live_points >> p) & 1u) != 0u, 0, 0, nullptr, acc);
+    } else {
+        european_payoffs<NSETS, false, kReduce>(cs, zsum[0], unit_live, 0, 0, nullptr, acc);
     }
     block_then_grid_reduce<NV>(acc, ws);
 }

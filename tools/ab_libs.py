@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of whole libolmc builds: one subprocess per (library, round), each timing the
 European path kernel with HIP events (olmc_kernel_time).  Usage (GPU box):
-    python tools/ab_libs.py libA.so libB.so ... [--n 1000000] [--m 252] [--rounds 7] [--case european|greeks8|greeks14|greeks8_lean|greeks14_lean|asian|asian_fast|asian_fast_anti|asian_anti|asian_geo|barrier|heston|merton|kou|autocall[_anti]|cliquet[_anti]]"""
+    python tools/ab_libs.py libA.so libB.so ... [--n 1000000] [--m 252] [--rounds 7] [--case european|greeks8|greeks14|greeks8_lean|greeks14_lean|asian|asian_fast|asian_fast_anti|asian_anti|asian_geo|barrier|heston|merton|kou|autocall[_anti]|cliquet[_anti]|american|qmc|qmc_cv|qmc_greeks8|qmc_greeks14]"""
 import argparse
 import json
 import os
@@ -38,6 +38,16 @@ CASES = {
     "cliquet_anti": lambda s: _hip.cliquet(100.0, 1.0, 0.05, 0.2, 0.0, 0.05, -0.05, 0.3, 0.0, 12, N, M, s, True),
     "heston": lambda s: _hip.heston(100.0, 100.0, 1.0, 0.05, 0.0, True, 2.0, 0.04, 0.3, -0.7, 0.04, N, M, s, False),
 }
+# round 4: the per-date launches of the American option, and the Sobol kernels (a table of `M` dimensions built once, seed 42)
+CASES["american"] = lambda s: _hip.american_lsm(*P, False, N, M, 3, s)
+if sys.argv[3].startswith("qmc"):
+    import numpy as np
+    from optionslab_amd.monte_carlo import sobol_tables
+    SV, SH = sobol_tables(M, 42)
+    CASES["qmc"] = lambda s: _hip.european_qmc(*P, True, N, SV, SH)
+    CASES["qmc_cv"] = lambda s: (lambda m: type("R", (), dict(price=m.value, sum=m.sum_d))())(_hip.european_qmc_cv(*P, True, N, SV, SH))
+    CASES["qmc_greeks8"] = lambda s: _hip.european_qmc_greeks_fd(*P, True, N, SV, SH, False)[1][0]
+    CASES["qmc_greeks14"] = lambda s: _hip.european_qmc_greeks_fd(*P, True, N, SV, SH, True)[1][0]
 run = CASES[sys.argv[3]]
 import os, time
 if os.environ.get("OLMC_AB_TUNE"):                      # "knob=value,knob=value" applied before anything runs

@@ -655,16 +655,19 @@ def worker(args):
     path_steps = n_global * N_STEPS
     value = path_steps * K_steps / pass_s
 
+    # calibration of the roofline: the shader clock held under this kernel's load and the per-class issue times, measured by the
+    # INSTRUMENTED build (include/olmc_probe.h, tools/probe/libolmc_probe.so) -- the product library carries no measurement kernels
     clock = None
     try:
+        from tools.probe import binding as probe
         for _ in range(3):
-            clock = _hip.clock_probe(PATHS_PER_GPU, N_STEPS, SEED)
+            clock = probe.clock_probe(PATHS_PER_GPU, N_STEPS, SEED)
     except Exception as e:
         clock = {"error": f"{type(e).__name__}: {e}"}
     clock_ghz = clock.get("ghz") if clock else None
     costs, mixes = None, load_isa_mix()
     try:
-        costs = _hip.issue_probe(8)         # ns per wave64 instruction per SIMD, per class, on this device, now
+        costs = probe.issue_probe(8)         # ns per wave64 instruction per SIMD, per class, on this device, now
     except Exception as e:
         print(f"[bench] issue probes unavailable: {type(e).__name__}: {e}", file=sys.stderr)
     if "c5_shard" not in mixes and "c2_european" in mixes:

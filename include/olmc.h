@@ -13,7 +13,11 @@
  *   - the caller owns every buffer it passes in; the library owns its device
  *     scratch (grown lazily, freed by olmc_shutdown) and returns no pointer
  *     that outlives the call except the thread-local error string;
- *   - entry points are re-entrant: a per-device mutex guards scratch + stream;
+ *   - Threading: entry points are re-entrant AND concurrent.  A call leases one of up to 8 contexts of its device (its own
+ *     stream, reduction workspace, pinned landing buffer and completion word) for its duration, so calls from different
+ *     threads overlap on the host and on the device instead of queueing behind one mutex (Streamlit runs a thread per
+ *     session; a ninth concurrent caller waits for a lease).  Results do not depend on which context served a call.  A
+ *     single-threaded caller always gets context 0.  olmc_shutdown must not race with calls in flight;
  *   - there is NO CPU fallback: without a usable HIP device every compute
  *     entry point fails with OLMC_ERR_HIP.
  *
@@ -40,9 +44,13 @@
 extern "C" {
 #endif
 
-#define OLMC_ABI_VERSION 3   /* 2: olmc_asian avg_kind 0 is the fp64-exponent kernel (2 = the fp32 one); probes, tune knobs 5-8
+#define OLMC_ABI_VERSION 4   /* 2: olmc_asian avg_kind 0 is the fp64-exponent kernel (2 = the fp32 one); probes, tune knobs 5-8
                               * 3: additions only -- olmc_european_qmc_batch, olmc_european_qmc_greeks_fd, olmc_multi_capacity,
-                              *    olmc_exp2_probe_form, olmc_phase_stamps, olmc_contract_layout, tune knob 9; every v2 entry point keeps its signature and meaning */
+                              *    olmc_exp2_probe_form, olmc_phase_stamps, olmc_contract_layout, tune knob 9; every v2 entry point keeps its signature and meaning
+                              * 4: the measurement entry points (olmc_*probe*, olmc_phase_stamps, olmc_clock_probe, olmc_normal_moments) and the
+                              *    fault-injection knobs 5 / 6 LEFT this library for the instrumented build (olmc_probe.h, libolmc_probe.so); added
+                              *    olmc_multi_gpu_greeks_fd, olmc_multi_gpu_european_cv; every pricing entry point keeps its signature and meaning;
+                              *    entry points are now concurrent across threads (a context per caller, olmc.h "Threading") */
 
 enum {
     OLMC_OK = 0,
@@ -338,14 +346,26 @@ int olmc_european_qmc_terminal(double S, double T, double r, double sigma, doubl
                                int antithetic, double* out_host /* [n_paths * (1 + antithetic)] */);
 
 /* ---- multi-GPU, single process ------------------------------------------
- * n_paths split into n_gpus contiguous global path ranges (devices 0 .. n_gpus - 1), one stream per device.  ONE host
- * thread -- the caller's -- queues every device's path kernel and then ONE grouped RCCL all-reduce of {sum, sumsq, n}
- * (3 x fp64) over xGMI before it waits for anything; the triple is handed to the host by device 0's polled completion word
- * (as olmc_fetch_dev), the other devices are drained before the call returns.  Identical finalisation on every rank
- * (SURVEY §8e).  On any error return the thread's device and the streams already launched on are restored / drained. */
+ * n_paths split into n_gpus contiguous global path ranges (rank d = device d, [d N / P, (d + 1) N / P)), one stream per rank.  ONE
+ * host thread -- the caller's -- queues every rank's path kernel and then ONE grouped RCCL all-reduce over xGMI before it waits
+ * for anything; the reduced sums are handed to the host by rank 0's polled completion word (as olmc_fetch_dev), the other ranks
+ * hold the same sums and are drained before the call returns.  Identical finalisation on every rank.  On any error
+ * return the thread's device and the streams already launched on are restored / drained.  Payload of the all-reduce:
+ *   olmc_multi_gpu_european      {sum, sumsq, n}                                   count = 3
+ *   olmc_multi_gpu_greeks_fd     the 8 / 14 bumped contracts of olmc_european_greeks_fd on the SAME normals, one launch per rank:
+ *                                {sum, sumsq} x 8 or 16 slots, n                   count = 17 / 33
+ *   olmc_multi_gpu_european_cv   the five control-variate moments, n              count = 6
+ * Prices agree with the one-GPU entry points to the rounding of the sums' association (same paths whatever n_gpus is: the Philox
+ * counter carries the global path index). */
 int olmc_multi_gpu_european(double S, double K, double T, double r, double sigma, double q, int is_call,
                             int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
                             int n_gpus, olmc_stats* out);
+int olmc_multi_gpu_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call,
+                             int64_t n_paths, int32_t n_steps, uint64_t seed, int second_order,
+                             int n_gpus, double* out9, olmc_stats* evals /* [14] or NULL */);
+int olmc_multi_gpu_european_cv(double S, double K, double T, double r, double sigma, double q, int is_call,
+                               int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
+                               int n_gpus, olmc_cv_moments* out);
 
 /* Blocking fetch of n (1..33) doubles that work ALREADY QUEUED on hip_stream leaves at d_src -- the triple after the caller's RCCL
  * all-reduce in the one-process-per-GPU form: a one-wave kernel behind that work hands them over through the library's pinned
@@ -356,48 +376,15 @@ int olmc_fetch_dev(const double* d_src, int32_t n, void* hip_stream, double* out
  * (sum, sumsq, n) with discount exp(-rT).  Pure function, no device needed. */
 int olmc_combine_stats(const olmc_stats* parts, int32_t n_parts, double r, double T, olmc_stats* out);
 
-/* ---- validation taps (tests, not the product path) ------------------------ */
+/* ---- validation taps (what the parity tests compare with the checker; not the product path) ------------------------ */
 /* Raw Philox4x32-10 words: out[(p*n_blocks + b)*4 + w], p < n_paths, b < n_blocks. */
 int olmc_philox_words(uint64_t seed, int64_t path_offset, int64_t n_paths,
                       int32_t block0, int32_t n_blocks, uint32_t stream_tag, uint32_t* out_host);
-/* The device's fp64 base-2 exponential (the per-date exponential of OLMC_AVG_ARITHMETIC): y[i] = 2^x[i], host arrays. */
-int olmc_exp2_probe(const double* x_host, int64_t n, double* y_host);
-/* The same for either form of it the library carries: form 0 = rint + degree-11 polynomial, 1 = 64-entry table + degree-5
- * polynomial (the one OLMC_AVG_ARITHMETIC uses). */
-int olmc_exp2_probe_form(const double* x_host, int64_t n, double* y_host, int form);
-/* Power sums of the normal stream: out4[m-1] = sum over paths and steps of z^m, m = 1..4 (fp64). */
-int olmc_normal_moments(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps, double* out4);
 /* The fp32 normal stream: out[p*n_steps + t]. */
 int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps,
                  float* out_host);
-
-/* Where one launch of the headline kernel (European call, antithetic, n_paths x n_steps, production launch shape) spends its
- * time: wave 0 of every workgroup stamps the device-wide 100 MHz counter (s_memrealtime) at entry, after the step loop, after
- * the workgroup sums and on return from the grid reduction, and notes where it ran (HW_ID | XCC_ID << 32); the wave that writes
- * the totals stamps once more.  stamps_host (caller-owned, `capacity` words >= 5 * workgroups + 1) receives [workgroup][5] then
- * the final stamp; info3 = {workgroups,
- * index of the first split workgroup (= workgroups when none), duration of the dispatch in ns by its own begin / end
- * timestamps}.  `lead_launches` identical launches are queued back to back in front of the recorded one, so that it runs at the
- * clock the device holds under this load.  Measurement only (tools/phase_stamps.py); prices nothing. */
-int olmc_phase_stamps(int64_t n_paths, int32_t n_steps, uint64_t seed, int32_t lead_launches, uint64_t* stamps_host, int64_t capacity,
-                      int64_t* info3);
-
-/* Shader clock the device holds while every SIMD runs the headline kernel's step loop (n_paths x n_steps, one
- * workgroup per 256 paths): out3 = {median shader cycles of a workgroup's loop (s_memtime), median 100 MHz ticks of
- * the same interval (s_memrealtime), median of their quotient in GHz}.  Feeds bench.py's roofline; prices nothing. */
-int olmc_clock_probe(int64_t n_paths, int32_t n_steps, uint64_t seed, double* out3);
-
-/* Issue cost of one VALU instruction class on this device: *ns_per_instr = nanoseconds one SIMD needs per wave64
- * instruction of class `op` with waves_per_simd (1..8) waves resident, measured by a kernel of independent instructions
- * of that class in the operand form the path kernels use.  Calibrates bench.py's issue-time roofline live. */
-enum { OLMC_PROBE_MAD_U64_U32 = 0, OLMC_PROBE_BITOP3_B32, OLMC_PROBE_CVT_F32_U32, OLMC_PROBE_FMAMK_F32, OLMC_PROBE_AND_OR_B32,
-       OLMC_PROBE_LOG_F32, OLMC_PROBE_SQRT_F32, OLMC_PROBE_SIN_F32, OLMC_PROBE_COS_F32, OLMC_PROBE_EXP_F32, OLMC_PROBE_ADD_F32,
-       OLMC_PROBE_FMA_F32, OLMC_PROBE_CVT_F64_F32, OLMC_PROBE_ADD_F64, OLMC_PROBE_FMA_F64, OLMC_PROBE_RNDNE_F64,
-       OLMC_PROBE_LDEXP_F64, OLMC_PROBE_CVT_I32_F64,
-       /* two-instruction bodies (the figure is per PAIR) and operand-form variants: do classes overlap in a mix? */
-       OLMC_PROBE_MIX_LOG_ADD, OLMC_PROBE_MIX_LOG_BITOP3, OLMC_PROBE_BITOP3_VVV, OLMC_PROBE_BITOP3_VVC, OLMC_PROBE_XOR_VV,
-       OLMC_PROBE_MIX_BITOP3_ADD, OLMC_PROBE_MIX_MAD_BITOP3, OLMC_PROBE_MAD_U64_U32_VV, OLMC_PROBE_COUNT };
-int olmc_issue_probe(int op, int waves_per_simd, double* ns_per_instr);
+/* Measurement kernels (instruction-issue probes, phase stamps, the clock probe), the moment and exp2 taps and the fault-injection /
+ * rehearsal seams are NOT in this library: they live in the instrumented build, include/olmc_probe.h -> libolmc_probe.so. */
 
 /* ---- measurement ----------------------------------------------------------
  * When enabled, every path-kernel launch carries a pair of HIP events attached to the dispatch itself
@@ -418,12 +405,8 @@ int olmc_profile_enable(int on);
  *   OLMC_TUNE_SPLIT_SAT  k in [1, 16]: when the whole workgroups per compute unit leave a last round (of `occupancy` resident
  *                        workgroups) with fewer than k of them, that round is handed to the split workgroups too; 0 = never
  *                        (default: measured at 1M x 252, no gain at any k)
- * and two fault-injection knobs for the tests of the error paths (0 = off, the default):
- *   OLMC_TUNE_FAULT_SHARD  k > 0: shard k - 1 of olmc_multi_gpu_european fails before it launches
- *   OLMC_TUNE_FORCE_NV     v > 0: reduction workspaces REPORT a capacity of v values per workgroup row, so a kernel
- *                          that reduces more than v values trips its device-side bound check (result NaN, nothing
- *                          written out of bounds, library usable afterwards) */
-enum { OLMC_TUNE_GRID_CAP = 2, OLMC_TUNE_QMC_BLOCK = 4, OLMC_TUNE_FAULT_SHARD = 5, OLMC_TUNE_FORCE_NV = 6, OLMC_TUNE_SPLIT_TAIL = 7, OLMC_TUNE_POLL = 8, OLMC_TUNE_SPLIT_SAT = 9 };
+ */
+enum { OLMC_TUNE_GRID_CAP = 2, OLMC_TUNE_QMC_BLOCK = 4, OLMC_TUNE_SPLIT_TAIL = 7, OLMC_TUNE_POLL = 8, OLMC_TUNE_SPLIT_SAT = 9 };
 int olmc_tune(int knob, int value);
 /* The two behavioural knobs can also be switched off from the environment, read once by the first olmc_init:
  * OLMC_POLL=0 (as OLMC_TUNE_POLL = -1) and OLMC_SPLIT_TAIL=0 (as OLMC_TUNE_SPLIT_TAIL = -1). */

@@ -88,15 +88,11 @@ PROTOTYPES = {
     "olmc_jump_diffusion": (_I, _SIX + [_I, _I, _D, _D, _D, _D, _I64, _I64, _I32, _U64T, C.POINTER(Stats)]),
     "olmc_heston": (_I, [_D] * 5 + [_I] + [_D] * 5 + [_I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_multi_gpu_european": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(Stats)]),
+    "olmc_multi_gpu_greeks_fd": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(_D), C.POINTER(Stats)]),
+    "olmc_multi_gpu_european_cv": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(CvMoments)]),
     "olmc_combine_stats": (_I, [C.POINTER(Stats), _I32, _D, _D, C.POINTER(Stats)]),
     "olmc_philox_words": (_I, [_U64T, _I64, _I64, _I32, _I32, C.c_uint32, C.POINTER(C.c_uint32)]),
-    "olmc_exp2_probe": (_I, [C.POINTER(_D), _I64, C.POINTER(_D)]),
-    "olmc_exp2_probe_form": (_I, [C.POINTER(_D), _I64, C.POINTER(_D), _I]),
-    "olmc_normal_moments": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(_D)]),
     "olmc_normals": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(C.c_float)]),
-    "olmc_phase_stamps": (_I, [_I64, _I32, _U64T, _I32, C.POINTER(C.c_uint64), _I64, C.POINTER(_I64)]),
-    "olmc_clock_probe": (_I, [_I64, _I32, _U64T, C.POINTER(_D)]),
-    "olmc_issue_probe": (_I, [_I, _I, C.POINTER(_D)]),
     "olmc_profile_enable": (_I, [_I]),
     "olmc_tune": (_I, [_I, _I]),
     "olmc_profile_reset": (_I, []),
@@ -502,6 +498,23 @@ def multi_gpu_european(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_step
     return out
 
 
+def multi_gpu_greeks_fd(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int, seed: int, second_order: bool, n_gpus: int,
+                        want_evals: bool = True) -> Tuple[List[float], List[Stats]]:
+    """As european_greeks_fd over n_gpus devices of this process: one launch per rank, ONE all-reduce of the 2 nsets + 1 sums."""
+    out9 = (C.c_double * 9)()
+    evals = (Stats * 14)() if want_evals else None
+    _check(lib().olmc_multi_gpu_greeks_fd(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(n_steps), seed64(seed), int(second_order),
+                                          int(n_gpus), out9, evals))
+    return list(out9), (list(evals) if want_evals else [])
+
+
+def multi_gpu_european_cv(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int, seed: int, antithetic: bool, n_gpus: int) -> CvMoments:
+    out = CvMoments()
+    _check(lib().olmc_multi_gpu_european_cv(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(n_steps), seed64(seed), int(antithetic),
+                                            int(n_gpus), C.byref(out)))
+    return out
+
+
 def combine_stats(parts: Sequence[Tuple[float, float, int]], r: float, T: float) -> Stats:
     """Pure host function: needs the library but no device."""
     k = len(parts)
@@ -527,8 +540,6 @@ def normals(seed: int, path_offset: int, n_paths: int, n_steps: int) -> np.ndarr
 
 TUNE_GRID_CAP = 2
 TUNE_QMC_BLOCK = 4
-TUNE_FAULT_SHARD = 5
-TUNE_FORCE_NV = 6
 TUNE_SPLIT_TAIL = 7
 TUNE_POLL = 8
 TUNE_SPLIT_SAT = 9
@@ -536,61 +547,6 @@ TUNE_SPLIT_SAT = 9
 
 def tune(knob: int, value: int) -> None:
     _check(load_library().olmc_tune(int(knob), int(value)))
-
-
-def exp2_probe(x: np.ndarray, form: Optional[int] = None) -> np.ndarray:
-    """2**x by the device's fp64 exponential (validation tap): the form the Asian kernel uses, or form 0 (degree-11 polynomial) /
-    1 (64-entry table) explicitly."""
-    x = np.ascontiguousarray(x, dtype=np.float64)
-    y = np.empty_like(x)
-    px, py = x.ctypes.data_as(C.POINTER(C.c_double)), y.ctypes.data_as(C.POINTER(C.c_double))
-    if form is None:
-        _check(lib().olmc_exp2_probe(px, x.size, py))
-    else:
-        _check(lib().olmc_exp2_probe_form(px, x.size, py, int(form)))
-    return y
-
-
-def normal_moments(seed: int, n_paths: int, n_steps: int, path_offset: int = 0):
-    """(sum z, sum z^2, sum z^3, sum z^4) over n_paths * n_steps normals of the device stream."""
-    out = (C.c_double * 4)()
-    _check(lib().olmc_normal_moments(seed64(seed), int(path_offset), int(n_paths), int(n_steps), out))
-    return tuple(out)
-
-
-def phase_stamps(n_paths: int = 1_000_000, n_steps: int = 252, seed: int = 42, lead_launches: int = 20):
-    """(stamps[workgroups, 5]: four stamps in 100 MHz ticks + HW_ID | XCC_ID << 32, final stamp, first split workgroup, dispatch ns) of
-    one instrumented launch (olmc_phase_stamps)."""
-    cap = 5 * ((int(n_paths) + 63) // 64 + 1024) + 1
-    buf = np.zeros(cap, dtype=np.uint64)
-    info = (C.c_int64 * 3)()
-    _check(lib().olmc_phase_stamps(int(n_paths), int(n_steps), seed64(seed), int(lead_launches), buf.ctypes.data_as(C.POINTER(C.c_uint64)), cap, info))
-    grid = int(info[0])
-    return buf[:5 * grid].reshape(grid, 5).astype(np.int64), int(buf[5 * grid]), int(info[1]), int(info[2])
-
-
-def clock_probe(n_paths: int = 1_000_000, n_steps: int = 252, seed: int = 42) -> dict:
-    """Shader clock held under the headline kernel's load: s_memtime / s_memrealtime around the step loop, median over workgroups."""
-    out = (C.c_double * 3)()
-    _check(lib().olmc_clock_probe(int(n_paths), int(n_steps), seed64(seed), out))
-    return dict(loop_cycles=out[0], loop_ticks_100mhz=out[1], ghz=out[2])
-
-
-PROBE_CLASSES = ("v_mad_u64_u32", "v_bitop3_b32", "v_cvt_f32_u32", "v_fmamk_f32", "v_and_or_b32", "v_log_f32", "v_sqrt_f32",
-                 "v_sin_f32", "v_cos_f32", "v_exp_f32", "v_add_f32", "v_fma_f32", "v_cvt_f64_f32", "v_add_f64", "v_fma_f64",
-                 "v_rndne_f64", "v_ldexp_f64", "v_cvt_i32_f64",
-                 "pair:v_log_f32+v_add_f32", "pair:v_log_f32+v_bitop3_b32", "v_bitop3_b32(v,v,v)", "v_bitop3_b32(v,v,const)", "v_xor_b32(v,v)",
-                 "pair:v_bitop3_b32+v_add_u32", "pair:v_mad_u64_u32+v_bitop3_b32", "v_mad_u64_u32(v,v)")   # order = the OLMC_PROBE_* enum of include/olmc.h
-
-
-def issue_probe(waves_per_simd: int = 8) -> dict:
-    """{instruction class: ns per wave64 instruction per SIMD} measured on this device (olmc_issue_probe)."""
-    out = {}
-    for op, name in enumerate(PROBE_CLASSES):
-        ns = C.c_double(0.0)
-        _check(lib().olmc_issue_probe(op, int(waves_per_simd), C.byref(ns)))
-        out[name] = ns.value
-    return out
 
 
 def profile_enable(on: bool) -> None:

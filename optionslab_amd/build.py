@@ -9,6 +9,12 @@ ROOT = os.path.dirname(PKG)
 SOURCES = [os.path.join(PKG, "csrc", "olmc.hip")]
 HEADERS = [os.path.join(PKG, "csrc", "olmc_kernels.h"), os.path.join(ROOT, "include", "olmc.h")]
 LIBRARY = os.path.join(PKG, "libolmc.so")
+# the instrumented build (include/olmc_probe.h): the same translation unit with its test seams compiled in + the measurement kernels.
+# Test / measurement infrastructure: lives under tools/, loaded by tests, tools and bench.py's calibration, never by the package.
+PROBE_DIR = os.path.join(ROOT, "tools", "probe")
+PROBE_SOURCES = [os.path.join(PROBE_DIR, "olmc_probe.hip")]
+PROBE_HEADERS = [os.path.join(PROBE_DIR, "olmc_probe_kernels.h"), os.path.join(ROOT, "include", "olmc_probe.h")]
+PROBE_LIBRARY = os.path.join(PROBE_DIR, "libolmc_probe.so")
 ARCH = "gfx950"
 
 
@@ -26,15 +32,35 @@ def is_stale() -> bool:
     return any(os.path.getmtime(p) > built for p in SOURCES + HEADERS)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
-        return LIBRARY
+def _compile(sources, output, extra_includes=(), verbose=False):
     cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"),
-           "-o", LIBRARY, *SOURCES, "-ldl"]
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), *["-I" + d for d in extra_includes],
+           "-o", output, *sources, "-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+
+
+def probe_is_stale() -> bool:
+    if not os.path.exists(PROBE_LIBRARY):
+        return True
+    built = os.path.getmtime(PROBE_LIBRARY)
+    return any(os.path.getmtime(p) > built for p in SOURCES + HEADERS + PROBE_SOURCES + PROBE_HEADERS)
+
+
+def build_probe_library(force: bool = False, verbose: bool = False) -> str:
+    """libolmc_probe.so (None when tools/probe is absent, e.g. in a packaged copy of the product)."""
+    if not os.path.exists(PROBE_SOURCES[0]):
+        return None
+    if force or probe_is_stale():
+        _compile(PROBE_SOURCES, PROBE_LIBRARY, extra_includes=(PROBE_DIR,), verbose=verbose)
+    return PROBE_LIBRARY
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIBRARY
+    _compile(SOURCES, LIBRARY, verbose=verbose)
     # the static instruction mix of the step loops (bench.py's issue-cycle roofline) belongs to this very build.  It is a
     # by-product: the library above is complete without it, so a failure here (tools/ absent in a packaged copy, a symbol
     # pattern that no longer matches after a kernel was renamed) is reported and leaves the previous isa_mix.json in place
@@ -49,3 +75,4 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
+    print(build_probe_library(force=True, verbose=True))

@@ -265,8 +265,11 @@ int g_poll = 0;              // OLMC_TUNE_POLL: 0 = blocking calls poll a host-m
 int g_split_tail = 0;        // OLMC_TUNE_SPLIT_TAIL: 0 = split workgroups for the remainder of a European launch (default), -1 = never
 int g_split_sat = 0;         // OLMC_TUNE_SPLIT_SAT: k > 0: a last round of fewer than k whole workgroups per CU is split too; 0 = never (default:
                              // measured, no gain -- see european_launch_shape)
-int g_fault_shard = 0;       // OLMC_TUNE_FAULT_SHARD: k > 0 makes shard k - 1 of olmc_multi_gpu_european fail (tests of the error path)
-int g_force_nv = 0;          // OLMC_TUNE_FORCE_NV: > 0 makes workspaces REPORT room for this many values per row (test of the device guard)
+#ifdef OLMC_WITH_PROBES      // the instrumented build (tools/probe/olmc_probe.hip -> libolmc_probe.so) only: test seams, see include/olmc_probe.h
+int g_fault_shard = 0;       // OLMC_PROBE_TUNE_FAULT_SHARD: k > 0 makes rank k - 1 of a multi-GPU call fail before it launches
+int g_force_nv = 0;          // OLMC_PROBE_TUNE_FORCE_NV: > 0 makes workspaces REPORT room for this many values per row (test of the device guard)
+int g_multi_rehearsal = 0;   // OLMC_PROBE_TUNE_MULTI_REHEARSAL: != 0 runs the n ranks of a multi-GPU call on the caller's ONE device
+#endif
 
 // Launch geometry: one workgroup per 256 paths, handed out by the hardware dispatcher
 // (measured faster than a fixed 8-workgroups-per-CU grid-stride); beyond kMaxGrid
@@ -359,12 +362,10 @@ int make_ws(DeviceCtx* c, hipStream_t stream, int32_t grid, int nv, double* d_ou
             c->next_slot = (c->next_slot + 1) % DeviceCtx::kSlots;
             DeviceCtx::WsSlot& taken = c->slots[idx];
             if (!taken.shared) {
-                // its owner's launches so far carry no event: drain them once, then guard by events.  (The owner may have been
-                // destroyed by the caller meanwhile; then its work may still be retiring: wait for the device instead.)
-                if (hipStreamSynchronize(taken.owner) != hipSuccess) {
-                    (void)hipGetLastError();
-                    HIP_TRY(hipDeviceSynchronize());
-                }
+                // its owner's launches so far carry no event: drain them once, then guard by events.  The owner is a CALLER's stream
+                // and may have been destroyed since (a handle this library must not touch again: hipStreamSynchronize on a dead stream
+                // is a use-after-free in the runtime, not an error code), so the whole device is drained -- once per slot, ever.
+                HIP_TRY(hipDeviceSynchronize());
                 taken.shared = true;
                 taken.used = false;
             }
@@ -390,7 +391,10 @@ int make_ws(DeviceCtx* c, hipStream_t stream, int32_t grid, int nv, double* d_ou
     ws->counters = sl.counters;
     ws->out = d_out;
     ws->tail = tail;
-    ws->row_capacity = g_force_nv > 0 ? static_cast<uint64_t>(grid) * g_force_nv : sl.cap;   // the knob UNDER-reports (test of the guard)
+    ws->row_capacity = sl.cap;
+#ifdef OLMC_WITH_PROBES
+    if (g_force_nv > 0) ws->row_capacity = static_cast<uint64_t>(grid) * g_force_nv;        // the knob UNDER-reports (test of the guard)
+#endif
     ws->done_flag = nullptr;
     ws->done_value = 0;
     c->armed = 0;
@@ -1936,6 +1940,13 @@ extern "C" int olmc_european_qmc_greeks_fd(double S, double K, double T, double 
 // ======================================================== multi-GPU (RCCL) ====
 // librccl is resolved lazily (dlopen) so single-GPU users never load it; the TYPES and ENUM VALUES come from
 // <rccl/rccl.h> at compile time, so a header / library mismatch is a build-time matter, not a guessed constant.
+//
+// One process, n ranks (rank d = device d), ONE host thread -- the caller's.  Per rank the engine owns a stream and a send / receive
+// buffer (never a pricing context: the shard launches lease one like any other call and use the rank's stream as a caller stream).
+// A call queues every rank's path kernel, then ONE grouped all-reduce of `count` doubles (3 for a price, 2 nsets + 1 for
+// finite-difference Greeks, 6 for the control variate: SURVEY §8e) before it waits for anything; the reduced values come home
+// through rank 0's polled completion word (olmc_fetch_dev), the other ranks hold the same values and are drained before the
+// call returns.
 namespace {
 struct Rccl {
     void* lib = nullptr;
@@ -1945,8 +1956,6 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    std::vector<ncclComm_t> comms;      // cached communicator set ...
-    std::vector<int> devices;           // ... of exactly this device list
 };
 Rccl g_rccl;
 
@@ -1978,71 +1987,233 @@ int rccl_load() {
                                            (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error")); \
     } while (0)
 
-// Whatever way olmc_multi_gpu_european leaves (any of its error returns included), the calling thread gets back
-// the library device and the HIP current device it came in with, and every stream a kernel was already queued on
-// has been drained, so no launch of a failed call is still running behind the caller's next one.
+constexpr int kMultiValues = kMaxNV + 1;            // the widest payload: 2 x 16 sums + n
+
+struct MultiRank {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    double* d_send = nullptr;                       // [kMultiValues] this rank's sums (written by its path kernel's last workgroup)
+    double* d_recv = nullptr;                       // [kMultiValues] the reduced sums
+    hipEvent_t queued = nullptr;                    // rehearsal only: the rank's path kernel is queued behind this
+};
+
+struct MultiEngine {
+    std::mutex mu;                                  // one multi-GPU call at a time
+    std::vector<MultiRank> ranks;
+    std::vector<int> devices;                       // device of every rank: what `ranks` and `comms` were built for
+    std::vector<ncclComm_t> comms;                  // empty in a rehearsal
+    bool rehearsal = false;
+};
+MultiEngine g_multi;
+
+// A rank stream is about to be destroyed: the workspace slots it claimed in the contexts of its device are handed back (a later
+// stream may get the same handle value; and a slot whose owner is gone would otherwise stay taken for good).
+void pool_forget_stream(int dev, hipStream_t stream) {
+    DevicePool* pool = g_pool[dev];
+    if (!pool) return;
+    std::unique_lock<std::mutex> lock(pool->mu);
+    pool->idle.wait(lock, [&] { return std::none_of(pool->all.begin(), pool->all.end(), [](const DeviceCtx* c) { return c->busy; }); });
+    for (DeviceCtx* c : pool->all)
+        for (int i = 0; i < DeviceCtx::kSlots; ++i) {
+            DeviceCtx::WsSlot& sl = c->slots[i];
+            if (sl.claimed && !sl.shared && sl.owner == stream) { sl.claimed = false; sl.owner = nullptr; sl.used = false; }
+        }
+}
+
+void multi_gpu_release() {
+    for (ncclComm_t cm : g_multi.comms)
+        if (cm && g_rccl.CommDestroy) g_rccl.CommDestroy(cm);
+    g_multi.comms.clear();
+    for (MultiRank& rk : g_multi.ranks) {
+        if (hipSetDevice(rk.device) != hipSuccess) continue;
+        if (rk.stream) { (void)hipStreamSynchronize(rk.stream); pool_forget_stream(rk.device, rk.stream); (void)hipStreamDestroy(rk.stream); }
+        if (rk.d_send) (void)hipFree(rk.d_send);
+        if (rk.queued) (void)hipEventDestroy(rk.queued);
+    }
+    g_multi.ranks.clear();
+    g_multi.devices.clear();
+    (void)hipGetLastError();
+}
+
+// Streams, buffers and communicators for exactly this list of devices (cached on the LIST, not its length).
+int multi_prepare(const std::vector<int>& devs, bool rehearsal) {
+    if (g_multi.devices == devs && g_multi.rehearsal == rehearsal && !g_multi.ranks.empty()) return OLMC_OK;
+    multi_gpu_release();
+    g_multi.rehearsal = rehearsal;
+    g_multi.ranks.resize(devs.size());
+    for (size_t d = 0; d < devs.size(); ++d) {
+        MultiRank& rk = g_multi.ranks[d];
+        rk.device = devs[d];
+        HIP_TRY(hipSetDevice(devs[d]));
+        HIP_TRY(hipStreamCreateWithFlags(&rk.stream, hipStreamNonBlocking));
+        HIP_TRY(hipMalloc(&rk.d_send, sizeof(double) * 2 * kMultiValues));
+        rk.d_recv = rk.d_send + kMultiValues;
+        HIP_TRY(hipEventCreateWithFlags(&rk.queued, hipEventDisableTiming));
+    }
+    if (!rehearsal) {
+        int rc = rccl_load();
+        if (rc) return rc;
+        g_multi.comms.assign(devs.size(), nullptr);
+        std::vector<int> list = devs;
+        RCCL_TRY(g_rccl.CommInitAll(g_multi.comms.data(), static_cast<int>(list.size()), list.data()));
+    }
+    g_multi.devices = devs;
+    return OLMC_OK;
+}
+
+// After a stream of a failed call could not be drained: the self-resetting counters of that device's workspaces may be dirty.
+void pool_recover(int dev) {
+    DevicePool* pool = g_pool[dev];
+    if (!pool) return;
+    std::lock_guard<std::mutex> lock(pool->mu);
+    for (DeviceCtx* c : pool->all) ws_recover(c);
+}
+
+// Whatever way a multi-GPU call leaves (any of its error returns included), the calling thread gets back the library device and
+// the HIP current device it came in with, and every rank stream a kernel was already queued on has been drained, so no launch of
+// a failed call is still running behind the caller's next one.
 struct MultiGpuScope {
     int saved_lib_device, saved_hip_device = -1;
-    std::vector<int> launched;          // devices with work queued by this call
+    std::vector<int> launched;          // ranks with work queued by this call
     explicit MultiGpuScope(int lib_device) : saved_lib_device(lib_device) { (void)hipGetDevice(&saved_hip_device); }
     ~MultiGpuScope() {
-        for (int d : launched)
-            if (g_ctx[d] && hipSetDevice(d) == hipSuccess) {
-                if (hipStreamSynchronize(g_ctx[d]->stream) != hipSuccess) ws_recover(g_ctx[d]);
-            }
+        for (int d : launched) {
+            const MultiRank& rk = g_multi.ranks[d];
+            if (hipSetDevice(rk.device) == hipSuccess && hipStreamSynchronize(rk.stream) != hipSuccess) pool_recover(rk.device);
+        }
         t_device = saved_lib_device;
         if (saved_hip_device >= 0) (void)hipSetDevice(saved_hip_device);
         (void)hipGetLastError();
     }
 };
 
-int multi_gpu_body(MultiGpuScope& scope, double S, double K, double T, double r, double sigma, double q, int is_call,
-                   int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic, int n_gpus, olmc_stats* out) {
-    int rc = rccl_load();
+#ifdef OLMC_WITH_PROBES
+// The instrumented build's stand-in for the collective when n ranks are REHEARSED on one device (RCCL refuses two ranks on one
+// GPU): every rank adds the n send buffers in rank order.
+struct RankBuffers {
+    const double* send[kMaxDevices];
+};
+__global__ void rehearsal_allreduce_kernel(RankBuffers in, int n_ranks, int count, double* __restrict__ recv) {
+    const int t = threadIdx.x;
+    if (t >= count) return;
+    double sum = 0.0;
+    for (int r = 0; r < n_ranks; ++r) sum += in.send[r][t];
+    recv[t] = sum;
+}
+#endif
+
+// The skeleton every multi-GPU entry point shares.  launch(rank, lo, n_local, stream, d_send) queues rank's path kernel on ITS
+// stream (the calling thread's library device is the rank's) and must leave `count` doubles at d_send; host receives their sums.
+template <typename Launch>
+int multi_gpu_run(int n_gpus, int64_t n_paths, int32_t n_steps, int count, Launch launch, double* host) {
+    if (n_gpus < 1 || n_gpus > kMaxDevices) return fail(OLMC_ERR_ARG, "n_gpus out of range");
+    int rc = check_paths(0, n_paths, n_steps);
     if (rc) return rc;
+    if (n_paths < n_gpus) return fail(OLMC_ERR_ARG, "fewer paths than GPUs");
+    if (count < 1 || count > kMultiValues) return fail(OLMC_ERR_STATE, "payload wider than the rank buffers");
+    bool rehearsal = false;
+#ifdef OLMC_WITH_PROBES
+    rehearsal = g_multi_rehearsal != 0;
+#endif
+    int visible = 0;
+    hipError_t e = hipGetDeviceCount(&visible);
+    if (e != hipSuccess || visible < (rehearsal ? 1 : n_gpus))
+        return fail(OLMC_ERR_HIP, "requested " + std::to_string(n_gpus) + " GPUs, " + std::to_string(visible) + " visible");
+    std::lock_guard<std::mutex> lock(g_multi.mu);
+    const int home = t_device >= 0 ? t_device : (g_default_device >= 0 ? g_default_device : 0);
+    MultiGpuScope scope(home);
     std::vector<int> devs(n_gpus);
-    for (int d = 0; d < n_gpus; ++d) devs[d] = d;
-    if (g_rccl.devices != devs) {                  // the cache is keyed on the device LIST, not its length
-        for (ncclComm_t cm : g_rccl.comms) if (cm) g_rccl.CommDestroy(cm);
-        g_rccl.comms.assign(n_gpus, nullptr);
-        g_rccl.devices.clear();
-        RCCL_TRY(g_rccl.CommInitAll(g_rccl.comms.data(), n_gpus, devs.data()));
-        g_rccl.devices = devs;
-    }
+    for (int d = 0; d < n_gpus; ++d) devs[d] = rehearsal ? home : d;
+    for (int d = 0; d < n_gpus; ++d) { rc = olmc_init(devs[d]); if (rc) return rc; }      // olmc_init moves t_device: the guard puts it back
+    rc = multi_prepare(devs, rehearsal);
+    if (rc) return rc;
     // contiguous global path ranges: rank d owns [d*N/P, (d+1)*N/P)  
-    std::vector<double*> triples(n_gpus, nullptr);
     for (int d = 0; d < n_gpus; ++d) {
-        DeviceCtx* c = g_ctx[d];
-        HIP_TRY(hipSetDevice(d));
-        triples[d] = c->d_triple;
+        const MultiRank& rk = g_multi.ranks[d];
+        HIP_TRY(hipSetDevice(rk.device));
+        t_device = rk.device;
         const int64_t lo = n_paths * d / n_gpus, hi = n_paths * (d + 1) / n_gpus;
-        t_device = d;
-        if (g_fault_shard == d + 1) return fail(OLMC_ERR_HIP, "injected shard failure (OLMC_TUNE_FAULT_SHARD)");
+#ifdef OLMC_WITH_PROBES
+        if (g_fault_shard == d + 1) return fail(OLMC_ERR_HIP, "injected shard failure (OLMC_PROBE_TUNE_FAULT_SHARD)");
+#endif
         scope.launched.push_back(d);
-        rc = olmc_european_shard_dev(S, K, T, r, sigma, q, is_call, lo, hi - lo, n_steps, seed, antithetic, triples[d], c->stream);
+        rc = launch(d, lo, hi - lo, rk.stream, rk.d_send);
         if (rc) return rc;
     }
-    RCCL_TRY(g_rccl.GroupStart());
-    for (int d = 0; d < n_gpus; ++d)
-        RCCL_TRY(g_rccl.AllReduce(triples[d], triples[d], 3, ncclFloat64, ncclSum, g_rccl.comms[d], g_ctx[d]->stream));
-    RCCL_TRY(g_rccl.GroupEnd());
-    // Every launch and the collective are queued on every device before the first wait (one host thread drives all devices: the
-    // calls above only enqueue).  The triple comes home the way every blocking pricing's result does: a one-wave kernel behind
-    // the all-reduce on device 0 writes it into that device's pinned buffer and raises the completion word the host polls
-    // (olmc_fetch_dev); the other devices hold the same triple and are drained afterwards -- they finish with the same collective.
-    double host[3] = {0, 0, 0};
-    HIP_TRY(hipSetDevice(0));
-    t_device = 0;
-    rc = olmc_fetch_dev(triples[0], 3, g_ctx[0]->stream, host);
+    if (!rehearsal) {
+        RCCL_TRY(g_rccl.GroupStart());
+        for (int d = 0; d < n_gpus; ++d) {
+            const MultiRank& rk = g_multi.ranks[d];
+            RCCL_TRY(g_rccl.AllReduce(rk.d_send, rk.d_recv, static_cast<size_t>(count), ncclFloat64, ncclSum, g_multi.comms[d], rk.stream));
+        }
+        RCCL_TRY(g_rccl.GroupEnd());
+    } else {
+#ifdef OLMC_WITH_PROBES
+        RankBuffers in{};
+        for (int d = 0; d < n_gpus; ++d) {
+            in.send[d] = g_multi.ranks[d].d_send;
+            HIP_TRY(hipEventRecord(g_multi.ranks[d].queued, g_multi.ranks[d].stream));
+        }
+        for (int d = 0; d < n_gpus; ++d) {
+            for (int o = 0; o < n_gpus; ++o)
+                if (o != d) HIP_TRY(hipStreamWaitEvent(g_multi.ranks[d].stream, g_multi.ranks[o].queued, 0));
+            hipLaunchKernelGGL(rehearsal_allreduce_kernel, dim3(1), dim3(kWave), 0, g_multi.ranks[d].stream, in, n_gpus, count, g_multi.ranks[d].d_recv);
+            HIP_TRY(hipGetLastError());
+        }
+#endif
+    }
+    // Every launch and the collective are queued on every rank before the first wait (the calls above only enqueue).  The sums come
+    // home the way every blocking pricing's result does: a one-wave kernel behind the all-reduce on rank 0 writes them into a pinned
+    // buffer and raises the completion word the host polls (olmc_fetch_dev); the other ranks hold the same sums and are drained
+    // afterwards -- they finish with the same collective.
+    const MultiRank& first = g_multi.ranks[0];
+    HIP_TRY(hipSetDevice(first.device));
+    t_device = first.device;
+    rc = olmc_fetch_dev(first.d_recv, count, first.stream, host);
     if (rc) return rc;
     for (int d = n_gpus - 1; d >= 1; --d) {
-        HIP_TRY(hipSetDevice(d));
-        HIP_TRY(hipStreamSynchronize(g_ctx[d]->stream));
+        HIP_TRY(hipSetDevice(g_multi.ranks[d].device));
+        HIP_TRY(hipStreamSynchronize(g_multi.ranks[d].stream));
     }
-    scope.launched.clear();                        // device 0 handed over by its completion word, the others drained: nothing left for the guard
-    finish_stats(host[0], host[1], static_cast<int64_t>(host[2]), r, T, out);
-    if (poisoned(S, K, T, r, sigma, q)) nan_stats(out->n, out);
+#ifdef OLMC_WITH_PROBES
+    // instrumented build: every rank must hold rank 0's bits (identical finalisation on every rank)
+    for (int d = 1; d < n_gpus; ++d) {
+        double other[kMultiValues];
+        HIP_TRY(hipSetDevice(g_multi.ranks[d].device));
+        HIP_TRY(hipMemcpy(other, g_multi.ranks[d].d_recv, sizeof(double) * count, hipMemcpyDeviceToHost));
+        if (std::memcmp(other, host, sizeof(double) * count) != 0) return fail(OLMC_ERR_STATE, "rank " + std::to_string(d) + " holds other sums than rank 0");
+    }
+#endif
+    scope.launched.clear();                        // rank 0 handed over by its completion word, the others drained: nothing left for the guard
     return OLMC_OK;
+}
+
+// k contracts on this rank's block of the common normals, queued on the rank's stream: {sum, sumsq} x nsets then n at d_out.
+int batch_shard_dev(const olmc_option* opts, int32_t k, int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic,
+                    double* d_out, hipStream_t s, int* pos) {
+    CtxLease lease;
+    int rc = ctx_lease(&lease);
+    if (rc) return rc;
+    const double n = static_cast<double>(n_local * (antithetic ? 2 : 1));
+    return run_batch_device(lease.c, s, opts, k, path_offset, n_local, n_steps, seed, antithetic, d_out, n, pos);
+}
+
+// The five control-variate moments of this rank's block (of the UNdiscounted payoff) then n at d_out.
+int cv_shard_dev(const olmc_option& o, int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic, double* d_out, hipStream_t s) {
+    CtxLease lease;
+    int rc = ctx_lease(&lease);
+    if (rc) return rc;
+    DeviceCtx* const c = lease.c;
+    PathRange pr = make_range(path_offset, n_local, n_steps, seed);
+    const int32_t grid = european_launch_shape(c, &pr, european_occupancy<1, kControlVariate>(antithetic != 0));
+    ContractSet<1> cs;
+    cs.c[0] = make_contract(o, n_steps);
+    cs.base_mask = 1u; cs.upper_continues_slot0 = 0;
+    ReduceWs ws;
+    rc = make_ws(c, s, grid, 5, d_out, static_cast<double>(n_local * (antithetic ? 2 : 1)), &ws);
+    if (rc) return rc;
+    launch_european<1, kControlVariate>(antithetic != 0, grid, s, pr, cs, ws, nullptr);
+    return after_launch(c, s);
 }
 }  // namespace
 
@@ -2050,19 +2221,59 @@ extern "C" int olmc_multi_gpu_european(double S, double K, double T, double r, d
                                        int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic, int n_gpus,
                                        olmc_stats* out) {
     if (!out) return fail(OLMC_ERR_ARG, "null pointer");
-    if (n_gpus < 1 || n_gpus > kMaxDevices) return fail(OLMC_ERR_ARG, "n_gpus out of range");
-    int rc = check_paths(0, n_paths, n_steps);
+    double host[3] = {0, 0, 0};
+    const int rc = multi_gpu_run(n_gpus, n_paths, n_steps, 3, [&](int, int64_t lo, int64_t n_local, hipStream_t s, double* d_send) {
+        return olmc_european_shard_dev(S, K, T, r, sigma, q, is_call, lo, n_local, n_steps, seed, antithetic, d_send, s);
+    }, host);
     if (rc) return rc;
-    if (n_paths < n_gpus) return fail(OLMC_ERR_ARG, "fewer paths than GPUs");
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count < n_gpus)
-        return fail(OLMC_ERR_HIP, "requested " + std::to_string(n_gpus) + " GPUs, " + std::to_string(count) + " visible");
-    static std::mutex multi_mu;
-    std::lock_guard<std::mutex> lock(multi_mu);
-    MultiGpuScope scope(t_device >= 0 ? t_device : (g_default_device >= 0 ? g_default_device : 0));
-    for (int d = 0; d < n_gpus; ++d) { rc = olmc_init(d); if (rc) return rc; }      // olmc_init moves t_device: the guard puts it back
-    return multi_gpu_body(scope, S, K, T, r, sigma, q, is_call, n_paths, n_steps, seed, antithetic, n_gpus, out);
+    finish_stats(host[0], host[1], static_cast<int64_t>(host[2]), r, T, out);
+    if (poisoned(S, K, T, r, sigma, q)) nan_stats(out->n, out);
+    return OLMC_OK;
+}
+
+extern "C" int olmc_multi_gpu_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                        int64_t n_paths, int32_t n_steps, uint64_t seed, int second_order, int n_gpus,
+                                        double* out9, olmc_stats* evals) {
+    if (!out9) return fail(OLMC_ERR_ARG, "null pointer");
+    if (!(T > 0.0)) return fail(OLMC_ERR_ARG, "T must be > 0 (price() returns intrinsic value without simulating)");
+    const GreeksSet gs(S, K, T, r, sigma, q, is_call, second_order);
+    const int nsets = gs.k <= 8 ? 8 : 16;
+    int pos[OLMC_MAX_BATCH] = {};
+    double host[kMultiValues] = {};
+    const int rc = multi_gpu_run(n_gpus, n_paths, n_steps, 2 * nsets + 1, [&](int, int64_t lo, int64_t n_local, hipStream_t s, double* d_send) {
+        return batch_shard_dev(gs.o, gs.k, lo, n_local, n_steps, seed, 1, d_send, s, pos);      // every rank lays the set out alike
+    }, host);
+    if (rc) return rc;
+    const int64_t n = static_cast<int64_t>(host[2 * nsets]);
+    olmc_stats st[OLMC_MAX_BATCH];
+    for (int i = 0; i < gs.k; ++i) {
+        finish_stats(host[2 * pos[i]], host[2 * pos[i] + 1], n, gs.o[i].r, gs.o[i].T, &st[i]);
+        if (poisoned(gs.o[i].S, gs.o[i].K, gs.o[i].T, gs.o[i].r, gs.o[i].sigma, gs.o[i].q)) nan_stats(n, &st[i]);
+    }
+    gs.finish(st, T, out9, evals);
+    return OLMC_OK;
+}
+
+extern "C" int olmc_multi_gpu_european_cv(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                          int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic, int n_gpus,
+                                          olmc_cv_moments* out) {
+    if (!out) return fail(OLMC_ERR_ARG, "null pointer");
+    const olmc_option o = make_option(S, K, T, r, sigma, q, is_call);
+    double host[6] = {};
+    const int rc = multi_gpu_run(n_gpus, n_paths, n_steps, 6, [&](int, int64_t lo, int64_t n_local, hipStream_t s, double* d_send) {
+        return cv_shard_dev(o, lo, n_local, n_steps, seed, antithetic, d_send, s);
+    }, host);
+    if (rc) return rc;
+    const double disc = std::exp(-r * T);          // device moments are of the UNdiscounted payoff x; d = disc * x (monte_carlo.py:175)
+    out->sum_d = disc * host[0];
+    out->sum_s = host[1];
+    out->sum_dd = disc * disc * host[2];
+    out->sum_ss = host[3];
+    out->sum_ds = disc * host[4];
+    out->n = static_cast<int64_t>(host[5]);
+    cv_finish(S, T, r, q, out);
+    if (poisoned(S, K, T, r, sigma, q)) out->value = std::nan("");
+    return OLMC_OK;
 }
 
 // ============================================================ validation taps ====
@@ -2087,41 +2298,6 @@ extern "C" int olmc_philox_words(uint64_t seed, int64_t path_offset, int64_t n_p
     return OLMC_OK;
 }
 
-extern "C" int olmc_exp2_probe_form(const double* x_host, int64_t n, double* y_host, int form) {
-    if (!x_host || !y_host || n < 1) return fail(OLMC_ERR_ARG, "bad arguments");
-    if (form != 0 && form != 1) return fail(OLMC_ERR_ARG, "form must be 0 (polynomial) or 1 (table)");
-    CtxLease lease;
-    int rc = ctx_lease(&lease);
-    if (rc) return rc;
-    DeviceCtx* const c = lease.c;
-    const size_t bytes = sizeof(double) * static_cast<size_t>(n);
-    rc = bulk_reserve(c, 2 * bytes);
-    if (rc) return rc;
-    double* d_x = static_cast<double*>(c->d_bulk);
-    double* d_y = d_x + n;
-    HIP_TRY(hipMemcpyAsync(d_x, x_host, bytes, hipMemcpyHostToDevice, c->stream));
-    const int grid = static_cast<int>(std::min<int64_t>((n + 255) / 256, 4096));
-    hipLaunchKernelGGL(exp2_probe_kernel, dim3(grid), dim3(256), 0, c->stream, d_x, n, d_y, form);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(y_host, d_y, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return OLMC_OK;
-}
-
-// the form the arithmetic Asian kernel is built with
-extern "C" int olmc_exp2_probe(const double* x_host, int64_t n, double* y_host) {
-    return olmc_exp2_probe_form(x_host, n, y_host, OLMC_EXP2_TABLE ? 1 : 0);
-}
-
-extern "C" int olmc_normal_moments(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps, double* out4) {
-    if (!out4) return fail(OLMC_ERR_ARG, "null pointer");
-    olmc_stats dummy;
-    return run_structured(path_offset, n_paths, n_steps, seed, 0, 0.0, 1.0, false, &dummy,
-                          [&](int32_t grid, hipStream_t st, const EventPair* timed, const PathRange& pr, const ReduceWs& ws) {
-                              launch_timed(normal_moments_kernel, dim3(grid), dim3(kBlock), st, timed, pr, ws);
-                          }, 4, out4);
-}
-
 extern "C" int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps, float* out_host) {
     if (!out_host || n_paths < 1 || n_steps < 1 || path_offset < 0) return fail(OLMC_ERR_ARG, "bad arguments");
     CtxLease lease;
@@ -2142,136 +2318,6 @@ extern "C" int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths,
     return OLMC_OK;
 }
 
-// Shader clock held under the headline kernel's load (see clock_probe_kernel): median over workgroups.
-extern "C" int olmc_clock_probe(int64_t n_paths, int32_t n_steps, uint64_t seed, double* out3) {
-    if (!out3) return fail(OLMC_ERR_ARG, "null pointer");
-    int rc = check_paths(0, n_paths, n_steps);
-    if (rc) return rc;
-    CtxLease lease;
-    rc = ctx_lease(&lease);
-    if (rc) return rc;
-    DeviceCtx* const c = lease.c;
-    const int32_t grid = static_cast<int32_t>(std::min<int64_t>((n_paths + kBlock - 1) / kBlock, kMaxGrid));
-    const size_t bytes = sizeof(uint64_t) * 2 * static_cast<size_t>(grid) + 256;
-    rc = bulk_reserve(c, bytes);
-    if (rc) return rc;
-    uint64_t* d_stamps = static_cast<uint64_t*>(c->d_bulk);
-    double* d_sink = reinterpret_cast<double*>(d_stamps + 2 * static_cast<size_t>(grid));
-    const PathRange pr = make_range(0, static_cast<int64_t>(grid) * kBlock, n_steps, seed);
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(grid), dim3(kBlock), 0, c->stream, pr, d_stamps, d_sink);
-    HIP_TRY(hipGetLastError());
-    std::vector<uint64_t> h(2 * static_cast<size_t>(grid));
-    HIP_TRY(hipMemcpyAsync(h.data(), d_stamps, sizeof(uint64_t) * h.size(), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    std::vector<double> cyc(grid), tick(grid), ghz;
-    for (int32_t b = 0; b < grid; ++b) {
-        cyc[b] = static_cast<double>(h[2 * b]);
-        tick[b] = static_cast<double>(h[2 * b + 1]);
-        if (tick[b] > 0) ghz.push_back(cyc[b] / tick[b] * 0.1);     // cycles per 10 ns tick -> GHz
-    }
-    auto median = [](std::vector<double>& v) {
-        if (v.empty()) return 0.0;
-        std::nth_element(v.begin(), v.begin() + v.size() / 2, v.end());
-        return v[v.size() / 2];
-    };
-    out3[0] = median(cyc);
-    out3[1] = median(tick);
-    out3[2] = median(ghz);
-    return OLMC_OK;
-}
-
-// Where a launch of the headline kernel spends its time (see european_stamp_kernel): one blocking launch of n_paths x n_steps in
-// the production launch shape; stamps_host receives 5 words per workgroup (4 stamps in 100 MHz ticks + where it ran) + the final stamp, info3 = {workgroups,
-// split_from (or workgroups when nothing is split), the dispatch's own duration in nanoseconds (begin / end timestamps)}.
-extern "C" int olmc_phase_stamps(int64_t n_paths, int32_t n_steps, uint64_t seed, int32_t lead_launches, uint64_t* stamps_host, int64_t capacity,
-                                 int64_t* info3) {
-    if (!stamps_host || !info3) return fail(OLMC_ERR_ARG, "null pointer");
-    int rc = check_paths(0, n_paths, n_steps);
-    if (rc) return rc;
-    CtxLease lease;
-    rc = ctx_lease(&lease);
-    if (rc) return rc;
-    DeviceCtx* const c = lease.c;
-    PathRange pr = make_range(0, n_paths, n_steps, seed);
-    const int32_t grid = european_launch_shape(c, &pr, european_occupancy<1, kReduce>(true));
-    if (static_cast<int64_t>(grid) * kBlock < n_paths) return fail(OLMC_ERR_ARG, "grid-striding launches are not instrumented");
-    const int64_t words = kStampWords * static_cast<int64_t>(grid) + 1;
-    if (capacity < words) return fail(OLMC_ERR_ARG, "stamp buffer too small: need 5 * workgroups + 1 words");
-    rc = bulk_reserve(c, sizeof(uint64_t) * static_cast<size_t>(words));
-    if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(c->d_bulk, 0, sizeof(uint64_t) * static_cast<size_t>(words), c->stream));
-    ContractSet<1> cs;
-    cs.c[0] = make_contract(make_option(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, 1), n_steps);
-    cs.base_mask = 1u; cs.upper_continues_slot0 = 0;
-    ReduceWs ws;
-    rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
-    if (rc) return rc;
-    EventPair ep{};
-    rc = prof_acquire(c, &ep);
-    if (rc) return rc;
-    // `lead_launches` identical launches go out back to back in front of the recorded one (each overwrites the stamps of the one
-    // before; only the last is armed to raise the completion word): the recorded launch then runs on a device that is already under
-    // this very load, at the clock it holds there -- a lone launch between a memset and a copy ran 16 % slow
-    if (lead_launches < 0 || lead_launches > 1000) return fail(OLMC_ERR_ARG, "lead_launches must be in [0, 1000]");
-    ReduceWs quiet = ws;
-    quiet.done_flag = nullptr;
-    for (int32_t k = 0; k < lead_launches; ++k) {
-        hipLaunchKernelGGL(european_stamp_kernel, dim3(grid), dim3(kBlock), 0, c->stream, pr, cs, quiet, static_cast<uint64_t*>(c->d_bulk));
-        rc = after_launch(c, c->stream);             // a failed launch leaves the self-resetting counters to ws_recover()
-        if (rc) return rc;
-    }
-    hipExtLaunchKernelGGL(european_stamp_kernel, dim3(grid), dim3(kBlock), 0, c->stream, ep.start, ep.stop, 0, pr, cs, ws, static_cast<uint64_t*>(c->d_bulk));
-    rc = after_launch(c, c->stream);
-    if (rc) return rc;
-    rc = sync_or_recover(c, c->stream);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(stamps_host, c->d_bulk, sizeof(uint64_t) * static_cast<size_t>(words), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, ep.start, ep.stop));
-    c->ev_free.push_back(ep);
-    info3[0] = grid;
-    info3[1] = pr.split_from == INT32_MAX ? grid : pr.split_from;
-    info3[2] = static_cast<int64_t>(static_cast<double>(ms) * 1e6);
-    return OLMC_OK;
-}
-
-// Issue cost of one instruction class on this device (see the probe kernels): nanoseconds one SIMD needs per wave64
-// instruction of the class with `waves_per_simd` waves resident.
-extern "C" int olmc_issue_probe(int op, int waves_per_simd, double* ns_per_instr) {
-    using Probe = void (*)(uint32_t*, uint32_t, uint32_t);
-    static const Probe table[] = {probe_mad_u64_u32, probe_bitop3, probe_cvt_f32_u32, probe_fmamk_f32, probe_and_or, probe_log_f32,
-                                  probe_sqrt_f32, probe_sin_f32, probe_cos_f32, probe_exp_f32, probe_add_f32, probe_fma_f32,
-                                  probe_cvt_f64_f32, probe_add_f64, probe_fma_f64, probe_rndne_f64, probe_ldexp_f64, probe_cvt_i32_f64,
-                                  probe_mix_log_add, probe_mix_log_bitop3, probe_bitop3_vvv, probe_bitop3_vvc, probe_xor_vv, probe_mix_bitop3_add,
-                                  probe_mix_mad_bitop3, probe_mad_u64_u32_vv};
-    constexpr int kOps = static_cast<int>(sizeof(table) / sizeof(table[0]));
-    static_assert(kOps == OLMC_PROBE_COUNT, "include/olmc.h lists the probe classes");
-    if (!ns_per_instr) return fail(OLMC_ERR_ARG, "null pointer");
-    if (op < 0 || op >= kOps) return fail(OLMC_ERR_ARG, "unknown probe class");
-    if (waves_per_simd < 1 || waves_per_simd > 8) return fail(OLMC_ERR_ARG, "waves_per_simd must be in [1, 8]");
-    CtxLease lease;
-    int rc = ctx_lease(&lease);
-    if (rc) return rc;
-    DeviceCtx* const c = lease.c;
-    rc = bulk_reserve(c, 256);
-    if (rc) return rc;
-    const dim3 grid(static_cast<uint32_t>(c->cus * waves_per_simd)), block(kBlock);    // one 4-wave workgroup per (CU, resident wave slot)
-    EventPair ep{};
-    rc = prof_acquire(c, &ep);
-    if (rc) return rc;
-    for (int rep = 0; rep < 2; ++rep) {          // first launch warms the instruction cache
-        hipExtLaunchKernelGGL(table[op], grid, block, 0, c->stream, ep.start, ep.stop, 0, static_cast<uint32_t*>(c->d_bulk), 1u, 0xD2511F53u);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, ep.start, ep.stop));
-    c->ev_free.push_back(ep);
-    *ns_per_instr = static_cast<double>(ms) * 1e6 / (static_cast<double>(kProbeIters) * 16.0 * waves_per_simd);
-    return OLMC_OK;
-}
-
 // ================================================================ measurement ====
 extern "C" int olmc_tune(int knob, int value) {
     if (knob == OLMC_TUNE_GRID_CAP && value >= 0) { g_grid_cap = value; return OLMC_OK; }
@@ -2279,8 +2325,6 @@ extern "C" int olmc_tune(int knob, int value) {
     if (knob == OLMC_TUNE_POLL && value >= -1 && value <= 0) { g_poll = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_SPLIT_TAIL && value >= -1 && value <= 0) { g_split_tail = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_SPLIT_SAT && value >= 0 && value <= 16) { g_split_sat = value; return OLMC_OK; }
-    if (knob == OLMC_TUNE_FAULT_SHARD && value >= 0 && value <= kMaxDevices) { g_fault_shard = value; return OLMC_OK; }
-    if (knob == OLMC_TUNE_FORCE_NV && value >= 0 && value <= kMaxNV) { g_force_nv = value; return OLMC_OK; }
     return fail(OLMC_ERR_ARG, "unknown tuning knob or value");
 }
 

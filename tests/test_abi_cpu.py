@@ -15,11 +15,17 @@ from optionslab_amd.exceptions import AccelerationError
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "olmc.h")
+PROBE_HEADER = os.path.join(ROOT, "include", "olmc_probe.h")
 
 
-def declared_symbols():
-    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+def declared_symbols(header=HEADER):
+    text = re.sub(r"/\*.*?\*/", "", open(header).read(), flags=re.S)
     return sorted(set(re.findall(r"\b(olmc_[a-z0-9_]+)\s*\(", text)))
+
+
+def exported_symbols(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return set(re.findall(r"\bT (olmc_[a-z0-9_]+)", out))
 
 
 @pytest.fixture(scope="module")
@@ -38,9 +44,29 @@ def test_header_declares_the_expected_surface():
 def test_library_exports_every_declared_symbol(library):
     for name in declared_symbols():
         assert hasattr(library, name), f"{name} declared in include/olmc.h but not exported"
-    out = subprocess.run(["nm", "-D", "--defined-only", LIBRARY], capture_output=True, text=True, check=True).stdout
-    exported = set(re.findall(r"\bT (olmc_[a-z0-9_]+)", out))
-    assert set(declared_symbols()) <= exported
+    assert set(declared_symbols()) == exported_symbols(LIBRARY)      # nothing undeclared is exported either
+
+
+def test_measurement_code_is_not_in_the_product_library():
+    """probe / stamp / clock / moment kernels, their entry points and the fault-injection knobs live in the
+    instrumented build (include/olmc_probe.h -> tools/probe/libolmc_probe.so), which also exports the whole pricing ABI."""
+    from optionslab_amd.build import PROBE_LIBRARY, build_probe_library
+    from tools.probe import binding as probe
+
+    build_probe_library()
+    product, instrumented = exported_symbols(LIBRARY), exported_symbols(PROBE_LIBRARY)
+    only_probe = set(declared_symbols(PROBE_HEADER))
+    assert only_probe == set(probe.PROBE_PROTOTYPES) and len(only_probe) == 7
+    assert not (only_probe & product)
+    assert not [n for n in product if any(w in n for w in ("probe", "stamp", "clock", "moments"))]
+    assert instrumented == product | only_probe
+    blob = open(LIBRARY, "rb").read()
+    for word in (b"probe_mad_u64_u32", b"european_stamp_kernel", b"clock_probe_kernel", b"normal_moments_kernel", b"FAULT_SHARD", b"injected shard failure"):
+        assert word not in blob, word
+    assert b"european_stamp_kernel" in open(PROBE_LIBRARY, "rb").read()
+    lib = probe.hip.load_library()
+    for name in only_probe:
+        assert hasattr(lib, name)
 
 
 def test_ctypes_prototypes_cover_the_header():
@@ -60,7 +86,7 @@ def test_struct_layouts_match_the_header():
 
 
 def test_abi_version_and_error_string(library):
-    assert library.olmc_abi_version() == 3
+    assert library.olmc_abi_version() == 4
     assert isinstance(library.olmc_last_error(), bytes)
 
 

@@ -1,0 +1,198 @@
+"""GPU tests that need the INSTRUMENTED build (include/olmc_probe.h -> tools/probe/libolmc_probe.so): the product's own translation
+unit compiled with its test seams in, plus the validation taps libolmc.so no longer carries.  `probe.hip` is the product's ctypes
+binding bound to that library, so `probe.hip.european(...)` runs the same code `_hip.european(...)` runs in libolmc.so.
+
+  * the multi-GPU engine REHEARSED with several ranks on the one GPU of the box (hand-over order, drain of ranks >= 1,
+    restoration of the thread's device, every payload: price 3, Greeks 17 / 33, control variate 6 doubles);
+  * the error paths behind fault injection (failing rank, device-side row-capacity guard);
+  * the exp2 and normal-moment taps.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import optionslab_amd as ol
+from optionslab_amd import _hip
+from tools.probe import binding as probe
+
+pytestmark = pytest.mark.gpu
+
+ATM = (100.0, 100.0, 1.0, 0.05, 0.2)
+hip = probe.hip
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _device():
+    assert hip.device_info()["arch"].startswith("gfx950")
+    yield
+    for knob in (probe.TUNE_FAULT_SHARD, probe.TUNE_FORCE_NV, probe.TUNE_MULTI_REHEARSAL):
+        probe.tune(knob, 0)
+    hip.shutdown()
+
+
+@pytest.fixture
+def rehearsal():
+    probe.tune(probe.TUNE_MULTI_REHEARSAL, 1)
+    yield
+    probe.tune(probe.TUNE_MULTI_REHEARSAL, 0)
+
+
+def test_the_instrumented_build_prices_what_the_product_prices():
+    a = hip.european(*ATM, 0.0, True, 300_000, 52, 42, True)
+    b = _hip.european(*ATM, 0.0, True, 300_000, 52, 42, True)
+    assert (a.sum, a.sumsq, a.n, a.price, a.std_error) == (b.sum, b.sumsq, b.n, b.price, b.std_error)
+
+
+# ------------------------------------------------------------------ multi-GPU engine, n ranks rehearsed on one device
+@pytest.mark.parametrize("n_ranks", [2, 3, 8, 11])
+def test_n_rank_price_equals_the_rank_ordered_sum_of_its_shards(rehearsal, n_ranks):
+    """olmc_multi_gpu_european with n ranks (each its own stream and buffers on this one device, the all-reduce emulated by a
+    rank-ordered sum behind every rank's kernel): the triple must be EXACTLY what olmc_combine_stats makes of the n shard triples
+    priced one by one -- same partition [d N / P, (d + 1) N / P), same paths, same association -- and the call itself checks that
+    ranks 1..n-1 ended with rank 0's bits.  11 ranks share the 8 workspace slots a context has for caller streams."""
+    S, K, T, r, v = ATM
+    N, M, seed = 1_000_003, 40, 9
+    got = hip.multi_gpu_european(S, K, T, r, v, 0.0, True, N, M, seed, True, n_ranks)
+    parts = []
+    for d in range(n_ranks):
+        lo, hi = N * d // n_ranks, N * (d + 1) // n_ranks
+        st = hip.european(S, K, T, r, v, 0.0, True, hi - lo, M, seed, True, path_offset=lo)
+        parts.append((st.sum, st.sumsq, st.n))
+    want = hip.combine_stats(parts, r, T)
+    assert (got.sum, got.sumsq, got.n, got.price, got.std_error) == (want.sum, want.sumsq, want.n, want.price, want.std_error)
+    whole = hip.european(S, K, T, r, v, 0.0, True, N, M, seed, True)
+    assert got.n == whole.n == 2 * N and got.sum == pytest.approx(whole.sum, rel=1e-13) and got.sumsq == pytest.approx(whole.sumsq, rel=1e-13)
+    assert hip.device_info()["device"] == 0                      # the thread's library device came back
+
+
+@pytest.mark.parametrize("second", [False, True])
+@pytest.mark.parametrize("n_ranks", [1, 4])
+def test_n_rank_greeks_equal_the_one_device_greeks(rehearsal, n_ranks, second):
+    """olmc_multi_gpu_greeks_fd: the 8 / 14 bumped contracts on the same normals, one launch per rank, ONE all-reduce of 17 / 33
+    doubles (count 2k + 1).  Against olmc_european_greeks_fd on one device: same paths, another association of the
+    sums -- 1e-12 x price x the finite-difference amplification on every Greek, and every evaluation's own sums to 1e-13."""
+    N, M, seed = 400_000, 20, 42
+    one, evals1 = hip.european_greeks_fd(*ATM, 0.0, True, N, M, seed, second, want_evals=True)
+    many, evalsn = hip.multi_gpu_greeks_fd(*ATM, 0.0, True, N, M, seed, second, n_ranks, want_evals=True)
+    k = 14 if second else 8
+    for a, b in zip(evals1[:k], evalsn[:k]):
+        assert b.n == a.n == 2 * N
+        assert b.sum == pytest.approx(a.sum, rel=1e-13) and b.sumsq == pytest.approx(a.sumsq, rel=1e-13)
+        assert b.price == pytest.approx(a.price, rel=1e-13) and b.std_error == pytest.approx(a.std_error, rel=1e-9)
+    h_s, h_v, h_r, h_t = 1.0, 0.01, 1e-4, 1 / 365.0
+    amp = [1, 1 / h_s, 4 / h_s**2, 1 / h_v, 2 / h_t, 1 / h_r, 1 / (h_s * h_v), 2 / (h_s * h_t), 4 / h_v**2]
+    for i in range(9 if second else 6):
+        assert many[i] == pytest.approx(one[i], abs=1e-12 * one[0] * amp[i] + 1e-13), i
+    lean, none = hip.multi_gpu_greeks_fd(*ATM, 0.0, True, N, M, seed, second, n_ranks, want_evals=False)
+    assert none == [] and lean[:6] == many[:6]
+
+
+@pytest.mark.parametrize("n_ranks", [1, 3])
+def test_n_rank_control_variate_equals_the_combined_shards(rehearsal, n_ranks):
+    """olmc_multi_gpu_european_cv: five moments + n in one all-reduce (count 6) against olmc_combine_cv of the shard moments."""
+    S, K, T, r, v = ATM
+    N, M, seed = 300_001, 12, 5
+    got = hip.multi_gpu_european_cv(S, K, T, r, v, 0.01, False, N, M, seed, True, n_ranks)
+    parts = []
+    for d in range(n_ranks):
+        lo, hi = N * d // n_ranks, N * (d + 1) // n_ranks
+        parts.append(hip.european_cv_shard(S, K, T, r, v, 0.01, False, lo, hi - lo, M, seed, True))
+    want = hip.combine_cv(parts, S, T, r, 0.01)
+    assert got.n == want.n == 2 * N
+    for f in ("sum_d", "sum_s", "sum_dd", "sum_ss", "sum_ds", "value"):
+        assert getattr(got, f) == pytest.approx(getattr(want, f), rel=1e-13), f
+    whole = hip.european_cv(S, K, T, r, v, 0.01, False, N, M, seed, True)
+    assert got.value == pytest.approx(whole.value, rel=1e-11)
+
+
+def test_a_failing_rank_in_the_middle_leaves_the_thread_and_the_library_usable(rehearsal):
+    """Error returns of the multi-GPU calls go through a scope guard: the ranks already queued are drained, the thread's library
+    device and HIP device restored.  Rank 2 of 4 is made to fail by the fault-injection knob: ranks 0 and 1 have kernels in flight."""
+    S, K, T, r, v = ATM
+    before = hip.european(S, K, T, r, v, 0.0, True, 50_000, 16, 5, True)
+    for bad in (1, 3, 4):
+        probe.tune(probe.TUNE_FAULT_SHARD, bad)
+        try:
+            with pytest.raises(ol.AccelerationError, match="injected shard failure"):
+                hip.multi_gpu_european(S, K, T, r, v, 0.0, True, 4_000_000, 64, 5, True, 4)
+            with pytest.raises(ol.AccelerationError, match="injected shard failure"):
+                hip.multi_gpu_greeks_fd(S, K, T, r, v, 0.0, True, 400_000, 16, 5, True, 4)
+        finally:
+            probe.tune(probe.TUNE_FAULT_SHARD, 0)
+        assert hip.device_info()["device"] == 0
+        after = hip.european(S, K, T, r, v, 0.0, True, 50_000, 16, 5, True)
+        assert (before.sum, before.sumsq) == (after.sum, after.sumsq)
+    again = hip.multi_gpu_european(S, K, T, r, v, 0.0, True, 50_000, 16, 5, True, 1)
+    assert (again.sum, again.sumsq) == (before.sum, before.sumsq)
+    with pytest.raises(ol.AccelerationError):               # a bad shard argument (n_steps = 0) is refused before any launch
+        hip.multi_gpu_european(S, K, T, r, v, 0.0, True, 1000, 0, 5, True, 2)
+    with pytest.raises(ol.AccelerationError):               # more ranks than paths
+        hip.multi_gpu_european(S, K, T, r, v, 0.0, True, 3, 4, 5, True, 4)
+    assert hip.european(S, K, T, r, v, 0.0, True, 50_000, 16, 5, True).sum == before.sum
+
+
+def test_one_rank_goes_through_rccl_in_the_instrumented_build_too():
+    S, K, T, r, v = ATM
+    a = hip.multi_gpu_european(S, K, T, r, v, 0.0, True, 200_000, 16, 5, True, 1)      # rehearsal off: the real all-reduce, 1 rank
+    b = hip.european(S, K, T, r, v, 0.0, True, 200_000, 16, 5, True)
+    assert (a.sum, a.sumsq, a.n, a.price, a.std_error) == (b.sum, b.sumsq, b.n, b.price, b.std_error)
+
+
+# ------------------------------------------------------------------ device-side guard
+def test_device_side_row_capacity_guard_answers_nan_and_keeps_the_library_usable():
+    """A launch whose rows would not fit the workspace it was given (the r1 fault: NV = 4 rows on an NV = 2 workspace)
+    must not store: olmc_kernels.h grid_reduce answers NaN instead.  The knob makes the workspace REPORT one value per
+    row while really holding enough, so tripping the guard is safe."""
+    S, K, T, r, v = ATM
+    ok = hip.european(S, K, T, r, v, 0.0, True, 300_000, 8, 3, True)
+    probe.tune(probe.TUNE_FORCE_NV, 1)
+    try:
+        bad = hip.european(S, K, T, r, v, 0.0, True, 300_000, 8, 3, True)
+        assert math.isnan(bad.sum) and math.isnan(bad.price)
+        bad4 = probe.normal_moments(3, 50_000, 8)             # NV = 4
+        assert math.isnan(bad4[0])
+        g, _ = hip.european_greeks_fd(*ATM, 0.0, True, 50_000, 8, 3, True, want_evals=False)     # NV = 16 through the workgroup-wide reduction
+        assert math.isnan(g[0])
+    finally:
+        probe.tune(probe.TUNE_FORCE_NV, 0)
+    again = hip.european(S, K, T, r, v, 0.0, True, 300_000, 8, 3, True)
+    assert (again.sum, again.sumsq, again.n) == (ok.sum, ok.sumsq, ok.n)
+    assert all(math.isfinite(m) for m in probe.normal_moments(3, 50_000, 8))
+
+
+# ------------------------------------------------------------------ taps
+@pytest.mark.parametrize("form", [None, 0, 1])
+def test_device_exp2_f64_is_within_two_ulp_of_libm_everywhere(form):
+    """The per-date exponential of the reference-precision Asian kernel (olmc_kernels.h), in both forms the sources carry:
+    exp2_f64 (form 0: rint + degree-11 polynomial on [-1/2, 1/2] + v_ldexp_f64) and exp2_f64_tab (form 1: 256-entry table of
+    2^(k/256) + degree-4 correction 1 + r q(r), q cubic; form None = whichever the kernel is built with, i.e. the table).  Against
+    the host libm (numpy.exp2, < 1 ulp): <= 2 ulp on a dense sweep of the range a cumulative log-return can take, on the reduction's
+    seams (half-integers and, for the table, the 128ths and 512ths where the table index rounds), and correct limits (0, inf, NaN)."""
+    rng = np.random.default_rng(7)
+    x = np.concatenate([rng.uniform(-60.0, 60.0, 400_000), rng.uniform(-1.0, 1.0, 400_000), rng.normal(0.0, 1e-3, 100_000),
+                        np.arange(-80, 81) + 0.5, np.nextafter(np.arange(-80, 81) + 0.5, np.inf), np.nextafter(np.arange(-80, 81) + 0.5, -np.inf),
+                        np.arange(-1000, 1001, 7.0), [0.0, -0.0, 1.0, -1.0, 1e-300, -1e-300, 1023.999, -1021.5],
+                        (np.arange(-4096, 4097) + 0.5) / 64.0, np.nextafter((np.arange(-4096, 4097) + 0.5) / 64.0, np.inf),
+                        (np.arange(-8192, 8193) + 0.5) / 256.0, np.nextafter((np.arange(-8192, 8193) + 0.5) / 256.0, -np.inf)])
+    y, want = probe.exp2_probe(x, form), np.exp2(x)
+    ulp = np.abs(y - want) / np.spacing(want)
+    assert np.isfinite(y).all() and ulp.max() <= 2.0, (ulp.max(), x[np.argmax(ulp)])
+    assert (y[np.isin(x, np.arange(-1000, 1001, 7.0))] == want[np.isin(x, np.arange(-1000, 1001, 7.0))]).all()     # exact powers of two
+    special = probe.exp2_probe(np.array([np.nan, 1025.0, 5000.0, 1e300, -1100.0, -5000.0, -1e300, np.inf, -np.inf]), form)
+    assert np.isnan(special[0]) and (special[1:4] == np.inf).all()          # overflow like exp2()
+    assert (special[4:7] == 0.0).all()                                       # below the subnormal range: zero like exp2()
+    # documented limit of the domain: an INFINITE argument answers NaN (inf - rint(inf)), where exp2() says inf / 0.  A
+    # cumulative log-return is infinite only for infinite parameters, for which the reference's own path is NaN as well.
+    assert np.isnan(special[7:]).all()
+
+
+def test_normal_moments_tap_agrees_with_the_normals_tap():
+    z = hip.normals(5, 100, 3000, 7).astype(np.float64)
+    assert np.array_equal(z, _hip.normals(5, 100, 3000, 7).astype(np.float64))          # both builds, one stream
+    s1, s2, s3, s4 = probe.normal_moments(5, 3000, 7, path_offset=100)
+    assert s1 == pytest.approx(z.sum(), rel=1e-5, abs=1e-3) and s2 == pytest.approx((z**2).sum(), rel=1e-6)
+    assert s3 == pytest.approx((z**3).sum(), rel=1e-5, abs=1e-2) and s4 == pytest.approx((z**4).sum(), rel=1e-6)
+    big = probe.normal_moments(9, 1 << 22, 64)              # 2.7e8 normals: variance to 9e-5
+    n = (1 << 22) * 64
+    assert abs(big[0] / n) < 5 / math.sqrt(n) and abs(big[1] / n - 1) < 5 * math.sqrt(2 / n) and abs(big[3] / n - 3) < 5 * math.sqrt(96 / n)

@@ -390,45 +390,16 @@ def test_single_process_multi_gpu_entry_point_on_one_gpu():
     assert (a.sum, a.sumsq, a.n, a.price, a.std_error) == (b.sum, b.sumsq, b.n, b.price, b.std_error)
     with pytest.raises(ol.AccelerationError):
         _hip.multi_gpu_european(S, K, T, r, v, 0.0, True, 1000, 4, 5, True, 64)
-
-
-def test_a_failing_shard_leaves_the_thread_and_the_library_usable():
-    """Error returns of olmc_multi_gpu_european go through a scope guard: queued streams drained, the thread's library
-    device and HIP device restored.  A shard is made to fail by the fault-injection knob (one GPU here, so shard 0)."""
-    S, K, T, r, v = ATM
-    before = _hip.european(S, K, T, r, v, 0.0, True, 50_000, 16, 5, True)
-    _hip.tune(_hip.TUNE_FAULT_SHARD, 1)
-    try:
-        with pytest.raises(ol.AccelerationError, match="injected shard failure"):
-            _hip.multi_gpu_european(S, K, T, r, v, 0.0, True, 200_000, 16, 5, True, 1)
-    finally:
-        _hip.tune(_hip.TUNE_FAULT_SHARD, 0)
-    again = _hip.multi_gpu_european(S, K, T, r, v, 0.0, True, 50_000, 16, 5, True, 1)
-    after = _hip.european(S, K, T, r, v, 0.0, True, 50_000, 16, 5, True)
-    assert (before.sum, before.sumsq) == (after.sum, after.sumsq) == (again.sum, again.sumsq)
+    # the other two payloads of the single-process form (count 17 / 33 and 6), one rank through the real all-reduce;
+    # several ranks are rehearsed on this one device in tests/test_gpu_instrumented.py
+    for second in (False, True):
+        one, e1 = _hip.european_greeks_fd(S, K, T, r, v, 0.0, True, 200_000, 16, 5, second)
+        many, e2 = _hip.multi_gpu_greeks_fd(S, K, T, r, v, 0.0, True, 200_000, 16, 5, second, 1)
+        assert many == one and [(x.sum, x.sumsq, x.n) for x in e1] == [(x.sum, x.sumsq, x.n) for x in e2]
+    m1 = _hip.european_cv(S, K, T, r, v, 0.0, True, 200_000, 16, 5, True)
+    m2 = _hip.multi_gpu_european_cv(S, K, T, r, v, 0.0, True, 200_000, 16, 5, True, 1)
+    assert (m1.sum_d, m1.sum_s, m1.sum_dd, m1.sum_ss, m1.sum_ds, m1.n, m1.value) == (m2.sum_d, m2.sum_s, m2.sum_dd, m2.sum_ss, m2.sum_ds, m2.n, m2.value)
     assert _hip.device_info()["device"] == 0
-    with pytest.raises(ol.AccelerationError):               # a bad shard argument (n_steps = 0) is refused before any launch
-        _hip.multi_gpu_european(S, K, T, r, v, 0.0, True, 1000, 0, 5, True, 1)
-    assert _hip.european(S, K, T, r, v, 0.0, True, 50_000, 16, 5, True).sum == before.sum
-
-
-def test_device_side_row_capacity_guard_answers_nan_and_keeps_the_library_usable():
-    """A launch whose rows would not fit the workspace it was given (the r1 fault: NV = 4 rows on an NV = 2 workspace)
-    must not store: olmc_kernels.h grid_reduce answers NaN instead.  The knob makes the workspace REPORT one value per
-    row while really holding enough, so tripping the guard is safe."""
-    S, K, T, r, v = ATM
-    ok = _hip.european(S, K, T, r, v, 0.0, True, 300_000, 8, 3, True)
-    _hip.tune(_hip.TUNE_FORCE_NV, 1)
-    try:
-        bad = _hip.european(S, K, T, r, v, 0.0, True, 300_000, 8, 3, True)
-        assert math.isnan(bad.sum) and math.isnan(bad.price)
-        bad4 = _hip.normal_moments(3, 50_000, 8)             # NV = 4
-        assert math.isnan(bad4[0])
-    finally:
-        _hip.tune(_hip.TUNE_FORCE_NV, 0)
-    again = _hip.european(S, K, T, r, v, 0.0, True, 300_000, 8, 3, True)
-    assert (again.sum, again.sumsq, again.n) == (ok.sum, ok.sumsq, ok.n)
-    assert all(math.isfinite(m) for m in _hip.normal_moments(3, 50_000, 8))
 
 
 # ------------------------------------------------------------------ Greeks
@@ -534,31 +505,6 @@ def test_asian_matches_same_stream_checker(geometric, typ, anti, N, M):
         st = _hip.asian(100.0, 100.0, 1.0, 0.05, 0.2, 0.02, typ == "call", geometric, N, M, 7, anti, fast=fast)
         assert st.n == n
         assert st.sum == pytest.approx(sx, rel=REL_STREAM_TOL) and st.sumsq == pytest.approx(sxx, rel=4 * REL_STREAM_TOL)
-
-
-@pytest.mark.parametrize("form", [None, 0, 1])
-def test_device_exp2_f64_is_within_two_ulp_of_libm_everywhere(form):
-    """The per-date exponential of the reference-precision Asian kernel (olmc_kernels.h), in both forms the library carries:
-    exp2_f64 (rint + degree-11 polynomial on [-1/2, 1/2] + v_ldexp_f64) and exp2_f64_tab (64-entry table + degree-5 polynomial;
-    form None = whichever the kernel is built with).  Against the host libm (numpy.exp2, < 1 ulp): <= 2 ulp on a dense sweep of
-    the range a cumulative log-return can take, on the reduction's seams (half-integers and, for the table, the 128ths where the
-    table index rounds), and correct limits (0, inf, NaN)."""
-    rng = np.random.default_rng(7)
-    x = np.concatenate([rng.uniform(-60.0, 60.0, 400_000), rng.uniform(-1.0, 1.0, 400_000), rng.normal(0.0, 1e-3, 100_000),
-                        np.arange(-80, 81) + 0.5, np.nextafter(np.arange(-80, 81) + 0.5, np.inf), np.nextafter(np.arange(-80, 81) + 0.5, -np.inf),
-                        np.arange(-1000, 1001, 7.0), [0.0, -0.0, 1.0, -1.0, 1e-300, -1e-300, 1023.999, -1021.5],
-                        (np.arange(-4096, 4097) + 0.5) / 64.0, np.nextafter((np.arange(-4096, 4097) + 0.5) / 64.0, np.inf),
-                        (np.arange(-8192, 8193) + 0.5) / 256.0, np.nextafter((np.arange(-8192, 8193) + 0.5) / 256.0, -np.inf)])
-    y, want = _hip.exp2_probe(x, form), np.exp2(x)
-    ulp = np.abs(y - want) / np.spacing(want)
-    assert np.isfinite(y).all() and ulp.max() <= 2.0, (ulp.max(), x[np.argmax(ulp)])
-    assert (y[np.isin(x, np.arange(-1000, 1001, 7.0))] == want[np.isin(x, np.arange(-1000, 1001, 7.0))]).all()     # exact powers of two
-    special = _hip.exp2_probe(np.array([np.nan, 1025.0, 5000.0, 1e300, -1100.0, -5000.0, -1e300, np.inf, -np.inf]), form)
-    assert np.isnan(special[0]) and (special[1:4] == np.inf).all()          # overflow like exp2()
-    assert (special[4:7] == 0.0).all()                                       # below the subnormal range: zero like exp2()
-    # documented limit of the domain: an INFINITE argument answers NaN (inf - rint(inf)), where exp2() says inf / 0.  A
-    # cumulative log-return is infinite only for infinite parameters, for which the reference's own path is NaN as well.
-    assert np.isnan(special[7:]).all()
 
 
 def test_asian_fp64_exponent_tracks_the_checker_more_closely_than_the_fp32_one():
@@ -683,6 +629,57 @@ def test_asian_greeks_through_exotic_adapter(golden):
 
 
 # ------------------------------------------------------------------ re-entrancy (Streamlit sessions are threads)
+def test_concurrent_callers_get_bit_identical_results_on_contexts_of_their_own():
+    """Round 4: a call leases one of up to 8 contexts of the device (stream, workspace, landing buffer, completion word of its own)
+    instead of holding one mutex from launch to result, so the pricings of N Streamlit sessions (threads) overlap.  Twelve threads
+    -- more than there are contexts: the ninth waits for a lease -- hammer the interactive sizes of the one live UI caller
+    (streamlit_app/pages/1_MonteCarlo_Basic.py:111-126: 10k - 200k paths x 1 - 100 steps) with every kind of entry point that owns
+    per-context scratch (reduction workspace, terminal array, Sobol table, batch workspace, LSM path matrix); every result must be
+    the bits the same call returns single-threaded."""
+    import threading
+    from optionslab_amd.monte_carlo_unified import MonteCarloPricerUni
+
+    sizes = [(10_000, 50), (100_000, 100), (200_000, 1), (50_000, 16)]
+    def calls(k):
+        N, M = sizes[k % len(sizes)]
+        p = ol.MonteCarloPricer(N, M, 100 + k)
+        qp = ol.MonteCarloPricer(1 << 12, 8 + k % 3, 7, ol.MCMethod.QMC)
+        return [
+            lambda: p.price(100.0 + k, 100.0, 1.0, 0.05, 0.2, "call", return_error=True),
+            lambda: tuple(p.greeks(*ATM, "put", include_second_order=bool(k & 1)).items()),
+            lambda: p.price_with_control_variate(*ATM, "call"),
+            lambda: p._simulate(100.0, 1.0, 0.05, 0.2, 0.0).tobytes(),
+            lambda: qp.price(*ATM, "call", return_error=True),
+            lambda: ol.AsianOption(*ATM, seed=k).price(20_000, 32, return_error=True),
+            lambda: ol.AmericanOption(*ATM, seed=k).price(5_000 + 100 * k, 10),
+            lambda: tuple(MonteCarloPricerUni(5_000, 10, seed=k).price_batch(np.array([90.0, 100.0 + k]), np.array([100.0, 100.0]), np.array([1.0, 0.5]),
+                                                                              np.array([0.05, 0.05]), np.array([0.2, 0.3]), "call")),
+        ]
+    n_threads = 12
+    want = {k: [f() for f in calls(k)] for k in range(n_threads)}
+    got, errs = {}, []
+    start = threading.Barrier(n_threads)
+
+    def work(k):
+        try:
+            fs = calls(k)
+            start.wait()
+            for _ in range(15):
+                got[k] = [f() for f in fs]
+                if got[k] != want[k]:
+                    raise AssertionError(f"thread {k}: a concurrent call returned other bits than the single-threaded one")
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            start.abort()
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs[:2]
+    assert got == want
+    assert [f() for f in calls(3)] == want[3]               # and single-threaded again afterwards
+
+
 def test_concurrent_calls_from_threads_are_serialised_correctly():
     import threading
     p = ol.MonteCarloPricer(50_000, 16, 7)
@@ -844,16 +841,6 @@ def test_monte_carlo_error_shrinks_like_one_over_sqrt_n():
     # the reported (naive, reference-formula) std_error overstates the true spread of the antithetic estimator
     rep = ol.MonteCarloPricer(640_000, 16, 1).price(*ATM, "call", return_error=True).std_error
     assert 0.4 * rep < stds[-1] < 1.05 * rep
-
-
-def test_normal_moments_tap_agrees_with_the_normals_tap():
-    z = _hip.normals(5, 100, 3000, 7).astype(np.float64)
-    s1, s2, s3, s4 = _hip.normal_moments(5, 3000, 7, path_offset=100)
-    assert s1 == pytest.approx(z.sum(), rel=1e-5, abs=1e-3) and s2 == pytest.approx((z**2).sum(), rel=1e-6)
-    assert s3 == pytest.approx((z**3).sum(), rel=1e-5, abs=1e-2) and s4 == pytest.approx((z**4).sum(), rel=1e-6)
-    big = _hip.normal_moments(9, 1 << 22, 64)              # 2.7e8 normals: variance to 9e-5
-    n = (1 << 22) * 64
-    assert abs(big[0] / n) < 5 / math.sqrt(n) and abs(big[1] / n - 1) < 5 * math.sqrt(2 / n) and abs(big[3] / n - 3) < 5 * math.sqrt(96 / n)
 
 
 # ------------------------------------------------------------------ full paths (simulate_gbm_paths counterpart)

@@ -14,6 +14,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from optionslab_amd import _hip  # noqa: E402
+from tools.probe import binding as probe  # noqa: E402  (the instrumented build: include/olmc_probe.h)
 
 SIZES = [(int(sys.argv[1]), int(sys.argv[2]))] if len(sys.argv) > 2 else [(65_536, 252), (458_752, 252), (1_000_000, 252), (8_000_000, 252), (1_000_000, 1024)]
 REPS = int(sys.argv[3]) if len(sys.argv) > 3 else 15
@@ -22,7 +23,7 @@ TICK_US = 0.01          # s_memrealtime: 100 MHz
 
 def one(n, m, seed):
     # 30 identical launches queued back to back in front of the recorded one: it runs at the clock the production kernel runs at
-    st, final, split_from, disp_ns = _hip.phase_stamps(n, m, seed, lead_launches=30)
+    st, final, split_from, disp_ns = probe.phase_stamps(n, m, seed, lead_launches=30)
     where = st[:, 4]
     st = st[:, :4]
     t0 = int(st[:, 0].min())

@@ -65,13 +65,32 @@ LANE_OPS_PER_PATH_STEP = 32   # SURVEY 8(d)'s algorithmic count (kept as a secon
 PEAK_TLANEOPS = N_SIMD * 32 * PEAK_GHZ * 1e9 / 1e12   # 78.6: SIMD-32 x 2.4 GHz (guide: 157.3 TF fp32 vector = 2 flop/FMA);
                                                       # SURVEY 8(d) assumed 64 lanes x 256 CU x 2.4 GHz = 39.3 (a SIMD-16 machine)
 
+def device_sources_sha256():
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("olmc.hip", "olmc_kernels.h"):
+        with open(os.path.join(ROOT, "optionslab_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def load_isa_mix():
-    """Static instruction mix of each kernel's step loop (tools/isa_mix.py: hipcc -S of this build, parsed)."""
+    """Static instruction mix of each kernel's step loop (tools/isa_mix.py: hipcc -S of this build, parsed).  The file names the
+    sha256 of the device sources it was read from: a mix of ANOTHER build (isa_mix.py failed after a kernel change, build.py only
+    warns) is refused -- {"_stale": why} -- and every roofline.frac that would have been priced with it is null with that reason."""
     try:
         with open(os.path.join(ROOT, "optionslab_amd", "isa_mix.json")) as f:
-            return json.load(f)
+            mix = json.load(f)
     except OSError:
-        return {}
+        return {"_stale": "optionslab_amd/isa_mix.json is missing (run tools/isa_mix.py)"}
+    try:
+        now = device_sources_sha256()
+    except OSError:
+        return mix                      # a packaged copy without sources: nothing to compare with
+    if mix.get("_sources_sha256") != now:
+        return {"_stale": f"optionslab_amd/isa_mix.json belongs to other device sources (its sha256 {str(mix.get('_sources_sha256'))[:12]}, "
+                          f"now {now[:12]}): run tools/isa_mix.py"}
+    return mix
 
 
 PMC_KERNELS = {         # substring of the demangled kernel name -> key in the JSON
@@ -82,7 +101,48 @@ PMC_KERNELS = {         # substring of the demangled kernel name -> key in the J
     "asian_exp64_kernel<true>": "c4_asian_fp64_antithetic",
     "asian_kernel<false, false>": "c4_asian_fp32",
     "asian_kernel<true, false>": "c4_asian_fp32_antithetic",
+    # SURVEY 8(f) kernels (round 4)
+    "asian_kernel<false, true>": "f_asian_geometric",
+    "extrema_kernel<false>": "f_extrema",
+    "heston_kernel<false>": "f_heston",
+    "european_multi_kernel<true>": "f_multi",
+    "european_qmc_kernel<0>": "f_qmc",
+    "european_qmc_block_kernel<0>": "f_qmc_block",
 }
+# the 8(f) workloads: (key, what, unit-steps per launch for the issue model = (paths or threads, steps or dims))
+F_PATHS, F_STEPS = 1_000_000, 252
+F_MULTI_CONTRACTS, F_MULTI_PATHS, F_MULTI_STEPS = 64, 65_536, 64
+F_QMC_POINTS, F_QMC_DIMS = 1 << 17, 252
+F_QMC_BLOCK_POINTS, F_QMC_BLOCK_DIMS = 1 << 22, 64
+
+
+def f_workloads(ol, _hip):
+    """{key: (callable making ONE blocking launch of that kernel, description, n_paths for the issue model, n_steps)}."""
+    import numpy as np
+    from optionslab_amd.monte_carlo import sobol_tables
+    from optionslab_amd.monte_carlo_unified import MonteCarloPricerUni
+    P = ATM + (0.0,)
+    sv1, sh1 = sobol_tables(F_QMC_DIMS, SEED)
+    sv8, sh8 = sobol_tables(F_QMC_BLOCK_DIMS, SEED)
+    uni = MonteCarloPricerUni(F_MULTI_PATHS, F_MULTI_STEPS, seed=SEED)
+    ks = np.linspace(80.0, 120.0, F_MULTI_CONTRACTS)
+    ones = np.ones(F_MULTI_CONTRACTS)
+    return {
+        "f_heston": (lambda: _hip.heston(100.0, 100.0, 1.0, 0.05, 0.0, True, 2.0, 0.04, 0.3, -0.7, 0.04, F_PATHS, F_STEPS, SEED, False),
+                     f"HestonPricer.price_monte_carlo, {F_PATHS:,} paths x {F_STEPS} steps (heston.py:184-255)", F_PATHS, F_STEPS),
+        "f_extrema": (lambda: _hip.barrier(*P, True, 120.0, 0, F_PATHS, F_STEPS, SEED, False),
+                      f"BarrierOption.price up-and-out call, {F_PATHS:,} paths x {F_STEPS} dates (exotic_options.py:174-224)", F_PATHS, F_STEPS),
+        "f_asian_geometric": (lambda: _hip.asian(*P, True, True, F_PATHS, ASIAN_STEPS, SEED, False),
+                              f"AsianOption.price geometric call, {F_PATHS:,} paths x {ASIAN_STEPS} dates (exotic_options.py:121-122)", F_PATHS, ASIAN_STEPS),
+        "f_multi": (lambda: uni.price_batch(100.0 * ones, ks, ones, 0.05 * ones, 0.2 * ones, "call"),
+                    f"MonteCarloPricerUni.price_batch, {F_MULTI_CONTRACTS} contracts x {F_MULTI_PATHS:,} paths x {F_MULTI_STEPS} steps, one launch "
+                    "(monte_carlo_unified.py:562-631)", F_MULTI_CONTRACTS * F_MULTI_PATHS, F_MULTI_STEPS),
+        "f_qmc": (lambda: _hip.european_qmc(*P, True, F_QMC_POINTS, sv1, sh1),
+                  f"MCMethod.QMC price, 2^17 Sobol points x {F_QMC_DIMS} dims, one point per thread (gbm_qmc.py:14-46)", F_QMC_POINTS, F_QMC_DIMS),
+        "f_qmc_block": (lambda: _hip.european_qmc(*P, True, F_QMC_BLOCK_POINTS, sv8, sh8),
+                        f"MCMethod.QMC price, 2^22 Sobol points x {F_QMC_BLOCK_DIMS} dims, eight points per thread (gbm_qmc.py:14-46)",
+                        F_QMC_BLOCK_POINTS // 8, F_QMC_BLOCK_DIMS),
+    }
 PMC_PASSES = [("sq", ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]),
               ("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"])]
 
@@ -105,6 +165,10 @@ def pmc_child():
         for anti in (False, True):
             for _ in range(3):
                 a.price(PATHS_PER_GPU, ASIAN_STEPS, "arithmetic", "call", antithetic=anti, precision=precision)
+    from optionslab_amd import _hip
+    for _key, (fn, _what, _n, _m) in f_workloads(ol, _hip).items():
+        for _ in range(3):
+            fn()
     print("pmc-child done", flush=True)
 
 
@@ -217,6 +281,8 @@ def roofline_for(pmc, key, avg_kernel_s, n_steps, n_paths, costs=None, mixes=Non
          "frac_valu_active_pmc": c["SQ_ACTIVE_INST_VALU"] * 4.0 / avg_kernel_s / peak,
          "pmc_cycles_per_valu_inst": (c["SQ_ACTIVE_INST_VALU"] * 4.0 / c["SQ_INSTS_VALU"]) if c.get("SQ_INSTS_VALU") else None}
     mix = (mixes or {}).get(key)
+    if (mixes or {}).get("_stale"):
+        r["why_null"] = mixes["_stale"]
     if mix and c.get("SQ_INSTS_VALU") and c.get("SQ_WAVES") and mix.get("steps_per_trip"):
         trips = n_steps // mix["steps_per_trip"]
         path_waves = n_paths / 64.0                     # whole-path wave equivalents (a split workgroup's four waves share 64 paths)
@@ -380,6 +446,23 @@ def compact_line(full, detail_name=None):
                       for k, v in a.items() if isinstance(v, dict) and "ms_per_call" in v}
         if a.get("gpu_over_cpu"):
             line["c4"]["gpu_over_cpu"] = _num(a["gpu_over_cpu"], 5)
+    f = full.get("f_kernels")
+    if isinstance(f, dict) and "error" not in f:
+        line["f"] = {}
+        for k, v in f.items():
+            if not isinstance(v, dict) or "error" in v:
+                continue
+            if k == "f_american_lsm":
+                line["f"]["american_lsm"] = {sz: {"ms": _num(d.get("ms_per_call"), 4), "frac": _num(d.get("frac"), 3)} for sz, d in (v.get("sizes") or {}).items()}
+            else:
+                line["f"][k[2:]] = {"ms": _num(v.get("avg_kernel_ms"), 4), "frac": _num(roof_frac(v), 3)}
+    w = full.get("c2_f64_normals")
+    if isinstance(w, dict) and "error" not in w:
+        line["c2_f64_normals"] = {"value": _num(w.get("value"), 4), "kernel_ms": _num(w.get("avg_kernel_ms"), 4), "x_product_kernel": _num(w.get("slowdown_vs_product_kernel"), 3),
+                                  "abs_diff_over_se": _num(w.get("abs_diff_over_se"), 3)}
+    sp = full.get("c5_single_process")
+    if isinstance(sp, dict) and "error" not in sp:
+        line.setdefault("c5", {})["single_process"] = _entry(sp.get("value"), sp.get("ms_per_step"), None, n_gpus=sp.get("n_gpus"), paths_per_gpu=sp.get("paths_per_gpu"))
     c5 = {}
     for k in ("c5_weak", "c5_strong", "c2_1m_per_gpu", "n1_basis", "pipelined"):
         v = full.get(k)
@@ -390,7 +473,7 @@ def compact_line(full, detail_name=None):
             line.setdefault("c5", {})[k[3:]] = c5.pop(k)
     line.update(c5)
     errs = []
-    for k in ("c3_greeks", "c4_asian", "c5_weak", "c5_strong", "c2_1m_per_gpu", "n1_basis", "pipelined"):
+    for k in ("c3_greeks", "c4_asian", "c5_weak", "c5_strong", "c2_1m_per_gpu", "n1_basis", "pipelined", "f_kernels", "c2_f64_normals", "c5_single_process"):
         if isinstance(full.get(k), dict) and "error" in full[k]:
             errs.append(f"{k}: {full[k]['error']}")
     errs += list(full.get("errors") or [])
@@ -400,7 +483,7 @@ def compact_line(full, detail_name=None):
         line["detail"] = detail_name
     text = json.dumps(line, separators=(",", ":"))
     if len(text) > LINE_BUDGET:                      # belt and braces: shed the secondary entries, never the contract keys
-        for k in ("pipelined", "c4", "c3", "c5", "errors"):
+        for k in ("pipelined", "f", "c2_f64_normals", "c4", "c3", "c5", "errors"):
             line.pop(k, None)
             if len(json.dumps(line, separators=(",", ":"))) <= LINE_BUDGET:
                 break
@@ -464,6 +547,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip pipelined / C3 / C4 / C5 (profiling runs)")
     ap.add_argument("--pmc-keep", default=None, help="directory to keep the rocprofv3 CSVs of the live passes in")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--single-process-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--min-seconds", type=float, default=1.5,
                     help="timed passes repeat until the plain ones alone cover this much wall time (as many instrumented ones ride along: the GPU "
                          "is busy for about twice this, which an outside utilisation sampler can see)")
@@ -472,6 +556,8 @@ def main():
     args = ap.parse_args()
     if args.pmc_child:
         return pmc_child()
+    if args.single_process_child:
+        return single_process_child(args)
     if args.steps < 1 or args.warmup < 0 or args.gpus < 1:
         raise SystemExit("--gpus and --steps must be >= 1 and --warmup >= 0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -495,8 +581,10 @@ def worker(args):
     paths_per_gpu = args.paths_per_gpu or (PATHS_PER_GPU if world == 1 else C5_PATHS_PER_GPU)
     pmc_key = {PATHS_PER_GPU: "c2_european", C5_PATHS_PER_GPU: "c5_shard"}.get(paths_per_gpu)
 
-    # Child-process work first, while this process has not touched the GPU: the live PMC passes and the CPU baseline's pool.
+    # Child-process work first, while this process has not touched the GPU: the live PMC passes, the CPU baseline's pool, and the
+    # (waiting) child that will measure the single-process multi-GPU form.
     pmc, cpu = None, None
+    sp_child = start_single_process_child(args, world) if (rank == 0 and not args.no_extras and not rehearsal) else None
     if world == 1 and rank == 0:
         if not args.no_pmc:
             pmc = collect_pmc(args.pmc_keep)
@@ -530,6 +618,11 @@ def worker(args):
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # a CPU-side barrier (a NCCL barrier is a kernel that spins on every GPU until the last rank arrives: not what ranks should do
+    # while rank 0's child measures the single-process form on the same devices)
+    gloo_group = None
+    if use_dist and world > 1:
+        gloo_group = dist.new_group(backend="gloo")
     info = _hip.device_info()
     S, K, T, r, sigma, q = (WORK[k] for k in ("S", "K", "T", "r", "sigma", "q"))
     bs = ol.black_scholes(S, K, T, r, sigma, "call", q)
@@ -742,6 +835,8 @@ def worker(args):
             os.write(json_fd, (json.dumps(compact_line(out, detail), separators=(",", ":")) + "\n").encode())
 
     def watchdog_fire():
+        if sp_child is not None and sp_child.poll() is None:
+            sp_child.kill()
         if rank == 0 and out is not None:
             out.setdefault("errors", []).append(f"section `{current['section']}` did not finish within its time limit; line printed by the watchdog, exit 3")
         emit()
@@ -792,8 +887,15 @@ def worker(args):
         if world == 1 and not use_dist:
             section("c3_greeks", lambda: c3_greeks(ol, _hip, pmc, costs, mixes, clock_ghz))
             section("c4_asian", lambda: c4_asian(ol, _hip, pmc, costs, mixes, clock_ghz, cpu))
+            section("f_kernels", lambda: f_kernels(ol, _hip, pmc, costs, mixes, clock_ghz))
+            section("c2_f64_normals", lambda: c2_f64_normals(ol, _hip, bs))
+        # the torch-free form north_star describes: ONE process, all N devices, olmc_multi_gpu_european (its own streams, one grouped RCCL
+        # all-reduce, no torch.distributed).  Measured by a fresh child of rank 0 while every rank of THIS job idles on a CPU barrier.
+        section("c5_single_process", lambda: c5_single_process(sp_child, dist, use_dist, rehearsal, world, rank, gloo_group))
     dog.cancel()
     emit()
+    if sp_child is not None and sp_child.poll() is None:
+        sp_child.kill()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -917,6 +1019,152 @@ def c4_asian(ol, _hip, pmc, costs, mixes, clock_ghz, cpu=None):
         out["cpu_baseline"] = cpu["c4_asian"]
         out["gpu_over_cpu"] = out["fp64"]["path_steps_per_s"] / cpu["c4_asian"]["value"]
     return out
+
+
+def f_kernels(ol, _hip, pmc, costs, mixes, clock_ghz):
+    """SURVEY 8(f) kernels: one workload each, the kernel's own duration (dispatch events), the issue-cycle fraction
+    of the same model as the headline kernel's -- live SQ_INSTS_VALU of this kernel, the static mix of its hot loop, 2 / 4 / 8 passes
+    per class -- and, for the American option's chain of per-date launches, an HBM + dependent-launch bound."""
+    out = {}
+    for key, (fn, what, n_units, n_steps) in f_workloads(ol, _hip).items():
+        try:
+            med, ks, per = _timed_calls(_hip, fn, 12, warm=4)
+            roof = roofline_for(pmc, key, ks, n_steps, n_units, costs, mixes, clock_ghz)
+            out[key] = {"ms_per_call": med * 1e3, "avg_kernel_ms": ks * 1e3 if ks else None, "launches_per_call": per, "workload": what,
+                        "roofline": roof, "vgprs": (mixes.get(key) or {}).get("vgprs")}
+        except Exception as e:
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+    # American LSM: 1 path kernel + one launch per exercise date, each dependent on the one before through five coefficients
+    try:
+        from tools.probe import binding as probe
+        gap_us = probe.launch_gap_us(2000)
+        chain = {}
+        for n, m in ((50_000, 50), (1_000_000, 50)):
+            fn = lambda: _hip.american_lsm(*ATM, 0.0, False, n, m, 3, SEED)
+            med, ks, per = _timed_calls(_hip, fn, 12, warm=4)
+            bytes_dates = 32.0 * n * m                   # per date and path: two prices + the cash flow read, the cash flow written
+            bytes_paths = 8.0 * n * (m + 1)              # the path matrix, written once
+            bound_s = (m + 1) * gap_us * 1e-6 + (bytes_dates + bytes_paths) / 8e12
+            chain[f"{n}x{m}"] = {"ms_per_call": med * 1e3, "call_kernel_ms": ks * 1e3 if ks else None, "launches": m + 1, "bound_ms": bound_s * 1e3,
+                                 "frac": bound_s / med, "algorithmic_bytes": bytes_dates + bytes_paths,
+                                 "hbm_gbps_algorithmic": (bytes_dates + bytes_paths) / med / 1e9}
+        out["f_american_lsm"] = {"bound": "hbm + dependent-launch chain", "dependent_launch_gap_us": gap_us, "sizes": chain,
+                                 "what": "bound = (M + 1) launches x the measured gap between two dependent EMPTY kernels on one stream + (32 B per "
+                                         "path and date + the 8 B path matrix) / 8 TB/s; frac = bound / blocking call"}
+    except Exception as e:
+        out["f_american_lsm"] = {"error": f"{type(e).__name__}: {e}"}
+    return out
+
+
+def c2_f64_normals(ol, _hip, bs):
+    """What the reference's own width would cost: the European call at 1M x 252 with fp64 normals -- same Philox
+    stream, two 53-bit uniforms per block, library-precision fp64 Box-Muller, fp64 sum -- by the INSTRUMENTED build's
+    european_f64_normals_kernel.  NOT a product path: a labelled number beside `dtype`: "f32 normals"."""
+    from tools.probe import binding as probe
+    fn = lambda: probe.european_f64_normals(*ATM, 0.0, True, PATHS_PER_GPU, N_STEPS, SEED)
+    med, ks, per = _timed_calls(probe.hip, fn, 10, warm=3)
+    f64 = fn()
+    f32 = _hip.european(*ATM, 0.0, True, PATHS_PER_GPU, N_STEPS, SEED, True)
+    ks32 = _timed_calls(_hip, lambda: _hip.european(*ATM, 0.0, True, PATHS_PER_GPU, N_STEPS, SEED, True), 10, warm=3)[1]
+    return {"value": PATHS_PER_GPU * N_STEPS / med, "unit": "path-steps/s", "ms_per_call": med * 1e3, "avg_kernel_ms": ks * 1e3 if ks else None,
+            "product_kernel_ms": ks32 * 1e3 if ks32 else None, "slowdown_vs_product_kernel": (ks / ks32) if ks and ks32 else None,
+            "price": f64.price, "std_error": f64.std_error, "product_price": f32.price, "product_std_error": f32.std_error,
+            "abs_diff_over_se": abs(f64.price - f32.price) / math.hypot(f64.std_error, f32.std_error),
+            "err_over_se_vs_bs": abs(f64.price - bs) / f64.std_error, "product_err_over_se_vs_bs": abs(f32.price - bs) / f32.std_error,
+            "dtype": "f64 normals (2 per Philox block, 53-bit uniforms, libm log / sincospi) / f64 prices",
+            "what": "instrumented build only (include/olmc_probe.h: olmc_european_f64_normals); the two prices use different normals of the same "
+                    "counter stream, so they differ by sampling noise: abs_diff_over_se is that difference in units of its own standard error"}
+
+
+def single_process_child(args):
+    """`bench.py --single-process-child --gpus N`: ONE process prices with all N devices through olmc_multi_gpu_european -- no torch,
+    no torch.distributed -- and prints one JSON object.  Started by rank 0 of the benchmark while the ranks idle."""
+    if sys.stdin.readline().strip() != "go":          # started before the parent touched a GPU; waits here, GPU untouched, until told
+        return 0
+    import optionslab_amd as ol
+    from optionslab_amd import _hip
+    n_gpus = args.gpus
+    per_gpu = args.paths_per_gpu or (PATHS_PER_GPU if n_gpus == 1 else C5_PATHS_PER_GPU)
+    n_global = per_gpu * n_gpus
+    S, K, T, r, sigma, q = (WORK[k] for k in ("S", "K", "T", "r", "sigma", "q"))
+    bs = ol.black_scholes(S, K, T, r, sigma, "call", q)
+    step = lambda k: _hip.multi_gpu_european(S, K, T, r, sigma, q, True, n_global, N_STEPS, SEED + k, True, n_gpus)
+    t0 = time.perf_counter()
+    first = step(0)
+    setup_s = time.perf_counter() - t0                  # contexts, rank streams, ncclCommInitAll
+    for k in range(max(args.warmup, 20)):
+        step(1000 + k)
+    passes, worst = [], 0.0
+    while len(passes) < 3 or (sum(passes) < 0.5 and len(passes) < 200):
+        t0 = time.perf_counter()
+        res = [step(len(passes) * args.steps + k) for k in range(args.steps)]
+        passes.append(time.perf_counter() - t0)
+        for st in res:
+            assert st.n == 2 * n_global
+            worst = max(worst, abs(st.price - bs) / st.std_error)
+    med = statistics.median(passes)
+    out = {"value": n_global * N_STEPS * args.steps / med, "unit": "path-steps/s", "ms_per_step": med / args.steps * 1e3, "n_gpus": n_gpus, "paths_per_gpu": per_gpu,
+           "global_paths": n_global, "steps": args.steps, "passes": len(passes), "max_abs_err_over_sigma": worst, "first_call_s": setup_s, "price": first.price,
+           "what": "olmc_multi_gpu_european: one process, one host thread, a stream per device, ONE grouped RCCL all-reduce of (sum, sumsq, n) per "
+                   "blocking pricing, result by rank 0's polled completion word; no torch"}
+    # the other two payloads of the same engine (count 33 and 6), at 1M paths per GPU
+    try:
+        g = lambda: _hip.multi_gpu_greeks_fd(S, K, T, r, sigma, q, True, PATHS_PER_GPU * n_gpus, N_STEPS, SEED, True, n_gpus, want_evals=False)
+        c = lambda: _hip.multi_gpu_european_cv(S, K, T, r, sigma, q, True, PATHS_PER_GPU * n_gpus, N_STEPS, SEED, True, n_gpus)
+        for name, fn in (("greeks14_1m_per_gpu", g), ("control_variate_1m_per_gpu", c)):
+            for _ in range(5):
+                fn()
+            ts = []
+            for _ in range(20):
+                t0 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t0)
+            out[name] = {"ms_per_call": statistics.median(ts) * 1e3, "path_steps_per_s": PATHS_PER_GPU * n_gpus * N_STEPS / statistics.median(ts)}
+    except Exception as e:
+        out["errors"] = [f"{type(e).__name__}: {e}"]
+    print(json.dumps(out), flush=True)
+    _hip.shutdown()
+    return 0
+
+
+def start_single_process_child(args, world):
+    """Rank 0, BEFORE it touches a GPU (no process that has initialised HIP forks here): `bench.py --single-process-child --gpus N`
+    as a child that waits on its stdin, GPU untouched, until c5_single_process tells it to go."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "OLMC_DEVICE", "MASTER_ADDR", "MASTER_PORT",
+                                                              "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "OLMC_BENCH_DETAIL")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--single-process-child", "--gpus", str(world), "--steps", str(min(args.steps, 20)),
+           "--warmup", str(args.warmup)] + (["--paths-per-gpu", str(args.paths_per_gpu)] if args.paths_per_gpu else [])
+    try:
+        return subprocess.Popen(cmd, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    except OSError as e:
+        print(f"[bench] cannot start the single-process child: {e}", file=sys.stderr)
+        return None
+
+
+def c5_single_process(child, dist, use_dist, rehearsal, world, rank, gloo_group):
+    """The child rank 0 started at the very beginning (a fresh process: its own HIP contexts on all N devices) measures between two
+    CPU barriers; the other ranks wait there with idle GPUs.  In a rehearsal (all ranks on one GPU) the child is not run."""
+    def cpu_barrier():
+        if use_dist and world > 1:
+            dist.barrier(group=None if rehearsal else gloo_group)
+    if rehearsal:
+        return {"error": "rehearsal: every rank sits on one GPU, the single-process form needs N devices"}
+    cpu_barrier()
+    res = None
+    if rank == 0:
+        if child is None:
+            res = {"error": "the child was not started"}
+        else:
+            try:
+                out, err = child.communicate("go\n", timeout=240)
+                line = next((l for l in reversed(out.splitlines()) if l.startswith("{")), None)
+                res = json.loads(line) if (child.returncode == 0 and line) else {"error": f"child rc {child.returncode}: {(err or out)[-300:]}"}
+            except (OSError, subprocess.TimeoutExpired, ValueError) as e:
+                child.kill()
+                res = {"error": f"{type(e).__name__}: {e}"}
+    cpu_barrier()
+    return res
 
 
 if __name__ == "__main__":

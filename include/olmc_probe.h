@@ -52,6 +52,18 @@ enum { OLMC_PROBE_MAD_U64_U32 = 0, OLMC_PROBE_BITOP3_B32, OLMC_PROBE_CVT_F32_U32
        OLMC_PROBE_MIX_BITOP3_ADD, OLMC_PROBE_MIX_MAD_BITOP3, OLMC_PROBE_MAD_U64_U32_VV, OLMC_PROBE_COUNT };
 int olmc_issue_probe(int op, int waves_per_simd, double* ns_per_instr);
 
+/* ---- what the reference's own width would cost -------------------------------
+ * European call with fp64 NORMALS (the reference draws fp64 normals, gbm_numpy.py:32-33): same Philox counter stream, but a block
+ * yields two normals from two 53-bit uniforms by a library-precision fp64 Box-Muller (log, sincospi), the path's sum of normals in
+ * fp64 throughout; launch shape, payoff and fused reduction of the product's european_path_kernel.  Antithetic.  Not a product
+ * path: bench.py prints its time and |price - product price| / se beside the product's "f32 normals" line (key c2_f64_normals). */
+int olmc_european_f64_normals(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t n_paths,
+                              int32_t n_steps, uint64_t seed, olmc_stats* out);
+
+/* Microseconds one more DEPENDENT kernel launch costs on a stream (a chain of n empty kernels): the command processor's floor under
+ * every per-date launch of olmc_american_lsm. */
+int olmc_launch_gap_probe(int32_t n, double* us_per_launch);
+
 /* ---- test seams (0 = off, the default) ------------------------------------
  *   OLMC_PROBE_TUNE_FAULT_SHARD      k > 0: rank k - 1 of a multi-GPU call fails before it launches (error-path tests)
  *   OLMC_PROBE_TUNE_FORCE_NV         v > 0: reduction workspaces REPORT a capacity of v values per workgroup row, so a kernel that

@@ -1790,16 +1790,23 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
     const int64_t units = blocks ? (point_offset + n_paths + kQmcBlock - 1) / kQmcBlock - point_offset / kQmcBlock : n_paths;
     const int32_t grid = grid_for(units);
     ReduceWs ws{};
+    EventPair ep{};
+    const EventPair* timed = nullptr;
+    double* const no_terminal = nullptr;
     if (cv) {
         rc = make_ws(c, c->stream, grid, 5, c->d_result, -1.0, &ws);
         if (rc) return rc;
-        if (blocks) hipLaunchKernelGGL((european_qmc_block_kernel<kControlVariate>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, nullptr);
-        else hipLaunchKernelGGL((european_qmc_kernel<kControlVariate>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, nullptr);
+        rc = prof_pair(c, &ep, &timed);
+        if (rc) return rc;
+        if (blocks) launch_timed(european_qmc_block_kernel<kControlVariate>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else launch_timed(european_qmc_kernel<kControlVariate>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
     } else if (!terminal_host) {
         rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
         if (rc) return rc;
-        if (blocks) hipLaunchKernelGGL((european_qmc_block_kernel<kReduce>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, nullptr);
-        else hipLaunchKernelGGL((european_qmc_kernel<kReduce>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, nullptr);
+        rc = prof_pair(c, &ep, &timed);
+        if (rc) return rc;
+        if (blocks) launch_timed(european_qmc_block_kernel<kReduce>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else launch_timed(european_qmc_kernel<kReduce>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
     } else {
         if (blocks) hipLaunchKernelGGL((european_qmc_block_kernel<kTerminal>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
         else hipLaunchKernelGGL((european_qmc_kernel<kTerminal>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);

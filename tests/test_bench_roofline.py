@@ -25,11 +25,18 @@ def bench():
 def test_isa_mix_covers_every_kernel_the_bench_prices(bench):
     mix = bench.load_isa_mix()
     assert set(bench.PMC_KERNELS.values()) <= set(mix)
+    assert "_stale" not in mix and mix["_sources_sha256"] == bench.device_sources_sha256()      # the mix belongs to THESE device sources
     for key in bench.PMC_KERNELS.values():
         m = mix[key]
-        assert m["steps_per_trip"] in (4, 16) and m["loop_valu_instructions"] == sum(m["by_class"].values())
+        assert m["loop_valu_instructions"] == sum(m["by_class"].values())
         assert set(m["by_class"]) <= set(bench.ISSUE_PASSES), key            # every class has a price
-        assert m["by_class"]["v_log_f32"] * 2 == m["steps_per_trip"]        # one Box-Muller log per two normals
+        if key in ("f_qmc", "f_qmc_block"):                                  # Sobol kernels: a trip is one dimension; no Box-Muller; the rare tail is not in the mix
+            assert m["steps_per_trip"] == 1 and "v_log_f32" not in m["by_class"] and m["cold_lines_skipped"] > 100
+            assert m["by_class"]["v_bitop3_b32"] >= 28 and m["by_class"]["v_fma_f64"] >= (8 if key == "f_qmc_block" else 1) * 40
+        elif key == "f_heston":                                              # two normals per step
+            assert m["steps_per_trip"] == m["by_class"]["v_log_f32"] == 2
+        else:
+            assert m["steps_per_trip"] in (4, 16) and m["by_class"]["v_log_f32"] * 2 == m["steps_per_trip"]        # one Box-Muller log per two normals
     # the headline loop: 17 multiplies and 19 XOR3 per Philox block, all but two of the XOR3 on three VGPRs (pinned round keys)
     c2 = mix["c2_european"]["by_class"]
     assert c2["v_mad_u64_u32"] == 68 and c2["v_bitop3_b32(v,v,v)"] + c2["v_bitop3_b32"] == 76 and c2["v_bitop3_b32"] <= 8
@@ -65,6 +72,27 @@ def test_roofline_pricing_is_bounded_and_uses_the_counters_it_says(bench):
         n_steps = 252 if key.startswith("c3") else 1024
         rr = bench.roofline_for(pmc, key, ms / 1e3, n_steps, 1_000_000, None, mix)
         assert 0.6 < rr["frac"] <= 1.0, (key, rr["frac"])
+
+
+def test_a_mix_of_other_device_sources_is_refused(bench, tmp_path, monkeypatch):
+    """isa_mix.json carries the sha256 of the device sources it was read from; bench.py prices nothing with a mix of
+    another build and says why."""
+    import shutil
+    fake = tmp_path / "repo"
+    (fake / "optionslab_amd" / "csrc").mkdir(parents=True)
+    for name in ("olmc.hip", "olmc_kernels.h"):
+        shutil.copy(os.path.join(ROOT, "optionslab_amd", "csrc", name), fake / "optionslab_amd" / "csrc" / name)
+    shutil.copy(os.path.join(ROOT, "optionslab_amd", "isa_mix.json"), fake / "optionslab_amd" / "isa_mix.json")
+    monkeypatch.setattr(bench, "ROOT", str(fake))
+    assert "_stale" not in bench.load_isa_mix()
+    with open(fake / "optionslab_amd" / "csrc" / "olmc_kernels.h", "a") as f:
+        f.write("\n// a kernel changed\n")
+    stale = bench.load_isa_mix()
+    assert set(stale) == {"_stale"} and "run tools/isa_mix.py" in stale["_stale"]
+    with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
+        pmc = json.load(f)
+    r = bench.roofline_for(pmc, "c2_european", 1e-4, 252, 1_000_000, None, stale)
+    assert r["frac"] is None and r["why_null"] == stale["_stale"] and r["frac_valu_active_pmc"] > 0
 
 
 def test_roofline_fallbacks(bench):

@@ -196,3 +196,25 @@ def test_normal_moments_tap_agrees_with_the_normals_tap():
     big = probe.normal_moments(9, 1 << 22, 64)              # 2.7e8 normals: variance to 9e-5
     n = (1 << 22) * 64
     assert abs(big[0] / n) < 5 / math.sqrt(n) and abs(big[1] / n - 1) < 5 * math.sqrt(2 / n) and abs(big[3] / n - 3) < 5 * math.sqrt(96 / n)
+
+
+# ------------------------------------------------------------------ measurement entry points of the instrumented build
+def test_fp64_normals_kernel_prices_the_same_option():
+    """olmc_european_f64_normals (bench.py's c2_f64_normals): the European call with fp64 normals -- two per Philox block from 53-bit
+    uniforms, library log / sincospi, fp64 sum.  Other normals than the product's (same counter stream, another mapping), so the two
+    prices differ by sampling noise only; both within 3.5 sigma of Black-Scholes, equal standard errors to 1 %."""
+    S, K, T, r, v = ATM
+    bs = ol.black_scholes(S, K, T, r, v, "call")
+    for N, M, seed in ((1_000_000, 252, 42), (300_000, 7, 3), (100_001, 1, 5)):
+        a = probe.european_f64_normals(S, K, T, r, v, 0.0, True, N, M, seed)
+        b = hip.european(S, K, T, r, v, 0.0, True, N, M, seed, True)
+        assert a.n == b.n == 2 * N
+        assert abs(a.price - bs) <= 3.5 * a.std_error and abs(b.price - bs) <= 3.5 * b.std_error
+        assert a.std_error == pytest.approx(b.std_error, rel=0.01)
+        assert abs(a.price - b.price) <= 4 * math.hypot(a.std_error, b.std_error)
+        assert a.price != b.price
+
+
+def test_launch_gap_probe_returns_a_few_microseconds():
+    gap = probe.launch_gap_us(500)
+    assert 0.5 < gap < 50.0, gap

@@ -28,7 +28,17 @@ KERNELS = {      # key in bench.py's JSON -> mangled-name regex
     "c4_asian_fp64_antithetic": r"^_ZN4olmc18asian_exp64_kernelILb1EEE",
     "c4_asian_fp32": r"^_ZN4olmc12asian_kernelILb0ELb0EEE",
     "c4_asian_fp32_antithetic": r"^_ZN4olmc12asian_kernelILb1ELb0EEE",
+    # round 4: the SURVEY 8(f) kernels
+    "f_asian_geometric": r"^_ZN4olmc12asian_kernelILb0ELb1EEE",
+    "f_extrema": r"^_ZN4olmc14extrema_kernelILb0EEE",
+    "f_heston": r"^_ZN4olmc13heston_kernelILb0EEE",
+    "f_multi": r"^_ZN4olmc21european_multi_kernelILb1EEE",
+    "f_qmc": r"^_ZN4olmc19european_qmc_kernelILi0EEE",
+    "f_qmc_block": r"^_ZN4olmc25european_qmc_block_kernelILi0EEE",
 }
+# steps (monitoring dates, Sobol dimensions) one trip of the hot loop advances a path by, where it is not "two per Box-Muller":
+# Heston consumes TWO normals per step; a Sobol kernel's trip is one dimension (of one point, or of a thread's eight points)
+STEPS_PER_TRIP = {"f_heston": lambda ops: ops.get("v_log_f32", 0), "f_qmc": lambda ops: 1, "f_qmc_block": lambda ops: 1}
 
 # mnemonic (encoding suffix stripped) -> probe class of optionslab_amd/_hip.py PROBE_CLASSES
 CLASS_OF = {
@@ -61,34 +71,72 @@ def function_body(lines, pattern):
     return lines[start:end + 1]
 
 
+def basic_blocks(body):
+    """[(first line, one past the last line, own label or None, header label of the innermost loop it belongs to or None, is that
+    loop's header, is an INNER loop's header)] from the compiler's own block comments (`.LBBn_m:` / `; %bb.k:` lines carry
+    "in Loop: Header=BBn_m" / "This Inner Loop Header")."""
+    starts = [i for i, l in enumerate(body) if re.match(r"^(\.LBB[0-9_]+:|; %bb\.\d+:)", l)]
+    blocks = []
+    for k, i in enumerate(starts):
+        end = starts[k + 1] if k + 1 < len(starts) else len(body)
+        line = body[i]
+        for j in range(i + 1, min(i + 4, end)):          # the annotation of a nested loop's header continues on comment-only lines
+            if re.match(r"^\s*;", body[j]):
+                line += " " + body[j]
+            else:
+                break
+        own = (m.group(1) if (m := re.match(r"^\.L(BB[0-9_]+):", line)) else None)
+        is_header = "Loop Header" in line
+        member = re.search(r"in Loop: Header=(BB[0-9_]+)", line)
+        loop = own if is_header else (member.group(1) if member else None)
+        blocks.append((i, end, own, loop, is_header, is_header and "Inner Loop Header" in line))
+    return blocks
+
+
 def hot_loop(body):
-    """Innermost loop (label ... backward branch to it) with the most vector instructions."""
-    label_at = {m.group(1): i for i, l in enumerate(body) if (m := re.match(r"^(\.LBB[0-9_]+):", l))}
-    spans = []
-    for i, l in enumerate(body):
-        m = re.match(r"^\s+s_cbranch_\w+\s+(\.LBB[0-9_]+)", l)
-        if m and m.group(1) in label_at and label_at[m.group(1)] < i:
-            spans.append((label_at[m.group(1)], i))
-    inner = [s for s in spans if not any(o != s and s[0] <= o[0] and o[1] <= s[1] for o in spans)]
-    count = lambda s: sum(1 for l in body[s[0]:s[1]] if re.match(r"^\s+v_", l))
-    steps = [s for s in inner if any("v_log_f32" in l for l in body[s[0]:s[1]])]      # the step loop generates normals (Box-Muller's log)
-    return max(steps or inner, key=count)
+    """Blocks of the innermost loop with the most vector instructions among those that generate normals (Box-Muller's v_log_f32), or,
+    for kernels without one (the Sobol kernels), among all innermost loops."""
+    blocks = basic_blocks(body)
+    inner = [b[3] for b in blocks if b[5]]
+    members = {h: [b for b in blocks if b[3] == h] for h in inner}
+    count = lambda h: sum(1 for b in members[h] for l in body[b[0]:b[1]] if re.match(r"^\s+v_", l))
+    steps = [h for h in inner if any("v_log_f32" in l for b in members[h] for l in body[b[0]:b[1]])]
+    return members[max(steps or inner, key=count)]
 
 
-def mix_of(body, span):
+def mix_of(body, blocks):
+    """VALU instructions of the loop's blocks by mnemonic and by probe class.  A block that holds an fp64 square root is COLD: it is the
+    tail of the inverse normal (0.1 % of the Sobol points, olmc_kernels.h ndtri_tail), skipped by a branch in nearly every wave."""
     ops = Counter()
-    for l in body[span[0]:span[1]]:
-        m = re.match(r"^\s+(v_[a-z0-9_]+)", l)
-        if not m:
+    n_cold = 0
+    for first, end, *_ in blocks:
+        if any(re.search(r"v_rsq_f64|v_sqrt_f64", l) for l in body[first:end]):
+            n_cold += end - first
             continue
-        op = re.sub(r"_(e32|e64|dpp|sdwa)$", "", m.group(1))
-        if op == "v_bitop3_b32" and re.search(r"\bs\d+\b|\bs\[", l.split(op, 1)[1]):
-            op = "v_bitop3_b32(sgpr)"        # an SGPR operand makes it a 4-cycle instruction; three VGPRs issue in ~2.6
-        ops[op] += 1
+        for l in body[first:end]:
+            m = re.match(r"^\s+(v_[a-z0-9_]+)", l)
+            if not m:
+                continue
+            op = re.sub(r"_(e32|e64|dpp|sdwa)$", "", m.group(1))
+            if op == "v_bitop3_b32" and re.search(r"\bs\d+\b|\bs\[", l.split(op, 1)[1]):
+                op = "v_bitop3_b32(sgpr)"        # an SGPR operand makes it a 4-cycle instruction; three VGPRs issue in ~2.6
+            ops[op] += 1
     classes = Counter()
     for op, n in ops.items():
-        classes[CLASS_OF.get(op, OTHER)] += n
-    return ops, classes
+        # any fp64 operation without a probe class of its own (v_max_f64, v_cmp_*_f64, v_frexp_*_f64, v_rcp_f64 ...) is priced as the
+        # cheapest fp64 class (4 passes = the fp64 vector peak): never below what it costs
+        classes[CLASS_OF.get(op, "v_add_f64" if re.search(r"_f64$|_f64_", op) else OTHER)] += n
+    return ops, classes, n_cold
+
+
+def source_digest():
+    """sha256 over the device sources the mix was read from: bench.py refuses a mix that belongs to another build."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("olmc.hip", "olmc_kernels.h"):
+        with open(os.path.join(PKG, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
 
 
 def main():
@@ -98,11 +146,14 @@ def main():
     for key, pat in KERNELS.items():
         body = function_body(lines, pat)
         span = hot_loop(body)
-        ops, classes = mix_of(body, span)
+        ops, classes, n_cold = mix_of(body, span)
         vgprs = next((int(m.group(1)) for l in lines[lines.index(body[0]):] if (m := re.match(r"^; NumVgprs: (\d+)", l))), None)
-        result[key] = {"loop_valu_instructions": sum(ops.values()), "steps_per_trip": 2 * ops.get("v_log_f32", 0), "by_class": dict(sorted(classes.items())), "by_mnemonic": dict(sorted(ops.items())),
-                       "unclassified_priced_as_" + OTHER: sum(n for op, n in ops.items() if op not in CLASS_OF), "vgprs": vgprs}
+        steps = STEPS_PER_TRIP[key](ops) if key in STEPS_PER_TRIP else 2 * ops.get("v_log_f32", 0)
+        result[key] = {"loop_valu_instructions": sum(ops.values()), "steps_per_trip": steps, "by_class": dict(sorted(classes.items())), "by_mnemonic": dict(sorted(ops.items())),
+                       "unclassified_priced_as_" + OTHER: sum(n for op, n in ops.items() if op not in CLASS_OF and not re.search(r"_f64$|_f64_", op)),
+                       "cold_lines_skipped": n_cold, "vgprs": vgprs}
         print(f"{key:28s} loop {sum(ops.values()):4d} VALU instr, {vgprs} VGPRs: {dict(classes)}", file=sys.stderr)
+    result["_sources_sha256"] = source_digest()
     with open(OUT, "w") as f:
         json.dump(result, f, indent=1)
     print(OUT)

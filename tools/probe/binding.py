@@ -41,13 +41,15 @@ def _second_binding():
         "olmc_clock_probe": (_I, [_I64, _I32, _U64T, C.POINTER(_D)]),
         "olmc_issue_probe": (_I, [_I, _I, C.POINTER(_D)]),
         "olmc_probe_tune": (_I, [_I, _I]),
+        "olmc_european_f64_normals": (_I, [_D] * 6 + [_I, _I64, _I32, _U64T, C.POINTER(mod.Stats)]),
+        "olmc_launch_gap_probe": (_I, [_I32, C.POINTER(_D)]),
     })
     return mod
 
 
 hip = _second_binding()
 PROBE_PROTOTYPES = ("olmc_exp2_probe", "olmc_exp2_probe_form", "olmc_normal_moments", "olmc_phase_stamps", "olmc_clock_probe",
-                    "olmc_issue_probe", "olmc_probe_tune")
+                    "olmc_issue_probe", "olmc_probe_tune", "olmc_european_f64_normals", "olmc_launch_gap_probe")
 _check, lib, seed64 = hip._check, hip.lib, hip.seed64
 
 TUNE_FAULT_SHARD = 5
@@ -112,3 +114,16 @@ def issue_probe(waves_per_simd: int = 8) -> dict:
         _check(lib().olmc_issue_probe(op, int(waves_per_simd), C.byref(ns)))
         out[name] = ns.value
     return out
+
+
+def european_f64_normals(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int, seed: int):
+    """The European call with fp64 normals (not a product path; see include/olmc_probe.h)."""
+    out = hip.Stats()
+    _check(lib().olmc_european_f64_normals(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(n_steps), seed64(seed), C.byref(out)))
+    return out
+
+
+def launch_gap_us(n: int = 2000) -> float:
+    us = C.c_double(0.0)
+    _check(lib().olmc_launch_gap_probe(int(n), C.byref(us)))
+    return us.value

@@ -181,6 +181,44 @@ extern "C" int olmc_issue_probe(int op, int waves_per_simd, double* ns_per_instr
 }
 
 
+
+// The European call with fp64 normals (european_f64_normals_kernel): one launch of n_paths x n_steps, one workgroup per 256 paths
+// (n_paths <= 2^18 x 256), antithetic.  Timed like every pricing when olmc_profile_enable is on.
+extern "C" int olmc_european_f64_normals(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t n_paths,
+                                         int32_t n_steps, uint64_t seed, olmc_stats* out) {
+    if (n_paths > static_cast<int64_t>(kMaxGrid) * kBlock) return fail(OLMC_ERR_ARG, "n_paths too large for one workgroup per 256 paths");
+    const olmc_option o = make_option(S, K, T, r, sigma, q, is_call);
+    ContractSet<1> cs;
+    cs.c[0] = make_contract(o, n_steps);
+    cs.base_mask = 1u; cs.upper_continues_slot0 = 0;
+    const int saved_cap = g_grid_cap;
+    g_grid_cap = kMaxGrid;                               // one workgroup per 256 paths whatever the step count (no short-path grid cap)
+    const int rc = run_structured(0, n_paths, n_steps, seed, 1, r, T, poisoned(S, K, T, r, sigma, q), out,
+                                  [&](int32_t grid, hipStream_t st, const EventPair* timed, const PathRange& pr, const ReduceWs& ws) {
+                                      launch_timed(european_f64_normals_kernel, dim3(grid), dim3(kBlock), st, timed, pr, cs, ws);
+                                  });
+    g_grid_cap = saved_cap;
+    return rc;
+}
+
+// Microseconds one more DEPENDENT launch costs on a stream: wall of a chain of `n` empty kernels, minus nothing, over n.
+extern "C" int olmc_launch_gap_probe(int32_t n, double* us_per_launch) {
+    if (!us_per_launch || n < 2 || n > 100000) return fail(OLMC_ERR_ARG, "bad arguments");
+    CtxLease lease;
+    int rc = ctx_lease(&lease);
+    if (rc) return rc;
+    DeviceCtx* const c = lease.c;
+    for (int rep = 0; rep < 2; ++rep) {                  // the first chain warms the code object
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int32_t k = 0; k < n; ++k) hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(kWave), 0, c->stream, reinterpret_cast<uint32_t*>(c->d_result));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        *us_per_launch = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / n;
+    }
+    return OLMC_OK;
+}
+
 // Test seams of the instrumented build (none of them exists in libolmc.so).
 extern "C" int olmc_probe_tune(int knob, int value) {
     if (knob == OLMC_PROBE_TUNE_FAULT_SHARD && value >= 0 && value <= kMaxDevices) { g_fault_shard = value; return OLMC_OK; }

@@ -259,4 +259,40 @@ __global__ void exp2_probe_kernel(const double* __restrict__ x, int64_t n, doubl
 }
 
 
+// ---------------------------------------------------------------- the price of the reference's own width (round 4) ----
+// The European step loop with fp64 NORMALS, as NumPy draws them (gbm_numpy.py:32-33: standard_normal of a PCG64 Generator, fp64):
+// the same Philox4x32-10 counter stream, but one block now yields TWO normals -- its four words make two 53-bit uniforms
+//   u_a = ((x0 << 21 ^ x1 >> 11) + 1/2) 2^-53  in (0, 1),   u_b = (x2 << 21 ^ x3 >> 11) 2^-53  (turn fraction),
+// and one fp64 Box-Muller: r = sqrt(-2 ln u_a) (library log), (sin, cos)(2 pi u_b) (library sincospi), the sum of a path's
+// normals carried in fp64 throughout.  Same launch shape, same fused reduction, same payoff code as european_path_kernel<1, true,
+// kReduce, false>.  NOT a product path: a labelled number beside the product's "f32 normals"  -- what the
+// reference's width would cost on this device, and that it moves the price by nothing measurable.
+__global__ __launch_bounds__(kBlock) void european_f64_normals_kernel(PathRange pr, ContractSet<1> cs, ReduceWs ws) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const uint64_t g = pr.first + static_cast<uint64_t>(i);
+    const uint32_t g_lo = static_cast<uint32_t>(g), g_hi = static_cast<uint32_t>(g >> 32);
+    double zsum = 0.0;
+    const int32_t pairs = (pr.n_steps + 1) >> 1;
+    for (int32_t b = 0; b < pairs; ++b) {
+        const Words4 w = philox4x32_10(g_lo, g_hi, static_cast<uint32_t>(b), 0u, pr.key0, pr.key1);
+        const uint64_t ma = (static_cast<uint64_t>(w.x0) << 21) ^ (static_cast<uint64_t>(w.x1) >> 11);
+        const uint64_t mb = (static_cast<uint64_t>(w.x2) << 21) ^ (static_cast<uint64_t>(w.x3) >> 11);
+        const double ua = (static_cast<double>(ma) + 0.5) * 0x1p-53, ub = static_cast<double>(mb) * 0x1p-53;
+        const double rad = sqrt(-2.0 * log(ua));
+        double sn, cs_;
+        sincospi(2.0 * ub, &sn, &cs_);
+        zsum += rad * cs_;
+        if (2 * b + 1 < pr.n_steps) zsum += rad * sn;
+    }
+    double acc[2] = {0.0, 0.0};
+    european_payoffs<1, true, kReduce>(cs, zsum, i < pr.count, i, pr.count, nullptr, acc);
+    block_then_grid_reduce<2>(acc, ws);
+}
+
+// A kernel that does nothing: a chain of them on one stream measures what two DEPENDENT launches cost each other (the command
+// processor's gap) -- the floor under every per-date launch of the American option.
+__global__ void empty_kernel(uint32_t* __restrict__ sink) {
+    if (sink == nullptr && threadIdx.x == 12345) __builtin_trap();
+}
+
 }  // namespace olmc

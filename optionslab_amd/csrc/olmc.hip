@@ -1747,6 +1747,24 @@ int qmc_check(const uint32_t* sv, const uint32_t* shift, int32_t bits, int32_t d
 }
 
 // gbm_qmc.py:38-44 as an olmc_option -> Contract: dt = T / dims, a = ln S + drift dims, vol = sigma sqrt(dt) = make_contract(o, dims)
+// Launch shape of a Sobol kernel.  From 2^20 points on (measured crossover between 2^19 and 2^20) a thread takes an aligned block of
+// eight consecutive points; up to 2^18 points (the interactive sizes: 2,048 waves of one-point threads at 2^17 points leave the vector
+// unit idle 30 % of the time) a workgroup takes 64 points and each of its four waves a quarter of the dimensions; between the two, one
+// point per thread.  OLMC_TUNE_QMC_BLOCK: 1 = always eight points per thread, -1 = never eight and never split (one point per thread).
+struct QmcShape {
+    bool blocks, split;
+    int64_t units;       // threads' worth of work: blocks of eight, or points
+    int32_t grid;
+};
+QmcShape qmc_shape(int64_t point_offset, int64_t n_paths, int32_t dims) {
+    QmcShape sh;
+    sh.blocks = g_qmc_block > 0 ? true : (g_qmc_block < 0 ? false : n_paths >= (int64_t(1) << 20));
+    sh.split = !sh.blocks && g_qmc_block == 0 && n_paths <= (int64_t(1) << 18) && dims >= 16;
+    sh.units = sh.blocks ? (point_offset + n_paths + kQmcBlock - 1) / kQmcBlock - point_offset / kQmcBlock : n_paths;
+    sh.grid = sh.split ? static_cast<int32_t>((n_paths + kWave - 1) / kWave) : grid_for(sh.units);
+    return sh;
+}
+
 int run_qmc(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t point_offset,
             int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
             olmc_stats* out, double* terminal_host, int mirror = 0, olmc_cv_moments* cv = nullptr) {
@@ -1784,11 +1802,9 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
     qr.count = n_paths;
     qr.dims = dims;
     qr.mirror = mirror ? 1 : 0;
-    // from 2^20 points on (measured crossover between 2^19 and 2^20) a thread takes an aligned block of eight
-    // consecutive points (european_qmc_block_kernel); smaller launches need the threads more than the saved instructions
-    const bool blocks = g_qmc_block > 0 ? true : (g_qmc_block < 0 ? false : n_paths >= (int64_t(1) << 20));
-    const int64_t units = blocks ? (point_offset + n_paths + kQmcBlock - 1) / kQmcBlock - point_offset / kQmcBlock : n_paths;
-    const int32_t grid = grid_for(units);
+    const QmcShape sh = qmc_shape(point_offset, n_paths, dims);
+    const bool blocks = sh.blocks;
+    const int32_t grid = sh.grid;
     ReduceWs ws{};
     EventPair ep{};
     const EventPair* timed = nullptr;
@@ -1799,17 +1815,20 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
         rc = prof_pair(c, &ep, &timed);
         if (rc) return rc;
         if (blocks) launch_timed(european_qmc_block_kernel<kControlVariate>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
-        else launch_timed(european_qmc_kernel<kControlVariate>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else if (sh.split) launch_timed(european_qmc_kernel<kControlVariate, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else launch_timed(european_qmc_kernel<kControlVariate, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
     } else if (!terminal_host) {
         rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
         if (rc) return rc;
         rc = prof_pair(c, &ep, &timed);
         if (rc) return rc;
         if (blocks) launch_timed(european_qmc_block_kernel<kReduce>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
-        else launch_timed(european_qmc_kernel<kReduce>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else if (sh.split) launch_timed(european_qmc_kernel<kReduce, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else launch_timed(european_qmc_kernel<kReduce, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
     } else {
         if (blocks) hipLaunchKernelGGL((european_qmc_block_kernel<kTerminal>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
-        else hipLaunchKernelGGL((european_qmc_kernel<kTerminal>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
+        else if (sh.split) hipLaunchKernelGGL((european_qmc_kernel<kTerminal, true>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
+        else hipLaunchKernelGGL((european_qmc_kernel<kTerminal, false>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
     }
     if (terminal_host) {            // no reduction workspace was handed out: only the launch status matters
         HIP_TRY(hipGetLastError());
@@ -1868,8 +1887,9 @@ int run_qmc_batch(const olmc_option* opts, int32_t k, int64_t point_offset, int6
     if (k < 1 || k > OLMC_MAX_BATCH) return fail(OLMC_ERR_ARG, "batch size must be in [1, OLMC_MAX_BATCH]");
     int rc = qmc_check(sv, shift, bits, dims, point_offset, n_paths);
     if (rc) return rc;
-    const bool blocks = g_qmc_block > 0 ? true : (g_qmc_block < 0 ? false : n_paths >= (int64_t(1) << 20));
-    const int64_t units = blocks ? (point_offset + n_paths + kQmcBlock - 1) / kQmcBlock - point_offset / kQmcBlock : n_paths;
+    const QmcShape sh = qmc_shape(point_offset, n_paths, dims);
+    const bool blocks = sh.blocks;
+    const int64_t units = sh.units;
     if (k == 1 || (units + kBlock - 1) / kBlock > kMaxGrid) {             // one contract, or more points than a grid covers: literal launches
         for (int i = 0; i < k; ++i) {
             rc = run_qmc(opts[i].S, opts[i].K, opts[i].T, opts[i].r, opts[i].sigma, opts[i].q, opts[i].is_call, point_offset, n_paths, dims, sv, shift,
@@ -1892,7 +1912,7 @@ int run_qmc_batch(const olmc_option* opts, int32_t k, int64_t point_offset, int6
     qr.count = n_paths;
     qr.dims = dims;
     qr.mirror = 0;
-    const int32_t grid = static_cast<int32_t>((units + kBlock - 1) / kBlock);
+    const int32_t grid = sh.split ? sh.grid : static_cast<int32_t>((units + kBlock - 1) / kBlock);     // the grid covers every point / block
     const int nsets = k <= 8 ? 8 : 16;
     ReduceWs ws;
     rc = make_ws(c, c->stream, grid, 2 * nsets, c->d_result, -1.0, &ws);
@@ -1906,13 +1926,15 @@ int run_qmc_batch(const olmc_option* opts, int32_t k, int64_t point_offset, int6
     if (nsets == 8) {
         ContractSet<8> cs;
         group_contracts<8>(opts, k, dims, &cs, pos);
-        if (blocks) launch_timed(european_qmc_batch_kernel<8, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
-        else launch_timed(european_qmc_batch_kernel<8, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+        if (blocks) launch_timed(european_qmc_batch_kernel<8, true, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+        else if (sh.split) launch_timed(european_qmc_batch_kernel<8, false, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+        else launch_timed(european_qmc_batch_kernel<8, false, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
     } else {
         ContractSet<16> cs;
         group_contracts<16>(opts, k, dims, &cs, pos);
-        if (blocks) launch_timed(european_qmc_batch_kernel<16, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
-        else launch_timed(european_qmc_batch_kernel<16, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+        if (blocks) launch_timed(european_qmc_batch_kernel<16, true, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+        else if (sh.split) launch_timed(european_qmc_batch_kernel<16, false, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+        else launch_timed(european_qmc_batch_kernel<16, false, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
     }
     rc = after_launch(c, c->stream);
     if (rc) return rc;

@@ -2110,36 +2110,76 @@ struct QmcRange {
     int32_t mirror;    // kTerminal only: also write terminal[count + i] = exp(a - vol sum z)  (simulate_gbm_qmc_antithetic, gbm_qmc.py:49-76)
 };
 
+// The sum of a point's inverse normals has ONE association in every Sobol kernel (round 4):  ((Q0 + Q1) + Q2) + Q3,  Q_w = the
+// dimensions [w D / 4, (w + 1) D / 4) added in order -- so that a point summed by one thread, by a thread that carries eight points,
+// and a point whose dimensions are SPLIT over the four waves of a workgroup (below) all give the same bits.
+__device__ __forceinline__ int32_t qmc_quarter_begin(int32_t dims, int w) {
+    return static_cast<int32_t>(static_cast<int64_t>(dims) * w / 4);
+}
+
+// Sum of the inverse normals of one Sobol point over the dimensions [t0, t1).
+__device__ __forceinline__ double qmc_point_sum(const uint32_t (&mask)[kSobolBits], int32_t t0, int32_t t1, const uint32_t* __restrict__ sv,
+                                                const uint32_t* __restrict__ shift) {
+    double q = 0.0;
+    for (int32_t t = t0; t < t1; ++t) {
+        const uint32_t* __restrict__ row = sv + static_cast<size_t>(t) * kSobolBits;
+        uint32_t x = shift[t];
+#pragma unroll
+        for (int b = 0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);   // x ^ (row & mask), one v_bitop3_b32
+        double u = static_cast<double>(x) * 9.313225746154785e-10;      // 2^-30
+        u = fmin(fmax(u, 1e-10), 1.0 - 1e-10);
+        q += ndtri_w(u, opaque_zero());
+    }
+    return q;
+}
+
 // Contract::a = ln S + drift * dims, Contract::vol = sigma sqrt(T / dims) (gbm_qmc.py:38-44).
-template <int MODE>
+//
+// SPLIT (round 4; launches of at most 2^18 points, the sizes an interactive caller uses): a workgroup owns 64 points and each of
+// its four waves walks a QUARTER of the dimensions -- the split workgroups of the pseudo-random kernel.  A 2^17-point launch is
+// 2,048 waves of one-point threads, two per SIMD, each a serial chain of ~45 dependent fp64 operations per dimension: the vector
+// unit idles 30 % of the time (`frac_valu_active_pmc` 0.70, profiles/r04_bench_detail.json).  Split, the same launch is 8,192 waves
+// of a quarter of the length.  The quarter sums meet in LDS, wave 0 adds them in the canonical order and prices the point.
+template <int MODE, bool SPLIT = false>
 __global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contract c, const uint32_t* __restrict__ sv,
                                                               const uint32_t* __restrict__ shift, ReduceWs ws,
                                                               double* __restrict__ terminal) {
     constexpr int NV = MODE == kControlVariate ? 5 : 2;
     double acc[NV] = {};
-    const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < qr.count; i += stride) {
-        const uint64_t k = qr.first + static_cast<uint64_t>(i);
-        const uint32_t gray = static_cast<uint32_t>(k ^ (k >> 1));
-        uint32_t mask[kSobolBits];
-#pragma unroll
-        for (int b = 0; b < kSobolBits; ++b) mask[b] = 0u - ((gray >> b) & 1u);
-        double zsum = 0.0;
-        for (int32_t t = 0; t < qr.dims; ++t) {
-            const uint32_t* __restrict__ row = sv + static_cast<size_t>(t) * kSobolBits;
-            uint32_t x = shift[t];
-#pragma unroll
-            for (int b = 0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);   // x ^ (row & mask), one v_bitop3_b32
-            double u = static_cast<double>(x) * 9.313225746154785e-10;      // 2^-30
-            u = fmin(fmax(u, 1e-10), 1.0 - 1e-10);
-            zsum += ndtri_w(u, opaque_zero());
-        }
+    auto price_point = [&](int64_t i, double zsum) {
         const double st = exp(c.a + c.vol * zsum);
         if constexpr (MODE == kTerminal) {
             terminal[i] = st;
             if (qr.mirror) terminal[qr.count + i] = exp(c.a - c.vol * zsum);
         } else {
             add_sample<MODE>(acc, fmax(c.sign * (st - c.strike), 0.0), st);
+        }
+    };
+    if constexpr (SPLIT) {
+        __shared__ double quarter_sum[kWavesPerBlock][kWave];
+        const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / kWave), lane = threadIdx.x & (kWave - 1);
+        const int64_t i = static_cast<int64_t>(blockIdx.x) * kWave + lane;             // the grid covers every point (host guarantee)
+        const uint64_t k = qr.first + static_cast<uint64_t>(i < qr.count ? i : 0);
+        const uint32_t gray = static_cast<uint32_t>(k ^ (k >> 1));
+        uint32_t mask[kSobolBits];
+#pragma unroll
+        for (int b = 0; b < kSobolBits; ++b) mask[b] = 0u - ((gray >> b) & 1u);
+        quarter_sum[wave][lane] = qmc_point_sum(mask, qmc_quarter_begin(qr.dims, wave), qmc_quarter_begin(qr.dims, wave + 1), sv, shift);
+        __syncthreads();
+        if (wave == 0 && i < qr.count)
+            price_point(i, ((quarter_sum[0][lane] + quarter_sum[1][lane]) + quarter_sum[2][lane]) + quarter_sum[3][lane]);
+    } else {
+        const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
+        for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < qr.count; i += stride) {
+            const uint64_t k = qr.first + static_cast<uint64_t>(i);
+            const uint32_t gray = static_cast<uint32_t>(k ^ (k >> 1));
+            uint32_t mask[kSobolBits];
+#pragma unroll
+            for (int b = 0; b < kSobolBits; ++b) mask[b] = 0u - ((gray >> b) & 1u);
+            double zsum = 0.0;
+#pragma unroll 1
+            for (int w = 0; w < 4; ++w) zsum += qmc_point_sum(mask, qmc_quarter_begin(qr.dims, w), qmc_quarter_begin(qr.dims, w + 1), sv, shift);
+            price_point(i, zsum);
         }
     }
     if constexpr (MODE != kTerminal) block_then_grid_reduce<NV>(acc, ws);
@@ -2151,6 +2191,44 @@ __global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contr
 // instead of 8 x 30, and eight independent inverse normals in flight per thread.  Same points, same uniforms, same z as
 // the one-point kernel; only the order in which a workgroup's payoffs are added differs (1e-16).
 constexpr int kQmcBlock = 8;
+
+// Sums of the inverse normals of the eight points of an aligned block over all dimensions, in the canonical association (quarters,
+// see qmc_quarter_begin), left in LDS: zs[p][threadIdx.x].  mask[b], b >= B0 = 2, are the Gray-code masks of the block's first point
+// (its bits 0 and 1 are clear).  The running totals live in LDS between the quarters (each thread touches only its own column: no
+// barrier), so the dimension loop carries the eight quarter sums in registers and nothing else -- the epilogues walk the eight
+// points by a run-time index anyway, which registers do not offer.
+template <int B0>
+__device__ __forceinline__ void qmc_block_sums(const uint32_t (&mask)[kSobolBits], int32_t dims, const uint32_t* __restrict__ sv,
+                                               const uint32_t* __restrict__ shift, double (*zs)[kBlock]) {
+#pragma unroll
+    for (int p = 0; p < kQmcBlock; ++p) zs[p][threadIdx.x] = 0.0;          // 0 + Q0 = Q0 exactly
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        double q[kQmcBlock];
+#pragma unroll
+        for (int p = 0; p < kQmcBlock; ++p) q[p] = 0.0;
+        const int32_t t1 = qmc_quarter_begin(dims, w + 1);
+        for (int32_t t = qmc_quarter_begin(dims, w); t < t1; ++t) {
+            const uint32_t* __restrict__ row = sv + static_cast<size_t>(t) * kSobolBits;
+            uint32_t x = shift[t];
+            const int z0 = opaque_zero();
+#pragma unroll
+            for (int b = B0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);
+            double u[kQmcBlock], z[kQmcBlock];
+#pragma unroll
+            for (int p = 0; p < kQmcBlock; ++p) {
+                if (p) x ^= row[__builtin_ctz(static_cast<unsigned>(p))];          // gray(k + 1) = gray(k) ^ (1 << ctz(k + 1))
+                u[p] = static_cast<double>(x) * 9.313225746154785e-10;          // 2^-30
+                u[p] = fmin(fmax(u[p], 1e-10), 1.0 - 1e-10);
+            }
+            ndtri_lockstep<kQmcBlock>(u, z, z0);
+#pragma unroll
+            for (int p = 0; p < kQmcBlock; ++p) q[p] += z[p];
+        }
+#pragma unroll
+        for (int p = 0; p < kQmcBlock; ++p) zs[p][threadIdx.x] += q[p];
+    }
+}
 
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void european_qmc_block_kernel(QmcRange qr, Contract c, const uint32_t* __restrict__ sv,
@@ -2168,31 +2246,10 @@ __global__ __launch_bounds__(kBlock) void european_qmc_block_kernel(QmcRange qr,
         uint32_t mask[kSobolBits];
 #pragma unroll
         for (int b = 2; b < kSobolBits; ++b) mask[b] = 0u - ((gray >> b) & 1u);
-        double zsum[kQmcBlock];
-#pragma unroll
-        for (int p = 0; p < kQmcBlock; ++p) zsum[p] = 0.0;
-        for (int32_t t = 0; t < qr.dims; ++t) {
-            const uint32_t* __restrict__ row = sv + static_cast<size_t>(t) * kSobolBits;
-            uint32_t x = shift[t];
-            const int z0 = opaque_zero();
-#pragma unroll
-            for (int b = 2; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);
-            double u[kQmcBlock], z[kQmcBlock];
-#pragma unroll
-            for (int p = 0; p < kQmcBlock; ++p) {
-                if (p) x ^= row[__builtin_ctz(static_cast<unsigned>(p))];          // gray(k + 1) = gray(k) ^ (1 << ctz(k + 1))
-                u[p] = static_cast<double>(x) * 9.313225746154785e-10;          // 2^-30
-                u[p] = fmin(fmax(u[p], 1e-10), 1.0 - 1e-10);
-            }
-            ndtri_lockstep<kQmcBlock>(u, z, z0);
-#pragma unroll
-            for (int p = 0; p < kQmcBlock; ++p) zsum[p] += z[p];
-        }
-        // the eight exponentials one after the other (a real loop over LDS-staged sums, as in european_qmc_batch_kernel): unrolled,
+        // the eight exponentials one after the other (a real loop over the LDS-staged sums, as in european_qmc_batch_kernel): unrolled,
         // their interleaving set the kernel's register count
         __shared__ double zs[kQmcBlock][kBlock];
-#pragma unroll
-        for (int p = 0; p < kQmcBlock; ++p) zs[p][threadIdx.x] = zsum[p];
+        qmc_block_sums<2>(mask, qr.dims, sv, shift, zs);
 #pragma unroll 1
         for (int p = 0; p < kQmcBlock; ++p) {
             const uint64_t k = k0 + static_cast<uint64_t>(p);
@@ -2219,69 +2276,73 @@ __global__ __launch_bounds__(kBlock) void european_qmc_block_kernel(QmcRange qr,
 // does for it alone; a contract that shares its vol with a base takes scale * S_T(base) (2-3 ulp from its own exp).
 // BLOCK8 = the eight-points-per-thread expansion of european_qmc_block_kernel.  The grid covers every point / block (host
 // guarantee), so the 2 NSETS sums are born after the dimension loop.
-template <int NSETS, bool BLOCK8>
+template <int NSETS, bool BLOCK8, bool SPLIT = false>
 __global__ __launch_bounds__(kBlock) void european_qmc_batch_kernel(QmcRange qr, ContractSet<NSETS> cs, const uint32_t* __restrict__ sv,
                                                                     const uint32_t* __restrict__ shift, ReduceWs ws) {
+    static_assert(!(BLOCK8 && SPLIT), "a thread either carries eight points or a quarter of one point's dimensions");
     constexpr int NV = 2 * NSETS;
-    constexpr int NP = BLOCK8 ? kQmcBlock : 1;
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
-    const uint64_t base = BLOCK8 ? qr.first / kQmcBlock : qr.first;
-    const uint64_t last = qr.first + static_cast<uint64_t>(qr.count);
-    const int64_t n_units = BLOCK8 ? static_cast<int64_t>((last + kQmcBlock - 1) / kQmcBlock - base) : qr.count;
-    const bool unit_live = i < n_units;
-    const uint64_t k0 = BLOCK8 ? (base + static_cast<uint64_t>(unit_live ? i : 0)) * kQmcBlock : qr.first + static_cast<uint64_t>(unit_live ? i : 0);
-    const uint32_t gray = static_cast<uint32_t>(k0 ^ (k0 >> 1));
-    constexpr int B0 = BLOCK8 ? 2 : 0;                   // an aligned block of eight starts with gray bits 0 and 1 clear
-    uint32_t mask[kSobolBits];
-#pragma unroll
-    for (int b = B0; b < kSobolBits; ++b) mask[b] = 0u - ((gray >> b) & 1u);
-    double zsum[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) zsum[p] = 0.0;
-    for (int32_t t = 0; t < qr.dims; ++t) {
-        const uint32_t* __restrict__ row = sv + static_cast<size_t>(t) * kSobolBits;
-        uint32_t x = shift[t];
-        [[maybe_unused]] const int z0 = BLOCK8 ? opaque_zero() : 0;
-#pragma unroll
-        for (int b = B0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);
-        double u[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            if (p) x ^= row[__builtin_ctz(static_cast<unsigned>(p))];
-            u[p] = static_cast<double>(x) * 9.313225746154785e-10;          // 2^-30
-            u[p] = fmin(fmax(u[p], 1e-10), 1.0 - 1e-10);
-        }
-        if constexpr (BLOCK8) {
-            double z[NP];
-            ndtri_lockstep<NP>(u, z, z0);
-#pragma unroll
-            for (int p = 0; p < NP; ++p) zsum[p] += z[p];
-        } else {
-            zsum[0] += ndtri_w(u[0], opaque_zero());
-        }
-    }
     double acc[NV];
+    if constexpr (SPLIT) {
+        // 64 points per workgroup, a quarter of the dimensions per wave (european_qmc_kernel<., true>): launches of <= 2^18 points
+        __shared__ double quarter_sum[kWavesPerBlock][kWave];
+        const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / kWave), lane = threadIdx.x & (kWave - 1);
+        const int64_t i = static_cast<int64_t>(blockIdx.x) * kWave + lane;
+        const uint64_t k = qr.first + static_cast<uint64_t>(i < qr.count ? i : 0);
+        const uint32_t gray = static_cast<uint32_t>(k ^ (k >> 1));
+        uint32_t mask[kSobolBits];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) acc[k] = 0.0;
-    if constexpr (BLOCK8) {
+        for (int b = 0; b < kSobolBits; ++b) mask[b] = 0u - ((gray >> b) & 1u);
+        quarter_sum[wave][lane] = qmc_point_sum(mask, qmc_quarter_begin(qr.dims, wave), qmc_quarter_begin(qr.dims, wave + 1), sv, shift);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NV; ++j) acc[j] = 0.0;
+        if (wave == 0) {
+            const double zsum = ((quarter_sum[0][lane] + quarter_sum[1][lane]) + quarter_sum[2][lane]) + quarter_sum[3][lane];
+            european_payoffs<NSETS, false, kReduce>(cs, zsum, i < qr.count, 0, 0, nullptr, acc);
+        }
+    } else if constexpr (BLOCK8) {
+        const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+        const uint64_t base = qr.first / kQmcBlock;
+        const uint64_t last = qr.first + static_cast<uint64_t>(qr.count);
+        const int64_t n_units = static_cast<int64_t>((last + kQmcBlock - 1) / kQmcBlock - base);
+        const bool unit_live = i < n_units;
+        const uint64_t k0 = (base + static_cast<uint64_t>(unit_live ? i : 0)) * kQmcBlock;
+        const uint32_t gray = static_cast<uint32_t>(k0 ^ (k0 >> 1));       // an aligned block of eight starts with gray bits 0 and 1 clear
+        uint32_t mask[kSobolBits];
+#pragma unroll
+        for (int b = 2; b < kSobolBits; ++b) mask[b] = 0u - ((gray >> b) & 1u);
+        __shared__ double zs[kQmcBlock][kBlock];
+        qmc_block_sums<2>(mask, qr.dims, sv, shift, zs);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) acc[j] = 0.0;
         // The eight points of the thread are priced ONE AFTER THE OTHER by a real loop (round 4).  Unrolled, the compiler interleaved
         // eight times NSETS payoffs with up to five library exponentials each: 12,600 instructions and 270 VGPRs for 14 contracts
         // (one wave per SIMD in a kernel whose dimension loop needs 127).  A loop needs the normal sums addressable by a run-time
         // index, which registers are not, so they pass through LDS: 16 KB per workgroup, each thread reads back only what it wrote
         // itself (no barrier).  The payoffs of a thread's points are still added in ascending order: same bits.
-        __shared__ double zs[kQmcBlock][kBlock];
         uint32_t live_points = 0u;                                          // bit p: point k0 + p lies in the range (its ragged ends)
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
+        for (int p = 0; p < kQmcBlock; ++p) {
             const uint64_t k = k0 + static_cast<uint64_t>(p);
             live_points |= (unit_live && k >= qr.first && k < last) ? (1u << p) : 0u;
-            zs[p][threadIdx.x] = zsum[p];
         }
 #pragma unroll 1
-        for (int p = 0; p < NP; ++p)
+        for (int p = 0; p < kQmcBlock; ++p)
             european_payoffs<NSETS, false, kReduce>(cs, zs[p][threadIdx.x], ((live_points >> p) & 1u) != 0u, 0, 0, nullptr, acc);
     } else {
-        european_payoffs<NSETS, false, kReduce>(cs, zsum[0], unit_live, 0, 0, nullptr, acc);
+        const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+        const bool live = i < qr.count;
+        const uint64_t k = qr.first + static_cast<uint64_t>(live ? i : 0);
+        const uint32_t gray = static_cast<uint32_t>(k ^ (k >> 1));
+        uint32_t mask[kSobolBits];
+#pragma unroll
+        for (int b = 0; b < kSobolBits; ++b) mask[b] = 0u - ((gray >> b) & 1u);
+        double zsum = 0.0;
+#pragma unroll 1
+        for (int w = 0; w < 4; ++w) zsum += qmc_point_sum(mask, qmc_quarter_begin(qr.dims, w), qmc_quarter_begin(qr.dims, w + 1), sv, shift);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) acc[j] = 0.0;
+        european_payoffs<NSETS, false, kReduce>(cs, zsum, live, 0, 0, nullptr, acc);
     }
     block_then_grid_reduce<NV>(acc, ws);
 }

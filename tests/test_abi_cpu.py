@@ -121,7 +121,7 @@ def test_compute_fails_loudly_without_a_gpu():
     assert ol.hip_available() is False and ol.HIP_AVAILABLE is False
 
 
-def _build_c_example(tmp_path):
+def _build_c_example(tmp_path, name="price_from_c", extra=()):
     import shutil
     import subprocess
 
@@ -130,10 +130,10 @@ def _build_c_example(tmp_path):
     if cc is None:
         pytest.skip("no C compiler")
     _hip.load_library()                                   # builds libolmc.so if it is stale
-    exe = str(tmp_path / "price_from_c")
+    exe = str(tmp_path / name)
     pkg = os.path.join(root, "optionslab_amd")
-    subprocess.run([cc, "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
-                    os.path.join(root, "examples", "price_from_c.c"), "-o", exe, "-L" + pkg, "-lolmc", "-Wl,-rpath," + pkg], check=True)
+    subprocess.run([cc, "-std=c99", "-O2", "-Wall", "-Wextra", "-Werror", *extra, "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", name + ".c"), "-o", exe, "-L" + pkg, "-lolmc", "-Wl,-rpath," + pkg], check=True)
     return exe
 
 
@@ -156,3 +156,19 @@ def test_c_host_example_prices_on_the_gpu(tmp_path):
     assert out.returncode == 0, out.stderr
     price = float(re.search(r"european call\s+price ([0-9.]+)", out.stdout).group(1))
     assert abs(price - 10.450583572185565) < 0.2 and "two shards" in out.stdout and "asian call" in out.stdout
+
+
+def test_the_threaded_c_host_compiles_against_the_header(tmp_path):
+    _build_c_example(tmp_path, "threads_from_c", extra=("-pthread",))
+
+
+@pytest.mark.gpu
+def test_c_host_threads_price_concurrently_with_identical_bits(tmp_path):
+    import json
+    import subprocess
+
+    out = subprocess.run([_build_c_example(tmp_path, "threads_from_c", extra=("-pthread",)), "10000", "50", "0.3"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr + out.stdout
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert [r["threads"] for r in rows] == [1, 2, 4, 8, 16] and all(r["bit_identical_results"] for r in rows)
+    assert max(r["calls_per_s"] for r in rows[1:]) > rows[0]["calls_per_s"]          # concurrent callers are not serialised

@@ -106,7 +106,8 @@ PMC_KERNELS = {         # substring of the demangled kernel name -> key in the J
     "extrema_kernel<false>": "f_extrema",
     "heston_kernel<false>": "f_heston",
     "european_multi_kernel<true>": "f_multi",
-    "european_qmc_kernel<0>": "f_qmc",
+    "european_qmc_kernel<0, true>": "f_qmc",               # the split form: what 2^17 points launch
+    "european_qmc_kernel<0, false>": "f_qmc_one_point",
     "european_qmc_block_kernel<0>": "f_qmc_block",
 }
 # the 8(f) workloads: (key, what, unit-steps per launch for the issue model = (paths or threads, steps or dims))
@@ -138,7 +139,10 @@ def f_workloads(ol, _hip):
                     f"MonteCarloPricerUni.price_batch, {F_MULTI_CONTRACTS} contracts x {F_MULTI_PATHS:,} paths x {F_MULTI_STEPS} steps, one launch "
                     "(monte_carlo_unified.py:562-631)", F_MULTI_CONTRACTS * F_MULTI_PATHS, F_MULTI_STEPS),
         "f_qmc": (lambda: _hip.european_qmc(*P, True, F_QMC_POINTS, sv1, sh1),
-                  f"MCMethod.QMC price, 2^17 Sobol points x {F_QMC_DIMS} dims, one point per thread (gbm_qmc.py:14-46)", F_QMC_POINTS, F_QMC_DIMS),
+                  f"MCMethod.QMC price, 2^17 Sobol points x {F_QMC_DIMS} dims, 64 points per workgroup, a quarter of the dims per wave "
+                  "(gbm_qmc.py:14-46)", F_QMC_POINTS, F_QMC_DIMS),
+        "f_qmc_one_point": (lambda: _hip.european_qmc(*P, True, 1 << 19, sv8, sh8),
+                            f"MCMethod.QMC price, 2^19 Sobol points x {F_QMC_BLOCK_DIMS} dims, one point per thread", 1 << 19, F_QMC_BLOCK_DIMS),
         "f_qmc_block": (lambda: _hip.european_qmc(*P, True, F_QMC_BLOCK_POINTS, sv8, sh8),
                         f"MCMethod.QMC price, 2^22 Sobol points x {F_QMC_BLOCK_DIMS} dims, eight points per thread (gbm_qmc.py:14-46)",
                         F_QMC_BLOCK_POINTS // 8, F_QMC_BLOCK_DIMS),

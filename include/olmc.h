@@ -144,7 +144,13 @@ int olmc_european_shard_dev(double S, double K, double T, double r, double sigma
  * numbers) in one pass: one RNG stream, k payoffs per path, 2k sums.  This is
  * the fused form of the 8 / 14 price() calls compute_greeks_unified makes
  * (src/greeks/unified_greeks.py:280-358).  All contracts share n_steps, so
- * they share sum_t Z exactly as the reference's re-seeded calls do. */
+ * they share sum_t Z exactly as the reference's re-seeded calls do.
+ * Rounding: a contract's payoff is formed in one of two ways, by launch shape.  Launches whose grid covers every path (up to
+ * 2^26 paths) use max(fma(sign * scale, S_T(base), -sign * K), 0) -- ONE rounding of sign * (scale * S_T - K); grid-striding
+ * launches beyond that and the Sobol batch kernels use sign * (scale * S_T(base) - K) with scale * S_T rounded first -- two.  For
+ * a contract that is its own base (scale = 1: every contract of k = 1, the first of each group of equal vol) the two are the
+ * same bits; for a scaled contract (the S- and r-bumps of a Greeks set) they differ by at most one ulp of S_T per sample, i.e.
+ * ~1e-16 relative on a price -- below the 1e-13 the tests allow between the fused and the literal forms. */
 int olmc_european_batch(const olmc_option* opts, int32_t k,
                         int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
                         int antithetic, olmc_stats* out /* [k] */);

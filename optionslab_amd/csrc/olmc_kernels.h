@@ -760,6 +760,12 @@ __device__ __forceinline__ void add_sample(double (&acc)[MODE == kControlVariate
 // over the chip in units four times finer -- and a launch smaller than one round of the chip (the interactive sizes)
 // finishes its step loops in a quarter of the time.  Wave 0 of a split workgroup evaluates the payoffs of its 64 paths.
 // Payoffs of one path (both legs) for every contract of the set, given its normal sum.
+// The dead-lane trick below (a NaN normal sum makes every payoff of the lane an exact zero through fmax(NaN, 0) = 0, IEEE maxnum)
+// holds only while the compiler may not assume finite arithmetic: under -ffinite-math-only / -ffast-math the ragged-end lanes
+// would add garbage to every price without a diagnostic.
+#if defined(__FINITE_MATH_ONLY__) && __FINITE_MATH_ONLY__
+#error "olmc_kernels.h relies on NaN propagation through fmax (dead lanes carry a NaN normal sum): do not build with -ffinite-math-only / -ffast-math"
+#endif
 template <int NSETS, bool ANTI, int MODE>
 __device__ __forceinline__ void european_payoffs(const ContractSet<NSETS>& cs, double zsum, bool live, int64_t i, int64_t count,
                                                  double* __restrict__ terminal, double (&acc)[(MODE == kControlVariate) ? 5 : 2 * NSETS]) {

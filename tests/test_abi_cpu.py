@@ -172,3 +172,17 @@ def test_c_host_threads_price_concurrently_with_identical_bits(tmp_path):
     rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
     assert [r["threads"] for r in rows] == [1, 2, 4, 8, 16] and all(r["bit_identical_results"] for r in rows)
     assert max(r["calls_per_s"] for r in rows[1:]) > rows[0]["calls_per_s"]          # concurrent callers are not serialised
+
+
+def test_the_kernels_refuse_a_finite_math_build():
+    """dead lanes are zeroed by fmax(NaN, 0) = 0; -ffinite-math-only / -ffast-math would silently break that."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-ffast-math", "--cuda-device-only", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "optionslab_amd", "csrc"), os.path.join(ROOT, "optionslab_amd", "csrc", "olmc.hip")],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "do not build with -ffinite-math-only" in r.stderr

@@ -63,7 +63,7 @@ def main(root):
     if line:
         r = line["roofline"]
         print("\n## python3 bench.py --steps 20 --warmup 5 (unprofiled; its live PMC passes are the tables below)")
-        print(f"value {line['value']:.4g} {line['unit']}  ms_per_step {line['ms_per_step']:.4f}  avg_kernel_ms {r['avg_kernel_ms']:.4f}  frac {r['frac']:.4f}  "
+        print(f"value {line['value']:.4g} {line['unit']}  ms_per_step {line['ms_per_step']:.4f}  avg_kernel_ms {r['avg_kernel_ms']:.4f}  frac {r['frac'] if r.get('frac') is None else format(r['frac'], '.4f')}  "
               f"frac_vs_isolated_rates {r.get('frac_vs_isolated_rates')}  frac_valu_active_pmc {r.get('frac_valu_active_pmc')}  traffic {r.get('traffic')} B/launch")
     for p in ("sq", "fetch", "write"):
         files = newest(os.path.join(root, "pmc", p, "**", "*_counter_collection.csv"))

@@ -2075,8 +2075,10 @@ int multi_prepare(const std::vector<int>& devs, bool rehearsal) {
         rk.device = devs[d];
         HIP_TRY(hipSetDevice(devs[d]));
         HIP_TRY(hipStreamCreateWithFlags(&rk.stream, hipStreamNonBlocking));
-        HIP_TRY(hipMalloc(&rk.d_send, sizeof(double) * 2 * kMultiValues));
-        rk.d_recv = rk.d_send + kMultiValues;
+        constexpr int kStride = 64;                  // doubles: the receive buffer starts on its own 512-byte boundary (the collective's vector accesses)
+        static_assert(kStride >= kMultiValues, "rank buffers hold the widest payload");
+        HIP_TRY(hipMalloc(&rk.d_send, sizeof(double) * 2 * kStride));
+        rk.d_recv = rk.d_send + kStride;
         HIP_TRY(hipEventCreateWithFlags(&rk.queued, hipEventDisableTiming));
     }
     if (!rehearsal) {

@@ -265,6 +265,24 @@ __device__ __forceinline__ void signal_done(const ReduceWs& ws) {
     if (threadIdx.x == 0) __hip_atomic_store(ws.done_flag, ws.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// What the workgroup that took the last ticket does before it loads the rows the others stored.  Every row is stored write-through
+// (`sc1`) and drained (`s_waitcnt vmcnt(0)`) by its writer before that writer's ticket; the counter is an agent-scope atomic; and EVERY
+// load of a row in the consumer is an `sc1` load to registers (load_sc1: `global_load_dwordx2 ... sc1`, L2-served, bypassing this CU's
+// L1).  That is the hand-off for which cdna_hip_programming.md Guideline 16 says the agent-scope acquire -- `s_waitcnt vmcnt(0);
+// buffer_inv sc1`, an L1 invalidate nobody reads through, ~1 us at the head of the last workgroup's work -- is replaced by a
+// wavefront-scope fence: no instruction, it only keeps the compiler from moving the loads above the ticket.  Rounds 1-3 paid the
+// invalidate at every level of every launch (two levels from 65,537 paths on).  -DOLMC_AGENT_ACQUIRE=1 restores it (A/B).
+#ifndef OLMC_AGENT_ACQUIRE
+#define OLMC_AGENT_ACQUIRE 0
+#endif
+__device__ __forceinline__ void acquire_rows() {
+#if OLMC_AGENT_ACQUIRE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 __device__ __forceinline__ void store_sc1(double* p, double v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -329,7 +347,7 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws, Epilog
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     if (ticket != static_cast<uint32_t>(group_size - 1)) return;
 
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    acquire_rows();
     const double g = wave_rows_sum<NV>(ws.block_rows + static_cast<size_t>(group) * kGroupBlocks * NV, group_size);
     if (n_groups == 1) {            // <= 65,536 paths (the interactive sizes): the only group IS the total, skip level 2
         if (lane < NV) ws.out[lane] = g;
@@ -350,7 +368,7 @@ __device__ __forceinline__ void grid_reduce(double v, const ReduceWs& ws, Epilog
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     if (ticket != static_cast<uint32_t>(n_groups - 1)) return;
 
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    acquire_rows();
     const double total = wave_rows_sum<NV>(ws.group_rows, n_groups);
     if (lane < NV) ws.out[lane] = total;
     if (lane == 0) {
@@ -426,7 +444,7 @@ __device__ __forceinline__ void grid_reduce_workgroup(double v, const ReduceWs& 
     __syncthreads();
     if (!last) return;                           // workgroup-uniform
 
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    acquire_rows();
     const double g = workgroup_rows_sum<NV>(ws.block_rows + static_cast<size_t>(group) * kGroupBlocks * NV, group_size, part);
     if (n_groups == 1) {                         // the only group IS the total
         if (wave0) {
@@ -452,7 +470,7 @@ __device__ __forceinline__ void grid_reduce_workgroup(double v, const ReduceWs& 
     __syncthreads();
     if (!last) return;
 
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    acquire_rows();
     const double total = workgroup_rows_sum<NV>(ws.group_rows, n_groups, part);
     if (wave0) {
         if (t < NV) ws.out[t] = total;
@@ -969,7 +987,7 @@ __global__ __launch_bounds__(kBlock) void european_multi_kernel(PathRange pr, co
     if (lane == 0) ticket = __hip_atomic_fetch_add(counters + static_cast<size_t>(opt) * kMultiCounterStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ticket = __builtin_amdgcn_readfirstlane(ticket);
     if (ticket != gridDim.x - 1) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    acquire_rows();
     const double total = wave_rows_sum<2>(rows, static_cast<int32_t>(gridDim.x));
     if (lane < 2) out[opt * 2 + lane] = total;
     if (lane == 0) __hip_atomic_store(counters + static_cast<size_t>(opt) * kMultiCounterStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -913,6 +913,45 @@ def test_qmc_eight_point_blocks_give_the_same_points():
         _hip.tune(_hip.TUNE_QMC_BLOCK, 0)
 
 
+def test_qmc_split_workgroups_return_the_bits_of_one_point_threads():
+    """Round 4: launches of <= 2^18 Sobol points with >= 16 dimensions give 64 points to a workgroup and a quarter of the dimensions
+    to each of its four waves (european_qmc_kernel<., true>, european_qmc_batch_kernel<., false, true>).  Every Sobol kernel adds a
+    point's inverse normals in the same association (quarters), so the split form must return the one-point form's terminal prices bit
+    for bit -- ragged point counts around the 64-point workgroup, dimension counts that do not divide by four, point offsets -- and the
+    same sums to reduction-order rounding, for the price, the control variate and the fused Greeks."""
+    S, K, T, r, v = ATM
+    try:
+        for N, M, off in ((1, 16, 0), (63, 17, 0), (64, 18, 5), (65, 19, 64), (1000, 33, 3), (4097, 252, 12345), (70_001, 63, 1), (1 << 18, 16, 0)):
+            tables = ol.monte_carlo.sobol_tables(M, 11)
+            _hip.tune(_hip.TUNE_QMC_BLOCK, -1)                       # one point per thread, never split
+            one = _hip.european_qmc_terminal(S, T, r, v, 0.01, N, *tables, point_offset=off)
+            mir = _hip.european_qmc_terminal(S, T, r, v, 0.01, N, *tables, point_offset=off, antithetic=True)
+            p1 = _hip.european_qmc(S, K, T, r, v, 0.01, True, N, *tables, point_offset=off)
+            c1 = _hip.european_qmc_cv(S, K, T, r, v, 0.01, False, N, *tables, point_offset=off)
+            g1, e1 = _hip.european_qmc_greeks_fd(S, K, T, r, v, 0.01, True, N, *tables, True) if off == 0 else (None, None)
+            _hip.tune(_hip.TUNE_QMC_BLOCK, 0)                        # the default shape: split at these sizes
+            assert np.array_equal(_hip.european_qmc_terminal(S, T, r, v, 0.01, N, *tables, point_offset=off), one), (N, M, off)
+            assert np.array_equal(_hip.european_qmc_terminal(S, T, r, v, 0.01, N, *tables, point_offset=off, antithetic=True), mir), (N, M, off)
+            p2 = _hip.european_qmc(S, K, T, r, v, 0.01, True, N, *tables, point_offset=off)
+            assert p2.n == p1.n == N and p2.sum == pytest.approx(p1.sum, rel=1e-13) and p2.sumsq == pytest.approx(p1.sumsq, rel=1e-13)
+            c2 = _hip.european_qmc_cv(S, K, T, r, v, 0.01, False, N, *tables, point_offset=off)
+            for f in ("sum_d", "sum_s", "sum_dd", "sum_ss", "sum_ds"):
+                assert getattr(c2, f) == pytest.approx(getattr(c1, f), rel=1e-13), (N, M, f)
+            if off == 0:
+                g2, e2 = _hip.european_qmc_greeks_fd(S, K, T, r, v, 0.01, True, N, *tables, True)
+                for a, b in zip(e1, e2):
+                    assert b.sum == pytest.approx(a.sum, rel=1e-13, abs=1e-300) and b.n == a.n
+        # below 16 dimensions nothing is split: the same launches, the same bits in every output
+        tables = ol.monte_carlo.sobol_tables(15, 3)
+        _hip.tune(_hip.TUNE_QMC_BLOCK, -1)
+        a = _hip.european_qmc(S, K, T, r, v, 0.0, True, 5000, *tables)
+        _hip.tune(_hip.TUNE_QMC_BLOCK, 0)
+        b = _hip.european_qmc(S, K, T, r, v, 0.0, True, 5000, *tables)
+        assert (a.sum, a.sumsq) == (b.sum, b.sumsq)
+    finally:
+        _hip.tune(_hip.TUNE_QMC_BLOCK, 0)
+
+
 def test_fetch_dev_hands_over_what_earlier_work_on_the_stream_left():
     """olmc_fetch_dev: the blocking hand-over of a shard's (all-reduced) triple from a device buffer -- queued behind the
     caller's work on the caller's stream, polled like a blocking pricing.  Checked with a torch stream and buffer as in

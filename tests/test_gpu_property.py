@@ -146,3 +146,47 @@ def test_european_batch_prices_every_contract_as_its_own_launch_does(cs, N, M, s
         assert g.n == one.n
         assert g.sum == pytest.approx(one.sum, rel=1e-11, abs=1e-9) and g.sumsq == pytest.approx(one.sumsq, rel=1e-11, abs=1e-7)
         assert g.price == pytest.approx(one.price, rel=1e-11, abs=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------- round 4
+@settings(max_examples=25 * SCALE, **COMMON)
+@given(N=st.integers(16, 200_000), M=steps, seed=seeds, ranks=st.integers(1, 12), S=spot, K=strike, v=vol, r=rate, q=div, T=mat, call=st.booleans(),
+       anti=st.booleans())
+def test_multi_rank_engine_equals_the_rank_ordered_sum_of_its_shards(N, M, seed, ranks, S, K, v, r, q, T, call, anti):
+    """olmc_multi_gpu_european with 1..12 ranks REHEARSED on this one device (instrumented build): the triple is bit for bit what
+    olmc_combine_stats makes of the shards [d N / P, (d + 1) N / P) priced one by one, for any path count, rank count and contract."""
+    from tools.probe import binding as probe
+    hip = probe.hip
+    ranks = min(ranks, N)
+    probe.tune(probe.TUNE_MULTI_REHEARSAL, 1)
+    try:
+        got = hip.multi_gpu_european(S, K, T, r, v, q, call, N, M, seed, anti, ranks)
+    finally:
+        probe.tune(probe.TUNE_MULTI_REHEARSAL, 0)
+    parts = []
+    for d in range(ranks):
+        lo, hi = N * d // ranks, N * (d + 1) // ranks
+        st_ = hip.european(S, K, T, r, v, q, call, hi - lo, M, seed, anti, path_offset=lo)
+        parts.append((st_.sum, st_.sumsq, st_.n))
+    want = hip.combine_stats(parts, r, T)
+    assert (got.sum, got.sumsq, got.n, got.price, got.std_error) == (want.sum, want.sumsq, want.n, want.price, want.std_error)
+    assert hip.device_info()["device"] == 0
+
+
+@settings(max_examples=25 * SCALE, **COMMON)
+@given(N=st.one_of(st.integers(1, 300), st.sampled_from([63, 64, 65, 4095, 4097]), st.integers(301, 20_000)), M=st.integers(1, 80), seed=st.integers(0, 2**31 - 1),
+       off=st.one_of(st.just(0), st.integers(0, 100_000)), S=spot, v=vol, r=rate, q=div, T=mat)
+def test_sobol_launch_shapes_return_the_same_terminal_prices(N, M, seed, off, S, v, r, q, T):
+    """One point per thread, eight points per thread and split workgroups (a quarter of the dimensions per wave): the same Sobol points,
+    the same canonical association of a point's normal sum -- terminal prices bit for bit, for any point count, dimension count and offset."""
+    import numpy as np
+    from optionslab_amd.monte_carlo import sobol_tables
+    tables = sobol_tables(M, seed)
+    try:
+        out = []
+        for knob in (-1, 0, 1):
+            _hip.tune(_hip.TUNE_QMC_BLOCK, knob)
+            out.append(_hip.european_qmc_terminal(S, T, r, v, q, N, *tables, point_offset=off))
+    finally:
+        _hip.tune(_hip.TUNE_QMC_BLOCK, 0)
+    assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])

@@ -1,11 +1,11 @@
 #!/bin/bash
 # usage: meta.sh [pattern]  -> compile device asm and list kernel resource usage
-cd /tmp/olmc
+mkdir -p ${TMPDIR:-/tmp}/olmc_meta && cd ${TMPDIR:-/tmp}/olmc_meta
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I/root/repo/include -I/root/repo/optionslab_amd/csrc -S --cuda-device-only -o olmc.s /root/repo/optionslab_amd/csrc/olmc.hip 2>&1 | grep -v warning | head -20
 python3 - "$1" <<'PY'
 import re,sys,subprocess
 pat=sys.argv[1] if len(sys.argv)>1 else ''
-txt=open('/tmp/olmc/olmc.s').read()
+txt=open('${TMPDIR:-/tmp}/olmc_meta/olmc.s').read()
 # metadata yaml at end
 for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)(?=\n  - \.|\Z)", txt, re.S):
     pass

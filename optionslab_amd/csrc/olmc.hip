@@ -1504,13 +1504,13 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
     const int32_t path_grid = grid_for(n_paths);
     // The per-date launches move 32 bytes per path and reduce 16 sums per workgroup: at most ONE workgroup per compute unit (a single
     // group of the grid reduction: one ticket round, <= 256 rows for the last workgroup to sum), each thread taking its paths U at a
-    // time with all 3 U loads in flight.  Measured per call, 51 launches (profiles/r04_lsm_ab.jsonl): 1M x 50 -- 959 us at U = 1,
+    // time (U <= 4: 98 VGPRs) with all 3 U loads in flight.  Measured per call, 51 launches (profiles/r04_lsm_ab.jsonl): 1M x 50 -- 959 us at U = 1,
     // 816 at 4, 804 at 8 (two workgroups per CU: 887 / 841 / 867; eight: 921 / 980 / 1081); 50k x 50, where a thread has one path --
     // 429 at U = 1, 441 at 4, 459 at 8 (the unrolled trip's dead slots).  Round 3's kernel (130 VGPRs, 256 B scratch, one path per
     // trip, two workgroups per CU, serial solve in one lane) took 1,123 / 490 us.
     const int32_t grid = std::min<int32_t>(path_grid, c->cus);
     const int64_t per_thread = (n_paths + static_cast<int64_t>(grid) * kBlock - 1) / (static_cast<int64_t>(grid) * kBlock);
-    const int lsm_unroll = per_thread <= 1 ? 1 : per_thread <= 2 ? 2 : per_thread <= 4 ? 4 : 8;
+    const int lsm_unroll = per_thread <= 1 ? 1 : per_thread <= 2 ? 2 : 4;      // U = 8 measured 1.5 % faster at 1M paths and needs 160 VGPRs: not kept
     EventPair ep{};
     if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
     hipLaunchKernelGGL((lsm_paths_kernel<false>), dim3(path_grid), dim3(kBlock), 0, c->stream, pr, lc, d_paths);
@@ -1535,7 +1535,6 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
         };
         if (lsm_unroll == 1) pick(std::integral_constant<int, 1>{});
         else if (lsm_unroll == 2) pick(std::integral_constant<int, 2>{});
-        else if (lsm_unroll == 8) pick(std::integral_constant<int, 8>{});
         else pick(std::integral_constant<int, 4>{});
         rc = after_launch(c, c->stream);
         if (rc) return rc;

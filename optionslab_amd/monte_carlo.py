@@ -113,12 +113,22 @@ class MCResult:
 
 
 class MonteCarloPricer:
-    __slots__ = ("num_simulations", "num_steps", "seed", "method", "_use_numba")
+    """monte_carlo.py:46-186 on the device.  Additive: `n_gpus` (keyword only, default 1) -- with n_gpus > 1 the pseudo-random
+    price(), greeks() and price_with_control_variate() shard `num_simulations` over the first n_gpus devices of THIS process
+    (contiguous global path ranges, one launch per device, ONE RCCL all-reduce of the sums over xGMI: olmc_multi_gpu_*, no
+    torch); the paths, hence the results up to the association of the sums, do not depend on n_gpus."""
+
+    __slots__ = ("num_simulations", "num_steps", "seed", "method", "_use_numba", "n_gpus")
 
     def __init__(self, num_simulations: int = 100000, num_steps: int = 1, seed: Optional[int] = None,
-                 method: MCMethod = MCMethod.NUMPY):
+                 method: MCMethod = MCMethod.NUMPY, *, n_gpus: int = 1):
         if num_simulations < 1:
             raise ValueError("num_simulations must be >= 1")
+        if n_gpus < 1:
+            raise ValueError("n_gpus must be >= 1")
+        if n_gpus > 1 and method == MCMethod.QMC:
+            raise ValueError("MCMethod.QMC prices on one device (shard its points with olmc_european_qmc's point_offset)")
+        self.n_gpus = int(n_gpus)
         self.num_simulations = num_simulations
         self.num_steps = num_steps
         # one 31-bit draw at construction, then fixed: repeated price() calls and
@@ -153,6 +163,9 @@ class MonteCarloPricer:
         if self.method == MCMethod.QMC:
             sv, shift = sobol_tables(self._steps(), actual_seed)
             st = _hip.european_qmc(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift)
+        elif self.n_gpus > 1:
+            st = _hip.multi_gpu_european(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(), actual_seed, True,
+                                         self.n_gpus)
         else:
             st = _hip.european(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(),
                                actual_seed, True)
@@ -168,8 +181,12 @@ class MonteCarloPricer:
         if self.method == MCMethod.QMC:   # the same five-moment reduction on the Sobol points (N samples, no mirror)
             sv, shift = sobol_tables(self.num_steps, actual_seed)
             return float(_hip.european_qmc_cv(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift).value)
-        m = _hip.european_cv(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(),
-                             actual_seed, True)
+        if self.n_gpus > 1:
+            m = _hip.multi_gpu_european_cv(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(), actual_seed, True,
+                                           self.n_gpus)
+        else:
+            m = _hip.european_cv(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(),
+                                 actual_seed, True)
         return float(m.value)
 
     # ------------------------------------------------------------------- greeks
@@ -196,6 +213,9 @@ class MonteCarloPricer:
             sv, shift = sobol_tables(self._steps(), actual_seed)
             vals, _ = _hip.european_qmc_greeks_fd(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift,
                                                   include_second_order, want_evals=False)
+        elif self.n_gpus > 1:
+            vals, _ = _hip.multi_gpu_greeks_fd(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(), actual_seed,
+                                               include_second_order, self.n_gpus, want_evals=False)
         else:
             vals, _ = _hip.european_greeks_fd(S, K, T, r, sigma, q, option_type == "call", self.num_simulations,
                                               self._steps(), actual_seed, include_second_order, want_evals=False)

@@ -106,6 +106,25 @@ def test_n_rank_control_variate_equals_the_combined_shards(rehearsal, n_ranks):
     assert got.value == pytest.approx(whole.value, rel=1e-11)
 
 
+def test_the_pricer_with_n_gpus_prices_what_the_one_gpu_pricer_prices(rehearsal, monkeypatch):
+    """MonteCarloPricer(..., n_gpus=P): price(), greeks() and price_with_control_variate() through the single-process engine.  The
+    pricer is pointed at the instrumented build (same code) so that P = 5 ranks can be rehearsed on this one device: same paths as
+    the one-GPU pricer, sums in another association."""
+    monkeypatch.setattr(ol.monte_carlo, "_hip", hip)
+    one = ol.MonteCarloPricer(300_000, 40, 42)
+    many = ol.MonteCarloPricer(300_000, 40, 42, n_gpus=5)
+    a, b = one.price(*ATM, "call", return_error=True), many.price(*ATM, "call", return_error=True)
+    assert b.n_paths == a.n_paths == 600_000 and b.price == pytest.approx(a.price, rel=1e-13) and b.std_error == pytest.approx(a.std_error, rel=1e-10)
+    assert many.price(*ATM, "put", q=0.01, seed=7) == pytest.approx(one.price(*ATM, "put", q=0.01, seed=7), rel=1e-13)
+    assert many.price_with_control_variate(*ATM, "call") == pytest.approx(one.price_with_control_variate(*ATM, "call"), rel=1e-11)
+    for second in (False, True):
+        g1, g5 = one.greeks(*ATM, "call", include_second_order=second), many.greeks(*ATM, "call", include_second_order=second)
+        assert list(g1) == list(g5)
+        for k in g1:
+            assert g5[k] == pytest.approx(g1[k], rel=1e-7, abs=1e-7), k
+        assert ol.compute_greeks_unified(many, *ATM, "call", include_second_order=second) == g5
+
+
 def test_a_failing_rank_in_the_middle_leaves_the_thread_and_the_library_usable(rehearsal):
     """Error returns of the multi-GPU calls go through a scope guard: the ranks already queued are drained, the thread's library
     device and HIP device restored.  Rank 2 of 4 is made to fail by the fault-injection knob: ranks 0 and 1 have kernels in flight."""

@@ -26,6 +26,21 @@ def test_constructor_contract():          # reference tests/test_monte_carlo.py:
         p.extra = 1
 
 
+def test_n_gpus_is_additive_and_keyword_only():
+    """The multi-GPU switch of the pricer: keyword only, default 1, validated; the reference's positional contract
+    (num_simulations, num_steps, seed, method) is untouched."""
+    p = ol.MonteCarloPricer(5000, 100, 123, ol.MCMethod.NUMPY)
+    assert p.n_gpus == 1
+    assert ol.MonteCarloPricer(5000, 100, 123, n_gpus=8).n_gpus == 8
+    with pytest.raises(TypeError):
+        ol.MonteCarloPricer(5000, 100, 123, ol.MCMethod.NUMPY, 8)          # not a fifth positional argument
+    with pytest.raises(ValueError):
+        ol.MonteCarloPricer(5000, n_gpus=0)
+    with pytest.raises(ValueError):
+        ol.MonteCarloPricer(5000, 16, 1, ol.MCMethod.QMC, n_gpus=2)
+    assert ol.MonteCarloPricer(1000, 10, 1, n_gpus=4).price(120, 100, 0.0, 0.05, 0.2, "call") == 20     # T <= 0: no device, whatever n_gpus
+
+
 def test_method_enum_keeps_reference_members():
     assert {m.value for m in ol.MCMethod} >= {"numpy", "numba", "qmc", "fast"}
     assert ol.MCMethod("hip") is ol.MCMethod.HIP

@@ -1477,7 +1477,7 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
     if (poly_degree < 1 || poly_degree > kLsmMaxDegree) return fail(OLMC_ERR_ARG, "poly_degree must be in [1, 4]");
     int rc = check_paths(0, n_paths, n_steps);
     if (rc) return rc;
-    const double path_bytes = 8.0 * static_cast<double>(n_paths) * (n_steps + 2.0) + 256.0;
+    const double path_bytes = 8.0 * static_cast<double>(n_paths) * (n_steps + 2.0) + 512.0;
     if (path_bytes > 64e9) return fail(OLMC_ERR_ARG, "path matrix would exceed 64 GB: lower n_paths or n_steps");
     CtxLease lease;
     rc = ctx_lease(&lease);
@@ -1488,6 +1488,7 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
     double* d_paths = static_cast<double*>(c->d_bulk);                                  // [n_steps + 1][n_paths]
     double* d_cash = d_paths + static_cast<size_t>(n_steps + 1) * n_paths;              // [n_paths]
     LsmCoeffs* d_coef = reinterpret_cast<LsmCoeffs*>(d_cash + n_paths);                  // fit handed from launch to launch
+    double* d_moments = reinterpret_cast<double*>(d_coef) + 16;                           // [kLsmNV + 1] the sums of the dates in between: nobody on the host reads them
     LsmContract lc;
     const double dt = T / n_steps;                      // exotic_options.py:54-56, 260-261
     lc.log_s0 = std::log(S);
@@ -1520,10 +1521,11 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
     int32_t init = 1;
     for (int32_t t_fit = n_steps - 1; t_fit >= 0; --t_fit) {
         ReduceWs ws;
-        rc = make_ws(c, c->stream, grid, kLsmNV, c->d_result, -1.0, &ws);
-        if (rc) return rc;
-        ws.done_flag = nullptr;                       // one call = many launches sharing d_result: the call waits for the stream itself
-        c->armed = 0;
+        // only the LAST launch (t_fit == 0: the moments of the time-0 cash flow) writes into the pinned host buffer; the sums of the dates
+        // in between go to device memory -- sixteen posted PCIe writes per date would sit between a launch's last wave and its
+        // completion, i.e. in front of the next, dependent launch
+        rc = make_ws(c, c->stream, grid, kLsmNV, t_fit == 0 ? c->d_result : d_moments, -1.0, &ws);
+        if (rc) return rc;                            // (make_ws arms the completion word for the launch that writes d_result: the last one)
         const bool first = init != 0, final_date = t_fit == 0;
         auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, c->stream, n_paths, lc, d_coef, t_fit, d_paths, d_cash, ws); };
         auto pick = [&](auto u) {

@@ -136,3 +136,39 @@ def test_the_launcher_path_is_taken_before_anything_touches_a_gpu():
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 7, (r.returncode, r.stderr[-500:])
     assert "SPAWN ['-m', 'torch.distributed.run']" in r.stderr and r.stdout.strip() == ""
+
+
+def test_the_single_process_child_waits_for_go_and_its_line_is_relayed(bench, monkeypatch):
+    """c5.single_process: rank 0 starts `bench.py --single-process-child` BEFORE it touches a GPU; the child sits on its stdin, GPU
+    untouched, until told to go; its JSON object becomes the section.  A stand-in child here (no GPU): the control flow is under test."""
+    # the real child, told something else than "go", leaves without importing the engine
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--single-process-child", "--gpus", "2"], input="no\n", capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip() == ""
+    seen = {}
+
+    class FakeChild:
+        returncode = 0
+
+        def communicate(self, text, timeout=None):
+            seen["sent"] = text
+            return 'banner\n{"value": 5.0e12, "ms_per_step": 0.8, "n_gpus": 8, "paths_per_gpu": 8000000}\n', ""
+
+        def poll(self):
+            return 0
+
+    def fake_popen(cmd, **kw):
+        seen["cmd"], seen["env"] = cmd, kw["env"]
+        return FakeChild()
+
+    monkeypatch.setattr(bench.subprocess, "Popen", fake_popen)
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    args = type("A", (), {"steps": 100, "warmup": 10, "paths_per_gpu": 0})()
+    child = bench.start_single_process_child(args, 8)
+    assert seen["cmd"][1:5] == [os.path.join(ROOT, "bench.py"), "--single-process-child", "--gpus", "8"]
+    assert "RANK" not in seen["env"] and "WORLD_SIZE" not in seen["env"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    res = bench.c5_single_process(child, None, False, False, 1, 0, None)
+    assert seen["sent"] == "go\n" and res["n_gpus"] == 8 and res["value"] == 5.0e12
+    line = bench.compact_line({"metric": "m", "value": 1.0, "config": {}, "roofline": {}, "c5_single_process": res})
+    assert line["c5"]["single_process"] == {"value": 5.0e12, "ms": 0.8, "n_gpus": 8, "paths_per_gpu": 8000000}
+    assert bench.c5_single_process(None, None, False, True, 1, 0, None)["error"].startswith("rehearsal")

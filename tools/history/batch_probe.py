@@ -1,5 +1,5 @@
 import sys, time, statistics, json
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import optionslab_amd as ol
 from optionslab_amd import _hip

@@ -7,7 +7,7 @@ import os
 import statistics
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from optionslab_amd import _hip  # noqa: E402
 
 N, M = 1_000_000, 252

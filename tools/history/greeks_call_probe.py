@@ -1,5 +1,5 @@
 import sys, time, statistics
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import optionslab_amd as ol
 from optionslab_amd import _hip
 ATM = (100.0, 100.0, 1.0, 0.05, 0.2)

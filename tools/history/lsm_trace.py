@@ -5,7 +5,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from optionslab_amd import _hip  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 50_000

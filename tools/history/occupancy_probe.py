@@ -8,7 +8,7 @@ import os
 import statistics
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from optionslab_amd import _hip  # noqa: E402
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 252

@@ -4,7 +4,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import optionslab_amd as ol  # noqa: E402
 
 for n, m in ((2**14, 16), (2**17, 64), (2**20, 64), (2**20, 252), (2**22, 252)):

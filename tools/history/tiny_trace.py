@@ -3,7 +3,7 @@
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from optionslab_amd import _hip  # noqa: E402
 
 for n, m in ((256, 1), (10_000, 1), (100_000, 1), (100_000, 16), (1_000_000, 1)):

@@ -90,7 +90,6 @@ struct DeviceCtx {
     double* h_result = nullptr;      // pinned + mapped [kMaxNV + 1 (+ flag)]: the last workgroup writes the sums straight to the host
     double* d_result = nullptr;      // device alias of h_result (zero-copy: no D2H copy node, only a stream sync)
     void* d_bulk = nullptr;          // terminal prices / validation taps
-    double* d_triple = nullptr;      // {sum, sumsq, n} of this device's shard in olmc_multi_gpu_european (never reallocated)
     size_t bulk_bytes = 0;
     // independent-contract batches (european_multi_kernel)
     void* d_multi = nullptr;         // device [ticket counters | done counter | contracts | rows], see olmc_european_multi
@@ -139,7 +138,6 @@ int ctx_allocate(DeviceCtx* c) {
         HIP_TRY(hipMemset(sl.counters, 0, sizeof(uint32_t) * (kMaxGroups + 1) * kCounterStride));
         HIP_TRY(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
     }
-    HIP_TRY(hipMalloc(&c->d_triple, 256));
     HIP_TRY(hipHostMalloc(&c->h_result, sizeof(double) * (kMaxNV + 1 + 15), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_result), c->h_result, 0));
     c->h_flag = reinterpret_cast<uint64_t*>(c->h_result + kMaxNV + 8);      // a cache line of its own
@@ -154,7 +152,6 @@ void ctx_release(DeviceCtx* c) {
     for (auto& ep : c->ev_pending) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
     for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
     if (c->d_bulk) (void)hipFree(c->d_bulk);
-    if (c->d_triple) (void)hipFree(c->d_triple);
     if (c->d_multi) (void)hipFree(c->d_multi);
     if (c->h_multi) (void)hipHostFree(c->h_multi);
     if (c->d_sobol) (void)hipFree(c->d_sobol);

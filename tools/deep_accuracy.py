@@ -10,6 +10,37 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import optionslab_amd as ol  # noqa: E402
 from optionslab_amd import _hip  # noqa: E402
 
+if "--round4" in sys.argv:
+    # Round 4: (i) the Sobol price against Black-Scholes as the point count grows -- through all three launch shapes (split workgroups up
+    # to 2^18 points, one point per thread, eight points per thread from 2^20): a wrong point, dimension or association would show as a
+    # plateau; (ii) the fp64-normals kernel of the instrumented build against the product kernel and Black-Scholes at 2^30 paths.
+    from optionslab_amd.monte_carlo import sobol_tables
+    from tools.probe import binding as probe
+    S, K, T, r, v = 100.0, 100.0, 1.0, 0.05, 0.2
+    bs = ol.black_scholes(S, K, T, r, v, "call")
+    for dims in (16, 64, 252):
+        sv, sh = sobol_tables(dims, 42)
+        for log_n in (10, 12, 14, 16, 18, 19, 20, 22, 24):
+            st = _hip.european_qmc(S, K, T, r, v, 0.0, True, 1 << log_n, sv, sh)
+            print(json.dumps(dict(kind="scrambled Sobol vs Black-Scholes", dims=dims, log2_points=log_n, price=st.price, bs=bs, abs_err=st.price - bs,
+                                  shape="split" if (log_n <= 18 and dims >= 16) else ("one point" if log_n < 20 else "eight points"))), flush=True)
+    import math
+    for M, batches in ((16, 16), (252, 4)):              # batches of 2^26 paths (the probe kernel's launch limit), distinct seeds, sums combined
+        tot = {"f64": [0.0, 0.0, 0], "f32": [0.0, 0.0, 0]}
+        for k in range(batches):
+            for name, st in (("f64", probe.european_f64_normals(S, K, T, r, v, 0.0, True, 1 << 26, M, 100 + k)),
+                             ("f32", _hip.european(S, K, T, r, v, 0.0, True, 1 << 26, M, 100 + k, True))):
+                tot[name][0] += st.sum; tot[name][1] += st.sumsq; tot[name][2] += st.n
+        out = {}
+        for name, (sx, sxx, n) in tot.items():
+            mean = sx / n
+            out[name] = (math.exp(-r * T) * mean, math.exp(-r * T) * math.sqrt(max(sxx / n - mean * mean, 0.0) / n))
+        print(json.dumps(dict(kind="fp64 normals (instrumented build) vs fp32 normals (product) vs Black-Scholes", n_paths=batches << 26, n_steps=M, bs=bs,
+                              f64_price=out["f64"][0], f64_z=(out["f64"][0] - bs) / out["f64"][1], f32_price=out["f32"][0], f32_z=(out["f32"][0] - bs) / out["f32"][1],
+                              std_error=out["f64"][1], diff_over_se=(out["f64"][0] - out["f32"][0]) / (2 ** 0.5 * out["f64"][1]),
+                              note="std_error is the naive formula over 2n antithetic samples (overstates the error): z is conservative")), flush=True)
+    raise SystemExit(0)
+
 N = 1 << 32
 rows = []
 for (S, K, T, r, v, q, call, M, seed) in [(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, True, 16, 1), (100.0, 100.0, 1.0, 0.05, 0.2, 0.0, False, 16, 2),

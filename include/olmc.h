@@ -402,8 +402,10 @@ int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_
 int olmc_profile_enable(int on);
 /* Tuning knob for A/B measurements (results never change, only the launch shape):
  *   OLMC_TUNE_GRID_CAP   max workgroups per launch, 0 = default (larger jobs grid-stride)
- *   OLMC_TUNE_QMC_BLOCK  Sobol kernels: 0 = eight consecutive points per thread from 2^20 points on (default),
- *                        1 = always, -1 = never (one point per thread)
+ *   OLMC_TUNE_QMC_BLOCK  Sobol kernels: 0 = by size (default): up to 2^18 points (and >= 16 dimensions) a workgroup takes 64 points and
+ *                        each of its four waves a quarter of the dimensions; from 2^20 points on a thread takes eight consecutive
+ *                        points; one point per thread in between.  1 = always eight points per thread, -1 = always one point per
+ *                        thread.  Every shape returns the same terminal prices bit for bit (one association of a point's normal sum)
  *   OLMC_TUNE_POLL       blocking calls: 0 = wait by polling the host-mapped flag the kernel raises behind its results
  *                        (default), -1 = hipStreamSynchronize
  *   OLMC_TUNE_SPLIT_TAIL European launches: 0 = the paths beyond a whole number of workgroups per compute unit go to split

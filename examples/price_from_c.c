@@ -3,7 +3,7 @@
  *
  *   gcc -O2 -Iinclude examples/price_from_c.c -o /tmp/price_from_c -Loptionslab_amd -lolmc \
  *       -Wl,-rpath,$PWD/optionslab_amd
- *   /tmp/price_from_c [n_paths] [n_steps]
+ *   /tmp/price_from_c [n_paths] [n_steps] [n_gpus]
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -54,6 +54,16 @@ int main(int argc, char** argv) {
     printf("two shards     price %.6f  (whole %.6f)\n", both.price, st.price);
     if (both.n != st.n || both.price < st.price * (1 - 1e-12) || both.price > st.price * (1 + 1e-12)) {
         fprintf(stderr, "shards do not add up\n");
+        return 1;
+    }
+    /* the same two halves priced by the library itself on `n_gpus` devices of this process: one launch per device, ONE RCCL
+     * all-reduce of (sum, sumsq, n) over xGMI, no torch, no extra processes (n_gpus = 1 here: any box can run the example) */
+    const int n_gpus = argc > 3 ? atoi(argv[3]) : 1;
+    olmc_stats multi;
+    CHECK(olmc_multi_gpu_european(S, K, T, r, sigma, q, 1, n_paths, n_steps, 42, 1, n_gpus, &multi));
+    printf("%d GPU(s)       price %.6f  std_error %.6f  n %lld\n", n_gpus, multi.price, multi.std_error, (long long)multi.n);
+    if (multi.n != st.n || multi.price < st.price * (1 - 1e-12) || multi.price > st.price * (1 + 1e-12)) {
+        fprintf(stderr, "the multi-GPU form prices other paths\n");
         return 1;
     }
     CHECK(olmc_shutdown());

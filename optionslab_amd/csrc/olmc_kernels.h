@@ -394,7 +394,10 @@ __device__ __forceinline__ double workgroup_rows_sum(const double* src, int32_t 
     const int c = threadIdx.x % NVP, sub = threadIdx.x / NVP;
     double v = 0.0;
     if (c < NV) {
-        constexpr int kBatch = 8;
+        // loads in flight per thread: a group of 256 rows is ONE round trip for every row width (NVP = 16: 16 threads per column, 16 rows
+        // each; NVP = 32: 8 threads, 32 rows = two trips).  Round 3 kept 8 in flight: two trips behind the last workgroup of every date
+        // of the American option (NV = 16), four behind the 14-contract Greeks'.
+        constexpr int kBatch = NVP >= 16 ? 16 : 8;
         for (int32_t row = sub; row < rows; row += SUBS * kBatch) {
             double t[kBatch];
 #pragma unroll

@@ -417,7 +417,7 @@ def compact_line(full, detail_name=None):
                                      "vs_baseline", "dtype", "data")}
     line["value"], line["ms_per_step"] = _num(line["value"], 7), _num(line["ms_per_step"], 6)
     cfg = full.get("config") or {}
-    line["config"] = {"workload": clip(cfg.get("workload", ""), 300), "paths_per_gpu": cfg.get("paths_per_gpu"), "n_steps": cfg.get("n_steps"),
+    line["config"] = {"workload": clip(cfg.get("workload", ""), 220), "paths_per_gpu": cfg.get("paths_per_gpu"), "n_steps": cfg.get("n_steps"),
                       "global_paths": cfg.get("global_paths"), "parallelism": clip(cfg.get("parallelism", ""), 120)}
     line["ranks_seen"] = full.get("ranks_seen")
     line["timed_s"] = _num(sum((full.get("passes") or {}).get("seconds") or []), 4)
@@ -427,7 +427,7 @@ def compact_line(full, detail_name=None):
     line["roofline"] = {"bound": r.get("bound", "valu"), "achieved": _num(r.get("achieved")), "peak": _num(r.get("peak")),
                         "unit": "G VALU issue-cycles/s", "frac": _num(r.get("frac"), 4), "traffic": _num(r.get("traffic")),
                         "avg_kernel_ms": _num(r.get("avg_kernel_ms"), 5), "kernel": clip(r.get("kernel", ""), 60),
-                        "pmc_source": clip(r.get("pmc_source") or r.get("why_null") or "", 90),
+                        "pmc_source": clip(r.get("pmc_source") or r.get("why_null") or "", 60),
                         "clock_ghz_under_load": _num(r.get("clock_ghz_under_load"), 4), "hbm_gbps": _num(r.get("hbm_gbps"), 4)}
     cpu = full.get("cpu_baseline")
     if cpu:
@@ -799,8 +799,7 @@ def worker(args):
             "ms_per_step": pass_s / K_steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 normals / f64 prices", "data": "synthetic",
             "config": {"workload": f"BASELINE {which}: European call S0=100 K=100 sigma=0.2 r=0.05 T=1, {paths_per_gpu:,} paths x 252 steps per GPU, "
-                                   "antithetic on, Philox4x32-10 + Box-Muller in registers, on-device reduction; "
-                                   "step = one blocking price(return_error=True), result on the host",
+                                   "antithetic, on-device reduction; step = one blocking price(return_error=True)",
                        "paths_per_gpu": paths_per_gpu, "n_steps": N_STEPS, "global_paths": n_global,
                        "parallelism": f"path-sharded x{world}" + (", 1 RCCL all-reduce of (sum,sumsq,n) per step" if world > 1 else "")
                                       + (" [REHEARSAL: all ranks on one GPU, gloo]" if rehearsal else "")},

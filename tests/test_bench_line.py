@@ -172,3 +172,16 @@ def test_the_single_process_child_waits_for_go_and_its_line_is_relayed(bench, mo
     line = bench.compact_line({"metric": "m", "value": 1.0, "config": {}, "roofline": {}, "c5_single_process": res})
     assert line["c5"]["single_process"] == {"value": 5.0e12, "ms": 0.8, "n_gpus": 8, "paths_per_gpu": 8000000}
     assert bench.c5_single_process(None, None, False, True, 1, 0, None)["error"].startswith("rehearsal")
+
+
+def test_round_4_record_keeps_every_section_within_the_budget(bench):
+    """The round-4 record (profiles/r04_bench_detail.json: f_kernels, c2_f64_normals, c5_single_process on top of round 3's sections) must
+    fit the line WITHOUT the belt-and-braces shedding: every section the record holds appears in the line."""
+    with open(os.path.join(ROOT, "profiles", "r04_bench_detail.json")) as f:
+        full = json.load(f)
+    line = _check_line(bench, bench.compact_line(full, "bench_detail.json"))
+    assert len(json.dumps(line, separators=(",", ":"))) <= bench.LINE_BUDGET - 64
+    assert set(line["f"]) == {"heston", "extrema", "asian_geometric", "multi", "qmc", "qmc_one_point", "qmc_block", "american_lsm"}
+    assert all(0 < v["frac"] <= 1 for k, v in line["f"].items() if k != "american_lsm") and set(line["f"]["american_lsm"]) == {"50000x50", "1000000x50"}
+    assert line["c2_f64_normals"]["x_product_kernel"] > 3 and line["c5"]["single_process"]["n_gpus"] == 1
+    assert {"c3", "c4", "pipelined"} <= set(line)

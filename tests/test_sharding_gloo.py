@@ -133,3 +133,47 @@ def test_finalize_matches_reference_formula():
     sd = math.sqrt(sum((x - mean) ** 2 for x in xs) / n)      # np.std, ddof=0
     assert price == pytest.approx(math.exp(-0.1) * mean, rel=1e-15)
     assert se == pytest.approx(math.exp(-0.1) * sd / math.sqrt(n), rel=1e-14)
+
+
+def _bench_section_worker(rank, world, port, out_dir):
+    """bench.py's c5_single_process section in a 2-rank job: every rank goes through the two CPU barriers, only rank 0 talks to the
+    (stand-in) child, and the barriers are gloo -- not an NCCL kernel spinning on the GPUs the child is measuring on."""
+    sys.path.insert(0, ROOT)
+    import importlib.util
+
+    import torch.distributed as dist
+
+    argv, sys.argv = sys.argv, ["bench.py"]
+    spec = importlib.util.spec_from_file_location("olmc_bench_gloo", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sys.argv = argv
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    group = dist.new_group(backend="gloo")
+
+    class Child:
+        returncode = 0
+        told = None
+
+        def communicate(self, text, timeout=None):
+            Child.told = text
+            return '{"value": 1.0e13, "ms_per_step": 1.6, "n_gpus": 2, "paths_per_gpu": 8000000}\n', ""
+
+        def kill(self):
+            pass
+
+    child = Child() if rank == 0 else None
+    res = bench.c5_single_process(child, dist, True, False, world, rank, group)
+    with open(os.path.join(out_dir, f"section{rank}.txt"), "w") as f:
+        f.write(repr((res, Child.told)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_single_process_section_in_a_two_rank_job(tmp_path):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_bench_section_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (eval(open(tmp_path / f"section{k}.txt").read()) for k in range(2))
+    assert r0 == ({"value": 1.0e13, "ms_per_step": 1.6, "n_gpus": 2, "paths_per_gpu": 8000000}, "go\n")
+    assert r1 == (None, None)                    # the other rank only waits on the barriers: it starts nothing and reports nothing

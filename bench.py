@@ -450,6 +450,8 @@ def compact_line(full, detail_name=None):
                       for k, v in a.items() if isinstance(v, dict) and "ms_per_call" in v}
         if a.get("gpu_over_cpu"):
             line["c4"]["gpu_over_cpu"] = _num(a["gpu_over_cpu"], 5)
+        if isinstance(a.get("greeks"), dict) and "fused_14" in a["greeks"]:
+            line["c4"]["greeks14"] = {"ms": _num(a["greeks"]["fused_14"]["ms"], 4), "x_literal": _num(a["greeks"].get("speedup_14"), 3)}
     f = full.get("f_kernels")
     if isinstance(f, dict) and "error" not in f:
         line["f"] = {}
@@ -1017,6 +1019,16 @@ def c4_asian(ol, _hip, pmc, costs, mixes, clock_ghz, cpu=None):
                     "dtype": "f32 normals / f64 cumulative log-return, f64 exp per date, f64 sums" if precision == "fp64"
                              else "f32 normals / f32 exponent + v_exp_f32 per date inside groups of 16 dates, f64 across groups",
                     "roofline": roofline_for(pmc, pk, ks, ASIAN_STEPS, PATHS_PER_GPU, costs, mixes, clock_ghz)}
+    # finite-difference Greeks over the same option (compute_greeks_unified through ExoticAdapter, unified_greeks.py:177-227): the 8 / 14
+    # evaluations as six path recursions in ONE launch (olmc_asian_greeks_fd) against the 8 / 14 launches of the kernel above
+    ad = ol.ExoticAdapter(ol.AsianOption(*ATM, seed=SEED), n_paths=PATHS_PER_GPU, n_steps=ASIAN_STEPS)
+    greeks = {}
+    for key, second, fused, reps in (("fused_8", False, True, 8), ("fused_14", True, True, 8), ("literal_8", False, False, 3), ("literal_14", True, False, 3)):
+        med, ks, per = _timed_calls(_hip, lambda: ol.compute_greeks_unified(ad, *ATM, "call", include_second_order=second, fused=fused), reps, warm=2)
+        greeks[key] = {"ms": med * 1e3, "launches_per_call": per, "kernel_ms_per_launch": ks * 1e3 if ks else None}
+    greeks["speedup_14"] = greeks["literal_14"]["ms"] / greeks["fused_14"]["ms"]
+    greeks["speedup_8"] = greeks["literal_8"]["ms"] / greeks["fused_8"]["ms"]
+    out["greeks"] = greeks
     out["headline"] = "fp64"
     if cpu and isinstance(cpu.get("c4_asian"), dict) and cpu["c4_asian"].get("value"):
         out["cpu_baseline"] = cpu["c4_asian"]

@@ -49,7 +49,7 @@ extern "C" {
                               *    olmc_exp2_probe_form, olmc_phase_stamps, olmc_contract_layout, tune knob 9; every v2 entry point keeps its signature and meaning
                               * 4: the measurement entry points (olmc_*probe*, olmc_phase_stamps, olmc_clock_probe, olmc_normal_moments) and the
                               *    fault-injection knobs 5 / 6 LEFT this library for the instrumented build (olmc_probe.h, libolmc_probe.so); added
-                              *    olmc_multi_gpu_greeks_fd, olmc_multi_gpu_european_cv; every pricing entry point keeps its signature and meaning;
+                              *    olmc_multi_gpu_greeks_fd, olmc_multi_gpu_european_cv, olmc_asian_greeks_fd; every pricing entry point keeps its signature and meaning;
                               *    entry points are now concurrent across threads (a context per caller, olmc.h "Threading") */
 
 enum {
@@ -232,6 +232,15 @@ int olmc_combine_cv(const olmc_cv_moments* parts, int32_t n_parts, double S, dou
 int olmc_asian(double S, double K, double T, double r, double sigma, double q, int is_call,
                int avg_kind, int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed,
                int antithetic, olmc_stats* out);
+
+/* Finite-difference Greeks of the arithmetic Asian (OLMC_AVG_ARITHMETIC: the reference's precision) in ONE launch: the 8 / 14 bumped
+ * contracts compute_greeks_unified prices through ExoticAdapter(AsianOption) (src/greeks/unified_greeks.py:177-227, 295-358: same
+ * bumps, same call order, same formulas as olmc_european_greeks_fd) on the SAME normals.  The contracts are at most six distinct
+ * path recursions ({mid, S+-}, sigma+-, T-, r+-: the spot only scales the average), so a date costs six exponentials instead of
+ * 8 / 14 in 8 / 14 launches.  out9 / evals as olmc_european_greeks_fd. */
+int olmc_asian_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call,
+                         int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic, int second_order,
+                         double* out9, olmc_stats* evals /* [14] or NULL */);
 
 /* ---- barrier and lookback (running extrema of the path, t = 0 included) ------
  * Replace BarrierOption.price (src/pricing_models/exotic_options.py:174-224) and

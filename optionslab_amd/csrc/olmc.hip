@@ -1263,6 +1263,77 @@ extern "C" int olmc_asian(double S, double K, double T, double r, double sigma, 
     return OLMC_OK;
 }
 
+// The 8 / 14 contracts of compute_greeks_unified over an arithmetic Asian (ExoticAdapter, unified_greeks.py:177-227) in one launch.
+extern "C" int olmc_asian_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t n_paths,
+                                    int32_t n_steps, uint64_t seed, int antithetic, int second_order, double* out9, olmc_stats* evals) {
+    if (!out9) return fail(OLMC_ERR_ARG, "null pointer");
+    if (!(T > 0.0)) return fail(OLMC_ERR_ARG, "T must be > 0");
+    int rc = check_paths(0, n_paths, n_steps);
+    if (rc) return rc;
+    const GreeksSet gs(S, K, T, r, sigma, q, is_call, second_order);
+    AsianGreeksSet as{};
+    int n_groups = 0;
+    for (int i = 0; i < gs.k; ++i) {
+        const olmc_option& o = gs.o[i];
+        const double dt = o.T / n_steps;                             // exotic_options.py:54-56, as olmc_asian
+        const double drift = (o.r - o.q - 0.5 * o.sigma * o.sigma) * dt, vol = o.sigma * std::sqrt(dt);
+        int g = 0;
+        while (g < n_groups && !(std::memcmp(&as.drift[g], &drift, sizeof drift) == 0 && std::memcmp(&as.vol[g], &vol, sizeof vol) == 0)) ++g;
+        if (g == n_groups) {
+            if (n_groups == kAsianGroups) return fail(OLMC_ERR_STATE, "more distinct path recursions than the fused Asian Greeks kernel carries");
+            as.drift[g] = drift;
+            as.vol[g] = vol;
+            ++n_groups;
+        }
+        as.group[i] = g;
+        as.s0[i] = o.S;
+    }
+    for (int g = n_groups; g < kAsianGroups; ++g) { as.drift[g] = as.drift[0]; as.vol[g] = as.vol[0]; }
+    {   // into the exponential's units, by the very products asian_exp64_kernel forms on the device (drift * kUnit; vol * kZScale * kUnit)
+        constexpr double kLog2e = 1.4426950408889634;
+        constexpr double kUnit = OLMC_EXP2_TABLE ? kExp2Entries * kLog2e : kLog2e;
+        for (int g = 0; g < kAsianGroups; ++g) {
+            as.drift[g] = as.drift[g] * kUnit;
+            as.vol[g] = as.vol[g] * kZScale * kUnit;
+        }
+    }
+    as.strike = K;
+    as.sign = is_call ? 1.0 : -1.0;
+    as.inv_steps = 1.0 / n_steps;
+    CtxLease lease;
+    rc = ctx_lease(&lease);
+    if (rc) return rc;
+    DeviceCtx* const c = lease.c;
+    if (n_paths > static_cast<int64_t>(kMaxGrid) * kBlock) return fail(OLMC_ERR_ARG, "n_paths beyond one launch of the fused Asian Greeks kernel (2^26)");
+    const PathRange pr = make_range(0, n_paths, n_steps, seed);
+    const int32_t grid = static_cast<int32_t>((n_paths + kBlock - 1) / kBlock);      // the grid covers every path
+    const int nsets = gs.k <= 8 ? 8 : 16;
+    ReduceWs ws;
+    rc = make_ws(c, c->stream, grid, 2 * nsets, c->d_result, -1.0, &ws);
+    if (rc) return rc;
+    EventPair ep{};
+    const EventPair* timed = nullptr;
+    rc = prof_pair(c, &ep, &timed);
+    if (rc) return rc;
+    const bool anti = antithetic != 0;
+    if (nsets == 8 && anti) launch_timed(asian_exp64_greeks_kernel<true, 8>, dim3(grid), dim3(kBlock), c->stream, timed, pr, as, ws);
+    else if (nsets == 8) launch_timed(asian_exp64_greeks_kernel<false, 8>, dim3(grid), dim3(kBlock), c->stream, timed, pr, as, ws);
+    else if (anti) launch_timed(asian_exp64_greeks_kernel<true, 16>, dim3(grid), dim3(kBlock), c->stream, timed, pr, as, ws);
+    else launch_timed(asian_exp64_greeks_kernel<false, 16>, dim3(grid), dim3(kBlock), c->stream, timed, pr, as, ws);
+    rc = after_launch(c, c->stream);
+    if (rc) return rc;
+    rc = sync_or_recover(c, c->stream);
+    if (rc) return rc;
+    const int64_t n = n_paths * (anti ? 2 : 1);
+    olmc_stats st[OLMC_MAX_BATCH];
+    for (int i = 0; i < gs.k; ++i) {
+        finish_stats(c->h_result[2 * i], c->h_result[2 * i + 1], n, gs.o[i].r, gs.o[i].T, &st[i]);
+        if (poisoned(gs.o[i].S, gs.o[i].K, gs.o[i].T, gs.o[i].r, gs.o[i].sigma, gs.o[i].q)) nan_stats(n, &st[i]);
+    }
+    gs.finish(st, T, out9, evals);
+    return OLMC_OK;
+}
+
 // ========================================================== barrier / lookback ====
 namespace {
 int run_extrema(double S, double K, double T, double r, double sigma, double q, int is_call, int payoff, double barrier,

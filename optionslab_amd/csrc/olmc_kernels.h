@@ -8,6 +8,7 @@
 // array-returning mode, the terminal prices).  The step loop is VALU-bound:
 // no LDS, no global loads, MFMA unused (there is no contraction to feed it).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -1194,6 +1195,90 @@ __global__ __launch_bounds__(kBlock) void asian_exp64_kernel(PathRange pr, Asian
         }
     }
     block_then_grid_reduce<2>(acc, ws);
+}
+
+// Finite-difference Greeks of the arithmetic Asian in ONE launch (round 4): the 8 / 14 bumped contracts of compute_greeks_unified
+// through ExoticAdapter(AsianOption) (src/greeks/unified_greeks.py:177-227, 295-358) on the SAME normals.  A contract enters the
+// date loop only through its per-step drift and volatility; the spot scales the average (S_t / S_0 does not depend on S) and the
+// strike and the discount act after the loop.  So the 8 / 14 contracts are at most kAsianGroups = 6 distinct PATH RECURSIONS --
+// {mid, S+, S-}, sigma+, sigma-, T-, r+, r-; the second-order set adds contracts ((S+-, sigma+-), (S+-, T-)), no recursion -- and
+// a date costs the normal (13.5 instructions) + 6 x (fma, add, 12-instruction exp2, add) instead of 8 / 14 x 29 in 8 / 14
+// launches.  Each recursion is asian_exp64_kernel's own arithmetic (same scaling of drift and vol into exponent units, same
+// exp2_f64_tab, same S_0 (run / M)), so a contract's payoffs are the bits its own launch produces; only the association of the sums
+// differs (16 / 32 values per workgroup row).
+constexpr int kAsianGroups = 6;
+
+struct AsianGreeksSet {
+    double drift[kAsianGroups], vol[kAsianGroups];      // per step, in the exponential's units: AsianContract's drift x kUnit, vol x kZScale x kUnit
+                                                        // (host side: the two products asian_exp64_kernel forms; unused groups repeat group 0)
+    double s0[16];                                      // spot of contract s (0 for an unused slot)
+    double strike, sign, inv_steps;
+    int32_t group[16];                                  // recursion of contract s
+};
+
+template <bool ANTI, int NSETS>
+__global__ __launch_bounds__(kBlock) void asian_exp64_greeks_kernel(PathRange pr, AsianGreeksSet gs, ReduceWs ws) {
+    constexpr int NV = 2 * NSETS, G = kAsianGroups, LEGS = ANTI ? 2 : 1;
+    __shared__ double tab[kExp2Entries];
+    if constexpr (OLMC_EXP2_TABLE) exp2_table_to_lds(tab);
+    double acc[NV];                                     // the grid covers every path (host guarantee): born after the date loop
+    const RoundKeys rk = pin_round_keys(pr.key0, pr.key1);
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    {
+        const double* __restrict__ drift = gs.drift;    // already in exponent units (host: the two multiplications of asian_exp64_kernel)
+        const double* __restrict__ vol = gs.vol;
+        const uint64_t gp = pr.first + static_cast<uint64_t>(i < pr.count ? i : 0);
+        const uint32_t g_lo = static_cast<uint32_t>(gp), g_hi = static_cast<uint32_t>(gp >> 32);
+        double cum[LEGS][G], run[LEGS][G];
+#pragma unroll
+        for (int leg = 0; leg < LEGS; ++leg)
+#pragma unroll
+            for (int g = 0; g < G; ++g) cum[leg][g] = run[leg][g] = 0.0;
+        auto dates = [&](const float (&z)[4], auto live) {      // `live` dates of one Philox block, every recursion
+#pragma unroll
+            for (int j = 0; j < decltype(live)::value; ++j) {
+                const double zj = static_cast<double>(z[j]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    cum[0][g] += __builtin_fma(vol[g], zj, drift[g]);
+                    run[0][g] += OLMC_EXP2_TABLE ? exp2_f64_tab(cum[0][g], tab) : exp2_f64(cum[0][g]);
+                    if constexpr (ANTI) {
+                        cum[1][g] += __builtin_fma(-vol[g], zj, drift[g]);
+                        run[1][g] += OLMC_EXP2_TABLE ? exp2_f64_tab(cum[1][g], tab) : exp2_f64(cum[1][g]);
+                    }
+                }
+            }
+        };
+        const int32_t full = pr.n_steps >> 2, rem = pr.n_steps & 3;
+        float z[4];
+        for (int32_t b = 0; b < full; ++b) {                    // branch-free body
+            raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(b), 0u, rk, z);
+            dates(z, std::integral_constant<int, 4>{});
+        }
+        if (rem) {
+            raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(full), 0u, rk, z);
+            if (rem == 1) dates(z, std::integral_constant<int, 1>{});
+            else if (rem == 2) dates(z, std::integral_constant<int, 2>{});
+            else dates(z, std::integral_constant<int, 3>{});
+        }
+        const bool alive = i < pr.count;
+#pragma unroll
+        for (int s = 0; s < NSETS; ++s) {
+            const int32_t g = gs.group[s];                       // launch-uniform
+            acc[2 * s] = acc[2 * s + 1] = 0.0;
+#pragma unroll
+            for (int leg = 0; leg < LEGS; ++leg) {
+                double r = run[leg][0];
+#pragma unroll
+                for (int k = 1; k < G; ++k) r = g == k ? run[leg][k] : r;
+                const double avg = gs.s0[s] * (r * gs.inv_steps);
+                const double x = alive ? fmax(gs.sign * (avg - gs.strike), 0.0) : 0.0;
+                acc[2 * s] += x;
+                acc[2 * s + 1] += x * x;
+            }
+        }
+    }
+    block_then_grid_reduce<NV>(acc, ws);
 }
 
 // Barrier and lookback options: both depend on the path only through its terminal value and

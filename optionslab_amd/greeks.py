@@ -45,6 +45,27 @@ class ExoticAdapter:
         kw.setdefault("option_type", option_type)
         return ex.price(n_paths=self.n_paths, n_steps=self.n_steps, **kw)
 
+    # -- additive: the 8 / 14 evaluations of compute_greeks_unified in ONE launch where the device has a fused kernel for the payoff:
+    #    the arithmetic Asian at the reference's precision with a fixed seed (an unseeded AsianOption draws fresh normals per evaluation,
+    #    as the reference's does: nothing to share).  Same bumps, same formulas, same normals as the 8 / 14 price() calls.
+    def _can_fuse(self, pricer_kwargs) -> bool:
+        from .exotic import AsianOption
+        kw = self.exotic_kwargs
+        return (not pricer_kwargs and type(self.exotic) is AsianOption and self.exotic.seed is not None
+                and set(kw) <= {"avg_type", "antithetic", "precision", "option_type"} and kw.get("avg_type", "arithmetic") == "arithmetic"
+                and kw.get("precision", "fp64") == "fp64" and 1 <= self.n_paths <= 1 << 26 and self.n_steps >= 1)
+
+    def _fused_greeks(self, S, K, T, r, sigma, option_type, q, include_second_order, seed=None):
+        import numpy as np
+
+        from . import _hip
+        ex, kw = self.exotic, self.exotic_kwargs
+        vals, _ = _hip.asian_greeks_fd(S, K, T, r, sigma, q, kw.get("option_type", option_type) == "call", self.n_paths, self.n_steps, ex.seed,
+                                       bool(kw.get("antithetic", False)), include_second_order, want_evals=False)
+        ex.S, ex.K, ex.T, ex.r, ex.sigma, ex.q = S, K, T, r, sigma, q
+        keys = ("price", "delta", "gamma", "vega", "theta", "rho", "vanna", "charm", "vomma")
+        return OrderedDict((k, np.float64(v)) for k, v in zip(keys if include_second_order else keys[:6], vals))
+
 
 def compute_greeks_unified(pricer: PricerProtocol, S: float, K: float, T: float, r: float, sigma: float,
                            option_type: Literal["call", "put"] = "call", q: float = 0.0,
@@ -52,11 +73,13 @@ def compute_greeks_unified(pricer: PricerProtocol, S: float, K: float, T: float,
                            **pricer_kwargs) -> "OrderedDict[str, float]":
     try:
         can_fuse = hasattr(pricer, "_fused_greeks") and T > 0 and set(pricer_kwargs) <= {"seed"}
+        if can_fuse and hasattr(pricer, "_can_fuse"):                  # an adapter knows whether ITS payoff has a fused kernel
+            can_fuse = pricer._can_fuse(pricer_kwargs)
         if fused is None:
             fused = can_fuse
         if fused:
             if not can_fuse:
-                raise ValueError("fused Greeks need the device MonteCarloPricer, T > 0 and no extra pricer kwargs")
+                raise ValueError("fused Greeks need the device MonteCarloPricer (or an ExoticAdapter over a seeded arithmetic AsianOption), T > 0 and no extra pricer kwargs")
             return pricer._fused_greeks(S, K, T, r, sigma, option_type, q, include_second_order,
                                         pricer_kwargs.get("seed"))
 

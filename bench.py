@@ -101,6 +101,7 @@ PMC_KERNELS = {         # substring of the demangled kernel name -> key in the J
     "asian_exp64_kernel<true>": "c4_asian_fp64_antithetic",
     "asian_kernel<false, false>": "c4_asian_fp32",
     "asian_kernel<true, false>": "c4_asian_fp32_antithetic",
+    "asian_exp64_greeks_kernel<false, 16>": "c4_asian_greeks14",
     # SURVEY 8(f) kernels (round 4)
     "asian_kernel<false, true>": "f_asian_geometric",
     "extrema_kernel<false>": "f_extrema",
@@ -169,6 +170,9 @@ def pmc_child():
         for anti in (False, True):
             for _ in range(3):
                 a.price(PATHS_PER_GPU, ASIAN_STEPS, "arithmetic", "call", antithetic=anti, precision=precision)
+    ad = ol.ExoticAdapter(ol.AsianOption(*ATM, seed=SEED), n_paths=PATHS_PER_GPU, n_steps=ASIAN_STEPS)
+    for _ in range(3):
+        ol.compute_greeks_unified(ad, *ATM, "call", include_second_order=True)
     from optionslab_amd import _hip
     for _key, (fn, _what, _n, _m) in f_workloads(ol, _hip).items():
         for _ in range(3):
@@ -451,7 +455,8 @@ def compact_line(full, detail_name=None):
         if a.get("gpu_over_cpu"):
             line["c4"]["gpu_over_cpu"] = _num(a["gpu_over_cpu"], 5)
         if isinstance(a.get("greeks"), dict) and "fused_14" in a["greeks"]:
-            line["c4"]["greeks14"] = {"ms": _num(a["greeks"]["fused_14"]["ms"], 4), "x_literal": _num(a["greeks"].get("speedup_14"), 3)}
+            line["c4"]["greeks14"] = {"ms": _num(a["greeks"]["fused_14"]["ms"], 4), "x_literal": _num(a["greeks"].get("speedup_14"), 3),
+                                      "frac": _num(roof_frac(a["greeks"]["fused_14"]), 3)}
     f = full.get("f_kernels")
     if isinstance(f, dict) and "error" not in f:
         line["f"] = {}
@@ -1026,6 +1031,8 @@ def c4_asian(ol, _hip, pmc, costs, mixes, clock_ghz, cpu=None):
     for key, second, fused, reps in (("fused_8", False, True, 8), ("fused_14", True, True, 8), ("literal_8", False, False, 3), ("literal_14", True, False, 3)):
         med, ks, per = _timed_calls(_hip, lambda: ol.compute_greeks_unified(ad, *ATM, "call", include_second_order=second, fused=fused), reps, warm=2)
         greeks[key] = {"ms": med * 1e3, "launches_per_call": per, "kernel_ms_per_launch": ks * 1e3 if ks else None}
+        if key == "fused_14":
+            greeks[key]["roofline"] = roofline_for(pmc, "c4_asian_greeks14", ks, ASIAN_STEPS, PATHS_PER_GPU, costs, mixes, clock_ghz)
     greeks["speedup_14"] = greeks["literal_14"]["ms"] / greeks["fused_14"]["ms"]
     greeks["speedup_8"] = greeks["literal_8"]["ms"] / greeks["fused_8"]["ms"]
     out["greeks"] = greeks

@@ -28,6 +28,7 @@ KERNELS = {      # key in bench.py's JSON -> mangled-name regex
     "c4_asian_fp64_antithetic": r"^_ZN4olmc18asian_exp64_kernelILb1EEE",
     "c4_asian_fp32": r"^_ZN4olmc12asian_kernelILb0ELb0EEE",
     "c4_asian_fp32_antithetic": r"^_ZN4olmc12asian_kernelILb1ELb0EEE",
+    "c4_asian_greeks14": r"^_ZN4olmc25asian_exp64_greeks_kernelILb0ELi16EEE",   # round 4: 14 contracts, six path recursions, one launch
     # round 4: the SURVEY 8(f) kernels
     "f_asian_geometric": r"^_ZN4olmc12asian_kernelILb0ELb1EEE",
     "f_extrema": r"^_ZN4olmc14extrema_kernelILb0EEE",

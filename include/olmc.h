@@ -49,7 +49,7 @@ extern "C" {
                               *    olmc_exp2_probe_form, olmc_phase_stamps, olmc_contract_layout, tune knob 9; every v2 entry point keeps its signature and meaning
                               * 4: the measurement entry points (olmc_*probe*, olmc_phase_stamps, olmc_clock_probe, olmc_normal_moments) and the
                               *    fault-injection knobs 5 / 6 LEFT this library for the instrumented build (olmc_probe.h, libolmc_probe.so); added
-                              *    olmc_multi_gpu_greeks_fd, olmc_multi_gpu_european_cv, olmc_asian_greeks_fd; every pricing entry point keeps its signature and meaning;
+                              *    olmc_multi_gpu_greeks_fd, olmc_multi_gpu_european_cv, olmc_asian_greeks_fd, olmc_extrema_greeks_fd; every pricing entry point keeps its signature and meaning;
                               *    entry points are now concurrent across threads (a context per caller, olmc.h "Threading") */
 
 enum {
@@ -255,6 +255,16 @@ int olmc_barrier(double S, double K, double T, double r, double sigma, double q,
 int olmc_lookback(double S, double K, double T, double r, double sigma, double q, int is_call,
                   int fixed_strike, int64_t path_offset, int64_t n_local, int32_t n_steps,
                   uint64_t seed, int antithetic, olmc_stats* out);
+
+/* Finite-difference Greeks of a barrier / lookback option in ONE launch: the 8 / 14 bumped contracts compute_greeks_unified prices
+ * through ExoticAdapter(BarrierOption | LookbackOption) (src/greeks/unified_greeks.py:177-227, 295-358; live caller
+ * streamlit_app/pages/7_Exotic_Options.py:266-284) on the SAME normals, as at most six recursions of (cumulative log-return, running
+ * max, running min) -- see olmc_asian_greeks_fd.  payoff: OLMC_BARRIER_UP_OUT .. OLMC_BARRIER_DOWN_IN (`barrier` = the level) or
+ * OLMC_LOOKBACK_FLOATING / OLMC_LOOKBACK_FIXED (`barrier` ignored).  out9 / evals as olmc_european_greeks_fd. */
+enum { OLMC_LOOKBACK_FLOATING = 4, OLMC_LOOKBACK_FIXED = 5 };
+int olmc_extrema_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call, int payoff, double barrier,
+                           int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic, int second_order,
+                           double* out9, olmc_stats* evals /* [14] or NULL */);
 
 /* ---- structured products on the step loop ----------------------------------------
  * olmc_autocallable replaces AutocallableOption.price (src/pricing_models/exotic_options.py:404-491):

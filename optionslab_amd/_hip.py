@@ -78,6 +78,7 @@ PROTOTYPES = {
     "olmc_european_qmc_terminal": (_I, [_D] * 5 + [_I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, _I, C.POINTER(_D)]),
     "olmc_asian": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_asian_greeks_fd": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(_D), C.POINTER(Stats)]),
+    "olmc_extrema_greeks_fd": (_I, _SIX + [_I, _I, _D, _I64, _I32, _U64T, _I, _I, C.POINTER(_D), C.POINTER(Stats)]),
     "olmc_barrier": (_I, _SIX + [_I, _D, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_lookback": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_autocallable": (_I, [_D] * 9 + [_I32, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
@@ -438,6 +439,19 @@ def asian_greeks_fd(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: 
     evals = (Stats * 14)() if want_evals else None
     _check(lib().olmc_asian_greeks_fd(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(n_steps), seed64(seed), int(antithetic),
                                       int(second_order), out9, evals))
+    return list(out9), (list(evals) if want_evals else [])
+
+
+LOOKBACK_FLOATING, LOOKBACK_FIXED = 4, 5
+
+
+def extrema_greeks_fd(S, K, T, r, sigma, q, is_call: bool, payoff: int, barrier: float, n_paths: int, n_steps: int, seed: int, antithetic: bool,
+                      second_order: bool, want_evals: bool = True) -> Tuple[List[float], List[Stats]]:
+    """As european_greeks_fd for a barrier (payoff = BARRIER_KINDS value) or lookback (LOOKBACK_FLOATING / LOOKBACK_FIXED) option: ONE launch."""
+    out9 = (C.c_double * 9)()
+    evals = (Stats * 14)() if want_evals else None
+    _check(lib().olmc_extrema_greeks_fd(S, K, T, r, sigma, q, int(is_call), int(payoff), float(barrier), int(n_paths), int(n_steps), seed64(seed),
+                                        int(antithetic), int(second_order), out9, evals))
     return list(out9), (list(evals) if want_evals else [])
 
 

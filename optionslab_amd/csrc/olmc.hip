@@ -1391,6 +1391,74 @@ extern "C" int olmc_lookback(double S, double K, double T, double r, double sigm
                        n_local, n_steps, seed, antithetic, out);
 }
 
+// The 8 / 14 contracts of compute_greeks_unified over a barrier / lookback option (ExoticAdapter, unified_greeks.py:177-227) in one launch.
+extern "C" int olmc_extrema_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call, int payoff, double barrier,
+                                      int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic, int second_order, double* out9,
+                                      olmc_stats* evals) {
+    if (!out9) return fail(OLMC_ERR_ARG, "null pointer");
+    if (!(T > 0.0)) return fail(OLMC_ERR_ARG, "T must be > 0");
+    if (payoff < kBarrierUpOut || payoff > kLookbackFixed) return fail(OLMC_ERR_ARG, "payoff must be a barrier kind (0..3) or OLMC_LOOKBACK_FLOATING / _FIXED (4, 5)");
+    const bool is_barrier = payoff <= kBarrierDownIn;
+    if (is_barrier && !(barrier > 0.0)) return fail(OLMC_ERR_ARG, "Barrier must be positive");
+    int rc = check_paths(0, n_paths, n_steps);
+    if (rc) return rc;
+    if (n_paths > static_cast<int64_t>(kMaxGrid) * kBlock) return fail(OLMC_ERR_ARG, "n_paths beyond one launch of the fused Greeks kernel (2^26)");
+    const GreeksSet gs(S, K, T, r, sigma, q, is_call, second_order);
+    ExtremaGreeksSet es{};
+    int n_groups = 0;
+    for (int i = 0; i < gs.k; ++i) {
+        const olmc_option& o = gs.o[i];
+        const double dt = o.T / n_steps;                             // exotic_options.py:54-56, as run_extrema
+        const double drift = (o.r - o.q - 0.5 * o.sigma * o.sigma) * dt, vol = o.sigma * std::sqrt(dt) * kZScale;
+        int g = 0;
+        while (g < n_groups && !(std::memcmp(&es.drift[g], &drift, sizeof drift) == 0 && std::memcmp(&es.vol[g], &vol, sizeof vol) == 0)) ++g;
+        if (g == n_groups) {
+            if (n_groups == kAsianGroups) return fail(OLMC_ERR_STATE, "more distinct path recursions than the fused Greeks kernel carries");
+            es.drift[g] = drift;
+            es.vol[g] = vol;
+            ++n_groups;
+        }
+        es.group[i] = g;
+        es.s0[i] = o.S;
+        es.log_barrier_rel[i] = is_barrier ? std::log(barrier / o.S) : 0.0;
+    }
+    for (int g = n_groups; g < kAsianGroups; ++g) { es.drift[g] = es.drift[0]; es.vol[g] = es.vol[0]; }
+    es.strike = K;
+    es.sign = is_call ? 1.0 : -1.0;
+    es.payoff = payoff;
+    CtxLease lease;
+    rc = ctx_lease(&lease);
+    if (rc) return rc;
+    DeviceCtx* const c = lease.c;
+    const PathRange pr = make_range(0, n_paths, n_steps, seed);
+    const int32_t grid = static_cast<int32_t>((n_paths + kBlock - 1) / kBlock);      // the grid covers every path
+    const int nsets = gs.k <= 8 ? 8 : 16;
+    ReduceWs ws;
+    rc = make_ws(c, c->stream, grid, 2 * nsets, c->d_result, -1.0, &ws);
+    if (rc) return rc;
+    EventPair ep{};
+    const EventPair* timed = nullptr;
+    rc = prof_pair(c, &ep, &timed);
+    if (rc) return rc;
+    const bool anti = antithetic != 0;
+    if (nsets == 8 && anti) launch_timed(extrema_greeks_kernel<true, 8>, dim3(grid), dim3(kBlock), c->stream, timed, pr, es, ws);
+    else if (nsets == 8) launch_timed(extrema_greeks_kernel<false, 8>, dim3(grid), dim3(kBlock), c->stream, timed, pr, es, ws);
+    else if (anti) launch_timed(extrema_greeks_kernel<true, 16>, dim3(grid), dim3(kBlock), c->stream, timed, pr, es, ws);
+    else launch_timed(extrema_greeks_kernel<false, 16>, dim3(grid), dim3(kBlock), c->stream, timed, pr, es, ws);
+    rc = after_launch(c, c->stream);
+    if (rc) return rc;
+    rc = sync_or_recover(c, c->stream);
+    if (rc) return rc;
+    const int64_t n = n_paths * (anti ? 2 : 1);
+    olmc_stats st[OLMC_MAX_BATCH];
+    for (int i = 0; i < gs.k; ++i) {
+        finish_stats(c->h_result[2 * i], c->h_result[2 * i + 1], n, gs.o[i].r, gs.o[i].T, &st[i]);
+        if (poisoned(gs.o[i].S, gs.o[i].K, gs.o[i].T, gs.o[i].r, gs.o[i].sigma, gs.o[i].q) || std::isnan(barrier)) nan_stats(n, &st[i]);
+    }
+    gs.finish(st, T, out9, evals);
+    return OLMC_OK;
+}
+
 // ======================================================= autocallable / cliquet ====
 namespace {
 template <typename Launch>

@@ -1364,6 +1364,90 @@ __global__ __launch_bounds__(kBlock) void extrema_kernel(PathRange pr, ExtremaCo
     block_then_grid_reduce<2>(acc, ws);
 }
 
+// Finite-difference Greeks of a barrier / lookback option in ONE launch (round 4; the live caller is streamlit_app/pages/
+// 7_Exotic_Options.py:266-284: compute_greeks_unified over ExoticAdapter(BarrierOption | LookbackOption)).  As for the Asian
+// (asian_exp64_greeks_kernel) a contract enters the step loop only through its drift and vol per step: the 8 / 14 contracts are at most
+// six recursions of (cumulative log-return, its running max, its running min); spot, strike and the barrier's level relative to the
+// spot act in the epilogue.  Each recursion is extrema_kernel's own arithmetic, each payoff extrema_payoff's.
+struct ExtremaGreeksSet {
+    double drift[kAsianGroups], vol[kAsianGroups];      // per step; vol already x kZScale (host: extrema_kernel's product)
+    double s0[16], log_barrier_rel[16];                 // contract s: spot, ln(B / S_s) (0 for lookbacks and unused slots)
+    double strike, sign;
+    int32_t group[16];
+    int32_t payoff, pad;
+};
+
+template <bool ANTI, int NSETS>
+__global__ __launch_bounds__(kBlock) void extrema_greeks_kernel(PathRange pr, ExtremaGreeksSet gs, ReduceWs ws) {
+    constexpr int NV = 2 * NSETS, G = kAsianGroups, LEGS = ANTI ? 2 : 1;
+    double acc[NV];                                     // the grid covers every path (host guarantee): born after the step loop
+    const RoundKeys rk = pin_round_keys(pr.key0, pr.key1);
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const uint64_t gp = pr.first + static_cast<uint64_t>(i < pr.count ? i : 0);
+    const uint32_t g_lo = static_cast<uint32_t>(gp), g_hi = static_cast<uint32_t>(gp >> 32);
+    double cum[LEGS][G], mx[LEGS][G], mn[LEGS][G];
+#pragma unroll
+    for (int leg = 0; leg < LEGS; ++leg)
+#pragma unroll
+        for (int g = 0; g < G; ++g) cum[leg][g] = mx[leg][g] = mn[leg][g] = 0.0;         // t = 0: ln(S_0 / S_0) = 0
+    auto dates = [&](const float (&z)[4], auto live) {
+#pragma unroll
+        for (int j = 0; j < decltype(live)::value; ++j) {
+            const double zj = static_cast<double>(z[j]);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                cum[0][g] += __builtin_fma(gs.vol[g], zj, gs.drift[g]);
+                mx[0][g] = fmax(mx[0][g], cum[0][g]);
+                mn[0][g] = fmin(mn[0][g], cum[0][g]);
+                if constexpr (ANTI) {
+                    cum[1][g] += __builtin_fma(-gs.vol[g], zj, gs.drift[g]);
+                    mx[1][g] = fmax(mx[1][g], cum[1][g]);
+                    mn[1][g] = fmin(mn[1][g], cum[1][g]);
+                }
+            }
+        }
+    };
+    const int32_t full = pr.n_steps >> 2, rem = pr.n_steps & 3;
+    float z[4];
+    for (int32_t b = 0; b < full; ++b) {                // branch-free body
+        raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(b), 0u, rk, z);
+        dates(z, std::integral_constant<int, 4>{});
+    }
+    if (rem) {
+        raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(full), 0u, rk, z);
+        if (rem == 1) dates(z, std::integral_constant<int, 1>{});
+        else if (rem == 2) dates(z, std::integral_constant<int, 2>{});
+        else dates(z, std::integral_constant<int, 3>{});
+    }
+    const bool alive = i < pr.count;
+#pragma unroll 1
+    for (int s = 0; s < NSETS; ++s) {                   // a real loop: the payoff holds up to three library exponentials
+        const int32_t g = gs.group[s];                  // launch-uniform
+        ExtremaContract c;
+        c.s0 = gs.s0[s]; c.log_barrier_rel = gs.log_barrier_rel[s]; c.drift = 0.0; c.vol = 0.0; c.strike = gs.strike; c.sign = gs.sign;
+        c.payoff = gs.payoff; c.pad = 0;
+        double sum = 0.0, sumsq = 0.0;
+#pragma unroll
+        for (int leg = 0; leg < LEGS; ++leg) {
+            double a = cum[leg][0], b = mx[leg][0], d = mn[leg][0];
+#pragma unroll
+            for (int k = 1; k < G; ++k) {
+                a = g == k ? cum[leg][k] : a;
+                b = g == k ? mx[leg][k] : b;
+                d = g == k ? mn[leg][k] : d;
+            }
+            const double x = alive ? extrema_payoff(c, a, b, d) : 0.0;
+            sum += x;
+            sumsq += x * x;
+        }
+        // acc[] is indexed by the loop variable: keep it in registers by writing through a compile-time switch
+#pragma unroll
+        for (int k = 0; k < NSETS; ++k)
+            if (k == s) { acc[2 * k] = sum; acc[2 * k + 1] = sumsq; }
+    }
+    block_then_grid_reduce<NV>(acc, ws);
+}
+
 // Structured products on the step loop, observation dates counted down in a scalar register.
 //   autocallable (exotic_options.py:404-491): on every observation date t = f, 2f, ... <= M an
 //     unredeemed path with S_t/S_0 >= autocall_barrier redeems (1 + c (i+1)/n_obs T) e^{-r t dt};

@@ -45,23 +45,45 @@ class ExoticAdapter:
         kw.setdefault("option_type", option_type)
         return ex.price(n_paths=self.n_paths, n_steps=self.n_steps, **kw)
 
-    # -- additive: the 8 / 14 evaluations of compute_greeks_unified in ONE launch where the device has a fused kernel for the payoff:
-    #    the arithmetic Asian at the reference's precision with a fixed seed (an unseeded AsianOption draws fresh normals per evaluation,
-    #    as the reference's does: nothing to share).  Same bumps, same formulas, same normals as the 8 / 14 price() calls.
+    # -- additive: the 8 / 14 evaluations of compute_greeks_unified in ONE launch where the device has a fused kernel for the payoff --
+    #    the arithmetic Asian at the reference's precision, barrier and lookback options (the payoffs streamlit_app/pages/
+    #    7_Exotic_Options.py:266-284 asks Greeks of) -- and the option has a fixed seed (an unseeded one draws fresh normals per
+    #    evaluation, as the reference's does: nothing to share).  Same bumps, same formulas, same normals as the 8 / 14 price() calls.
+    def _fused_plan(self):
+        """(kind, payoff code, barrier level) of the fused kernel that prices this adapter's option, or None."""
+        from .exotic import AsianOption, BarrierOption, LookbackOption
+        ex, kw = self.exotic, self.exotic_kwargs
+        if ex.seed is None or not (1 <= self.n_paths <= 1 << 26) or self.n_steps < 1:
+            return None
+        if type(ex) is AsianOption:
+            ok = set(kw) <= {"avg_type", "antithetic", "precision", "option_type"} and kw.get("avg_type", "arithmetic") == "arithmetic" and kw.get("precision", "fp64") == "fp64"
+            return ("asian", 0, 0.0) if ok else None
+        if type(ex) is BarrierOption:
+            kind = kw.get("barrier_type", "up-and-out")
+            if not (set(kw) <= {"barrier_type", "antithetic", "option_type"} and isinstance(kind, str) and ex.barrier > 0):
+                return None
+            return ("extrema", (0 if kind.startswith("up") else 2) + (0 if kind.endswith("out") else 1), float(ex.barrier))      # exotic_options.py:201-212
+        if type(ex) is LookbackOption:
+            if not set(kw) <= {"lookback_type", "antithetic", "option_type"}:
+                return None
+            return ("extrema", 4 if kw.get("lookback_type", "floating") == "floating" else 5, 0.0)
+        return None
+
     def _can_fuse(self, pricer_kwargs) -> bool:
-        from .exotic import AsianOption
-        kw = self.exotic_kwargs
-        return (not pricer_kwargs and type(self.exotic) is AsianOption and self.exotic.seed is not None
-                and set(kw) <= {"avg_type", "antithetic", "precision", "option_type"} and kw.get("avg_type", "arithmetic") == "arithmetic"
-                and kw.get("precision", "fp64") == "fp64" and 1 <= self.n_paths <= 1 << 26 and self.n_steps >= 1)
+        return not pricer_kwargs and self._fused_plan() is not None
 
     def _fused_greeks(self, S, K, T, r, sigma, option_type, q, include_second_order, seed=None):
         import numpy as np
 
         from . import _hip
         ex, kw = self.exotic, self.exotic_kwargs
-        vals, _ = _hip.asian_greeks_fd(S, K, T, r, sigma, q, kw.get("option_type", option_type) == "call", self.n_paths, self.n_steps, ex.seed,
-                                       bool(kw.get("antithetic", False)), include_second_order, want_evals=False)
+        kind, payoff, level = self._fused_plan()
+        is_call, anti = kw.get("option_type", option_type) == "call", bool(kw.get("antithetic", False))
+        if kind == "asian":
+            vals, _ = _hip.asian_greeks_fd(S, K, T, r, sigma, q, is_call, self.n_paths, self.n_steps, ex.seed, anti, include_second_order, want_evals=False)
+        else:
+            vals, _ = _hip.extrema_greeks_fd(S, K, T, r, sigma, q, is_call, payoff, level, self.n_paths, self.n_steps, ex.seed, anti, include_second_order,
+                                             want_evals=False)
         ex.S, ex.K, ex.T, ex.r, ex.sigma, ex.q = S, K, T, r, sigma, q
         keys = ("price", "delta", "gamma", "vega", "theta", "rho", "vanna", "charm", "vomma")
         return OrderedDict((k, np.float64(v)) for k, v in zip(keys if include_second_order else keys[:6], vals))
@@ -79,7 +101,7 @@ def compute_greeks_unified(pricer: PricerProtocol, S: float, K: float, T: float,
             fused = can_fuse
         if fused:
             if not can_fuse:
-                raise ValueError("fused Greeks need the device MonteCarloPricer (or an ExoticAdapter over a seeded arithmetic AsianOption), T > 0 and no extra pricer kwargs")
+                raise ValueError("fused Greeks need the device MonteCarloPricer (or an ExoticAdapter over a seeded arithmetic Asian, barrier or lookback option), T > 0 and no extra pricer kwargs")
             return pricer._fused_greeks(S, K, T, r, sigma, option_type, q, include_second_order,
                                         pricer_kwargs.get("seed"))
 

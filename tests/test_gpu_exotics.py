@@ -531,6 +531,62 @@ def test_fused_asian_greeks_equal_the_literal_bump_and_reprice(second, anti):
     assert isinstance(fused["delta"], np.float64)
 
 
+@pytest.mark.parametrize("second", [False, True])
+@pytest.mark.parametrize("kind", ["up-and-out", "up-and-in", "down-and-out", "down-and-in", "floating", "fixed"])
+def test_fused_barrier_and_lookback_greeks_equal_the_literal_bump_and_reprice(kind, second):
+    """olmc_extrema_greeks_fd (the Greeks streamlit_app/pages/7_Exotic_Options.py:266-284 asks for): the 8 / 14 bumped contracts as six
+    recursions of (cumulative log-return, running max, running min) in ONE launch against the 8 / 14 launches of extrema_kernel on the
+    same normals -- every evaluation's own sums to 1e-13 (a spot bump moves the barrier's RELATIVE level, not the path), every Greek to
+    1e-8, through ExoticAdapter as the page calls it."""
+    S, K, T, r, v, q = 100.0, 100.0, 1.0, 0.05, 0.2, 0.01
+    N, M, seed, anti = 60_001, 50, 42, kind == "down-and-out"
+    barrier = 125.0 if kind.startswith("up") else 82.0
+    is_call = kind not in ("down-and-in", "fixed")
+    if kind in ("floating", "fixed"):
+        payoff, level = (4 if kind == "floating" else 5), 0.0
+        one_launch = lambda S_, T_, r_, v_: _hip.lookback(S_, K, T_, r_, v_, q, is_call, kind == "fixed", N, M, seed, anti)
+        opt, kw = ol.LookbackOption(S, K, T, r, v, q, seed=seed), dict(lookback_type=kind)
+    else:
+        payoff, level = _hip.BARRIER_KINDS[kind], barrier
+        one_launch = lambda S_, T_, r_, v_: _hip.barrier(S_, K, T_, r_, v_, q, is_call, barrier, payoff, N, M, seed, anti)
+        opt, kw = ol.BarrierOption(S, K, T, r, v, q, seed=seed, barrier=barrier), dict(barrier_type=kind)
+    vals, evals = _hip.extrema_greeks_fd(S, K, T, r, v, q, is_call, payoff, level, N, M, seed, anti, second)
+    h_S, h_v, h_r, h_T = max(1e-4, 0.01 * S), 0.01, 1e-4, 1 / 365.0
+    bumps = [(S, T, r, v), (S + h_S, T, r, v), (S - h_S, T, r, v), (S, T, r, v + h_v), (S, T, r, v - h_v), (S, T - h_T, r, v), (S, T, r + h_r, v), (S, T, r - h_r, v)]
+    if second:
+        bumps += [(S + h_S, T, r, v + h_v), (S + h_S, T, r, v - h_v), (S - h_S, T, r, v + h_v), (S - h_S, T, r, v - h_v), (S + h_S, T - h_T, r, v), (S - h_S, T - h_T, r, v)]
+    for bump, got in zip(bumps, evals):
+        one = one_launch(*bump)
+        assert got.n == one.n and got.sum == pytest.approx(one.sum, rel=1e-13) and got.sumsq == pytest.approx(one.sumsq, rel=1e-13), (kind, bump)
+    ad = ol.ExoticAdapter(opt, n_paths=N, n_steps=M, antithetic=anti, **kw)
+    typ = "call" if is_call else "put"
+    fused = ol.compute_greeks_unified(ad, S, K, T, r, v, typ, q, include_second_order=second)
+    assert (opt.S, opt.T, opt.sigma) == (S, T, v)
+    literal = ol.compute_greeks_unified(ad, S, K, T, r, v, typ, q, include_second_order=second, fused=False)
+    assert list(fused) == list(literal) and [float(x) for x in fused.values()] == vals[:len(fused)]
+    for k in fused:
+        assert fused[k] == pytest.approx(literal[k], rel=1e-8, abs=1e-8), (kind, k)
+    assert fused["price"] > 0 and isinstance(fused["vega"], np.float64)
+
+
+def test_the_exotic_page_greeks_take_one_launch_each():
+    """streamlit_app/pages/7_Exotic_Options.py:266-284 as it calls: ExoticAdapter(option, n_paths=10000, n_steps=50, <type kwarg>) and
+    compute_greeks_unified(..., include_second_order=False), for the three payoffs it offers Greeks of."""
+    S, K, T, r, v = ATM if "ATM" in globals() else (100.0, 100.0, 1.0, 0.05, 0.2)
+    _hip.profile_enable(True)
+    try:
+        for opt, kw in ((ol.AsianOption(S, K, T, r, v, seed=42), dict(avg_type="arithmetic")),
+                        (ol.BarrierOption(S, K, T, r, v, seed=42, barrier=120.0), dict(barrier_type="up-and-out")),
+                        (ol.LookbackOption(S, K, T, r, v, seed=42), dict(lookback_type="floating"))):
+            ad = ol.ExoticAdapter(opt, n_paths=10000, n_steps=50, **kw)
+            _hip.profile_reset()
+            g = ol.compute_greeks_unified(ad, S, K, T, r, v, "call", include_second_order=False)
+            launches, _ms = _hip.kernel_time()
+            assert launches == 1 and list(g) == ["price", "delta", "gamma", "vega", "theta", "rho"] and g["price"] > 0, (type(opt).__name__, launches)
+    finally:
+        _hip.profile_enable(False)
+
+
 def test_fused_asian_greeks_fall_back_where_there_is_no_fused_kernel():
     """An unseeded option (fresh normals per evaluation, as the reference's), the geometric average and the fp32 form take the literal
     path; asking for fused=True there is an error, as it is for any pricer without a fused form."""

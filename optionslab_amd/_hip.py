@@ -77,7 +77,7 @@ PROTOTYPES = {
     "olmc_european_qmc_greeks_fd": (_I, _SIX + [_I, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, _I, C.POINTER(_D), C.POINTER(Stats)]),
     "olmc_european_qmc_terminal": (_I, [_D] * 5 + [_I64, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, _I, C.POINTER(_D)]),
     "olmc_asian": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
-    "olmc_asian_greeks_fd": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(_D), C.POINTER(Stats)]),
+    "olmc_asian_greeks_fd": (_I, _SIX + [_I, _I, _I64, _I32, _U64T, _I, _I, C.POINTER(_D), C.POINTER(Stats)]),
     "olmc_extrema_greeks_fd": (_I, _SIX + [_I, _I, _D, _I64, _I32, _U64T, _I, _I, C.POINTER(_D), C.POINTER(Stats)]),
     "olmc_barrier": (_I, _SIX + [_I, _D, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
     "olmc_lookback": (_I, _SIX + [_I, _I, _I64, _I64, _I32, _U64T, _I, C.POINTER(Stats)]),
@@ -433,12 +433,13 @@ def asian(S, K, T, r, sigma, q, is_call: bool, geometric: bool, n_paths: int, n_
 
 
 def asian_greeks_fd(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_steps: int, seed: int, antithetic: bool, second_order: bool,
-                    want_evals: bool = True) -> Tuple[List[float], List[Stats]]:
-    """As european_greeks_fd for the arithmetic Asian at the reference's precision: the 8 / 14 bumped contracts in ONE launch."""
+                    want_evals: bool = True, geometric: bool = False) -> Tuple[List[float], List[Stats]]:
+    """As european_greeks_fd for the Asian option (arithmetic at the reference's precision, or geometric): the 8 / 14 bumped contracts in
+    ONE launch."""
     out9 = (C.c_double * 9)()
     evals = (Stats * 14)() if want_evals else None
-    _check(lib().olmc_asian_greeks_fd(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(n_steps), seed64(seed), int(antithetic),
-                                      int(second_order), out9, evals))
+    _check(lib().olmc_asian_greeks_fd(S, K, T, r, sigma, q, int(is_call), AVG_GEOMETRIC if geometric else AVG_ARITHMETIC, int(n_paths), int(n_steps),
+                                      seed64(seed), int(antithetic), int(second_order), out9, evals))
     return list(out9), (list(evals) if want_evals else [])
 
 

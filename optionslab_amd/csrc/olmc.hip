@@ -1264,10 +1264,13 @@ extern "C" int olmc_asian(double S, double K, double T, double r, double sigma, 
 }
 
 // The 8 / 14 contracts of compute_greeks_unified over an arithmetic Asian (ExoticAdapter, unified_greeks.py:177-227) in one launch.
-extern "C" int olmc_asian_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t n_paths,
+extern "C" int olmc_asian_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call, int avg_kind, int64_t n_paths,
                                     int32_t n_steps, uint64_t seed, int antithetic, int second_order, double* out9, olmc_stats* evals) {
     if (!out9) return fail(OLMC_ERR_ARG, "null pointer");
     if (!(T > 0.0)) return fail(OLMC_ERR_ARG, "T must be > 0");
+    if (avg_kind != OLMC_AVG_ARITHMETIC && avg_kind != OLMC_AVG_GEOMETRIC)
+        return fail(OLMC_ERR_ARG, "avg_kind must be OLMC_AVG_ARITHMETIC or OLMC_AVG_GEOMETRIC (the fp32-exponent form has no fused Greeks)");
+    const bool geo = avg_kind == OLMC_AVG_GEOMETRIC;
     int rc = check_paths(0, n_paths, n_steps);
     if (rc) return rc;
     const GreeksSet gs(S, K, T, r, sigma, q, is_call, second_order);
@@ -1287,11 +1290,13 @@ extern "C" int olmc_asian_greeks_fd(double S, double K, double T, double r, doub
         }
         as.group[i] = g;
         as.s0[i] = o.S;
+        as.log_s0[i] = std::log(o.S);
     }
     for (int g = n_groups; g < kAsianGroups; ++g) { as.drift[g] = as.drift[0]; as.vol[g] = as.vol[0]; }
-    {   // into the exponential's units, by the very products asian_exp64_kernel forms on the device (drift * kUnit; vol * kZScale * kUnit)
+    {   // into the units the kernel sums in, by the very products the one-contract kernels form on the device: arithmetic (asian_exp64_kernel)
+        // drift * kUnit, vol * kZScale * kUnit; geometric (asian_kernel<., true>) drift * 1.0, vol * kZScale * 1.0
         constexpr double kLog2e = 1.4426950408889634;
-        constexpr double kUnit = OLMC_EXP2_TABLE ? kExp2Entries * kLog2e : kLog2e;
+        const double kUnit = geo ? 1.0 : (OLMC_EXP2_TABLE ? kExp2Entries * kLog2e : kLog2e);
         for (int g = 0; g < kAsianGroups; ++g) {
             as.drift[g] = as.drift[g] * kUnit;
             as.vol[g] = as.vol[g] * kZScale * kUnit;
@@ -1316,7 +1321,12 @@ extern "C" int olmc_asian_greeks_fd(double S, double K, double T, double r, doub
     rc = prof_pair(c, &ep, &timed);
     if (rc) return rc;
     const bool anti = antithetic != 0;
-    if (nsets == 8 && anti) launch_timed(asian_exp64_greeks_kernel<true, 8>, dim3(grid), dim3(kBlock), c->stream, timed, pr, as, ws);
+    if (geo) {
+        if (nsets == 8 && anti) launch_timed(asian_geometric_greeks_kernel<true, 8>, dim3(grid), dim3(kBlock), c->stream, timed, pr, as, ws);
+        else if (nsets == 8) launch_timed(asian_geometric_greeks_kernel<false, 8>, dim3(grid), dim3(kBlock), c->stream, timed, pr, as, ws);
+        else if (anti) launch_timed(asian_geometric_greeks_kernel<true, 16>, dim3(grid), dim3(kBlock), c->stream, timed, pr, as, ws);
+        else launch_timed(asian_geometric_greeks_kernel<false, 16>, dim3(grid), dim3(kBlock), c->stream, timed, pr, as, ws);
+    } else if (nsets == 8 && anti) launch_timed(asian_exp64_greeks_kernel<true, 8>, dim3(grid), dim3(kBlock), c->stream, timed, pr, as, ws);
     else if (nsets == 8) launch_timed(asian_exp64_greeks_kernel<false, 8>, dim3(grid), dim3(kBlock), c->stream, timed, pr, as, ws);
     else if (anti) launch_timed(asian_exp64_greeks_kernel<true, 16>, dim3(grid), dim3(kBlock), c->stream, timed, pr, as, ws);
     else launch_timed(asian_exp64_greeks_kernel<false, 16>, dim3(grid), dim3(kBlock), c->stream, timed, pr, as, ws);

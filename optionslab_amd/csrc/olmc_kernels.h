@@ -1210,8 +1210,10 @@ constexpr int kAsianGroups = 6;
 
 struct AsianGreeksSet {
     double drift[kAsianGroups], vol[kAsianGroups];      // per step, in the exponential's units: AsianContract's drift x kUnit, vol x kZScale x kUnit
-                                                        // (host side: the two products asian_exp64_kernel forms; unused groups repeat group 0)
+                                                        // (host side: the two products asian_exp64_kernel forms; unused groups repeat group 0).
+                                                        // Geometric: unit 1 (drift, vol x kZScale), as asian_kernel<., true>
     double s0[16];                                      // spot of contract s (0 for an unused slot)
+    double log_s0[16];                                  // geometric: ln of it
     double strike, sign, inv_steps;
     int32_t group[16];                                  // recursion of contract s
 };
@@ -1277,6 +1279,91 @@ __global__ __launch_bounds__(kBlock) void asian_exp64_greeks_kernel(PathRange pr
                 acc[2 * s + 1] += x * x;
             }
         }
+    }
+    block_then_grid_reduce<NV>(acc, ws);
+}
+
+// The geometric average (asian_kernel<., true>) under the same 8 / 14 bumps.  Here even the six recursions share almost everything:
+// inside a group of 16 dates only the fp32 prefix sum p of the group's RAW normals and the sum pp of those prefixes move, and neither
+// depends on the contract; a recursion enters when a group CLOSES -- run += vol pp + n base + drift n(n+1)/2, base += vol p + n drift,
+// five fp64 operations per 16 dates.  All 14 contracts of second-order Greeks therefore cost ONE geometric pricing (+ 6 x 5 fp64
+// operations per 16 dates and 14 exponentials per path).  Same operations in the same order as asian_kernel<ANTI, true> per recursion.
+template <bool ANTI, int NSETS>
+__global__ __launch_bounds__(kBlock) void asian_geometric_greeks_kernel(PathRange pr, AsianGreeksSet gs, ReduceWs ws) {
+    constexpr int NV = 2 * NSETS, G = kAsianGroups, LEGS = ANTI ? 2 : 1;
+    double acc[NV];                                     // the grid covers every path (host guarantee): born after the date loop
+    const RoundKeys rk = pin_round_keys(pr.key0, pr.key1);
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const uint64_t gp = pr.first + static_cast<uint64_t>(i < pr.count ? i : 0);
+    const uint32_t g_lo = static_cast<uint32_t>(gp), g_hi = static_cast<uint32_t>(gp >> 32);
+    double base[LEGS][G], run[LEGS][G];
+#pragma unroll
+    for (int leg = 0; leg < LEGS; ++leg)
+#pragma unroll
+        for (int g = 0; g < G; ++g) base[leg][g] = run[leg][g] = 0.0;
+    float p = 0.0f, pp = 0.0f;                          // the group in flight: prefix sum of its raw normals, sum of those prefixes
+    auto close_group = [&](int32_t n) {
+        const double pd = static_cast<double>(p), ppd = static_cast<double>(pp), nd = static_cast<double>(n);
+        const double tri = 0.5 * nd * (nd + 1.0);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            run[0][g] += __builtin_fma(gs.vol[g], ppd, __builtin_fma(nd, base[0][g], gs.drift[g] * tri));
+            base[0][g] += __builtin_fma(gs.vol[g], pd, nd * gs.drift[g]);
+            if constexpr (ANTI) {
+                run[1][g] += __builtin_fma(-gs.vol[g], ppd, __builtin_fma(nd, base[1][g], gs.drift[g] * tri));
+                base[1][g] += __builtin_fma(-gs.vol[g], pd, nd * gs.drift[g]);
+            }
+        }
+        p = 0.0f; pp = 0.0f;
+    };
+    auto dates = [&](const float (&z)[4], auto live) {
+#pragma unroll
+        for (int j = 0; j < decltype(live)::value; ++j) { p += z[j]; pp += p; }
+    };
+    const int32_t full = pr.n_steps >> 2, rem = pr.n_steps & 3;
+    float z[4];
+    int32_t b = 0;
+    for (; b + kAsianGroupBlocks <= full; b += kAsianGroupBlocks) {
+#pragma unroll
+        for (int k = 0; k < kAsianGroupBlocks; ++k) {
+            raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(b + k), 0u, rk, z);
+            dates(z, std::integral_constant<int, 4>{});
+        }
+        close_group(4 * kAsianGroupBlocks);
+    }
+    const int32_t tail_blocks = full - b;
+#pragma unroll
+    for (int k = 0; k < kAsianGroupBlocks; ++k) {
+        if (k < tail_blocks) {
+            raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(b + k), 0u, rk, z);
+            dates(z, std::integral_constant<int, 4>{});
+        } else if (k == tail_blocks && rem) {
+            raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(full), 0u, rk, z);
+            if (rem == 1) dates(z, std::integral_constant<int, 1>{});
+            else if (rem == 2) dates(z, std::integral_constant<int, 2>{});
+            else dates(z, std::integral_constant<int, 3>{});
+        }
+    }
+    const int32_t open_dates = 4 * tail_blocks + rem;
+    if (open_dates) close_group(open_dates);
+    const bool alive = i < pr.count;
+#pragma unroll 1
+    for (int s = 0; s < NSETS; ++s) {                   // a real loop: one library exponential per contract and leg
+        const int32_t g = gs.group[s];                  // launch-uniform
+        double sum = 0.0, sumsq = 0.0;
+#pragma unroll
+        for (int leg = 0; leg < LEGS; ++leg) {
+            double r = run[leg][0];
+#pragma unroll
+            for (int k = 1; k < G; ++k) r = g == k ? run[leg][k] : r;
+            const double avg = exp(gs.log_s0[s] + r * gs.inv_steps);
+            const double x = alive ? fmax(gs.sign * (avg - gs.strike), 0.0) : 0.0;
+            sum += x;
+            sumsq += x * x;
+        }
+#pragma unroll
+        for (int k = 0; k < NSETS; ++k)
+            if (k == s) { acc[2 * k] = sum; acc[2 * k + 1] = sumsq; }
     }
     block_then_grid_reduce<NV>(acc, ws);
 }

@@ -46,7 +46,7 @@ class ExoticAdapter:
         return ex.price(n_paths=self.n_paths, n_steps=self.n_steps, **kw)
 
     # -- additive: the 8 / 14 evaluations of compute_greeks_unified in ONE launch where the device has a fused kernel for the payoff --
-    #    the arithmetic Asian at the reference's precision, barrier and lookback options (the payoffs streamlit_app/pages/
+    #    the Asian (arithmetic at the reference's precision, or geometric), barrier and lookback options (the payoffs streamlit_app/pages/
     #    7_Exotic_Options.py:266-284 asks Greeks of) -- and the option has a fixed seed (an unseeded one draws fresh normals per
     #    evaluation, as the reference's does: nothing to share).  Same bumps, same formulas, same normals as the 8 / 14 price() calls.
     def _fused_plan(self):
@@ -56,8 +56,9 @@ class ExoticAdapter:
         if ex.seed is None or not (1 <= self.n_paths <= 1 << 26) or self.n_steps < 1:
             return None
         if type(ex) is AsianOption:
-            ok = set(kw) <= {"avg_type", "antithetic", "precision", "option_type"} and kw.get("avg_type", "arithmetic") == "arithmetic" and kw.get("precision", "fp64") == "fp64"
-            return ("asian", 0, 0.0) if ok else None
+            geometric = kw.get("avg_type", "arithmetic") != "arithmetic"             # AsianOption.price: anything but "arithmetic" is geometric
+            ok = set(kw) <= {"avg_type", "antithetic", "precision", "option_type"} and kw.get("precision", "fp64") in (("fp64", "fp32") if geometric else ("fp64",))
+            return ("asian", 1 if geometric else 0, 0.0) if ok else None
         if type(ex) is BarrierOption:
             kind = kw.get("barrier_type", "up-and-out")
             if not (set(kw) <= {"barrier_type", "antithetic", "option_type"} and isinstance(kind, str) and ex.barrier > 0):
@@ -80,7 +81,8 @@ class ExoticAdapter:
         kind, payoff, level = self._fused_plan()
         is_call, anti = kw.get("option_type", option_type) == "call", bool(kw.get("antithetic", False))
         if kind == "asian":
-            vals, _ = _hip.asian_greeks_fd(S, K, T, r, sigma, q, is_call, self.n_paths, self.n_steps, ex.seed, anti, include_second_order, want_evals=False)
+            vals, _ = _hip.asian_greeks_fd(S, K, T, r, sigma, q, is_call, self.n_paths, self.n_steps, ex.seed, anti, include_second_order, want_evals=False,
+                                           geometric=payoff == 1)
         else:
             vals, _ = _hip.extrema_greeks_fd(S, K, T, r, sigma, q, is_call, payoff, level, self.n_paths, self.n_steps, ex.seed, anti, include_second_order,
                                              want_evals=False)
@@ -101,7 +103,7 @@ def compute_greeks_unified(pricer: PricerProtocol, S: float, K: float, T: float,
             fused = can_fuse
         if fused:
             if not can_fuse:
-                raise ValueError("fused Greeks need the device MonteCarloPricer (or an ExoticAdapter over a seeded arithmetic Asian, barrier or lookback option), T > 0 and no extra pricer kwargs")
+                raise ValueError("fused Greeks need the device MonteCarloPricer (or an ExoticAdapter over a seeded Asian, barrier or lookback option), T > 0 and no extra pricer kwargs")
             return pricer._fused_greeks(S, K, T, r, sigma, option_type, q, include_second_order,
                                         pricer_kwargs.get("seed"))
 

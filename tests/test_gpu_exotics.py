@@ -506,22 +506,23 @@ def test_jump_rates_beyond_the_inversion_samplers_range_are_refused():
 # ------------------------------------------------------------------ fused Asian Greeks (round 4)
 @pytest.mark.parametrize("second", [False, True])
 @pytest.mark.parametrize("anti", [False, True])
-def test_fused_asian_greeks_equal_the_literal_bump_and_reprice(second, anti):
+@pytest.mark.parametrize("geometric", [False, True])
+def test_fused_asian_greeks_equal_the_literal_bump_and_reprice(second, anti, geometric):
     """olmc_asian_greeks_fd: the 8 / 14 bumped contracts of compute_greeks_unified over ExoticAdapter(AsianOption)
     (unified_greeks.py:177-227, 295-358) as at most six path recursions in ONE launch, against the 8 / 14 launches of the default
-    (fp64-exponent) Asian kernel on the same normals: every evaluation's own sums to 1e-13, every Greek to 1e-8."""
+    (fp64-exponent) arithmetic / the geometric Asian kernel on the same normals: every evaluation's own sums to 1e-13, every Greek to 1e-8."""
     S, K, T, r, v, q = 100.0, 95.0, 0.75, 0.04, 0.25, 0.01
     N, M, seed = 150_001, 67, 9
-    vals, evals = _hip.asian_greeks_fd(S, K, T, r, v, q, True, N, M, seed, anti, second)
+    vals, evals = _hip.asian_greeks_fd(S, K, T, r, v, q, True, N, M, seed, anti, second, geometric=geometric)
     h_S, h_v, h_r, h_T = max(1e-4, 0.01 * S), 0.01, 1e-4, 1 / 365.0
     bumps = [(S, T, r, v), (S + h_S, T, r, v), (S - h_S, T, r, v), (S, T, r, v + h_v), (S, T, r, v - h_v), (S, T - h_T, r, v), (S, T, r + h_r, v), (S, T, r - h_r, v)]
     if second:
         bumps += [(S + h_S, T, r, v + h_v), (S + h_S, T, r, v - h_v), (S - h_S, T, r, v + h_v), (S - h_S, T, r, v - h_v), (S + h_S, T - h_T, r, v), (S - h_S, T - h_T, r, v)]
     for (S_, T_, r_, v_), got in zip(bumps, evals):
-        one = _hip.asian(S_, K, T_, r_, v_, q, True, False, N, M, seed, anti)
+        one = _hip.asian(S_, K, T_, r_, v_, q, True, geometric, N, M, seed, anti)
         assert got.n == one.n and got.sum == pytest.approx(one.sum, rel=1e-13) and got.sumsq == pytest.approx(one.sumsq, rel=1e-13)
         assert got.price == pytest.approx(one.price, rel=1e-13)
-    ad = ol.ExoticAdapter(ol.AsianOption(S, K, T, r, v, q, seed=seed), n_paths=N, n_steps=M, antithetic=anti)
+    ad = ol.ExoticAdapter(ol.AsianOption(S, K, T, r, v, q, seed=seed), n_paths=N, n_steps=M, antithetic=anti, avg_type="geometric" if geometric else "arithmetic")
     fused = ol.compute_greeks_unified(ad, S, K, T, r, v, "call", q, include_second_order=second)
     assert (ad.exotic.S, ad.exotic.T, ad.exotic.sigma) == (S, T, v)          # the fused form leaves the option at the base point
     literal = ol.compute_greeks_unified(ad, S, K, T, r, v, "call", q, include_second_order=second, fused=False)
@@ -571,11 +572,12 @@ def test_fused_barrier_and_lookback_greeks_equal_the_literal_bump_and_reprice(ki
 
 def test_the_exotic_page_greeks_take_one_launch_each():
     """streamlit_app/pages/7_Exotic_Options.py:266-284 as it calls: ExoticAdapter(option, n_paths=10000, n_steps=50, <type kwarg>) and
-    compute_greeks_unified(..., include_second_order=False), for the three payoffs it offers Greeks of."""
+    compute_greeks_unified(..., include_second_order=False), for the payoffs it offers Greeks of (both averages of the Asian)."""
     S, K, T, r, v = ATM if "ATM" in globals() else (100.0, 100.0, 1.0, 0.05, 0.2)
     _hip.profile_enable(True)
     try:
         for opt, kw in ((ol.AsianOption(S, K, T, r, v, seed=42), dict(avg_type="arithmetic")),
+                        (ol.AsianOption(S, K, T, r, v, seed=42), dict(avg_type="geometric")),
                         (ol.BarrierOption(S, K, T, r, v, seed=42, barrier=120.0), dict(barrier_type="up-and-out")),
                         (ol.LookbackOption(S, K, T, r, v, seed=42), dict(lookback_type="floating"))):
             ad = ol.ExoticAdapter(opt, n_paths=10000, n_steps=50, **kw)
@@ -588,14 +590,14 @@ def test_the_exotic_page_greeks_take_one_launch_each():
 
 
 def test_fused_asian_greeks_fall_back_where_there_is_no_fused_kernel():
-    """An unseeded option (fresh normals per evaluation, as the reference's), the geometric average and the fp32 form take the literal
-    path; asking for fused=True there is an error, as it is for any pricer without a fused form."""
+    """An unseeded option (fresh normals per evaluation, as the reference's), the fp32 form of the arithmetic average and a keyword the
+    fused entry point does not know take the literal path; asking for fused=True there is an error, as it is for any pricer without
+    a fused form."""
     base = dict(n_paths=5_000, n_steps=12)
-    geo = ol.ExoticAdapter(ol.AsianOption(100.0, 100.0, 1.0, 0.05, 0.2, seed=3), avg_type="geometric", **base)
-    g = ol.compute_greeks_unified(geo, 100.0, 100.0, 1.0, 0.05, 0.2, "call", include_second_order=False)
-    assert g == ol.compute_greeks_unified(geo, 100.0, 100.0, 1.0, 0.05, 0.2, "call", include_second_order=False, fused=False)
+    odd = ol.ExoticAdapter(ol.AsianOption(100.0, 100.0, 1.0, 0.05, 0.2, seed=3), avg_type="geometric", precision="fp16", **base)
+    assert not odd._can_fuse({})                              # price() rejects it; the literal path is the one that says so
     with pytest.raises(ol.GreeksError):
-        ol.compute_greeks_unified(geo, 100.0, 100.0, 1.0, 0.05, 0.2, "call", fused=True)
+        ol.compute_greeks_unified(odd, 100.0, 100.0, 1.0, 0.05, 0.2, "call", fused=True)
     unseeded = ol.ExoticAdapter(ol.AsianOption(100.0, 100.0, 1.0, 0.05, 0.2), **base)
     assert not unseeded._can_fuse({}) and unseeded.price(100.0, 100.0, 1.0, 0.05, 0.2, "call") > 0
     fast = ol.ExoticAdapter(ol.AsianOption(100.0, 100.0, 1.0, 0.05, 0.2, seed=3), precision="fp32", **base)

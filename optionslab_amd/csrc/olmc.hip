@@ -1623,7 +1623,7 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
     if (poly_degree < 1 || poly_degree > kLsmMaxDegree) return fail(OLMC_ERR_ARG, "poly_degree must be in [1, 4]");
     int rc = check_paths(0, n_paths, n_steps);
     if (rc) return rc;
-    const double path_bytes = 8.0 * static_cast<double>(n_paths) * (n_steps + 2.0) + 512.0;
+    const double path_bytes = 8.0 * static_cast<double>(n_paths) * (n_steps + 2.0) + 8.0 * 2 * 1024 * kLsmNV;   // + two buffers of <= 1024 workgroup rows
     if (path_bytes > 64e9) return fail(OLMC_ERR_ARG, "path matrix would exceed 64 GB: lower n_paths or n_steps");
     CtxLease lease;
     rc = ctx_lease(&lease);
@@ -1633,8 +1633,7 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
     if (rc) return rc;
     double* d_paths = static_cast<double*>(c->d_bulk);                                  // [n_steps + 1][n_paths]
     double* d_cash = d_paths + static_cast<size_t>(n_steps + 1) * n_paths;              // [n_paths]
-    LsmCoeffs* d_coef = reinterpret_cast<LsmCoeffs*>(d_cash + n_paths);                  // fit handed from launch to launch
-    double* d_moments = reinterpret_cast<double*>(d_coef) + 16;                           // [kLsmNV + 1] the sums of the dates in between: nobody on the host reads them
+    double* d_rows = d_cash + n_paths;                                                  // [2][grid][kLsmNV]: the regression sums a date hands to the next launch
     LsmContract lc;
     const double dt = T / n_steps;                      // exotic_options.py:54-56, 260-261
     lc.log_s0 = std::log(S);
@@ -1649,31 +1648,29 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
     lc.n_steps = n_steps;
     const PathRange pr = make_range(0, n_paths, n_steps, seed);
     const int32_t path_grid = grid_for(n_paths);
-    // The per-date launches move 32 bytes per path and reduce 16 sums per workgroup: at most ONE workgroup per compute unit (a single
-    // group of the grid reduction: one ticket round, <= 256 rows for the last workgroup to sum), each thread taking its paths U at a
-    // time (U <= 4: 98 VGPRs) with all 3 U loads in flight.  Measured per call, 51 launches (profiles/r04_lsm_ab.jsonl): 1M x 50 -- 959 us at U = 1,
-    // 816 at 4, 804 at 8 (two workgroups per CU: 887 / 841 / 867; eight: 921 / 980 / 1081); 50k x 50, where a thread has one path --
-    // 429 at U = 1, 441 at 4, 459 at 8 (the unrolled trip's dead slots).  Round 3's kernel (130 VGPRs, 256 B scratch, one path per
-    // trip, two workgroups per CU, serial solve in one lane) took 1,123 / 490 us.
-    const int32_t grid = std::min<int32_t>(path_grid, c->cus);
+    // The per-date launches move 32 bytes per path and hand 16 sums per workgroup to the next launch, EVERY workgroup of which sums all
+    // the rows: at most ONE workgroup per compute unit (<= 256 rows: one round trip), each thread taking its paths U at a time with all
+    // 3 U loads in flight.  With one wave per SIMD the register count buys nothing, so U follows the paths a thread has (1, 2, 4, 8:
+    // 98 ... 170 VGPRs).  Measured per call, 51 launches (profiles/r04_lsm_ab.jsonl): 1M x 50 -- 898 us at U = 1, 771 / 658 / 628 / 662 at
+    // 2 / 4 / 8 / 16; two workgroups per CU 792 / 717 / 674 (U = 1 / 2 / 4), four 978 / 971 / 952 (a workgroup re-reads every row);
+    // 200k x 50 -- 366 / 343 / 328 / 345 at U = 1 / 2 / 4 / 8; 50k x 50, where a thread has one path, 275 - 300 whatever U.
+    const int32_t grid = std::min<int32_t>(path_grid, std::min<int32_t>(c->cus, 1024));
     const int64_t per_thread = (n_paths + static_cast<int64_t>(grid) * kBlock - 1) / (static_cast<int64_t>(grid) * kBlock);
-    const int lsm_unroll = per_thread <= 1 ? 1 : per_thread <= 2 ? 2 : 4;      // U = 8 measured 1.5 % faster at 1M paths and needs 160 VGPRs: not kept
+    const int lsm_unroll = per_thread <= 1 ? 1 : per_thread <= 2 ? 2 : per_thread <= 4 ? 4 : 8;
     EventPair ep{};
     if (g_profile) { rc = prof_begin(c, c->stream, &ep); if (rc) return rc; }
     hipLaunchKernelGGL((lsm_paths_kernel<false>), dim3(path_grid), dim3(kBlock), 0, c->stream, pr, lc, d_paths);
     HIP_TRY(hipGetLastError());
-    // every launch reads the fit of the later date from d_coef and (its last workgroup) writes its own fit there:
-    // stream order is the only synchronisation, the host waits once at the end
+    // every launch sums the rows the launch before it stored, fits the later date from them and stores its own rows: stream order is
+    // the only synchronisation, the host waits once at the end.  Only the LAST launch (t_fit == 0: the moments of the time-0 cash
+    // flow) goes through the grid reduction and writes into the pinned host buffer.
+    ReduceWs ws;
+    rc = make_ws(c, c->stream, grid, kLsmNV, c->d_result, -1.0, &ws);          // arms the completion word for the launch that writes d_result
+    if (rc) return rc;
     int32_t init = 1;
     for (int32_t t_fit = n_steps - 1; t_fit >= 0; --t_fit) {
-        ReduceWs ws;
-        // only the LAST launch (t_fit == 0: the moments of the time-0 cash flow) writes into the pinned host buffer; the sums of the dates
-        // in between go to device memory -- sixteen posted PCIe writes per date would sit between a launch's last wave and its
-        // completion, i.e. in front of the next, dependent launch
-        rc = make_ws(c, c->stream, grid, kLsmNV, t_fit == 0 ? c->d_result : d_moments, -1.0, &ws);
-        if (rc) return rc;                            // (make_ws arms the completion word for the launch that writes d_result: the last one)
         const bool first = init != 0, final_date = t_fit == 0;
-        auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, c->stream, n_paths, lc, d_coef, t_fit, d_paths, d_cash, ws); };
+        auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, c->stream, n_paths, lc, d_rows, t_fit, d_paths, d_cash, ws); };
         auto pick = [&](auto u) {
             constexpr int U = decltype(u)::value;
             if (first && final_date) go(lsm_step_kernel<U, true, true>);
@@ -1683,7 +1680,8 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
         };
         if (lsm_unroll == 1) pick(std::integral_constant<int, 1>{});
         else if (lsm_unroll == 2) pick(std::integral_constant<int, 2>{});
-        else pick(std::integral_constant<int, 4>{});
+        else if (lsm_unroll == 4) pick(std::integral_constant<int, 4>{});
+        else pick(std::integral_constant<int, 8>{});
         rc = after_launch(c, c->stream);
         if (rc) return rc;
         init = 0;

@@ -582,6 +582,30 @@ __device__ __forceinline__ void block_then_grid_reduce_from(double (&w)[pow2_cei
     else grid_reduce_workgroup<NV, Epilogue>(s, ws, done);                         // wide rows: the whole workgroup sums them
 }
 
+// The workgroup half alone: threads < NV return the workgroup's sum of component threadIdx.x (the row block_then_grid_reduce stores).
+// Ends on a barrier-free read of `stage`: a caller that reuses LDS afterwards synchronises itself.
+template <int NV>
+__device__ __forceinline__ double block_row_sum(const double (&v)[NV]) {
+    constexpr int P = pow2_ceil(NV);
+    constexpr int SHIFT = 6 - log2_of(P);
+    __shared__ double stage[kWavesPerBlock][P];
+    double w[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) w[i] = i < NV ? v[i] : 0.0;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    wave_transpose_reduce<P, kWave / 2>(w);
+    if ((lane & ((1 << SHIFT) - 1)) == 0) stage[wave][lane >> SHIFT] = w[0];
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x < NV) {
+        s = stage[0][threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < kWavesPerBlock; ++k) s += stage[k][threadIdx.x];
+    }
+    return s;
+}
+
 template <int NV, typename Epilogue = NoEpilogue>
 __device__ __forceinline__ void block_then_grid_reduce(const double (&v)[NV], const ReduceWs& ws, Epilogue done = Epilogue()) {
     constexpr int P = pow2_ceil(NV);
@@ -1848,8 +1872,8 @@ __device__ __forceinline__ double lsm_intrinsic(const LsmContract& c, double s) 
 
 // Runs in the wave that holds the grid totals of one exercise date (all 64 lanes active): lane m < 2d+1 has sum x^m,
 // lane 9+k has sum x^k cf, lane 14 the in-the-money count.  The wave solves the (d+1)x(d+1) normal equations (Gaussian
-// elimination, partial pivoting, fp64 -- the moments of x = S/K in (0, ~2) are benign) and publishes the coefficients for
-// the NEXT launch, which is ordered behind this one on the stream: no host round trip per exercise date.
+// elimination, partial pivoting, fp64 -- the moments of x = S/K in (0, ~2) are benign) and leaves the coefficients in `coef`
+// (LDS of the workgroup that applies them): no host round trip per exercise date.
 //
 // Round 4: the augmented 5 x 6 matrix lives ONE ELEMENT PER LANE (lane = 8 row + column) instead of thirty doubles in lane 0.
 // Round 3's form indexed its private array with the run-time pivot row (`a[piv][col]`), which put the whole matrix into a
@@ -1918,21 +1942,26 @@ struct LsmFit {
 
 // One exercise date for this thread's paths.  t_fit: the date whose moments are accumulated (>= 1);
 // the date finished first is t_fit + 1 (skipped when init: the terminal payoff needs no regression).
-// init != 0: cash flow starts as the terminal intrinsic value.  `prev` = fit of date t_fit + 1.
+// init != 0: cash flow starts as the terminal intrinsic value.  `fit()` = the regression of date t_fit + 1.
 //
 // A date is 24 bytes read and 8 written per path and ~40 flops: the loop is bounded by how many loads the few resident waves
 // keep in flight, so a thread issues the loads of U of its paths (3 U doubles) before it touches any of them (round 4; round 3
 // walked one path at a time: three dependent load round trips per path, eight paths per thread at 1M paths).  The paths of a
 // thread are still consumed in ascending order, so the sixteen per-thread sums -- and the bits of the price -- do not depend on U.
-template <int U, bool INIT, bool FINAL>
-__device__ __forceinline__ void lsm_date(int64_t n, const LsmContract& c, const LsmCoeffs& prev, int32_t t_fit,
+// `fit()` is called by every thread, ONCE, after the loads of its first U paths are on their way: the coefficients arrive while
+// those loads are in flight.
+template <int U, bool INIT, bool FINAL, typename Fit>
+__device__ __forceinline__ void lsm_date(int64_t n, const LsmContract& c, Fit fit, int32_t t_fit,
                                          const double* __restrict__ paths, double* __restrict__ cash, double (&acc)[kLsmNV]) {
 #pragma unroll
     for (int k = 0; k < kLsmNV; ++k) acc[k] = 0.0;
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
     const double* __restrict__ row1 = paths + static_cast<size_t>(INIT ? c.n_steps : t_fit + 1) * n;     // the later date
     const double* __restrict__ row0 = paths + static_cast<size_t>(t_fit) * n;                            // the date being fitted
-    for (int64_t i0 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i0 < n; i0 += stride * U) {
+    LsmCoeffs prev;
+    bool fitted = false;
+    int64_t i0 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    do {                                                // at least one trip: every thread of the workgroup meets the barriers inside fit()
         double cfv[U], s1v[U], s0v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1942,6 +1971,7 @@ __device__ __forceinline__ void lsm_date(int64_t n, const LsmContract& c, const 
             cfv[u] = (in && !INIT) ? cash[i] : 0.0;
             s0v[u] = (in && !FINAL) ? row0[i] : 0.0;
         }
+        if (!fitted) { prev = fit(); fitted = true; }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + u * stride;
@@ -1982,23 +2012,49 @@ __device__ __forceinline__ void lsm_date(int64_t n, const LsmContract& c, const 
                 }
             }
         }
-    }
+        i0 += stride * U;
+    } while (i0 < n);
 }
 
-// One launch per exercise date: `coef` is read at entry (fit of date t_fit + 1, written by the previous
-// launch) and overwritten at the very end by this launch's fit; stream order is the synchronisation.
+// One launch per exercise date; stream order is the only synchronisation between dates.
 // INIT: the cash flow starts as the terminal intrinsic value (first launch); FINAL: t_fit == 0, the launch that leaves the
-// moments of the time-0 cash flow instead of a regression.
+// moments of the time-0 cash flow (through the grid reduction, for the host) instead of regression sums.
+//
+// Round 4, second form.  The first form finished a date inside its own launch: row store (sc1) -> drain -> ticket -> the LAST
+// workgroup loads the rows, solves, stores five coefficients, which the next launch loads.  That is three dependent memory round
+// trips behind the last wave of every date and one in front of the next.  Here a launch only STORES its workgroup rows (plain
+// stores: the kernel boundary publishes them) and the NEXT launch -- every workgroup of it, redundantly -- sums those <= 256 rows in
+// the same index order (workgroup_rows_sum: one round trip, served by L2, overlapped with the loads of the workgroup's first paths),
+// solves the 5 x 5 system in its first wave and hands the coefficients to its threads through LDS.  No ticket, no drain, no
+// coefficient buffer, nothing but the row store behind a date's last wave.  The rows alternate between two buffers by date
+// parity: a workgroup of date t may store its row while a slower one still reads date t + 1's.  Same sums in the same order
+// as the first form, so the same coefficients, exercise decisions and price bits.
 template <int U, bool INIT, bool FINAL>
-__global__ __launch_bounds__(kBlock) void lsm_step_kernel(int64_t n, LsmContract c, LsmCoeffs* __restrict__ coef, int32_t t_fit,
-                                                          const double* __restrict__ paths, double* __restrict__ cash, ReduceWs ws) {
+__global__ __launch_bounds__(kBlock) void lsm_step_kernel(int64_t n, LsmContract c, double* __restrict__ rows /* [2][gridDim.x][kLsmNV] */,
+                                                          int32_t t_fit, const double* __restrict__ paths, double* __restrict__ cash, ReduceWs ws) {
+    __shared__ double part[kBlock];
+    __shared__ LsmCoeffs shared_fit;
+    const size_t buffer = static_cast<size_t>(gridDim.x) * kLsmNV;
+    const double* rows_prev = rows + static_cast<size_t>((t_fit + 1) & 1) * buffer;
+    auto fit = [&]() -> LsmCoeffs {
+        LsmCoeffs f;
+        f.valid = 0;
+        if constexpr (!INIT) {
+            const double total = workgroup_rows_sum<kLsmNV>(rows_prev, static_cast<int32_t>(gridDim.x), part);
+            if (threadIdx.x < kWave) LsmFit{&shared_fit, c.degree}(total);
+            __syncthreads();
+            f = shared_fit;
+        }
+        return f;
+    };
     double acc[kLsmNV];
-    LsmCoeffs prev;
-    prev.valid = 0;
-    if constexpr (!INIT) prev = *coef;
-    lsm_date<U, INIT, FINAL>(n, c, prev, t_fit, paths, cash, acc);
-    if constexpr (!FINAL) block_then_grid_reduce<kLsmNV>(acc, ws, LsmFit{coef, c.degree});
-    else block_then_grid_reduce<kLsmNV>(acc, ws);
+    lsm_date<U, INIT, FINAL>(n, c, fit, t_fit, paths, cash, acc);
+    if constexpr (!FINAL) {
+        const double s = block_row_sum<kLsmNV>(acc);
+        if (threadIdx.x < kLsmNV) rows[static_cast<size_t>(t_fit & 1) * buffer + static_cast<size_t>(blockIdx.x) * kLsmNV + threadIdx.x] = s;
+    } else {
+        block_then_grid_reduce<kLsmNV>(acc, ws);
+    }
 }
 
 // Heston full-truncation Euler (src/pricing_models/heston.py:184-255): per step two normals

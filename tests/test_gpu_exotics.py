@@ -196,6 +196,9 @@ def test_autocallable_and_cliquet_against_reference_golden(golden):
     (100.0, 100.0, 1.0, 0.05, 0.2, 0.0, False, 50000, 50, 3), (90.0, 100.0, 0.5, 0.03, 0.3, 0.0, False, 20000, 25, 2),
     (100.0, 100.0, 1.0, 0.05, 0.2, 0.08, True, 20000, 40, 3), (100.0, 100.0, 1.0, 0.05, 0.2, 0.0, False, 5000, 1, 3),
     (100.0, 95.0, 1.0, 0.05, 0.25, 0.0, False, 7001, 13, 4), (100.0, 100.0, 1.0, 0.05, 0.2, 0.0, False, 3000, 2, 1),
+    # the launch shapes of the larger sizes (one workgroup per compute unit, a thread's paths 2 / 4 / 8 at a time, ragged last trip)
+    (100.0, 100.0, 1.0, 0.05, 0.2, 0.0, False, 100_003, 6, 3), (100.0, 100.0, 1.0, 0.05, 0.2, 0.0, False, 200_001, 5, 3),
+    (100.0, 100.0, 1.0, 0.05, 0.2, 0.0, False, 400_003, 6, 3),
 ])
 def test_american_matches_same_stream_checker(S, K, T, r, v, q, call, N, M, deg):
     """Same paths, same regression algebra: exercise decisions agree path by path, so the sums agree to rounding."""

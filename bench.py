@@ -1035,6 +1035,12 @@ def c4_asian(ol, _hip, pmc, costs, mixes, clock_ghz, cpu=None):
             greeks[key]["roofline"] = roofline_for(pmc, "c4_asian_greeks14", ks, ASIAN_STEPS, PATHS_PER_GPU, costs, mixes, clock_ghz)
     greeks["speedup_14"] = greeks["literal_14"]["ms"] / greeks["fused_14"]["ms"]
     greeks["speedup_8"] = greeks["literal_8"]["ms"] / greeks["fused_8"]["ms"]
+    # the geometric average: its six recursions share the whole date loop (asian_geometric_greeks_kernel) -- detail file only
+    geo = ol.ExoticAdapter(ol.AsianOption(*ATM, seed=SEED), n_paths=PATHS_PER_GPU, n_steps=ASIAN_STEPS, avg_type="geometric")
+    for key, fused, reps in (("geometric_fused_14", True, 8), ("geometric_literal_14", False, 3)):
+        med, ks, per = _timed_calls(_hip, lambda: ol.compute_greeks_unified(geo, *ATM, "call", include_second_order=True, fused=fused), reps, warm=2)
+        greeks[key] = {"ms": med * 1e3, "launches_per_call": per, "kernel_ms_per_launch": ks * 1e3 if ks else None}
+    greeks["geometric_speedup_14"] = greeks["geometric_literal_14"]["ms"] / greeks["geometric_fused_14"]["ms"]
     out["greeks"] = greeks
     out["headline"] = "fp64"
     if cpu and isinstance(cpu.get("c4_asian"), dict) and cpu["c4_asian"].get("value"):

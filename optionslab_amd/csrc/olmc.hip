@@ -1275,22 +1275,40 @@ extern "C" int olmc_asian_greeks_fd(double S, double K, double T, double r, doub
     if (rc) return rc;
     const GreeksSet gs(S, K, T, r, sigma, q, is_call, second_order);
     AsianGreeksSet as{};
-    int n_groups = 0;
+    // Recursions: contracts that share (drift, vol) per step share one (a spot bump only scales the average).  Geometric: up to six, all
+    // alike.  Arithmetic: slots 0..3 are recursions of their own; a contract whose vol is slot 0's and whose drift is not (the r bumps)
+    // rides on slot 0 through a per-date factor (slots 4..5, rate_step = its drift - slot 0's).
+    const int real_slots = geo ? kAsianGroups : kAsianRealGroups;
+    int n_groups = 0, n_riders = 0;
+    double rider_drift[kAsianGroups - kAsianRealGroups] = {0.0, 0.0};
+    auto same = [](const double& a, const double& b) { return std::memcmp(&a, &b, sizeof a) == 0; };
     for (int i = 0; i < gs.k; ++i) {
         const olmc_option& o = gs.o[i];
         const double dt = o.T / n_steps;                             // exotic_options.py:54-56, as olmc_asian
         const double drift = (o.r - o.q - 0.5 * o.sigma * o.sigma) * dt, vol = o.sigma * std::sqrt(dt);
+        as.s0[i] = o.S;
+        as.log_s0[i] = std::log(o.S);
+        if (!geo && n_groups > 0 && same(as.vol[0], vol) && !same(as.drift[0], drift)) {
+            int d = 0;
+            while (d < n_riders && !same(rider_drift[d], drift)) ++d;
+            if (d == n_riders) {
+                if (n_riders == kAsianGroups - kAsianRealGroups) return fail(OLMC_ERR_STATE, "more drift-only bumps than the fused Asian Greeks kernel carries");
+                rider_drift[d] = drift;
+                as.rate_step[d] = drift - as.drift[0];
+                ++n_riders;
+            }
+            as.group[i] = kAsianRealGroups + d;
+            continue;
+        }
         int g = 0;
-        while (g < n_groups && !(std::memcmp(&as.drift[g], &drift, sizeof drift) == 0 && std::memcmp(&as.vol[g], &vol, sizeof vol) == 0)) ++g;
+        while (g < n_groups && !(same(as.drift[g], drift) && same(as.vol[g], vol))) ++g;
         if (g == n_groups) {
-            if (n_groups == kAsianGroups) return fail(OLMC_ERR_STATE, "more distinct path recursions than the fused Asian Greeks kernel carries");
+            if (n_groups == real_slots) return fail(OLMC_ERR_STATE, "more distinct path recursions than the fused Asian Greeks kernel carries");
             as.drift[g] = drift;
             as.vol[g] = vol;
             ++n_groups;
         }
         as.group[i] = g;
-        as.s0[i] = o.S;
-        as.log_s0[i] = std::log(o.S);
     }
     for (int g = n_groups; g < kAsianGroups; ++g) { as.drift[g] = as.drift[0]; as.vol[g] = as.vol[0]; }
     {   // into the units the kernel sums in, by the very products the one-contract kernels form on the device: arithmetic (asian_exp64_kernel)

@@ -1231,6 +1231,7 @@ __global__ __launch_bounds__(kBlock) void asian_exp64_kernel(PathRange pr, Asian
 // exp2_f64_tab, same S_0 (run / M)), so a contract's payoffs are the bits its own launch produces; only the association of the sums
 // differs (16 / 32 values per workgroup row).
 constexpr int kAsianGroups = 6;
+constexpr int kAsianRealGroups = 4;                     // arithmetic kernel: slots 0..3 are recursions of their own, 4..5 ride on slot 0
 
 struct AsianGreeksSet {
     double drift[kAsianGroups], vol[kAsianGroups];      // per step, in the exponential's units: AsianContract's drift x kUnit, vol x kZScale x kUnit
@@ -1239,12 +1240,15 @@ struct AsianGreeksSet {
     double s0[16];                                      // spot of contract s (0 for an unused slot)
     double log_s0[16];                                  // geometric: ln of it
     double strike, sign, inv_steps;
+    double rate_step[kAsianGroups - kAsianRealGroups];  // arithmetic kernel: slot 4 + d is slot 0 with the per-step drift moved by this much
+                                                        // (natural units; 0 for an unused slot)
     int32_t group[16];                                  // recursion of contract s
 };
 
 template <bool ANTI, int NSETS>
 __global__ __launch_bounds__(kBlock) void asian_exp64_greeks_kernel(PathRange pr, AsianGreeksSet gs, ReduceWs ws) {
-    constexpr int NV = 2 * NSETS, G = kAsianGroups, LEGS = ANTI ? 2 : 1;
+    constexpr int NV = 2 * NSETS, G = kAsianGroups, R = kAsianRealGroups, D = G - R, LEGS = ANTI ? 2 : 1;
+    constexpr int32_t kRefreshBlocks = 64;              // the rate factors are re-anchored on the library exponential every 256 dates
     __shared__ double tab[kExp2Entries];
     if constexpr (OLMC_EXP2_TABLE) exp2_table_to_lds(tab);
     double acc[NV];                                     // the grid covers every path (host guarantee): born after the date loop
@@ -1255,33 +1259,62 @@ __global__ __launch_bounds__(kBlock) void asian_exp64_greeks_kernel(PathRange pr
         const double* __restrict__ vol = gs.vol;
         const uint64_t gp = pr.first + static_cast<uint64_t>(i < pr.count ? i : 0);
         const uint32_t g_lo = static_cast<uint32_t>(gp), g_hi = static_cast<uint32_t>(gp >> 32);
-        double cum[LEGS][G], run[LEGS][G];
+        double cum[LEGS][R], run[LEGS][G];
 #pragma unroll
-        for (int leg = 0; leg < LEGS; ++leg)
+        for (int leg = 0; leg < LEGS; ++leg) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) cum[leg][g] = run[leg][g] = 0.0;
+            for (int g = 0; g < G; ++g) run[leg][g] = 0.0;
+#pragma unroll
+            for (int g = 0; g < R; ++g) cum[leg][g] = 0.0;
+        }
+        // A bump of r moves the per-step drift and nothing else: the price relative of such a contract at date t is slot 0's times
+        // exp(rate_step t), the same number for every path.  factor[d] carries it from date to date as f += f * expm1(rate_step) -- ONE
+        // fma whose rounding is unbiased; multiplying by the rounded constant exp(rate_step) = 1 + 1e-7 instead would commit the same
+        // 1e-16 at every date, a drift of the whole average (measured: 1.2e-13 of the r + h price at 1,024 dates) -- and is set afresh
+        // from exp() every 256 dates.
+        double factor[D], factor_step[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { factor[d] = 1.0; factor_step[d] = expm1(gs.rate_step[d]); }
         auto dates = [&](const float (&z)[4], auto live) {      // `live` dates of one Philox block, every recursion
 #pragma unroll
             for (int j = 0; j < decltype(live)::value; ++j) {
                 const double zj = static_cast<double>(z[j]);
+                double x0[LEGS];
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
+                for (int g = 0; g < R; ++g) {
                     cum[0][g] += __builtin_fma(vol[g], zj, drift[g]);
-                    run[0][g] += OLMC_EXP2_TABLE ? exp2_f64_tab(cum[0][g], tab) : exp2_f64(cum[0][g]);
+                    const double x = OLMC_EXP2_TABLE ? exp2_f64_tab(cum[0][g], tab) : exp2_f64(cum[0][g]);
+                    run[0][g] += x;
+                    if (g == 0) x0[0] = x;
                     if constexpr (ANTI) {
                         cum[1][g] += __builtin_fma(-vol[g], zj, drift[g]);
-                        run[1][g] += OLMC_EXP2_TABLE ? exp2_f64_tab(cum[1][g], tab) : exp2_f64(cum[1][g]);
+                        const double y = OLMC_EXP2_TABLE ? exp2_f64_tab(cum[1][g], tab) : exp2_f64(cum[1][g]);
+                        run[1][g] += y;
+                        if (g == 0) x0[1] = y;
                     }
+                }
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    factor[d] = __builtin_fma(factor[d], factor_step[d], factor[d]);
+#pragma unroll
+                    for (int leg = 0; leg < LEGS; ++leg) run[leg][R + d] = __builtin_fma(x0[leg], factor[d], run[leg][R + d]);
                 }
             }
         };
         const int32_t full = pr.n_steps >> 2, rem = pr.n_steps & 3;
         float z[4];
-        for (int32_t b = 0; b < full; ++b) {                    // branch-free body
-            raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(b), 0u, rk, z);
-            dates(z, std::integral_constant<int, 4>{});
+        for (int32_t b0 = 0; b0 < full; b0 += kRefreshBlocks) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) factor[d] = exp(gs.rate_step[d] * static_cast<double>(4 * b0));
+            const int32_t b1 = min(b0 + kRefreshBlocks, full);
+            for (int32_t b = b0; b < b1; ++b) {                 // branch-free body
+                raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(b), 0u, rk, z);
+                dates(z, std::integral_constant<int, 4>{});
+            }
         }
         if (rem) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) factor[d] = exp(gs.rate_step[d] * static_cast<double>(4 * full));
             raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(full), 0u, rk, z);
             if (rem == 1) dates(z, std::integral_constant<int, 1>{});
             else if (rem == 2) dates(z, std::integral_constant<int, 2>{});

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of whole libolmc builds: one subprocess per (library, round), each timing the
 European path kernel with HIP events (olmc_kernel_time).  Usage (GPU box):
-    python tools/ab_libs.py libA.so libB.so ... [--n 1000000] [--m 252] [--rounds 7] [--case european|greeks8|greeks14|greeks8_lean|greeks14_lean|asian|asian_fast|asian_fast_anti|asian_anti|asian_geo|barrier|heston|merton|kou|autocall[_anti]|cliquet[_anti]|american|qmc|qmc_cv|qmc_greeks8|qmc_greeks14]"""
+    python tools/ab_libs.py libA.so libB.so ... [--n 1000000] [--m 252] [--rounds 7] [--case european|greeks8|greeks14|greeks8_lean|greeks14_lean|asian|asian_fast|asian_fast_anti|asian_anti|asian_geo|barrier|heston|merton|kou|autocall[_anti]|cliquet[_anti]|american|asian_greeks8|asian_greeks14[_rho]|qmc|qmc_cv|qmc_greeks8|qmc_greeks14]"""
 import argparse
 import json
 import os
@@ -39,6 +39,9 @@ CASES = {
     "heston": lambda s: _hip.heston(100.0, 100.0, 1.0, 0.05, 0.0, True, 2.0, 0.04, 0.3, -0.7, 0.04, N, M, s, False),
 }
 # round 4: the per-date launches of the American option, and the Sobol kernels (a table of `M` dimensions built once, seed 42)
+CASES["asian_greeks8"] = lambda s: _hip.asian_greeks_fd(*P, True, N, M, s, False, False)[1][0]
+CASES["asian_greeks14"] = lambda s: _hip.asian_greeks_fd(*P, True, N, M, s, False, True)[1][0]
+CASES["asian_greeks14_rho"] = lambda s: _hip.asian_greeks_fd(*P, True, N, M, s, False, True)[1][6]       # the r + h evaluation
 CASES["american"] = lambda s: _hip.american_lsm(*P, False, N, M, 3, s)
 if sys.argv[3].startswith("qmc"):
     import numpy as np

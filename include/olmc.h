@@ -237,8 +237,10 @@ int olmc_asian(double S, double K, double T, double r, double sigma, double q, i
  * fused form costs ONE geometric pricing: between group boundaries the path state is the same for every contract) -- in ONE launch: the 8 / 14 bumped
  * contracts compute_greeks_unified prices through ExoticAdapter(AsianOption) (src/greeks/unified_greeks.py:177-227, 295-358: same
  * bumps, same call order, same formulas as olmc_european_greeks_fd) on the SAME normals.  The contracts are at most six distinct
- * path recursions ({mid, S+-}, sigma+-, T-, r+-: the spot only scales the average), so a date costs six exponentials instead of
- * 8 / 14 in 8 / 14 launches.  out9 / evals as olmc_european_greeks_fd. */
+ * path recursions ({mid, S+-}, sigma+-, T-, r+-: the spot only scales the average); in the arithmetic kernel the two r bumps are not
+ * even recursions -- their price relative at date t is the mid contract's times exp(+-h_r dt t), one factor per date for every path --
+ * so a date costs FOUR exponentials instead of 8 / 14 in 8 / 14 launches.  Every evaluation is its own launch's result to rounding
+ * (bitwise but for the two r evaluations, which agree to ~1e-15 relative).  out9 / evals as olmc_european_greeks_fd. */
 int olmc_asian_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call, int avg_kind,
                          int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic, int second_order,
                          double* out9, olmc_stats* evals /* [14] or NULL */);

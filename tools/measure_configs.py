@@ -107,6 +107,21 @@ def main():
            lambda r: dict(price=float(r[0]), std_error=r[1]), reps=10)
     report("American put LSM 1M x 50, degree 3", N * 50, lambda: ol.AmericanOption(*ATM, seed=42).price(N, 50, "put", 3, return_error=True),
            lambda r: dict(price=float(r[0]), std_error=r[1]), reps=5)
+    # the exotic page's Greeks (streamlit_app/pages/7_Exotic_Options.py:266-284: ExoticAdapter at 10,000 x 50, first order) and the same at C4's shape
+    for name, opt, kw in (("Asian arithmetic", ol.AsianOption(*ATM, seed=42), dict(avg_type="arithmetic")), ("Asian geometric", ol.AsianOption(*ATM, seed=42), dict(avg_type="geometric")),
+                          ("barrier up-and-out", ol.BarrierOption(*ATM, barrier=120.0, seed=42), dict(barrier_type="up-and-out")),
+                          ("lookback floating", ol.LookbackOption(*ATM, seed=42), dict(lookback_type="floating"))):
+        ad = ol.ExoticAdapter(opt, n_paths=10_000, n_steps=50, **kw)
+        report(f"ExoticAdapter Greeks, {name}, 10k x 50, first order: one launch", 10_000 * 50,
+               lambda: ol.compute_greeks_unified(ad, *ATM, "call", include_second_order=False), lambda g: dict(greeks={k: float(v) for k, v in g.items()}))
+        report(f"ExoticAdapter Greeks, {name}, 10k x 50, first order: the 8 launches of bump-and-reprice", 8 * 10_000 * 50,
+               lambda: ol.compute_greeks_unified(ad, *ATM, "call", include_second_order=False, fused=False), lambda g: dict(greeks={k: float(v) for k, v in g.items()}), reps=10)
+    for name, kw in (("arithmetic", dict(avg_type="arithmetic")), ("geometric", dict(avg_type="geometric"))):
+        ad = ol.ExoticAdapter(ol.AsianOption(*ATM, seed=42), n_paths=N, n_steps=MA, **kw)
+        report(f"ExoticAdapter Greeks, Asian {name}, 1M x 1024, second order: one launch", N * MA,
+               lambda: ol.compute_greeks_unified(ad, *ATM, "call", include_second_order=True), lambda g: dict(greeks={k: float(v) for k, v in g.items()}), reps=5)
+        report(f"ExoticAdapter Greeks, Asian {name}, 1M x 1024, second order: the 14 launches of bump-and-reprice", 14 * N * MA,
+               lambda: ol.compute_greeks_unified(ad, *ATM, "call", include_second_order=True, fused=False), lambda g: dict(greeks={k: float(v) for k, v in g.items()}), reps=3)
     mj = ol.MertonJumpDiffusion(0.5, -0.1, 0.2)
     report("Merton jump diffusion 1M x 252", N * M, lambda: mj.price_monte_carlo(*ATM, "call", 0.0, N, M, 42, return_error=True),
            lambda r: dict(price=float(r[0]), std_error=r[1], series=float(mj.price(*ATM, "call"))), reps=10)

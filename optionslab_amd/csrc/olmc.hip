@@ -1635,6 +1635,29 @@ extern "C" int olmc_exercise_boundary(double S, double K, double T, double r, do
 }
 
 // ================================================================ American (LSM) ====
+namespace {
+// Mean and standard deviation of S_t / K over the in-the-money side of the strike under the model's lognormal law (truncated
+// lognormal moments, closed form): the affine map that standardises the regressor of the date-t regression (LsmScale).
+// Any finite, positive pair gives the same least-squares fit in exact arithmetic; this one keeps the normal equations well conditioned.
+void lsm_regressor_scale(double S, double K, double r, double q, double sigma, double dt, int32_t t, bool is_call, double* centre, double* inv_width) {
+    *centre = 1.0;
+    *inv_width = 1.0;
+    const double m = std::log(S) + (r - q - 0.5 * sigma * sigma) * dt * t, s = sigma * std::sqrt(dt * t), a = std::log(K);
+    if (!(s > 0.0) || !std::isfinite(m) || !std::isfinite(a)) return;
+    const double side = is_call ? 1.0 : -1.0;            // in the money: side * (ln S_t - ln K) > 0
+    auto phi = [](double u) { return 0.5 * std::erfc(-u * 0.70710678118654752440); };
+    const double p0 = phi(side * (m - a) / s);
+    const double m1 = std::exp(m + 0.5 * s * s) * phi(side * (m + s * s - a) / s);
+    const double m2 = std::exp(2.0 * m + 2.0 * s * s) * phi(side * (m + 2.0 * s * s - a) / s);
+    if (!(p0 > 1e-280) || !std::isfinite(m1) || !std::isfinite(m2)) return;
+    const double mean = m1 / p0, var = m2 / p0 - mean * mean;
+    const double width = std::max(std::sqrt(std::max(var, 0.0)), 1e-6 * mean);
+    if (!(mean > 0.0) || !std::isfinite(width) || !(width > 0.0)) return;
+    *centre = mean / K;
+    *inv_width = K / width;
+}
+}  // namespace
+
 extern "C" int olmc_american_lsm(double S, double K, double T, double r, double sigma, double q, int is_call,
                                  int64_t n_paths, int32_t n_steps, int32_t poly_degree, uint64_t seed, olmc_stats* out) {
     if (!out) return fail(OLMC_ERR_ARG, "null pointer");
@@ -1685,10 +1708,13 @@ extern "C" int olmc_american_lsm(double S, double K, double T, double r, double 
     ReduceWs ws;
     rc = make_ws(c, c->stream, grid, kLsmNV, c->d_result, -1.0, &ws);          // arms the completion word for the launch that writes d_result
     if (rc) return rc;
+    std::vector<double> centre(static_cast<size_t>(n_steps) + 1, 1.0), inv_width(static_cast<size_t>(n_steps) + 1, 1.0);   // while the path kernel runs
+    for (int32_t t = 1; t < n_steps; ++t) lsm_regressor_scale(S, K, r, q, sigma, dt, t, is_call != 0, &centre[t], &inv_width[t]);
     int32_t init = 1;
     for (int32_t t_fit = n_steps - 1; t_fit >= 0; --t_fit) {
         const bool first = init != 0, final_date = t_fit == 0;
-        auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, c->stream, n_paths, lc, d_rows, t_fit, d_paths, d_cash, ws); };
+        const LsmScale sc{centre[t_fit], inv_width[t_fit], centre[t_fit + 1], inv_width[t_fit + 1]};
+        auto go = [&](auto kernel) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), 0, c->stream, n_paths, lc, sc, d_rows, t_fit, d_paths, d_cash, ws); };
         auto pick = [&](auto u) {
             constexpr int U = decltype(u)::value;
             if (first && final_date) go(lsm_step_kernel<U, true, true>);

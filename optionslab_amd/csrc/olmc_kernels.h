@@ -1757,9 +1757,13 @@ __global__ __launch_bounds__(kBlock) void cliquet_kernel(PathRange pr, CliquetCo
 //   3. accumulate, over paths in the money at t, the normal-equation moments of the polynomial
 //      regression of cash flow on x = S_t / K:  sum x^m (m = 0..2d), sum x^k cf (k = 0..d), count
 //      -- through the fused deterministic grid reduction.
-// The (d+1)x(d+1) solve happens on the host between launches (the sums land in mapped memory).
-// The basis is the reference's raw powers X^k re-scaled by the strike (same polynomial space,
-// well-conditioned moments); its lstsq(rcond=None) is replaced by the normal equations.
+// The basis spans the reference's raw powers X^k (same polynomial space, so the same least-squares fit in exact arithmetic),
+// written in the STANDARDISED regressor z = (S/K - c_t) / w_t, where c_t and w_t are the mean and standard deviation of S_t/K over
+// the in-the-money side of the strike under the model's own lognormal law (closed form, computed on the host per date:
+// lsm_regressor_scale in olmc.hip).  The reference's lstsq(rcond=None) -- an SVD -- is replaced by the normal equations, which
+// square the condition number: in powers of S/K itself the moment matrix of a degree-4 fit over a narrow in-the-money range (deep
+// in the money, low vol, an early date) has a condition number beyond 1e14 and fp64 leaves nothing of the coefficients (round 4's
+// property hunt: device and checker disagreed on exercise decisions at 236 paths, degree 4); in z it stays below ~1e6.
 constexpr int kLsmMaxDegree = 4;
 constexpr int kLsmNV = 16;          // 2d+1 + d+1 + 1 <= 15 sums, padded
 
@@ -1895,6 +1899,10 @@ __global__ __launch_bounds__(kBoundaryThreads) void exercise_boundary_kernel(con
     }
 }
 
+struct LsmScale {                   // regressor z = (S / K - centre) * inv_width of the date being FITTED and of the date whose fit is APPLIED
+    double fit_centre, fit_inv_width, prev_centre, prev_inv_width;
+};
+
 struct LsmCoeffs {
     double beta[kLsmMaxDegree + 1];
     int32_t valid;                  // regression at the date being finished was fitted
@@ -1905,7 +1913,7 @@ __device__ __forceinline__ double lsm_intrinsic(const LsmContract& c, double s) 
 
 // Runs in the wave that holds the grid totals of one exercise date (all 64 lanes active): lane m < 2d+1 has sum x^m,
 // lane 9+k has sum x^k cf, lane 14 the in-the-money count.  The wave solves the (d+1)x(d+1) normal equations (Gaussian
-// elimination, partial pivoting, fp64 -- the moments of x = S/K in (0, ~2) are benign) and leaves the coefficients in `coef`
+// elimination, partial pivoting, fp64 -- the moments of the standardised regressor are benign) and leaves the coefficients in `coef`
 // (LDS of the workgroup that applies them): no host round trip per exercise date.
 //
 // Round 4: the augmented 5 x 6 matrix lives ONE ELEMENT PER LANE (lane = 8 row + column) instead of thirty doubles in lane 0.
@@ -1984,7 +1992,7 @@ struct LsmFit {
 // `fit()` is called by every thread, ONCE, after the loads of its first U paths are on their way: the coefficients arrive while
 // those loads are in flight.
 template <int U, bool INIT, bool FINAL, typename Fit>
-__device__ __forceinline__ void lsm_date(int64_t n, const LsmContract& c, Fit fit, int32_t t_fit,
+__device__ __forceinline__ void lsm_date(int64_t n, const LsmContract& c, const LsmScale& sc, Fit fit, int32_t t_fit,
                                          const double* __restrict__ paths, double* __restrict__ cash, double (&acc)[kLsmNV]) {
 #pragma unroll
     for (int k = 0; k < kLsmNV; ++k) acc[k] = 0.0;
@@ -2016,7 +2024,7 @@ __device__ __forceinline__ void lsm_date(int64_t n, const LsmContract& c, Fit fi
                     cf = cfv[u];
                     const double iv = lsm_intrinsic(c, s1v[u]);
                     if (prev.valid && iv > 0.0) {
-                        const double x = s1v[u] * c.inv_strike;
+                        const double x = (s1v[u] * c.inv_strike - sc.prev_centre) * sc.prev_inv_width;
                         double cont = prev.beta[kLsmMaxDegree];
 #pragma unroll
                         for (int k = kLsmMaxDegree - 1; k >= 0; --k) cont = cont * x + prev.beta[k];
@@ -2029,7 +2037,7 @@ __device__ __forceinline__ void lsm_date(int64_t n, const LsmContract& c, Fit fi
                     // every power up to 2 kLsmMaxDegree is summed whatever the degree: LsmFit replaces the rows and columns beyond
                     // `degree` by the identity, so the surplus sums are never read (and a sum that IS read is the same chain of adds)
                     const bool itm = lsm_intrinsic(c, s0v[u]) > 0.0;
-                    const double x = s0v[u] * c.inv_strike;
+                    const double x = (s0v[u] * c.inv_strike - sc.fit_centre) * sc.fit_inv_width;
                     double p = itm ? 1.0 : 0.0;                 // out-of-the-money paths add exact zeros (x is finite)
                     const double w = itm ? cf : 0.0;
 #pragma unroll
@@ -2063,7 +2071,7 @@ __device__ __forceinline__ void lsm_date(int64_t n, const LsmContract& c, Fit fi
 // parity: a workgroup of date t may store its row while a slower one still reads date t + 1's.  Same sums in the same order
 // as the first form, so the same coefficients, exercise decisions and price bits.
 template <int U, bool INIT, bool FINAL>
-__global__ __launch_bounds__(kBlock) void lsm_step_kernel(int64_t n, LsmContract c, double* __restrict__ rows /* [2][gridDim.x][kLsmNV] */,
+__global__ __launch_bounds__(kBlock) void lsm_step_kernel(int64_t n, LsmContract c, LsmScale sc, double* __restrict__ rows /* [2][gridDim.x][kLsmNV] */,
                                                           int32_t t_fit, const double* __restrict__ paths, double* __restrict__ cash, ReduceWs ws) {
     __shared__ double part[kBlock];
     __shared__ LsmCoeffs shared_fit;
@@ -2081,7 +2089,7 @@ __global__ __launch_bounds__(kBlock) void lsm_step_kernel(int64_t n, LsmContract
         return f;
     };
     double acc[kLsmNV];
-    lsm_date<U, INIT, FINAL>(n, c, fit, t_fit, paths, cash, acc);
+    lsm_date<U, INIT, FINAL>(n, c, sc, fit, t_fit, paths, cash, acc);
     if constexpr (!FINAL) {
         const double s = block_row_sum<kLsmNV>(acc);
         if (threadIdx.x < kLsmNV) rows[static_cast<size_t>(t_fit & 1) * buffer + static_cast<size_t>(blockIdx.x) * kLsmNV + threadIdx.x] = s;

@@ -384,6 +384,25 @@ static int lsm_solve(const long double* mom, const long double* rhs, int degree,
     return 1;
 }
 
+/* The standardised regressor of the date-t regression: mean and standard deviation of S_t / K over the in-the-money side of the strike
+ * under the lognormal law (restates lsm_regressor_scale of the device library's host side; any positive pair spans the same fit). */
+static void lsm_scale(double S, double K, double r, double q, double sigma, double dt, int32_t t, int is_call, double* centre, double* inv_width) {
+    *centre = 1.0;
+    *inv_width = 1.0;
+    const double m = log(S) + (r - q - 0.5 * sigma * sigma) * dt * t, s = sigma * sqrt(dt * t), a = log(K);
+    if (!(s > 0.0) || !isfinite(m) || !isfinite(a)) return;
+    const double side = is_call ? 1.0 : -1.0;
+    const double p0 = 0.5 * erfc(-(side * (m - a) / s) * 0.70710678118654752440);
+    const double m1 = exp(m + 0.5 * s * s) * (0.5 * erfc(-(side * (m + s * s - a) / s) * 0.70710678118654752440));
+    const double m2 = exp(2.0 * m + 2.0 * s * s) * (0.5 * erfc(-(side * (m + 2.0 * s * s - a) / s) * 0.70710678118654752440));
+    if (!(p0 > 1e-280) || !isfinite(m1) || !isfinite(m2)) return;
+    const double mean = m1 / p0, var = m2 / p0 - mean * mean;
+    const double width = fmax(sqrt(fmax(var, 0.0)), 1e-6 * mean);
+    if (!(mean > 0.0) || !isfinite(width) || !(width > 0.0)) return;
+    *centre = mean / K;
+    *inv_width = K / width;
+}
+
 int ol_american_lsm(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t n, int32_t n_steps,
                     int32_t degree, uint64_t seed, double moments[2]) {
     const double dt = T / n_steps, drift = (r - q - 0.5 * sigma * sigma) * dt, vol = sigma * sqrt(dt) * Z_SCALE;
@@ -407,11 +426,13 @@ int ol_american_lsm(double S, double K, double T, double r, double sigma, double
     for (int32_t t = n_steps - 1; t >= 1; --t) {
         long double mom[9] = {0}, rhs[5] = {0};
         int64_t count = 0;
+        double centre, inv_width;
+        lsm_scale(S, K, r, q, sigma, dt, t, is_call, &centre, &inv_width);
         for (int64_t i = 0; i < n; ++i) {
             cf[i] *= disc;
             const double s = paths[(size_t)t * n + i];
             if (fmax(sign * (s - K), 0.0) > 0.0) {
-                const double x = s / K;
+                const double x = (s * (1.0 / K) - centre) * inv_width;
                 double p = 1.0;
                 for (int m = 0; m <= 2 * degree; ++m) {
                     mom[m] += p;
@@ -426,7 +447,7 @@ int ol_american_lsm(double S, double K, double T, double r, double sigma, double
             for (int64_t i = 0; i < n; ++i) {
                 const double s = paths[(size_t)t * n + i], iv = fmax(sign * (s - K), 0.0);
                 if (iv > 0.0) {
-                    const double x = s / K;
+                    const double x = (s * (1.0 / K) - centre) * inv_width;
                     double cont = beta[4];
                     for (int k = 3; k >= 0; --k) cont = cont * x + beta[k];
                     if (iv > cont) cf[i] = iv;

@@ -396,6 +396,26 @@ def test_heston_monte_carlo_against_the_characteristic_function_price(golden):
         assert abs(c["mc"] - want) <= 0.12                                              # the reference's own Monte Carlo agrees too
 
 
+@pytest.mark.parametrize("S,K,T,r,v,call,N,M,deg", [
+    (80.0, 85.0, 1.0, 0.03, 0.1, False, 100_000, 12, 4),       # deep in the money, low vol: S_t / K of the in-the-money paths spans a few percent
+    (100.0, 100.0, 1.0, 0.05, 0.2, False, 100_000, 50, 4), (120.0, 100.0, 0.5, 0.02, 0.15, True, 60_000, 20, 4),
+    (100.0, 100.0, 1.0, 0.05, 0.2, False, 236, 12, 4),          # few paths, where the property hunt found device and checker apart before the regressor was standardised
+])
+def test_american_where_the_regression_is_ill_conditioned(S, K, T, r, v, call, N, M, deg):
+    """Degree-4 fits over a narrow in-the-money range: in powers of S / K the normal equations have a condition number beyond 1e14;
+    the device fits in the standardised regressor z = (S/K - c_t) / w_t (olmc_kernels.h, LsmScale).  Against (i) the checker on the
+    same paths -- the same exercise decisions, sums to 2e-6 -- and (ii) the reference's own algorithm (exotic_options.py:237-305,
+    np.linalg.lstsq on raw powers of S, restated in oracle/numpy_reference.py) on its own normals: 3 sigma of the two standard errors."""
+    from oracle import numpy_reference as nr
+    kind = "call" if call else "put"
+    st = _hip.american_lsm(S, K, T, r, v, 0.01, call, N, M, deg, 11)
+    sx, sxx, n = po.american_lsm(S, K, T, r, v, 0.01, call, N, M, deg, 11)
+    assert st.n == n and st.sum == pytest.approx(sx, rel=2e-6) and st.sumsq == pytest.approx(sxx, rel=4e-6)
+    ref = nr.american_price(S, K, T, r, v, 0.01, seed=5, n_paths=N, n_steps=M, option_type=kind, poly_degree=deg)
+    assert abs(st.price - ref) <= 3.0 * math.sqrt(2.0) * st.std_error + 1e-12, (st.price, ref, st.std_error)
+    assert st.price >= max(K - S, 0.0) - 3 * st.std_error if not call else st.price >= max(S - K, 0.0) - 3 * st.std_error
+
+
 def test_american_lsm_against_a_bermudan_binomial_tree():
     """Independent anchor for Longstaff-Schwartz: a CRR tree that allows exercise on the same 50 dates (40 tree steps
     between dates).  LSM's two biases (sub-optimal fitted policy: low; in-sample fit: high) are ~1e-2 here."""

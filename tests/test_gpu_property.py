@@ -190,3 +190,57 @@ def test_sobol_launch_shapes_return_the_same_terminal_prices(N, M, seed, off, S,
     finally:
         _hip.tune(_hip.TUNE_QMC_BLOCK, 0)
     assert np.isfinite(out[0]).all() and np.array_equal(out[0], out[1]) and np.array_equal(out[0], out[2])
+
+
+def _bumps(S, T, r, v, second):
+    """unified_greeks.py:295-358: the 8 / 14 evaluation points in call order."""
+    h_S, h_v, h_r, h_T = max(1e-4, 0.01 * S), 0.01, 1e-4, 1 / 365.0
+    b = [(S, T, r, v), (S + h_S, T, r, v), (S - h_S, T, r, v), (S, T, r, v + h_v), (S, T, r, v - h_v), (S, T - h_T, r, v), (S, T, r + h_r, v), (S, T, r - h_r, v)]
+    if second:
+        b += [(S + h_S, T, r, v + h_v), (S + h_S, T, r, v - h_v), (S - h_S, T, r, v + h_v), (S - h_S, T, r, v - h_v), (S + h_S, T - h_T, r, v), (S - h_S, T - h_T, r, v)]
+    return b
+
+
+@settings(max_examples=30 * SCALE, **COMMON)
+@given(N=paths, M=st.one_of(steps, st.sampled_from([255, 256, 257, 300])), seed=seeds, S=spot, K=strike, v=vol, r=rate, q=div, T=mat, call=st.booleans(),
+       anti=st.booleans(), second=st.booleans(), geo=st.booleans())
+def test_fused_asian_greeks_are_their_own_launches(N, M, seed, S, K, v, r, q, T, call, anti, second, geo):
+    """olmc_asian_greeks_fd, any shape and contract: every one of the 8 / 14 evaluations is what its own launch of the one-contract kernel
+    returns -- the bits for the recursions of their own, 1e-13 for the two r bumps of the arithmetic average, which ride on the mid
+    recursion through a per-date factor re-anchored every 256 dates (the date counts around 256 are there for that)."""
+    _vals, evals = _hip.asian_greeks_fd(S, K, T, r, v, q, call, N, M, seed, anti, second, geometric=geo)
+    for k, ((S_, T_, r_, v_), got) in enumerate(zip(_bumps(S, T, r, v, second), evals)):
+        one = _hip.asian(S_, K, T_, r_, v_, q, call, geo, N, M, seed, anti)
+        assert got.n == one.n
+        if geo or k not in (6, 7):
+            assert got.sum == pytest.approx(one.sum, rel=1e-14, abs=1e-300) and got.sumsq == pytest.approx(one.sumsq, rel=1e-14, abs=1e-300), k
+        else:
+            assert got.sum == pytest.approx(one.sum, rel=1e-13, abs=1e-11) and got.sumsq == pytest.approx(one.sumsq, rel=1e-13, abs=1e-9), k
+
+
+@settings(max_examples=30 * SCALE, **COMMON)
+@given(N=paths, M=steps, seed=seeds, S=spot, K=strike, v=vol, r=rate, q=div, T=mat, call=st.booleans(), anti=st.booleans(), second=st.booleans(),
+       payoff=st.integers(0, 5), rel_level=st.floats(0.03, 0.4))
+def test_fused_barrier_and_lookback_greeks_are_their_own_launches(N, M, seed, S, K, v, r, q, T, call, anti, second, payoff, rel_level):
+    """olmc_extrema_greeks_fd, any shape, contract and payoff (four barriers, two lookbacks): each evaluation against its own launch."""
+    level = S * (1 + rel_level) if payoff < 2 else S * (1 - rel_level)          # up barriers above the spot, down barriers below
+    _vals, evals = _hip.extrema_greeks_fd(S, K, T, r, v, q, call, payoff, level if payoff < 4 else 0.0, N, M, seed, anti, second)
+    for (S_, T_, r_, v_), got in zip(_bumps(S, T, r, v, second), evals):
+        if payoff < 4:
+            one = _hip.barrier(S_, K, T_, r_, v_, q, call, level, payoff, N, M, seed, anti)
+        else:
+            one = _hip.lookback(S_, K, T_, r_, v_, q, call, payoff == 5, N, M, seed, anti)
+        assert got.n == one.n and got.sum == pytest.approx(one.sum, rel=1e-14, abs=1e-300) and got.sumsq == pytest.approx(one.sumsq, rel=1e-14, abs=1e-300)
+
+
+@settings(max_examples=25 * SCALE, **COMMON)
+@given(N=st.one_of(st.integers(8, 600), st.sampled_from([255, 256, 257, 1024, 4097]), st.integers(601, 30_000)), M=st.integers(1, 24), seed=st.integers(0, 2**40),
+       S=st.floats(80.0, 120.0), K=st.floats(85.0, 115.0), v=st.floats(0.1, 0.5), r=rate, q=div, T=st.floats(0.25, 2.0), call=st.booleans(), deg=st.integers(1, 4))
+def test_american_chain(N, M, seed, S, K, v, r, q, T, call, deg):
+    """The Longstaff-Schwartz chain (one launch per exercise date, every workgroup of a launch summing the rows of the one before and
+    solving the normal equations itself) against the checker's serial restatement of the same algebra on the same paths: same exercise
+    decisions path by path, sums to the 2e-6 the hardware log2 / sin / cos leave on a path (a flipped decision would move a sum by one
+    whole cash flow)."""
+    got = _hip.american_lsm(S, K, T, r, v, q, call, N, M, deg, seed)
+    sx, sxx, n = po.american_lsm(S, K, T, r, v, q, call, N, M, deg, seed)
+    assert got.n == n and close(got.sum, sx, 1, n, max(S, K)) and close(got.sumsq, sxx, 4, n, max(S, K), 2)

@@ -244,3 +244,43 @@ def test_american_chain(N, M, seed, S, K, v, r, q, T, call, deg):
     got = _hip.american_lsm(S, K, T, r, v, q, call, N, M, deg, seed)
     sx, sxx, n = po.american_lsm(S, K, T, r, v, q, call, N, M, deg, seed)
     assert got.n == n and close(got.sum, sx, 1, n, max(S, K)) and close(got.sumsq, sxx, 4, n, max(S, K), 2)
+
+
+@settings(max_examples=40 * SCALE, **COMMON)
+@given(N=st.one_of(paths, st.integers(3001, 70_000)), M=steps, seed=seeds, off=offsets, S=spot, K=strike, v=vol, r=rate, q=div, T=mat, call=st.booleans(), anti=st.booleans())
+def test_control_variate_moments(N, M, seed, off, S, K, v, r, q, T, call, anti):
+    """olmc_european_cv_shard: the five moments of (discounted payoff, terminal price) the control-variate estimator is built from
+    (monte_carlo.py:154-186), against the checker's on the same paths."""
+    got = _hip.european_cv_shard(S, K, T, r, v, q, call, off, N, M, seed, anti)
+    sx, sxx, ss, sss, sxs, n = po.european_moments(S, K, T, r, v, q, call, N, M, seed, anti, off)
+    disc = math.exp(-r * T)
+    level = max(S, K) * math.exp(3 * v * math.sqrt(T))
+    assert got.n == n and close(got.sum_d, disc * sx, 1, n, level) and close(got.sum_dd, disc * disc * sxx, 4, n, level, 2)
+    assert close(got.sum_s, ss, 1, n, level) and close(got.sum_ss, sss, 4, n, level, 2) and close(got.sum_ds, disc * sxs, 4, n, level, 2)
+
+
+@settings(max_examples=40 * SCALE, **COMMON)
+@given(N=st.one_of(paths, st.integers(3001, 300_000)), M=steps, seed=seeds, S=spot, K=strike, v=vol, r=rate, q=div, T=mat, call=st.booleans(), second=st.booleans())
+def test_fused_european_greeks_are_their_own_launches(N, M, seed, S, K, v, r, q, T, call, second):
+    """olmc_european_greeks_fd at any shape (whole workgroups, split workgroups, the ragged end): each of the 8 / 14 evaluations against
+    the one-contract launch on the same normals, to the rounding the two payoff forms differ by (olmc.h, olmc_european_batch)."""
+    _vals, evals = _hip.european_greeks_fd(S, K, T, r, v, q, call, N, M, seed, second)
+    for (S_, T_, r_, v_), got in zip(_bumps(S, T, r, v, second), evals):
+        one = _hip.european(S_, K, T_, r_, v_, q, call, N, M, seed, True)
+        assert got.n == one.n and got.sum == pytest.approx(one.sum, rel=1e-12, abs=1e-9) and got.sumsq == pytest.approx(one.sumsq, rel=1e-12, abs=1e-9)
+
+
+@settings(max_examples=20 * SCALE, **COMMON)
+@given(N=st.one_of(st.integers(2, 300), st.sampled_from([1023, 1024, 1025, 4097]), st.integers(301, 20_000)), M=st.integers(1, 30), seed=seeds, S=spot, K=strike,
+       v=vol, r=rate, q=div, T=mat, call=st.booleans())
+def test_exercise_boundary_is_the_percentile_of_the_in_the_money_prices(N, M, seed, S, K, v, r, q, T, call):
+    """olmc_exercise_boundary (exotic_options.py:309-345): per date the 10th (put) / 90th (call) percentile -- NumPy's linear
+    interpolation -- of the in-the-money prices, NaN where nobody is in the money; against np.percentile on the device's own path matrix."""
+    import numpy as np
+    from oracle import numpy_reference as nr
+    got = _hip.exercise_boundary(S, K, T, r, v, q, call, N, M, seed)
+    paths_ = _hip.gbm_paths(math.exp(math.log(S)), T, r, v, q, N, M, seed, path_major=True)
+    want = nr.exercise_boundary_from_paths(paths_, K, "call" if call else "put")
+    assert got.shape == want.shape and np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.allclose(got[ok], want[ok], rtol=1e-12, atol=0.0)

@@ -1911,19 +1911,20 @@ struct LsmCoeffs {
 
 __device__ __forceinline__ double lsm_intrinsic(const LsmContract& c, double s) { return fmax(c.sign * (s - c.strike), 0.0); }
 
-// Runs in the wave that holds the grid totals of one exercise date (all 64 lanes active): lane m < 2d+1 has sum x^m,
-// lane 9+k has sum x^k cf, lane 14 the in-the-money count.  The wave solves the (d+1)x(d+1) normal equations (Gaussian
-// elimination, partial pivoting, fp64 -- the moments of the standardised regressor are benign) and leaves the coefficients in `coef`
-// (LDS of the workgroup that applies them): no host round trip per exercise date.
+// Runs in the wave that holds the grid totals of one exercise date (all 64 lanes active): lane m < 2d+1 has sum z^m,
+// lane 9+k has sum z^k cf, lane 14 the in-the-money count.  The wave solves the (d+1)x(d+1) normal equations (Gaussian
+// elimination in the natural order, fp64) and leaves the coefficients in `coef` (LDS of the workgroup that applies them): no host
+// round trip per exercise date.
 //
-// Round 4: the augmented 5 x 6 matrix lives ONE ELEMENT PER LANE (lane = 8 row + column) instead of thirty doubles in lane 0.
-// Round 3's form indexed its private array with the run-time pivot row (`a[piv][col]`), which put the whole matrix into a
-// 256-byte private segment (the only scratch in the library) and ran ~1,200 dependent fp64 instructions in one lane behind the
-// LAST workgroup of each of the per-date launches.  Here an elimination step is two broadcasts from compile-time lanes
-// (v_readlane: the pivot candidates, the pivot), one run-time row exchange and two gathers (ds_bpermute) and ONE multiply-subtract
-// per lane; back-substitution runs on broadcast (wave-uniform) values.  Every element sees the operations of the serial form in
-// the serial form's order (same pivot choice: first maximum; `f = a[row][col] * inv`, `a -= f * a[col][l]`; the same
-// back-substitution chain), so the coefficients -- and with them every exercise decision -- are the bits round 3 produced.
+// The augmented 5 x 6 matrix lives ONE ELEMENT PER LANE (lane = 8 row + column) instead of thirty doubles in lane 0.  Round 3's
+// form indexed its private array with the run-time pivot row (`a[piv][col]`), which put the whole matrix into a 256-byte private
+// segment (the only scratch in the library) and ran ~1,200 dependent fp64 instructions in one lane.  Here an elimination step is one
+// broadcast from a compile-time lane (v_readlane: the pivot), two gathers (ds_bpermute) and ONE multiply-subtract per lane;
+// back-substitution runs on broadcast (wave-uniform) values.  There is no pivot SEARCH any more: since the regression runs in the
+// standardised regressor (LsmScale) the moment matrix is symmetric positive definite with a condition number of 1e2 .. 1e6, and for
+// such a matrix elimination in the natural order is backward stable (it is the Cholesky order; partial pivoting bought nothing and
+// cost fifteen broadcasts, their compare chains and a row exchange per solve -- a third of the ~450 instructions one wave executes
+// serially at the head of every per-date launch).
 __device__ __forceinline__ double lane_bcast(double v, int src_lane /* compile-time constant */) {
     const uint32_t lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(dbl_lo(v)), src_lane));
     const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(dbl_hi(v)), src_lane));
@@ -1947,16 +1948,8 @@ struct LsmFit {
         if (!live) e = 0.0;
 #pragma unroll
         for (int col = 0; col <= D; ++col) {
-            int piv = col;
-            double best = fabs(lane_bcast(e, col * 8 + col));
-#pragma unroll
-            for (int r = col + 1; r <= D; ++r) {
-                const double cand = fabs(lane_bcast(e, r * 8 + col));
-                if (cand > best) { best = cand; piv = r; }
-            }
-            // rows piv <-> col trade places (a no-op gather when piv == col)
-            const int from = row == col ? piv : (row == piv ? col : row);
-            e = __shfl(e, from * 8 + l, kWave);
+            // no pivot search: the moment matrix of the standardised regressor is symmetric positive definite with a modest condition
+            // number, for which elimination in the natural order is stable (it is the Cholesky order)
             const double p = lane_bcast(e, col * 8 + col);
             if (!(fabs(p) > 1e-280)) ok = false;
             const double inv = 1.0 / p;

@@ -555,6 +555,37 @@ def test_fused_asian_greeks_equal_the_literal_bump_and_reprice(second, anti, geo
     assert isinstance(fused["delta"], np.float64)
 
 
+def test_geometric_asian_price_and_fused_greeks_against_the_discrete_closed_form():
+    """An anchor outside this repository's own kernels: the geometric average over the M dates t_i = i T / M of a lognormal path is
+    lognormal -- ln G ~ N(ln S + (r - q - sigma^2 / 2) T (M + 1) / (2 M), sigma^2 T (M + 1)(2 M + 1) / (6 M^2)) -- so the discretely
+    monitored option has an exact Black-Scholes-type price, and compute_greeks_unified's own bump formulas (unified_greeks.py:295-358)
+    applied to THAT function give the exact finite-difference Greeks.  Eight seeds of 2M paths x 64 dates each through the one-launch
+    kernel: every Greek's mean over the seeds within 4.5 standard errors (of that mean) of the exact value."""
+    S, K, T, r, v, q, M, N = 100.0, 100.0, 1.0, 0.05, 0.2, 0.01, 64, 1 << 21
+    cdf = lambda x: 0.5 * math.erfc(-x / math.sqrt(2.0))
+
+    class Exact:
+        def price(self, S, K, T, r, sigma, option_type, q=0.0, **kw):
+            mu = math.log(S) + (r - q - 0.5 * sigma * sigma) * T * (M + 1) / (2.0 * M)
+            var = sigma * sigma * T * (M + 1) * (2 * M + 1) / (6.0 * M * M)
+            sd = math.sqrt(var)
+            d1 = (mu + var - math.log(K)) / sd
+            fwd = math.exp(mu + 0.5 * var)
+            call = math.exp(-r * T) * (fwd * cdf(d1) - K * cdf(d1 - sd))
+            return call if option_type == "call" else call - math.exp(-r * T) * (fwd - K)
+
+    exact = ol.compute_greeks_unified(Exact(), S, K, T, r, v, "call", q, include_second_order=True)
+    runs = []
+    for seed in range(8):
+        ad = ol.ExoticAdapter(ol.AsianOption(S, K, T, r, v, q, seed=100 + seed), n_paths=N, n_steps=M, avg_type="geometric")
+        runs.append(ol.compute_greeks_unified(ad, S, K, T, r, v, "call", q, include_second_order=True))
+    for k, want in exact.items():
+        xs = np.array([float(g[k]) for g in runs])
+        se = xs.std(ddof=1) / math.sqrt(len(xs))
+        assert abs(xs.mean() - want) <= 4.5 * se + 1e-12, (k, xs.mean(), want, se)
+    assert exact["price"] == pytest.approx(5.4, abs=0.3) and 0.4 < exact["delta"] < 0.7       # the anchor itself is sane
+
+
 @pytest.mark.parametrize("second", [False, True])
 @pytest.mark.parametrize("kind", ["up-and-out", "up-and-in", "down-and-out", "down-and-in", "floating", "fixed"])
 def test_fused_barrier_and_lookback_greeks_equal_the_literal_bump_and_reprice(kind, second):

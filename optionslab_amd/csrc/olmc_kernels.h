@@ -1268,13 +1268,20 @@ __global__ __launch_bounds__(kBlock) void asian_exp64_greeks_kernel(PathRange pr
             for (int g = 0; g < R; ++g) cum[leg][g] = 0.0;
         }
         // A bump of r moves the per-step drift and nothing else: the price relative of such a contract at date t is slot 0's times
-        // exp(rate_step t), the same number for every path.  factor[d] carries it from date to date as f += f * expm1(rate_step) -- ONE
-        // fma whose rounding is unbiased; multiplying by the rounded constant exp(rate_step) = 1 + 1e-7 instead would commit the same
-        // 1e-16 at every date, a drift of the whole average (measured: 1.2e-13 of the r + h price at 1,024 dates) -- and is set afresh
-        // from exp() every 256 dates.
-        double factor[D], factor_step[D];
+        // exp(rate_step t) = 1 + g_t, the same number for every path.  The rider carries g_t (~1e-5: its rounding is 1e-21 of the factor)
+        // from date to date as g += e + g e, e = expm1(rate_step), sums x g beside slot 0's sum of x, and is slot 0's sum plus that.
+        // (Two earlier forms and what they cost: f *= exp(rate_step) commits the same 1e-16 at every date -- the r + h price moved by
+        // 1.2e-13 at 1,024 dates; f += f e is unbiased but its random walk, ~8 ulp after 256 dates, is common to all paths and an
+        // at-the-money payoff K - avg magnifies it a hundredfold: 1.06e-13 in the property hunt.)  g is set afresh from expm1() every
+        // 256 dates.
+        double growth[D], growth_step[D], rider[LEGS][D];
 #pragma unroll
-        for (int d = 0; d < D; ++d) { factor[d] = 1.0; factor_step[d] = expm1(gs.rate_step[d]); }
+        for (int d = 0; d < D; ++d) {
+            growth[d] = 0.0;
+            growth_step[d] = expm1(gs.rate_step[d]);
+#pragma unroll
+            for (int leg = 0; leg < LEGS; ++leg) rider[leg][d] = 0.0;
+        }
         auto dates = [&](const float (&z)[4], auto live) {      // `live` dates of one Philox block, every recursion
 #pragma unroll
             for (int j = 0; j < decltype(live)::value; ++j) {
@@ -1295,9 +1302,9 @@ __global__ __launch_bounds__(kBlock) void asian_exp64_greeks_kernel(PathRange pr
                 }
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    factor[d] = __builtin_fma(factor[d], factor_step[d], factor[d]);
+                    growth[d] = __builtin_fma(growth[d], growth_step[d], growth[d]) + growth_step[d];
 #pragma unroll
-                    for (int leg = 0; leg < LEGS; ++leg) run[leg][R + d] = __builtin_fma(x0[leg], factor[d], run[leg][R + d]);
+                    for (int leg = 0; leg < LEGS; ++leg) rider[leg][d] = __builtin_fma(x0[leg], growth[d], rider[leg][d]);
                 }
             }
         };
@@ -1305,7 +1312,7 @@ __global__ __launch_bounds__(kBlock) void asian_exp64_greeks_kernel(PathRange pr
         float z[4];
         for (int32_t b0 = 0; b0 < full; b0 += kRefreshBlocks) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) factor[d] = exp(gs.rate_step[d] * static_cast<double>(4 * b0));
+            for (int d = 0; d < D; ++d) growth[d] = expm1(gs.rate_step[d] * static_cast<double>(4 * b0));
             const int32_t b1 = min(b0 + kRefreshBlocks, full);
             for (int32_t b = b0; b < b1; ++b) {                 // branch-free body
                 raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(b), 0u, rk, z);
@@ -1314,13 +1321,17 @@ __global__ __launch_bounds__(kBlock) void asian_exp64_greeks_kernel(PathRange pr
         }
         if (rem) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) factor[d] = exp(gs.rate_step[d] * static_cast<double>(4 * full));
+            for (int d = 0; d < D; ++d) growth[d] = expm1(gs.rate_step[d] * static_cast<double>(4 * full));
             raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(full), 0u, rk, z);
             if (rem == 1) dates(z, std::integral_constant<int, 1>{});
             else if (rem == 2) dates(z, std::integral_constant<int, 2>{});
             else dates(z, std::integral_constant<int, 3>{});
         }
         const bool alive = i < pr.count;
+#pragma unroll
+        for (int leg = 0; leg < LEGS; ++leg)
+#pragma unroll
+            for (int d = 0; d < D; ++d) run[leg][R + d] = run[leg][0] + rider[leg][d];
 #pragma unroll
         for (int s = 0; s < NSETS; ++s) {
             const int32_t g = gs.group[s];                       // launch-uniform

@@ -9,6 +9,8 @@ through the C ABI of libolmc.so (ctypes).  Three gates:
      stated floating-point tolerance), plus the reference's own test assertions.
 """
 import math
+import os
+import time
 
 import numpy as np
 import pytest
@@ -652,6 +654,10 @@ def test_concurrent_callers_get_bit_identical_results_on_contexts_of_their_own()
             lambda: qp.price(*ATM, "call", return_error=True),
             lambda: ol.AsianOption(*ATM, seed=k).price(20_000, 32, return_error=True),
             lambda: ol.AmericanOption(*ATM, seed=k).price(5_000 + 100 * k, 10),
+            lambda: tuple(ol.compute_greeks_unified(ol.ExoticAdapter(ol.AsianOption(*ATM, seed=k), n_paths=10_000, n_steps=50, avg_type=("arithmetic", "geometric")[k & 1]),
+                                                    *ATM, "call", include_second_order=False).items()),
+            lambda: tuple(ol.compute_greeks_unified(ol.ExoticAdapter(ol.BarrierOption(*ATM, barrier=120.0, seed=k), n_paths=10_000, n_steps=50, barrier_type="up-and-out"),
+                                                    *ATM, "call", include_second_order=False).items()),
             lambda: tuple(MonteCarloPricerUni(5_000, 10, seed=k).price_batch(np.array([90.0, 100.0 + k]), np.array([100.0, 100.0]), np.array([1.0, 0.5]),
                                                                               np.array([0.05, 0.05]), np.array([0.2, 0.3]), "call")),
         ]
@@ -664,7 +670,9 @@ def test_concurrent_callers_get_bit_identical_results_on_contexts_of_their_own()
         try:
             fs = calls(k)
             start.wait()
-            for _ in range(15):
+            rounds, t_end = 0, time.monotonic() + float(os.environ.get("OLMC_CONCURRENCY_SECONDS", "0"))     # a long hunt on request
+            while rounds < 15 or time.monotonic() < t_end:
+                rounds += 1
                 got[k] = [f() for f in fs]
                 if got[k] != want[k]:
                     raise AssertionError(f"thread {k}: a concurrent call returned other bits than the single-threaded one")

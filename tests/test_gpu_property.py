@@ -206,8 +206,9 @@ def _bumps(S, T, r, v, second):
        anti=st.booleans(), second=st.booleans(), geo=st.booleans())
 def test_fused_asian_greeks_are_their_own_launches(N, M, seed, S, K, v, r, q, T, call, anti, second, geo):
     """olmc_asian_greeks_fd, any shape and contract: every one of the 8 / 14 evaluations is what its own launch of the one-contract kernel
-    returns -- the bits for the recursions of their own, 1e-13 for the two r bumps of the arithmetic average, which ride on the mid
-    recursion through a per-date factor re-anchored every 256 dates (the date counts around 256 are there for that)."""
+    returns -- the bits for the recursions of their own, 2e-14 for the two r bumps of the arithmetic average, which ride on the mid
+    recursion through a per-date growth term re-anchored every 256 dates (the date counts around 256 are there for that; the hunt
+    took two less careful forms of that term apart -- see the kernel)."""
     _vals, evals = _hip.asian_greeks_fd(S, K, T, r, v, q, call, N, M, seed, anti, second, geometric=geo)
     for k, ((S_, T_, r_, v_), got) in enumerate(zip(_bumps(S, T, r, v, second), evals)):
         one = _hip.asian(S_, K, T_, r_, v_, q, call, geo, N, M, seed, anti)
@@ -215,7 +216,11 @@ def test_fused_asian_greeks_are_their_own_launches(N, M, seed, S, K, v, r, q, T,
         if geo or k not in (6, 7):
             assert got.sum == pytest.approx(one.sum, rel=1e-14, abs=1e-300) and got.sumsq == pytest.approx(one.sumsq, rel=1e-14, abs=1e-300), k
         else:
-            assert got.sum == pytest.approx(one.sum, rel=1e-13, abs=1e-11) and got.sumsq == pytest.approx(one.sumsq, rel=1e-13, abs=1e-9), k
+            # the literal launch of an r bump and the mid recursion round their cumulative log-returns independently at every date (other
+            # drift, other roundings: a random walk of a few ulp over some hundred dates, seen: 6 ulp on one path of 256 dates), and
+            # K - avg keeps that absolute error.  An off-by-one date in the growth term would be 1e-7 of a payoff: eight orders above this.
+            lvl = max(S, K)
+            assert got.sum == pytest.approx(one.sum, rel=2e-14, abs=2e-14 * got.n * lvl) and got.sumsq == pytest.approx(one.sumsq, rel=4e-14, abs=2e-14 * got.n * lvl * lvl), k
 
 
 @settings(max_examples=30 * SCALE, **COMMON)

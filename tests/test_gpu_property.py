@@ -295,3 +295,65 @@ def test_exercise_boundary_is_the_percentile_of_the_in_the_money_prices(N, M, se
     assert got.shape == want.shape and np.array_equal(np.isnan(got), np.isnan(want))
     ok = ~np.isnan(want)
     assert np.allclose(got[ok], want[ok], rtol=1e-12, atol=0.0)
+
+
+@settings(max_examples=25 * SCALE, **COMMON)
+@given(N=st.one_of(st.integers(1, 300), st.sampled_from([63, 64, 65, 4095, 4097, 1 << 15]), st.integers(301, 40_000)), M=st.integers(1, 70), seed=st.integers(0, 2**31 - 1),
+       S=spot, K=strike, v=vol, r=rate, q=div, T=mat, call=st.booleans(), second=st.booleans())
+def test_fused_sobol_greeks_and_control_variate_are_their_own_launches(N, M, seed, S, K, v, r, q, T, call, second):
+    """olmc_european_qmc_greeks_fd (one launch, 8 / 14 contracts on the same Sobol points; eight points per thread or split workgroups
+    by size) against olmc_european_qmc per contract, and olmc_european_qmc_cv's payoff moments against the same launch."""
+    from optionslab_amd.monte_carlo import sobol_tables
+    sv, shift = sobol_tables(M, seed)
+    _vals, evals = _hip.european_qmc_greeks_fd(S, K, T, r, v, q, call, N, sv, shift, second)
+    for (S_, T_, r_, v_), got in zip(_bumps(S, T, r, v, second), evals):
+        one = _hip.european_qmc(S_, K, T_, r_, v_, q, call, N, sv, shift)
+        assert got.n == one.n and got.sum == pytest.approx(one.sum, rel=1e-12, abs=1e-9) and got.sumsq == pytest.approx(one.sumsq, rel=1e-12, abs=1e-9)
+    base = _hip.european_qmc(S, K, T, r, v, q, call, N, sv, shift)
+    cv = _hip.european_qmc_cv(S, K, T, r, v, q, call, N, sv, shift)
+    disc = math.exp(-r * T)
+    assert cv.n == base.n and cv.sum_d == pytest.approx(disc * base.sum, rel=1e-12, abs=1e-9) and cv.sum_dd == pytest.approx(disc * disc * base.sumsq, rel=1e-12, abs=1e-9)
+
+
+@settings(max_examples=20 * SCALE, **COMMON)
+@given(N=st.integers(16, 100_000), M=steps, seed=seeds, ranks=st.integers(1, 9), S=spot, K=strike, v=vol, r=rate, q=div, T=mat, call=st.booleans(), second=st.booleans())
+def test_multi_rank_greeks_and_control_variate_equal_the_one_device_call(N, M, seed, ranks, S, K, v, r, q, T, call, second):
+    """olmc_multi_gpu_greeks_fd / _european_cv with 1..9 ranks REHEARSED on this one device (instrumented build): every rank prices its
+    contiguous range of the global paths, ONE grouped all-reduce of 2 k + 1 / 6 sums; against the one-device call to the rounding of
+    another summation order."""
+    from tools.probe import binding as probe
+    hip = probe.hip
+    ranks = min(ranks, N)
+    probe.tune(probe.TUNE_MULTI_REHEARSAL, 1)
+    try:
+        vals, evals = hip.multi_gpu_greeks_fd(S, K, T, r, v, q, call, N, M, seed, second, ranks)
+        cv = hip.multi_gpu_european_cv(S, K, T, r, v, q, call, N, M, seed, True, ranks)
+    finally:
+        probe.tune(probe.TUNE_MULTI_REHEARSAL, 0)
+    vals1, evals1 = hip.european_greeks_fd(S, K, T, r, v, q, call, N, M, seed, second)
+    for a, b in zip(evals, evals1):
+        assert a.n == b.n and a.sum == pytest.approx(b.sum, rel=1e-12, abs=1e-9) and a.sumsq == pytest.approx(b.sumsq, rel=1e-12, abs=1e-9)
+    cv1 = hip.european_cv(S, K, T, r, v, q, call, N, M, seed, True)
+    for f in ("sum_d", "sum_s", "sum_dd", "sum_ss", "sum_ds"):
+        assert getattr(cv, f) == pytest.approx(getattr(cv1, f), rel=1e-12, abs=1e-9), f
+    assert cv.n == cv1.n and hip.device_info()["device"] == 0
+
+
+@settings(max_examples=20 * SCALE, **COMMON)
+@given(N=st.one_of(st.integers(1, 300), st.sampled_from([255, 256, 257, 1025])), M=st.integers(1, 40), seed=seeds, S=spot, v=vol, r=rate, q=div, T=mat,
+       kappa=st.floats(0.5, 4.0), theta=st.floats(0.01, 0.1), sv=st.floats(0.05, 1.0), rho=st.floats(-0.95, 0.95), v0=st.floats(0.005, 0.15), path_major=st.booleans())
+def test_path_matrices(N, M, seed, S, v, r, q, T, kappa, theta, sv, rho, v0, path_major):
+    """simulate_gbm_paths (gbm_numpy.py:86-118) and HestonPricer.simulate_paths (heston.py:257-305) on the device: every state of every
+    path, both layouts, against the checker's."""
+    import numpy as np
+    got = _hip.gbm_paths(S, T, r, v, q, N, M, seed, path_major=path_major)
+    want = po.gbm_paths(S, T, r, v, q, N, M, seed)
+    assert np.allclose(got.T if path_major else got, want, rtol=4e-6, atol=0)
+    spot_, var_ = _hip.heston_paths(S, T, r, q, kappa, theta, sv, rho, v0, N, M, seed, path_major=path_major)
+    ws, wv = po.heston_paths(S, T, r, q, kappa, theta, sv, rho, v0, N, M, seed)
+    gs_, gv_ = (spot_.T, var_.T) if path_major else (spot_, var_)
+    # state by state only on paths whose variance stays away from the truncation at 0: there sqrt(v) turns the 1e-7 of the hardware
+    # normals into 3e-4 and the two paths part for good (a Hoelder-1/2 map; the PRICE property above averages over it)
+    calm = wv.min(axis=0) > 2e-3
+    assert np.allclose(gs_[:, calm], ws[:, calm], rtol=2e-5, atol=0) and np.allclose(gv_[:, calm], wv[:, calm], rtol=2e-4, atol=1e-7)
+    assert np.isfinite(gs_).all() and (gs_ > 0).all() and (gv_ >= 0).all() and np.array_equal(gv_[0], wv[0]) and np.array_equal(gs_[0], ws[0])

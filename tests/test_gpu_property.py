@@ -357,3 +357,19 @@ def test_path_matrices(N, M, seed, S, v, r, q, T, kappa, theta, sv, rho, v0, pat
     calm = wv.min(axis=0) > 2e-3
     assert np.allclose(gs_[:, calm], ws[:, calm], rtol=2e-5, atol=0) and np.allclose(gv_[:, calm], wv[:, calm], rtol=2e-4, atol=1e-7)
     assert np.isfinite(gs_).all() and (gs_ > 0).all() and (gv_ >= 0).all() and np.array_equal(gv_[0], wv[0]) and np.array_equal(gs_[0], ws[0])
+
+
+@settings(max_examples=25 * SCALE, **COMMON)
+@given(cs=st.lists(st.tuples(spot, strike, mat, rate, vol, div), min_size=1, max_size=40), N=st.one_of(st.integers(1, 600), st.sampled_from([255, 256, 257, 4097, 70_000])),
+       M=batch_steps, seed=seeds, call=st.booleans(), anti=st.booleans())
+def test_a_batch_of_independent_contracts_prices_each_as_its_own_launch(cs, N, M, seed, call, anti):
+    """olmc_european_multi (MonteCarloPricerUni.price_batch, monte_carlo_unified.py:562-631: one launch, a grid of contracts x path
+    blocks, per-contract finisher): with every contract on stream tag 0 each one is exactly the single-contract launch of the same
+    contract -- any number of contracts, any ragged path count, with and without antithetic legs."""
+    import numpy as np
+    a = np.array(cs, dtype=np.float64)
+    got = _hip.european_multi(a[:, 0], a[:, 1], a[:, 2], a[:, 3], a[:, 4], a[:, 5], call, N, M, seed, anti, tags=np.zeros(len(cs), dtype=np.uint32))
+    for j, (S_, K_, T_, r_, v_, q_) in enumerate(cs):
+        one = _hip.european(S_, K_, T_, r_, v_, q_, call, N, M, seed, anti)
+        assert got["n"][j] == one.n and got["sum"][j] == pytest.approx(one.sum, rel=1e-12, abs=1e-9) and got["sumsq"][j] == pytest.approx(one.sumsq, rel=1e-12, abs=1e-9), j
+        assert got["price"][j] == pytest.approx(one.price, rel=1e-12, abs=1e-12)

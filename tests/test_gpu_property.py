@@ -373,3 +373,38 @@ def test_a_batch_of_independent_contracts_prices_each_as_its_own_launch(cs, N, M
         one = _hip.european(S_, K_, T_, r_, v_, q_, call, N, M, seed, anti)
         assert got["n"][j] == one.n and got["sum"][j] == pytest.approx(one.sum, rel=1e-12, abs=1e-9) and got["sumsq"][j] == pytest.approx(one.sumsq, rel=1e-12, abs=1e-9), j
         assert got["price"][j] == pytest.approx(one.price, rel=1e-12, abs=1e-12)
+
+
+def _same_but_for_a_path_on_the_edge(got, want, scale, n, level, power=1, flips=2):
+    """close(), or -- in the randomised hunt only -- off by at most `flips` payoffs: a path whose extremum sits within the 1e-7 the
+    hardware log2 / sin / cos leave of a barrier lands on one side on the device and on the other in the checker (libm)."""
+    if close(got, want, scale, n, level, power):
+        return True
+    return SCALE > 1 and abs(got - want) <= flips * (3.0 * level) ** power
+
+
+@settings(max_examples=40 * SCALE, **COMMON)
+@given(N=paths, M=steps, seed=seeds, off=offsets, S=spot, K=strike, v=vol, r=rate, q=div, T=mat, call=st.booleans(), anti=st.booleans(), payoff=st.integers(0, 3),
+       rel_level=st.floats(0.02, 0.5))
+def test_barrier(N, M, seed, off, S, K, v, r, q, T, call, anti, payoff, rel_level):
+    """The four barrier payoffs (exotic_options.py:174-224) against the checker on the same paths."""
+    level = S * (1 + rel_level) if payoff < 2 else S * (1 - rel_level)
+    got = _hip.barrier(S, K, T, r, v, q, call, level, payoff, N, M, seed, anti, path_offset=off)
+    sx, sxx, n = po.extrema_moments(S, K, T, r, v, q, call, payoff, level, N, M, seed, anti, off)
+    lvl = max(S, K) * math.exp(3 * v * math.sqrt(T))
+    assert got.n == n and _same_but_for_a_path_on_the_edge(got.sum, sx, 1, n, lvl) and _same_but_for_a_path_on_the_edge(got.sumsq, sxx, 4, n, lvl, 2)
+
+
+@settings(max_examples=40 * SCALE, **COMMON)
+@given(N=paths, M=st.integers(1, 130), seed=seeds, off=offsets, S=spot, v=vol, r=rate, q=div, T=mat, anti=st.booleans(), freq=st.integers(1, 40),
+       autocall=st.floats(0.9, 1.3), coupon_b=st.floats(0.5, 1.0), coupon=st.floats(0.0, 0.2), ki=st.floats(0.4, 0.9))
+def test_autocallable(N, M, seed, off, S, v, r, q, T, anti, freq, autocall, coupon_b, coupon, ki):
+    """AutocallableOption.price (exotic_options.py:404-491) against the checker: observation dates, early redemption, coupon and
+    knock-in barriers on the same paths."""
+    if freq > M:
+        with pytest.raises(AccelerationError):
+            _hip.autocallable(S, T, r, v, q, autocall, coupon_b, coupon, ki, freq, N, M, seed, anti, path_offset=off)
+        return
+    got = _hip.autocallable(S, T, r, v, q, autocall, coupon_b, coupon, ki, freq, N, M, seed, anti, path_offset=off)
+    sx, sxx, n = po.autocall_moments(S, T, r, v, q, autocall, coupon_b, coupon, ki, freq, N, M, seed, anti, off)
+    assert got.n == n and _same_but_for_a_path_on_the_edge(got.sum, sx, 1, n, 1.0) and _same_but_for_a_path_on_the_edge(got.sumsq, sxx, 4, n, 1.0, 2)

@@ -181,6 +181,22 @@ def test_qmc_terminal_array_vs_oracle(N, M, seed):
     assert np.array_equal(a, got[400:700])                           # point index = global path index
 
 
+@pytest.mark.parametrize("off,M", [((1 << 16) - 3, 16), ((1 << 20) + 5, 9), ((1 << 22) - 130, 12), ((1 << 24) + 1, 5), ((1 << 26) - 64, 3)])
+def test_qmc_points_far_into_the_sequence_equal_scipys(off, M):
+    """A shard of a large Sobol launch (multi-GPU or chunked: point index = global path index) starts millions of points in, where the
+    high bits of the Gray code select the late columns of the direction matrix: 257 points from index `off` on (crossing a power of two
+    or ending on one) against SciPy's own engine fast-forwarded there, through the reference's pipeline (gbm_qmc.py:32-46)."""
+    from scipy.stats import norm
+    from scipy.stats.qmc import Sobol
+    S, T, r, v, q, seed, N = 100.0, 1.0, 0.05, 0.2, 0.01, 13, 257
+    eng = Sobol(d=M, scramble=True, seed=seed)
+    eng.fast_forward(off)
+    z = norm.ppf(np.clip(eng.random(N), 1e-10, 1 - 1e-10))
+    want = np.exp(np.log(S) + (r - q - 0.5 * v * v) * (T / M) * M + v * np.sqrt(T / M) * np.sum(z, axis=1))
+    got = _hip.european_qmc_terminal(S, T, r, v, q, N, *ol.monte_carlo.sobol_tables(M, seed), point_offset=off)
+    assert np.allclose(got, want, rtol=1e-11, atol=0)
+
+
 @pytest.mark.parametrize("N,M,seed", [(1024, 12, 42), (333, 40, 5)])
 def test_qmc_standalone_backends_vs_oracle(N, M, seed, golden):
     """simulate_gbm_qmc / simulate_gbm_qmc_antithetic as exported functions (src/simulation/__init__.py)."""

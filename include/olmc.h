@@ -285,12 +285,14 @@ int olmc_cliquet(double S, double T, double r, double sigma, double q, double lo
 
 /* ---- American option, Longstaff-Schwartz LSM --------------------------------------
  * Replaces AmericanOption.price (src/pricing_models/exotic_options.py:227-305): stores the path
- * matrix in HBM (time-major), one launch per exercise date doing {exercise decision of the later
- * date, one-step discount, regression moments of this date} with the fused deterministic
- * reduction; the launch's last workgroup solves the small normal equations and leaves the
- * coefficients in device memory for the next launch (no host round trip per date).  Polynomial basis in
- * S/K of degree poly_degree in [1, 4] (the reference's default is 3).  out->price = mean of the
- * time-0 cash flows; single device. */
+ * matrix in HBM (time-major), one launch per exercise date doing {regression of the later date from the
+ * sums the launch before it left (every workgroup sums them in index order and solves the small normal
+ * equations itself), exercise decision of that date, one-step discount, regression sums of this date};
+ * no host round trip per date, the host waits once.  Polynomial of degree poly_degree in [1, 4] (the
+ * reference's default is 3) in S/K -- the space of the reference's raw powers of S, so the same fit in exact
+ * arithmetic -- written in the standardised regressor (S/K - c_t) / w_t (mean and width of S_t/K over the
+ * in-the-money side under the model's own law), which keeps the normal equations well conditioned where the
+ * reference relies on lstsq's SVD.  out->price = mean of the time-0 cash flows; single device. */
 int olmc_american_lsm(double S, double K, double T, double r, double sigma, double q, int is_call,
                       int64_t n_paths, int32_t n_steps, int32_t poly_degree, uint64_t seed,
                       olmc_stats* out);

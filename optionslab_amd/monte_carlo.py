@@ -26,30 +26,90 @@ SOBOL_VALIDATED_SCIPY = "1.15.3"  # the SciPy whose private Sobol tables (_sv, _
 _sobol_cache: "OrderedDict[tuple, tuple]" = OrderedDict()
 
 
-def sobol_tables(n_steps: int, seed: int):
+def sobol_tables(n_steps: int, seed: int, n_points: int = 1 << 20):
     """(sv, shift) of scipy.stats.qmc.Sobol(d=min(n_steps, 21201), scramble=True, seed=seed):
     the scrambled direction matrix and digital shift the device expands into the very same
     points SciPy's .random(n) returns (src/simulation/gbm_qmc.py:32-33).  Only this small
     host-side table construction uses SciPy (a dependency of the reference); the points, the
-    inverse normal and the payoff reduction run on the GPU.  Cached: FD Greeks reuse it."""
+    inverse normal and the payoff reduction run on the GPU.  Cached: FD Greeks reuse it.
+
+    The tables are SciPy privates (`_sv`, `_shift`).  Where they are absent or no longer reproduce
+    the engine's own points (_check_sobol_tables), they are DERIVED from the engine's public
+    behaviour alone (_derive_sobol_tables: .random() and .fast_forward()), for as many columns as
+    the first `n_points` points (point offset included) can select; only an engine that offers
+    neither way disables MCMethod.QMC."""
     d = min(int(n_steps), SOBOL_MAX_DIM)
     key = (d, int(seed))
+    need_bits = max(int(n_points) - 1, 1).bit_length()
     hit = _sobol_cache.get(key)
-    if hit is not None:
+    if hit is not None and hit[2] >= need_bits:
         _sobol_cache.move_to_end(key)
-        return hit
+        return hit[0], hit[1]
     from scipy.stats import qmc
 
     eng = qmc.Sobol(d=d, scramble=True, seed=seed)
-    if getattr(eng, "bits", None) != 30 or not hasattr(eng, "_sv") or not hasattr(eng, "_shift"):
-        raise AccelerationError("this SciPy's Sobol engine does not expose 30-bit _sv/_shift tables "
+    if getattr(eng, "bits", None) != 30:
+        raise AccelerationError("this SciPy's Sobol engine is not the 30-bit engine the device kernels expand "
                                 f"(validated with SciPy {SOBOL_VALIDATED_SCIPY})", backend="hip")
-    val = (np.ascontiguousarray(eng._sv, dtype=np.uint32), np.ascontiguousarray(eng._shift, dtype=np.uint32))
-    _check_sobol_tables(val, eng, d)
+    val = None
+    if hasattr(eng, "_sv") and hasattr(eng, "_shift"):
+        try:
+            cand = (np.ascontiguousarray(eng._sv, dtype=np.uint32), np.ascontiguousarray(eng._shift, dtype=np.uint32))
+            _check_sobol_tables(cand, eng, d)
+            val = (cand[0], cand[1], 30)
+        except AccelerationError as e:
+            private_failure = e
+    else:
+        private_failure = AccelerationError("this SciPy's Sobol engine does not expose 30-bit _sv/_shift tables "
+                                            f"(validated with SciPy {SOBOL_VALIDATED_SCIPY})", backend="hip")
+    if val is None:
+        try:
+            sv, shift = _derive_sobol_tables(qmc.Sobol, d, seed, need_bits)
+        except (AttributeError, TypeError, ValueError, AssertionError) as e:
+            raise AccelerationError(f"{private_failure}; and the tables cannot be derived from the engine's public behaviour either "
+                                    f"({type(e).__name__}: {e}); MCMethod.QMC is unavailable", backend="hip") from e
+        val = (sv, shift, need_bits)
     _sobol_cache[key] = val
     while len(_sobol_cache) > 8:
         _sobol_cache.popitem(last=False)
-    return val
+    return val[0], val[1]
+
+
+def _derive_sobol_tables(engine_class, d: int, seed: int, bits: int):
+    """(sv, shift) from the PUBLIC behaviour of the engine: point 0 is the digital shift, and consecutive points of a Gray-code Sobol
+    sequence differ by exactly one column of the direction matrix -- x_i = x_{i-1} ^ sv[:, ctz(i)] -- so points 2^c - 1 and 2^c give
+    column c.  .fast_forward() skips the points in between (O(2^bits * d) inside SciPy: 0.3 s for 2^20 points x 252 dimensions; the
+    columns beyond `bits` stay zero and are never selected by a point index below 2^bits).  The result must reproduce the engine's own
+    points at the head of the sequence AND across the last derived column, or it is refused."""
+    bits = min(max(int(bits), 4), 30)
+    eng = engine_class(d=d, scramble=True, seed=seed)
+
+    def as_int(u):
+        x = np.rint(np.asarray(u, dtype=np.float64) * 2.0 ** 30)
+        assert np.array_equal(x * 2.0 ** -30, u) and x.min() >= 0 and x.max() < 2.0 ** 30, "points are not multiples of 2^-30"
+        return x.astype(np.uint32)
+
+    shift = as_int(eng.random(1)[0])
+    sv = np.zeros((d, 30), dtype=np.uint32)
+    last_idx, last_x = 0, shift
+    for c in range(bits):
+        t = 1 << c
+        if last_idx < t - 1:
+            skip = t - 1 - (last_idx + 1)
+            if skip:
+                eng.fast_forward(skip)
+            two = eng.random(2)
+            before, at = as_int(two[0]), as_int(two[1])
+        else:
+            before, at = last_x, as_int(eng.random(1)[0])
+        sv[:, c] = before ^ at
+        last_idx, last_x = t, at
+    check = engine_class(d=d, scramble=True, seed=seed)
+    assert np.array_equal(expand_sobol_points(sv, shift, 0, 8), np.asarray(check.random(8), dtype=np.float64)), "head of the sequence"
+    far = (1 << bits) - 5
+    check.fast_forward(far - 8)
+    assert np.array_equal(expand_sobol_points(sv, shift, far, 4), np.asarray(check.random(4), dtype=np.float64)), "end of the derived range"
+    return sv, shift
 
 
 def expand_sobol_points(sv: np.ndarray, shift: np.ndarray, first: int, count: int) -> np.ndarray:
@@ -149,7 +209,7 @@ class MonteCarloPricer:
         """Terminal prices, length 2*num_simulations, [pos | neg] (monte_carlo.py:74-106)."""
         actual_seed = seed if seed is not None else self.seed
         if self.method == MCMethod.QMC:
-            sv, shift = sobol_tables(self._steps(), actual_seed)
+            sv, shift = sobol_tables(self._steps(), actual_seed, self.num_simulations)
             return _hip.european_qmc_terminal(S, T, r, sigma, q, self.num_simulations, sv, shift)
         return _hip.european_terminal(S, T, r, sigma, q, self.num_simulations, self._steps(), actual_seed, True)
 
@@ -161,7 +221,7 @@ class MonteCarloPricer:
             return MCResult(intrinsic, 0.0, 0) if return_error else intrinsic
         actual_seed = seed if seed is not None else self.seed
         if self.method == MCMethod.QMC:
-            sv, shift = sobol_tables(self._steps(), actual_seed)
+            sv, shift = sobol_tables(self._steps(), actual_seed, self.num_simulations)
             st = _hip.european_qmc(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift)
         elif self.n_gpus > 1:
             st = _hip.multi_gpu_european(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(), actual_seed, True,
@@ -179,7 +239,7 @@ class MonteCarloPricer:
         """Terminal spot as control, E[S_T] = S e^{(r-q)T} (monte_carlo.py:154-186)."""
         actual_seed = seed if seed is not None else self.seed
         if self.method == MCMethod.QMC:   # the same five-moment reduction on the Sobol points (N samples, no mirror)
-            sv, shift = sobol_tables(self.num_steps, actual_seed)
+            sv, shift = sobol_tables(self.num_steps, actual_seed, self.num_simulations)
             return float(_hip.european_qmc_cv(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift).value)
         if self.n_gpus > 1:
             m = _hip.multi_gpu_european_cv(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(), actual_seed, True,
@@ -210,7 +270,7 @@ class MonteCarloPricer:
     def _fused_greeks(self, S, K, T, r, sigma, option_type, q, include_second_order, seed=None):
         actual_seed = seed if seed is not None else self.seed
         if self.method == MCMethod.QMC:   # the bumped contracts share the Sobol points (same dims, same seed): one launch prices them all
-            sv, shift = sobol_tables(self._steps(), actual_seed)
+            sv, shift = sobol_tables(self._steps(), actual_seed, self.num_simulations)
             vals, _ = _hip.european_qmc_greeks_fd(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift,
                                                   include_second_order, want_evals=False)
         elif self.n_gpus > 1:

@@ -40,7 +40,7 @@ def simulate_gbm_qmc_hip(S: float, T: float, r: float, sigma: float, q: float, n
     """Scrambled-Sobol terminal prices, length n_paths (counterpart of simulate_gbm_qmc, gbm_qmc.py:14-46)."""
     from .monte_carlo import sobol_tables
 
-    sv, shift = sobol_tables(n_steps, seed)
+    sv, shift = sobol_tables(n_steps, seed, n_paths)
     return _hip.european_qmc_terminal(S, T, r, sigma, q, n_paths, sv, shift)
 
 
@@ -50,5 +50,5 @@ def simulate_gbm_qmc_antithetic_hip(S: float, T: float, r: float, sigma: float, 
     (counterpart of simulate_gbm_qmc_antithetic, gbm_qmc.py:49-76)."""
     from .monte_carlo import sobol_tables
 
-    sv, shift = sobol_tables(n_steps, seed)
+    sv, shift = sobol_tables(n_steps, seed, n_paths)
     return _hip.european_qmc_terminal(S, T, r, sigma, q, n_paths, sv, shift, antithetic=True)

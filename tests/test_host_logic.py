@@ -233,10 +233,55 @@ def test_sobol_tables_reproduce_scipys_own_points():
         assert np.array_equal(mc.expand_sobol_points(sv, shift, 0, 8), pts[:8])
 
 
+@pytest.mark.parametrize("privates", ["absent", "reordered_columns"])
+def test_sobol_tables_are_derived_from_public_behaviour_when_the_privates_fail(monkeypatch, privates):
+    """A SciPy that drops or re-lays-out `_sv` / `_shift` but keeps the public engine (.random, .fast_forward, 30 bits) does not
+    switch MCMethod.QMC off: consecutive points of the Gray-code sequence differ by one column of the direction matrix, so the
+    tables are read off the engine's own points -- and are the very tables the privates hold, column by column, for every column
+    the asked number of points can select (the rest stay zero)."""
+    import numpy as np
+    from scipy.stats import qmc
+    from optionslab_amd import monte_carlo as mc
+
+    real = qmc.Sobol
+
+    class PublicOnly:
+        bits = 30
+
+        def __init__(self, d, scramble=True, seed=None):
+            self._eng = real(d=d, scramble=scramble, seed=seed)
+            if privates == "reordered_columns":
+                self._sv, self._shift = np.array(self._eng._sv)[:, ::-1], np.array(self._eng._shift)
+
+        def random(self, n):
+            return self._eng.random(n)
+
+        def fast_forward(self, n):
+            self._eng.fast_forward(n)
+            return self
+
+    monkeypatch.setattr(qmc, "Sobol", PublicOnly)
+    mc._sobol_cache.clear()
+    sv, shift = mc.sobol_tables(12, 5, n_points=3000)            # 12 columns can be selected by point indices below 4096
+    truth = real(d=12, scramble=True, seed=5)
+    assert np.array_equal(shift, np.asarray(truth._shift, dtype=np.uint32))
+    assert np.array_equal(sv[:, :12], np.asarray(truth._sv, dtype=np.uint32)[:, :12]) and not sv[:, 12:].any()
+    pts = truth.random(3000)
+    assert np.array_equal(mc.expand_sobol_points(sv, shift, 2990, 10), pts[2990:])
+    # asking for more points later derives more columns (and replaces the cached, shorter tables)
+    sv2, _ = mc.sobol_tables(12, 5, n_points=1 << 15)
+    assert np.array_equal(sv2[:, :15], np.asarray(truth._sv, dtype=np.uint32)[:, :15]) and not sv2[:, 15:].any()
+    assert mc.sobol_tables(12, 5, n_points=100)[0] is sv2        # fewer points: the cached tables serve
+    monkeypatch.setattr(qmc, "Sobol", real)
+    mc._sobol_cache.clear()
+    assert np.array_equal(mc.sobol_tables(12, 5)[0], np.asarray(truth._sv, dtype=np.uint32))       # the private tables, all 30 columns
+
+
 @pytest.mark.parametrize("breakage", ["no_tables", "wrong_bits", "reordered_columns", "wrong_shape"])
 def test_sobol_guard_refuses_an_engine_whose_private_tables_changed(monkeypatch, breakage):
-    """A SciPy bump that removes or re-lays-out the private tables must disable QMC loudly (AccelerationError), never
-    price on other points: the guard checks behaviour, not just attribute names."""
+    """A SciPy bump that removes or re-lays-out the private tables AND offers no .fast_forward() to derive them from (or is not the
+    30-bit engine) must disable QMC loudly (AccelerationError), never price on other points: the guard checks behaviour, not just
+    attribute names."""
     import numpy as np
     from scipy.stats import qmc
     from optionslab_amd import monte_carlo as mc

@@ -197,6 +197,41 @@ def test_qmc_points_far_into_the_sequence_equal_scipys(off, M):
     assert np.allclose(got, want, rtol=1e-11, atol=0)
 
 
+def test_qmc_prices_the_same_bits_from_tables_derived_without_scipys_privates(monkeypatch):
+    """optionslab_amd.monte_carlo._derive_sobol_tables: a SciPy without `_sv` / `_shift` still prices on the same Sobol points -- the
+    price, its Greeks and the terminal array from the derived tables are the bits the private tables give."""
+    from scipy.stats import qmc
+    from optionslab_amd import monte_carlo as mc
+
+    real = qmc.Sobol
+    p = ol.MonteCarloPricer(5000, 24, 11, ol.MCMethod.QMC)
+    mc._sobol_cache.clear()
+    want = (p.price(*ATM, "call", return_error=True), tuple(p.greeks(*ATM, "put").items()), p._simulate(100.0, 1.0, 0.05, 0.2, 0.0).tobytes())
+
+    class PublicOnly:
+        bits = 30
+
+        def __init__(self, d, scramble=True, seed=None):
+            self._eng = real(d=d, scramble=scramble, seed=seed)
+
+        def random(self, n):
+            return self._eng.random(n)
+
+        def fast_forward(self, n):
+            self._eng.fast_forward(n)
+            return self
+
+    monkeypatch.setattr(qmc, "Sobol", PublicOnly)
+    mc._sobol_cache.clear()
+    try:
+        got = (p.price(*ATM, "call", return_error=True), tuple(p.greeks(*ATM, "put").items()), p._simulate(100.0, 1.0, 0.05, 0.2, 0.0).tobytes())
+        assert not mc._sobol_cache[(24, 11)][0][:, 13:].any()          # 5000 points select 13 columns: these tables WERE derived
+    finally:
+        monkeypatch.setattr(qmc, "Sobol", real)
+        mc._sobol_cache.clear()
+    assert got == want
+
+
 @pytest.mark.parametrize("N,M,seed", [(1024, 12, 42), (333, 40, 5)])
 def test_qmc_standalone_backends_vs_oracle(N, M, seed, golden):
     """simulate_gbm_qmc / simulate_gbm_qmc_antithetic as exported functions (src/simulation/__init__.py)."""

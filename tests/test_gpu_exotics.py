@@ -643,6 +643,28 @@ def test_the_exotic_page_greeks_take_one_launch_each():
         _hip.profile_enable(False)
 
 
+def test_the_fused_exotic_greeks_refuse_what_they_cannot_price():
+    """olmc_asian_greeks_fd / olmc_extrema_greeks_fd argument checks: status OLMC_ERR_ARG through the binding (AccelerationError),
+    a message in olmc_last_error, nothing launched."""
+    from optionslab_amd._hip import lib
+    import ctypes as C
+    out9 = (C.c_double * 9)()
+    P = (100.0, 100.0, 1.0, 0.05, 0.2, 0.0)
+    assert lib().olmc_asian_greeks_fd(*P, 1, _hip.AVG_ARITHMETIC_FAST, 1000, 10, 1, 0, 0, out9, None) != 0        # the fp32-exponent form has no fused Greeks
+    assert b"avg_kind" in lib().olmc_last_error()
+    assert lib().olmc_asian_greeks_fd(*P, 1, _hip.AVG_ARITHMETIC, 1000, 10, 1, 0, 0, None, None) != 0                # no landing place
+    assert lib().olmc_asian_greeks_fd(100.0, 100.0, 0.0, 0.05, 0.2, 0.0, 1, _hip.AVG_ARITHMETIC, 1000, 10, 1, 0, 0, out9, None) != 0     # T = 0 is the caller's branch
+    assert lib().olmc_asian_greeks_fd(*P, 1, _hip.AVG_ARITHMETIC, 0, 10, 1, 0, 0, out9, None) != 0 and lib().olmc_asian_greeks_fd(*P, 1, _hip.AVG_GEOMETRIC, 10, 0, 1, 0, 0, out9, None) != 0
+    with pytest.raises(ol.AccelerationError):
+        _hip.extrema_greeks_fd(*P, True, 6, 120.0, 1000, 10, 1, False, False)                                       # not a payoff
+    with pytest.raises(ol.AccelerationError):
+        _hip.extrema_greeks_fd(*P, True, 0, 120.0, (1 << 26) + 1, 10, 1, False, False)                              # beyond one launch of the fused kernel
+    with pytest.raises(ol.AccelerationError):
+        _hip.asian_greeks_fd(*P, True, (1 << 26) + 1, 10, 1, False, False)
+    vals, _ = _hip.asian_greeks_fd(*P, True, 1000, 10, 1, False, False)                                             # and the library is fine afterwards
+    assert math.isfinite(vals[0]) and vals[0] > 0
+
+
 def test_fused_asian_greeks_fall_back_where_there_is_no_fused_kernel():
     """An unseeded option (fresh normals per evaluation, as the reference's), the fp32 form of the arithmetic average and a keyword the
     fused entry point does not know take the literal path; asking for fused=True there is an error, as it is for any pricer without

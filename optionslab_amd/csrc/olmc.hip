@@ -25,6 +25,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <sys/prctl.h>
 
 namespace {
 
@@ -686,11 +687,25 @@ int run_batch_device(DeviceCtx* c, hipStream_t s, const olmc_option* opts, int32
 // The poll is a spin only for as long as a spin is cheap: the first kSpinUs (200 us: every interactive size, the 1M x 252
 // headline at 100 us) spin with `pause`; from then on every poll is followed by sched_yield(), so a host thread waiting for a
 // 6 ms pricing of 64M paths hands its core to any other runnable thread (Streamlit runs one thread per session) instead of
-// burning it; after kYieldUs (2 ms) the polls are kSleepUs apart (nanosleep: < 3 % on anything that long; the calling thread's
+// burning it; after kYieldUs (2 ms) the polls are kSleepUs apart (nanosleep at a 1 us timer slack: < 1 % on anything that long; the calling thread's
 // CPU share over a 6 ms pricing falls from 1.0 to 0.34, profiles/r03_call_overhead.jsonl).  Insurance: from 2 ms on the stream
 // is queried as well, about once a millisecond -- an error is reported as such, and a stream that reports completion without
 // the flag having shown up falls back to the runtime's own wait.
-constexpr int64_t kSpinUs = 200, kYieldUs = 2000, kSleepUs = 50;
+constexpr int64_t kSpinUs = 200, kYieldUs = 2000, kSleepUs = 20;
+
+// A nanosleep() wakes up to the thread's timer slack late -- 50 us by default, as long again as the nap asked for: a 2.3 ms pricing
+// came back 0.16 ms after its kernel had ended.  While a call naps its thread's slack is 1 us (restored on the way out).
+struct TimerSlack {
+    long old = -1;
+    void tighten() {
+        if (old >= 0) return;
+        old = prctl(PR_GET_TIMERSLACK, 0, 0, 0, 0);
+        if (old >= 0 && prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0) != 0) old = -1;
+    }
+    ~TimerSlack() {
+        if (old >= 0) (void)prctl(PR_SET_TIMERSLACK, static_cast<unsigned long>(old), 0, 0, 0);
+    }
+};
 
 int wait_armed(DeviceCtx* c, hipStream_t s) {
     if (c->armed != 0) {
@@ -700,6 +715,7 @@ int wait_armed(DeviceCtx* c, hipStream_t s) {
         const auto t0 = clock::now();
         bool queried = false;
         int phase = 0;                                                           // 0 spin, 1 yield, 2 sleep + query
+        TimerSlack slack;
         for (uint32_t spins = 0;; ++spins) {
             if (__atomic_load_n(c->h_flag, __ATOMIC_ACQUIRE) == want) {
                 if (queried) (void)hipGetLastError();                        // a hipErrorNotReady answer must not linger as this thread's last error
@@ -715,7 +731,7 @@ int wait_armed(DeviceCtx* c, hipStream_t s) {
                 if ((spins & 0xF) == 0xF && clock::now() - t0 >= std::chrono::microseconds(kYieldUs)) phase = 2;
                 continue;
             }
-            if ((spins & 0xF) == 0) {                                        // the stream is asked every 16th nap (~1 ms), the word every time
+            if ((spins & 0x3F) == 0) {                                       // the stream is asked every 64th nap (~1.5 ms), the word every time
                 const hipError_t q = hipStreamQuery(s);
                 queried = true;
                 if (q == hipSuccess) break;                                  // retired: fall through to the runtime's wait
@@ -724,6 +740,7 @@ int wait_armed(DeviceCtx* c, hipStream_t s) {
                     return fail(OLMC_ERR_HIP, std::string("hipStreamQuery: ") + hipGetErrorString(q));
                 }
             }
+            slack.tighten();
             const timespec nap{0, kSleepUs * 1000};
             nanosleep(&nap, nullptr);
         }

@@ -18,6 +18,9 @@
  *     threads overlap on the host and on the device instead of queueing behind one mutex (Streamlit runs a thread per
  *     session; a ninth concurrent caller waits for a lease).  Results do not depend on which context served a call.  A
  *     single-threaded caller always gets context 0.  olmc_shutdown must not race with calls in flight;
+ *   - a blocking call waits by polling a completion word in pinned memory: it spins for 200 us, yields between polls up to 2 ms and
+ *     naps (20 us) between them from then on.  While it naps, the CALLING thread's timer slack is 1 us (prctl(PR_SET_TIMERSLACK); the
+ *     previous value is restored before the call returns) -- at the default 50 us every nap returned as late again as it was long;
  *   - there is NO CPU fallback: without a usable HIP device every compute
  *     entry point fails with OLMC_ERR_HIP.
  *

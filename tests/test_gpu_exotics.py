@@ -416,6 +416,19 @@ def test_american_where_the_regression_is_ill_conditioned(S, K, T, r, v, call, N
     assert st.price >= max(K - S, 0.0) - 3 * st.std_error if not call else st.price >= max(S - K, 0.0) - 3 * st.std_error
 
 
+def test_american_has_no_bias_against_the_references_algorithm_over_many_seeds():
+    """Sharper than one 3-sigma comparison: the mean of 24 device prices (seeds 0..23, the reference's default 50,000 x 50, degree 3)
+    against the mean of 24 prices of the reference's algorithm (np.linalg.lstsq on raw powers of S, its own normals; restated in
+    oracle/numpy_reference.py): the two means differ by less than 3.5 standard errors of their difference -- a fifth of what a single
+    pricing can resolve -- for an at-the-money put and an in-the-money put with dividends."""
+    from oracle import numpy_reference as nr
+    for (S, K, T, r, v, q) in ((100.0, 100.0, 1.0, 0.05, 0.2, 0.0), (92.0, 100.0, 0.75, 0.04, 0.3, 0.02)):
+        dev = np.array([_hip.american_lsm(S, K, T, r, v, q, False, 50_000, 50, 3, seed).price for seed in range(24)])
+        ref = np.array([nr.american_price(S, K, T, r, v, q, seed=1000 + seed, n_paths=50_000, n_steps=50, option_type="put", poly_degree=3) for seed in range(24)])
+        se = math.sqrt(dev.var(ddof=1) / len(dev) + ref.var(ddof=1) / len(ref))
+        assert abs(dev.mean() - ref.mean()) <= 3.5 * se, (dev.mean(), ref.mean(), se)
+
+
 def test_american_lsm_against_a_bermudan_binomial_tree():
     """Independent anchor for Longstaff-Schwartz: a CRR tree that allows exercise on the same 50 dates (40 tree steps
     between dates).  LSM's two biases (sub-optimal fitted policy: low; in-sample fit: high) are ~1e-2 here."""

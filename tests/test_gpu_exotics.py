@@ -416,6 +416,42 @@ def test_american_where_the_regression_is_ill_conditioned(S, K, T, r, v, call, N
     assert st.price >= max(K - S, 0.0) - 3 * st.std_error if not call else st.price >= max(S - K, 0.0) - 3 * st.std_error
 
 
+_BIAS_CASES = {
+    # name: (device price of seed s, the reference's algorithm -- oracle/numpy_reference.py, pinned bitwise to the reference -- on ITS normals of seed s)
+    "asian arithmetic call": (lambda s: _hip.asian(100.0, 100.0, 1.0, 0.05, 0.2, 0.01, True, False, 40_000, 64, s).price,
+                              lambda nr, s: nr.asian_price(100.0, 100.0, 1.0, 0.05, 0.2, 0.01, s, 40_000, 64, "arithmetic", "call")),
+    "asian geometric put": (lambda s: _hip.asian(100.0, 105.0, 1.0, 0.05, 0.2, 0.01, False, True, 40_000, 64, s).price,
+                            lambda nr, s: nr.asian_price(100.0, 105.0, 1.0, 0.05, 0.2, 0.01, s, 40_000, 64, "geometric", "put")),
+    "barrier up-and-out call": (lambda s: _hip.barrier(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, True, 125.0, 0, 40_000, 64, s).price,
+                                lambda nr, s: nr.barrier_price(100.0, 100.0, 1.0, 0.05, 0.2, 125.0, 0.0, s, 40_000, 64, "up-and-out", "call")),
+    "barrier down-and-in put": (lambda s: _hip.barrier(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, False, 85.0, 3, 40_000, 64, s).price,
+                                lambda nr, s: nr.barrier_price(100.0, 100.0, 1.0, 0.05, 0.2, 85.0, 0.0, s, 40_000, 64, "down-and-in", "put")),
+    "lookback floating call": (lambda s: _hip.lookback(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, True, False, 40_000, 64, s).price,
+                               lambda nr, s: nr.lookback_price(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, s, 40_000, 64, "floating", "call")),
+    "lookback fixed put": (lambda s: _hip.lookback(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, False, True, 40_000, 64, s).price,
+                           lambda nr, s: nr.lookback_price(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, s, 40_000, 64, "fixed", "put")),
+    "autocallable": (lambda s: _hip.autocallable(100.0, 1.0, 0.05, 0.2, 0.0, 1.0, 0.8, 0.10, 0.6, 21, 40_000, 126, s).price,
+                     lambda nr, s: nr.autocallable_price(100.0, 1.0, 0.05, 0.2, 0.0, s, 40_000, 126, 21)),
+    "cliquet": (lambda s: _hip.cliquet(100.0, 1.0, 0.05, 0.2, 0.0, 0.05, -0.05, 0.30, 0.0, 12, 40_000, 120, s).price,
+                lambda nr, s: nr.cliquet_price(100.0, 1.0, 0.05, 0.2, 0.0, s, 40_000, 120, 12)),
+    "heston call": (lambda s: _hip.heston(100.0, 100.0, 1.0, 0.05, 0.0, True, 2.0, 0.04, 0.3, -0.7, 0.04, 40_000, 64, s).price,
+                    lambda nr, s: nr.heston_price_mc(100.0, 100.0, 1.0, 0.05, 0.0, "call", 2.0, 0.04, 0.3, -0.7, 0.04, 40_000, 64, s)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_BIAS_CASES))
+def test_no_bias_against_the_references_algorithm_over_many_seeds(name):
+    """One price within 3 sigma of one reference price (the golden tests) resolves a bias of ~3 standard errors.  Sixteen device prices
+    against sixteen prices of the reference's own algorithm on its own normals resolve a quarter of that: the two means differ by less
+    than 3.5 standard errors of their difference, payoff by payoff."""
+    from oracle import numpy_reference as nr
+    dev_fn, ref_fn = _BIAS_CASES[name]
+    dev = np.array([float(dev_fn(s)) for s in range(16)])
+    ref = np.array([float(ref_fn(nr, 500 + s)) for s in range(16)])
+    se = math.sqrt(dev.var(ddof=1) / len(dev) + ref.var(ddof=1) / len(ref))
+    assert abs(dev.mean() - ref.mean()) <= 3.5 * se, (name, dev.mean(), ref.mean(), se)
+
+
 def test_american_has_no_bias_against_the_references_algorithm_over_many_seeds():
     """Sharper than one 3-sigma comparison: the mean of 24 device prices (seeds 0..23, the reference's default 50,000 x 50, degree 3)
     against the mean of 24 prices of the reference's algorithm (np.linalg.lstsq on raw powers of S, its own normals; restated in

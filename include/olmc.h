@@ -47,13 +47,16 @@
 extern "C" {
 #endif
 
-#define OLMC_ABI_VERSION 4   /* 2: olmc_asian avg_kind 0 is the fp64-exponent kernel (2 = the fp32 one); probes, tune knobs 5-8
+#define OLMC_ABI_VERSION 5   /* 2: olmc_asian avg_kind 0 is the fp64-exponent kernel (2 = the fp32 one); probes, tune knobs 5-8
                               * 3: additions only -- olmc_european_qmc_batch, olmc_european_qmc_greeks_fd, olmc_multi_capacity,
                               *    olmc_exp2_probe_form, olmc_phase_stamps, olmc_contract_layout, tune knob 9; every v2 entry point keeps its signature and meaning
                               * 4: the measurement entry points (olmc_*probe*, olmc_phase_stamps, olmc_clock_probe, olmc_normal_moments) and the
                               *    fault-injection knobs 5 / 6 LEFT this library for the instrumented build (olmc_probe.h, libolmc_probe.so); added
                               *    olmc_multi_gpu_greeks_fd, olmc_multi_gpu_european_cv, olmc_asian_greeks_fd, olmc_extrema_greeks_fd; every pricing entry point keeps its signature and meaning;
-                              *    entry points are now concurrent across threads (a context per caller, olmc.h "Threading") */
+                              *    entry points are now concurrent across threads (a context per caller, olmc.h "Threading")
+                              * 5: additions only -- olmc_multi_gpu_european_qmc, olmc_multi_gpu_spans, tune knobs 10, 11 (OLMC_TUNE_MULTI_LAUNCH, OLMC_TUNE_STAGED_COPY); the multi-GPU
+                              *    entry points launch their ranks from one launcher thread per device; the grid reduction's consumer side is an
+                              *    agent-scope acquire again (numbers unchanged) */
 
 enum {
     OLMC_OK = 0,
@@ -379,17 +382,27 @@ int olmc_european_qmc_terminal(double S, double T, double r, double sigma, doubl
                                int antithetic, double* out_host /* [n_paths * (1 + antithetic)] */);
 
 /* ---- multi-GPU, single process ------------------------------------------
- * n_paths split into n_gpus contiguous global path ranges (rank d = device d, [d N / P, (d + 1) N / P)), one stream per rank.  ONE
- * host thread -- the caller's -- queues every rank's path kernel and then ONE grouped RCCL all-reduce over xGMI before it waits
- * for anything; the reduced sums are handed to the host by rank 0's polled completion word (as olmc_fetch_dev), the other ranks
- * hold the same sums and are drained before the call returns.  Identical finalisation on every rank.  On any error
- * return the thread's device and the streams already launched on are restored / drained.  Payload of the all-reduce:
+ * n_paths split into n_gpus contiguous global path ranges (rank d = device d, [d N / P, (d + 1) N / P)).  Per list of devices the
+ * library keeps an engine: a stream, a send / receive buffer and a LAUNCHER THREAD per rank (bound to the rank's device once, at
+ * birth; parked on a futex between calls) and the list's RCCL communicators (ncclCommInitAll).  A call posts the launch to the
+ * launchers -- every rank's path kernel is queued at the same time --, then the calling thread queues ONE grouped RCCL all-reduce
+ * over xGMI (only after every rank has launched: a failed rank leaves no peer inside a collective; the group is closed on every
+ * error path), and the reduced sums are handed to the host by rank 0's polled completion word (as olmc_fetch_dev) while the
+ * launchers drain the other ranks, which hold the same sums.  Identical finalisation on every rank.  On any error
+ * return the thread's device and the streams already launched on are restored / drained.  Calls on lists that share no device run
+ * concurrently; lists that share a device take turns.  Payload of the all-reduce:
  *   olmc_multi_gpu_european      {sum, sumsq, n}                                   count = 3
  *   olmc_multi_gpu_greeks_fd     the 8 / 14 bumped contracts of olmc_european_greeks_fd on the SAME normals, one launch per rank:
  *                                {sum, sumsq} x 8 or 16 slots, n                   count = 17 / 33
  *   olmc_multi_gpu_european_cv   the five control-variate moments, n              count = 6
+ *   olmc_multi_gpu_european_qmc  {sum, sumsq, n} of the rank's block of Sobol POINTS (src/simulation/gbm_qmc.py:14-46)   count = 3
  * Prices agree with the one-GPU entry points to the rounding of the sums' association (same paths whatever n_gpus is: the Philox
- * counter carries the global path index). */
+ * counter carries the global path index, the Sobol kernels take the global point index).
+ *
+ * STATUS: with n_gpus >= 2 the RCCL branch is UNVERIFIED ON HARDWARE -- no box with more than one GPU has been available to this
+ * build.  What is verified: n_gpus = 1 through RCCL on a real device; 1 .. 12 ranks REHEARSED on one device in the instrumented
+ * build (same engine, same launchers, the collective replaced by a kernel that adds the send buffers in rank order);
+ * tests/test_gpu_multi_device.py compares 2 .. N devices with the one-device results and skips itself where only one is visible. */
 int olmc_multi_gpu_european(double S, double K, double T, double r, double sigma, double q, int is_call,
                             int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
                             int n_gpus, olmc_stats* out);
@@ -399,6 +412,12 @@ int olmc_multi_gpu_greeks_fd(double S, double K, double T, double r, double sigm
 int olmc_multi_gpu_european_cv(double S, double K, double T, double r, double sigma, double q, int is_call,
                                int64_t n_paths, int32_t n_steps, uint64_t seed, int antithetic,
                                int n_gpus, olmc_cv_moments* out);
+int olmc_multi_gpu_european_qmc(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
+                                int n_gpus, olmc_stats* out);
+/* Host microseconds of the calling thread's last multi-GPU call: out5 = {launch phase (first rank's launch begun -> every rank's
+ * kernel queued), collective queued, result fetched (contains the kernels' run time), other ranks drained, total}. */
+int olmc_multi_gpu_spans(double* out5);
 
 /* Blocking fetch of n (1..33) doubles that work ALREADY QUEUED on hip_stream leaves at d_src -- the triple after the caller's RCCL
  * all-reduce in the one-process-per-GPU form: a one-wave kernel behind that work hands them over through the library's pinned
@@ -440,8 +459,14 @@ int olmc_profile_enable(int on);
  *   OLMC_TUNE_SPLIT_SAT  k in [1, 16]: when the whole workgroups per compute unit leave a last round (of `occupancy` resident
  *                        workgroups) with fewer than k of them, that round is handed to the split workgroups too; 0 = never
  *                        (default: measured at 1M x 252, no gain at any k)
+ *   OLMC_TUNE_STAGED_COPY results of 32 MB and more (path matrices, large terminal arrays): 0 = they leave the device in 16 MB chunks by DMA
+ *                        into two pinned staging buffers while up to 8 host threads copy the previous chunk into the caller's buffer
+ *                        (default), -1 = one hipMemcpyAsync into the caller's pageable buffer (round 4's form).  Same bytes either way
+ *   OLMC_TUNE_MULTI_LAUNCH multi-GPU entry points: 0 = one launcher thread per device queues the ranks' kernels in parallel
+ *                        (default), -1 = the calling thread queues them one after the other (round 4's form)
  */
-enum { OLMC_TUNE_GRID_CAP = 2, OLMC_TUNE_QMC_BLOCK = 4, OLMC_TUNE_SPLIT_TAIL = 7, OLMC_TUNE_POLL = 8, OLMC_TUNE_SPLIT_SAT = 9 };
+enum { OLMC_TUNE_GRID_CAP = 2, OLMC_TUNE_QMC_BLOCK = 4, OLMC_TUNE_SPLIT_TAIL = 7, OLMC_TUNE_POLL = 8, OLMC_TUNE_SPLIT_SAT = 9,
+       OLMC_TUNE_MULTI_LAUNCH = 10, OLMC_TUNE_STAGED_COPY = 11 };
 int olmc_tune(int knob, int value);
 /* The two behavioural knobs can also be switched off from the environment, read once by the first olmc_init:
  * OLMC_POLL=0 (as OLMC_TUNE_POLL = -1) and OLMC_SPLIT_TAIL=0 (as OLMC_TUNE_SPLIT_TAIL = -1). */

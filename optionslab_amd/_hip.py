@@ -92,6 +92,8 @@ PROTOTYPES = {
     "olmc_multi_gpu_european": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(Stats)]),
     "olmc_multi_gpu_greeks_fd": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(_D), C.POINTER(Stats)]),
     "olmc_multi_gpu_european_cv": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(CvMoments)]),
+    "olmc_multi_gpu_european_qmc": (_I, _SIX + [_I, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, _I, C.POINTER(Stats)]),
+    "olmc_multi_gpu_spans": (_I, [C.POINTER(_D)]),
     "olmc_combine_stats": (_I, [C.POINTER(Stats), _I32, _D, _D, C.POINTER(Stats)]),
     "olmc_philox_words": (_I, [_U64T, _I64, _I64, _I32, _I32, C.c_uint32, C.POINTER(C.c_uint32)]),
     "olmc_normals": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(C.c_float)]),
@@ -368,11 +370,23 @@ def _u32(a: np.ndarray):
     return a, a.ctypes.data_as(C.POINTER(C.c_uint32))
 
 
+def _sobol_args(sv, shift, point_offset: int, n_paths: int):
+    """The tables as C pointers -- after checking that the point range lies inside the columns the table KNOWS: tables derived from
+    the engine's public behaviour (monte_carlo.SobolDirections.valid_bits < 30) hold zeros beyond, and a point index there would
+    silently repeat earlier points.  Plain arrays count as complete (30 bits)."""
+    bits = int(getattr(sv, "valid_bits", 30))
+    if int(point_offset) + int(n_paths) > (1 << bits):
+        raise ValueError(f"Sobol points [{int(point_offset)}, {int(point_offset) + int(n_paths)}) reach beyond the 2**{bits} points these tables were "
+                         f"derived for: ask sobol_tables(n_steps, seed, n_points=point_offset + n_paths)")
+    sv, psv = _u32(sv)
+    shift, psh = _u32(shift)
+    return sv, psv, shift, psh
+
+
 def european_qmc(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv: np.ndarray, shift: np.ndarray,
                  point_offset: int = 0) -> Stats:
     """sv: (dims, 30) uint32 scrambled direction matrix, shift: (dims,) uint32 (see olmc.h)."""
-    sv, psv = _u32(sv)
-    shift, psh = _u32(shift)
+    sv, psv, shift, psh = _sobol_args(sv, shift, point_offset, n_paths)
     out = Stats()
     _check(lib().olmc_european_qmc(S, K, T, r, sigma, q, int(is_call), int(point_offset), int(n_paths), int(sv.shape[0]),
                                    psv, psh, int(sv.shape[1]), C.byref(out)))
@@ -380,8 +394,7 @@ def european_qmc(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv: np.ndarr
 
 
 def european_qmc_cv(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv: np.ndarray, shift: np.ndarray, point_offset: int = 0) -> CvMoments:
-    sv, psv = _u32(sv)
-    shift, psh = _u32(shift)
+    sv, psv, shift, psh = _sobol_args(sv, shift, point_offset, n_paths)
     out = CvMoments()
     _check(lib().olmc_european_qmc_cv(S, K, T, r, sigma, q, int(is_call), int(point_offset), int(n_paths), int(sv.shape[0]), psv, psh,
                                       int(sv.shape[1]), C.byref(out)))
@@ -391,8 +404,7 @@ def european_qmc_cv(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv: np.nd
 def european_qmc_batch(options: Sequence[Tuple[float, float, float, float, float, float, bool]], n_paths: int, sv: np.ndarray, shift: np.ndarray,
                        point_offset: int = 0) -> List[Stats]:
     """k <= 16 contracts (S, K, T, r, sigma, q, is_call) on the same Sobol points, one launch (olmc_european_qmc_batch)."""
-    sv, psv = _u32(sv)
-    shift, psh = _u32(shift)
+    sv, psv, shift, psh = _sobol_args(sv, shift, point_offset, n_paths)
     k = len(options)
     arr = (Option * k)(*[Option(S, K, T, r, v, q, int(c), 0) for (S, K, T, r, v, q, c) in options])
     out = (Stats * k)()
@@ -403,8 +415,7 @@ def european_qmc_batch(options: Sequence[Tuple[float, float, float, float, float
 def european_qmc_greeks_fd(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv: np.ndarray, shift: np.ndarray, second_order: bool,
                            want_evals: bool = True) -> Tuple[List[float], List[Stats]]:
     """As european_greeks_fd, on the Sobol points of a MCMethod.QMC pricer: the 8 / 14 bumped contracts in ONE launch."""
-    sv, psv = _u32(sv)
-    shift, psh = _u32(shift)
+    sv, psv, shift, psh = _sobol_args(sv, shift, 0, n_paths)
     out9 = (C.c_double * 9)()
     evals = (Stats * 14)() if want_evals else None
     _check(lib().olmc_european_qmc_greeks_fd(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(sv.shape[0]), psv, psh, int(sv.shape[1]),
@@ -414,8 +425,7 @@ def european_qmc_greeks_fd(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv
 
 def european_qmc_terminal(S, T, r, sigma, q, n_paths: int, sv: np.ndarray, shift: np.ndarray,
                           point_offset: int = 0, antithetic: bool = False) -> np.ndarray:
-    sv, psv = _u32(sv)
-    shift, psh = _u32(shift)
+    sv, psv, shift, psh = _sobol_args(sv, shift, point_offset, n_paths)
     out = np.empty(int(n_paths) * (2 if antithetic else 1), dtype=np.float64)
     _check(lib().olmc_european_qmc_terminal(S, T, r, sigma, q, int(point_offset), int(n_paths), int(sv.shape[0]), psv, psh,
                                             int(sv.shape[1]), int(antithetic), out.ctypes.data_as(C.POINTER(C.c_double))))
@@ -541,6 +551,22 @@ def multi_gpu_european_cv(S, K, T, r, sigma, q, is_call: bool, n_paths: int, n_s
     return out
 
 
+def multi_gpu_european_qmc(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv: np.ndarray, shift: np.ndarray, n_gpus: int) -> Stats:
+    """As european_qmc over n_gpus devices of this process: rank d prices points [d N / P, (d + 1) N / P), one all-reduce of 3 sums."""
+    sv, psv, shift, psh = _sobol_args(sv, shift, 0, n_paths)
+    out = Stats()
+    _check(lib().olmc_multi_gpu_european_qmc(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(sv.shape[0]), psv, psh, int(sv.shape[1]),
+                                             int(n_gpus), C.byref(out)))
+    return out
+
+
+def multi_gpu_spans() -> dict:
+    """Host microseconds of this thread's last multi-GPU call (olmc_multi_gpu_spans)."""
+    out = (C.c_double * 5)()
+    _check(lib().olmc_multi_gpu_spans(out))
+    return dict(zip(("launch_us", "collective_us", "fetch_us", "drain_us", "total_us"), out))
+
+
 def combine_stats(parts: Sequence[Tuple[float, float, int]], r: float, T: float) -> Stats:
     """Pure host function: needs the library but no device."""
     k = len(parts)
@@ -569,6 +595,8 @@ TUNE_QMC_BLOCK = 4
 TUNE_SPLIT_TAIL = 7
 TUNE_POLL = 8
 TUNE_SPLIT_SAT = 9
+TUNE_MULTI_LAUNCH = 10
+TUNE_STAGED_COPY = 11
 
 
 def tune(knob: int, value: int) -> None:

@@ -15,6 +15,7 @@
 #include <rccl/rccl.h>      // types and enum values only: the library itself is dlopen()ed on first multi-GPU use
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <condition_variable>
@@ -22,10 +23,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
+#include <linux/futex.h>
 #include <sys/prctl.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 namespace {
 
@@ -92,6 +98,9 @@ struct DeviceCtx {
     double* d_result = nullptr;      // device alias of h_result (zero-copy: no D2H copy node, only a stream sync)
     void* d_bulk = nullptr;          // terminal prices / validation taps
     size_t bulk_bytes = 0;
+    // large results on their way home (copy_to_host): two pinned staging buffers, an event per buffer (allocated by the first large copy)
+    void* h_stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_landed[2] = {nullptr, nullptr};
     // independent-contract batches (european_multi_kernel)
     void* d_multi = nullptr;         // device [ticket counters | done counter | contracts | rows], see olmc_european_multi
     void* h_multi = nullptr;         // pinned + mapped [contracts | sums]
@@ -126,9 +135,9 @@ struct DevicePool {
     int device = -1;
 };
 
-std::mutex g_mu;                        // guards g_pool[] slots, g_default_device (olmc_init / olmc_shutdown)
-DevicePool* g_pool[kMaxDevices] = {};
-int g_default_device = -1;
+std::mutex g_mu;                        // serialises the WRITERS of g_pool[] and g_default_device (olmc_init / olmc_shutdown);
+std::atomic<DevicePool*> g_pool[kMaxDevices] = {};      // readers (every call's ctx_lease, possibly while another thread initialises a
+std::atomic<int> g_default_device{-1};                  // device) take no lock
 bool g_profile = false;
 
 int ctx_allocate(DeviceCtx* c) {
@@ -153,6 +162,10 @@ void ctx_release(DeviceCtx* c) {
     for (auto& ep : c->ev_pending) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
     for (auto& ep : c->ev_free) { (void)hipEventDestroy(ep.start); (void)hipEventDestroy(ep.stop); }
     if (c->d_bulk) (void)hipFree(c->d_bulk);
+    for (int i = 0; i < 2; ++i) {
+        if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
+        if (c->stage_landed[i]) (void)hipEventDestroy(c->stage_landed[i]);
+    }
     if (c->d_multi) (void)hipFree(c->d_multi);
     if (c->h_multi) (void)hipHostFree(c->h_multi);
     if (c->d_sobol) (void)hipFree(c->d_sobol);
@@ -203,13 +216,15 @@ struct CtxLease {
             std::lock_guard<std::mutex> lock(pool->mu);
             c->busy = false;
         }
-        pool->idle.notify_one();
+        // notify_all: the pool's one condition variable has two kinds of waiter (a lease, in ctx_lease_on; "every context idle", in
+        // pool_forget_stream / with_all_contexts) -- notify_one could hand the only wake-up to a waiter whose predicate is still false
+        pool->idle.notify_all();
         c = nullptr;
     }
 };
 
 int ctx_lease_on(int dev, CtxLease* out) {
-    DevicePool* pool = g_pool[dev];
+    DevicePool* pool = g_pool[dev].load(std::memory_order_acquire);
     if (!pool) return fail(OLMC_ERR_STATE, "device not initialised (call olmc_init)");
     HIP_TRY(hipSetDevice(dev));
     std::unique_lock<std::mutex> lock(pool->mu);
@@ -236,7 +251,7 @@ int ctx_lease_on(int dev, CtxLease* out) {
 }
 
 int ctx_lease(CtxLease* out) {
-    int dev = t_device >= 0 ? t_device : g_default_device;
+    int dev = t_device >= 0 ? t_device : g_default_device.load(std::memory_order_acquire);
     if (dev < 0) {
         // lazy init on device 0 so a bare compute call still works (or fails loudly)
         int rc = olmc_init(0);
@@ -253,6 +268,78 @@ int bulk_reserve(DeviceCtx* c, size_t bytes) {
     c->bulk_bytes = 0;
     HIP_TRY(hipMalloc(&c->d_bulk, bytes));
     c->bulk_bytes = bytes;
+    return OLMC_OK;
+}
+
+// A large result (a path matrix: 100k x 252 doubles = 202 MB; a terminal array of 64M paths = 1 GB) on its way to the CALLER's buffer,
+// which is pageable and, coming fresh from NumPy, not even faulted in.  One hipMemcpyAsync into it runs at 10-17 GB/s (round 4: 20 ms for
+// the 202 MB): the runtime stages through pinned memory and ONE host thread copies every chunk out, paying every first-touch page
+// fault on the way.  Here the device result leaves in 16 MB chunks by DMA into two pinned staging buffers (link rate: ~50 GB/s), and
+// while chunk i + 1 is on the link, a handful of host threads copy chunk i out, a slice each -- so the page faults of the destination
+// are taken in parallel too.  Work queued on c->stream before the call (the kernel that writes d_src) is ordered before the first DMA;
+// the call returns when the last byte is in `dst`.  Bytes are copied, never interpreted: same array as the direct copy, bit for bit.
+constexpr size_t kStageBytes = size_t(16) << 20, kStagedFrom = size_t(32) << 20;
+int g_staged_copy = 0;       // OLMC_TUNE_STAGED_COPY: 0 = results of 32 MB and more come home through pinned staging buffers and parallel host
+                             // copies (default), -1 = always one hipMemcpyAsync into the caller's buffer
+
+int copy_to_host(DeviceCtx* c, void* dst, const void* d_src, size_t bytes) {
+    if (bytes < kStagedFrom || g_staged_copy < 0) {
+        HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return OLMC_OK;
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (!c->h_stage[i]) HIP_TRY(hipHostMalloc(&c->h_stage[i], kStageBytes, hipHostMallocDefault));
+        if (!c->stage_landed[i]) HIP_TRY(hipEventCreateWithFlags(&c->stage_landed[i], hipEventDisableTiming));
+    }
+    cpu_set_t cpus;
+    int allowed = 4;
+    if (sched_getaffinity(0, sizeof cpus, &cpus) == 0) allowed = CPU_COUNT(&cpus);
+    const int n_threads = std::max(1, std::min(8, allowed / 2));
+    const int64_t n_chunks = static_cast<int64_t>((bytes + kStageBytes - 1) / kStageBytes);
+    std::atomic<int64_t> landed{0};                 // chunks whose DMA has completed: [0, landed) may be copied out
+    std::atomic<int> copied[2] = {{0}, {0}};        // threads done with the chunk that sits in staging buffer 0 / 1
+    std::atomic<bool> give_up{false};
+    auto chunk_len = [&](int64_t i) { return std::min(kStageBytes, bytes - static_cast<size_t>(i) * kStageBytes); };
+    auto worker = [&](int w) {
+        for (int64_t i = 0; i < n_chunks; ++i) {
+            for (uint32_t spins = 0; landed.load(std::memory_order_acquire) <= i; ++spins) {
+                if (give_up.load(std::memory_order_relaxed)) return;
+                if ((spins & 0xFF) == 0xFF) sched_yield(); else __builtin_ia32_pause();
+            }
+            const size_t len = chunk_len(i), per = (len / n_threads + 4095) & ~size_t(4095);      // page-sized slices: each page of dst has one toucher
+            const size_t lo = std::min(len, per * w), hi = std::min(len, lo + per);
+            if (hi > lo) std::memcpy(static_cast<char*>(dst) + static_cast<size_t>(i) * kStageBytes + lo, static_cast<const char*>(c->h_stage[i & 1]) + lo, hi - lo);
+            copied[i & 1].fetch_add(1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> threads;
+    threads.reserve(n_threads);
+    for (int w = 0; w < n_threads; ++w) threads.emplace_back(worker, w);
+    hipError_t err = hipSuccess;
+    for (int64_t i = 0; i < n_chunks && err == hipSuccess; ++i) {
+        const int slot = static_cast<int>(i & 1);
+        if (i >= 2) {                               // the chunk that sat in this buffer has been copied out by every thread
+            for (uint32_t spins = 0; copied[slot].load(std::memory_order_acquire) < n_threads; ++spins)
+                if ((spins & 0xFF) == 0xFF) sched_yield(); else __builtin_ia32_pause();
+            copied[slot].store(0, std::memory_order_relaxed);
+        }
+        err = hipMemcpyAsync(c->h_stage[slot], static_cast<const char*>(d_src) + static_cast<size_t>(i) * kStageBytes, chunk_len(i), hipMemcpyDeviceToHost, c->stream);
+        if (err == hipSuccess) err = hipEventRecord(c->stage_landed[slot], c->stream);
+        if (err == hipSuccess && i >= 1) {
+            err = hipEventSynchronize(c->stage_landed[slot ^ 1]);
+            if (err == hipSuccess) landed.store(i, std::memory_order_release);
+        }
+    }
+    if (err == hipSuccess) err = hipEventSynchronize(c->stage_landed[(n_chunks - 1) & 1]);
+    if (err == hipSuccess) landed.store(n_chunks, std::memory_order_release);
+    else give_up.store(true);
+    for (std::thread& t : threads) t.join();
+    if (err != hipSuccess) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipGetLastError();
+        return fail(OLMC_ERR_HIP, std::string("copy_to_host: ") + hipGetErrorString(err));
+    }
     return OLMC_OK;
 }
 
@@ -478,103 +565,8 @@ int prof_drain(DeviceCtx* c) {
     return OLMC_OK;
 }
 
-// ---- host-side constants (reference arithmetic order) ----------------------
-// gbm_numpy.py:35-39 (multi-step) and :73-75 (single-step; identical when M == 1
-// up to the exact product drift*1).
-Contract make_contract(const olmc_option& o, int32_t n_steps) {
-    const double dt = o.T / n_steps;
-    const double drift = (o.r - o.q - 0.5 * o.sigma * o.sigma) * dt;
-    const double vol = o.sigma * std::sqrt(dt);
-    const double total_drift = drift * n_steps;
-    Contract c;
-    c.a = std::log(o.S) + total_drift;
-    c.vol = vol;
-    c.strike = o.K;
-    c.sign = o.is_call ? 1.0 : -1.0;
-    c.scale = 1.0;                                   // a base until group_contracts says otherwise
-    c.neg_sign_strike = -c.sign * o.K;
-    c.sign_scale = c.sign;
-    return c;
-}
-
-// Orders k contracts so that those with bit-identical vol are contiguous, the first of each group being its
-// base (its bit in base_mask, scale 1) and the others carrying scale = exp(a - a_base); fills `set` (padded to nsets with
-// scale-1 copies of the last contract) and pos[i] = slot of contract i.  The kernel walks the two halves of the set as two
-// streams, each with its own "latest base" (european_payoffs_folded), so slot NSETS / 2 is ALWAYS a base: a group that
-// straddles the middle gets a second base there (one more pair of exponentials per path; the first-order Greeks set
-// {mid, S+, S-, r+, r-} + 3 pays it, the second-order set of 14 does not).
-template <int NSETS>
-void group_contracts(const olmc_option* opts, int32_t k, int32_t n_steps, ContractSet<NSETS>* set, int* pos) {
-    Contract all[OLMC_MAX_BATCH];
-    bool placed[OLMC_MAX_BATCH] = {};
-    for (int i = 0; i < k; ++i) all[i] = make_contract(opts[i], n_steps);
-    int slot = 0;
-    set->base_mask = 0;
-    set->upper_continues_slot0 = 0;
-    auto put = [&](int j, int base_slot) -> int {   // returns the slot of the base the NEXT member of the group should refer to
-        set->c[slot] = all[j];
-        // the second stream (slots >= NSETS / 2) starts without a base of its own -- unless the group that straddles the middle is slot
-        // 0's, whose prices the kernel hands over to it (one pair of exponentials saved for first-order Greeks)
-        const bool needs_own_base = slot == NSETS / 2 && base_slot != 0;
-        if (slot == NSETS / 2 && base_slot == 0) set->upper_continues_slot0 = 1;
-        if (base_slot < 0 || needs_own_base) {
-            set->c[slot].scale = 1.0;
-            set->base_mask |= 1u << slot;
-            base_slot = slot;
-        } else {
-            set->c[slot].scale = std::exp(all[j].a - set->c[base_slot].a);
-        }
-        set->c[slot].sign_scale = set->c[slot].sign * set->c[slot].scale;
-        pos[j] = slot++;
-        placed[j] = true;
-        return base_slot;
-    };
-    for (int i = 0; i < k; ++i) {
-        if (placed[i]) continue;
-        int base = put(i, -1);                       // base of a new group
-        for (int j = i + 1; j < k; ++j)
-            if (!placed[j] && std::memcmp(&all[j].vol, &all[i].vol, sizeof(double)) == 0 && std::isfinite(all[j].a - all[i].a))
-                base = put(j, base);
-    }
-    for (; slot < NSETS; ++slot) {                   // padding: cheap non-base copies (a base of its own if it opens the second half)
-        set->c[slot] = set->c[slot - 1];
-        set->c[slot].scale = 1.0;
-        set->c[slot].sign_scale = set->c[slot].sign;
-        if (slot == NSETS / 2) set->base_mask |= 1u << slot;
-    }
-}
-
-void finish_stats(double sum, double sumsq, int64_t n, double r, double T, olmc_stats* out) {
-    const double disc = std::exp(-r * T);
-    const double mean = sum / static_cast<double>(n);
-    double var = sumsq / static_cast<double>(n) - mean * mean;   // ddof = 0, monte_carlo.py:149
-    if (var < 0.0) var = 0.0;
-    out->sum = sum;
-    out->sumsq = sumsq;
-    out->n = n;
-    out->price = disc * mean;
-    out->std_error = disc * std::sqrt(var) / std::sqrt(static_cast<double>(n));
-}
-
-// The reference validates nothing at call time (tests/test_monte_carlo.py:143-151 skip it): a negative
-// spot or a NaN input makes np.log / the arithmetic produce NaN, np.maximum PROPAGATES it, and the price
-// is NaN.  Device fmax() would swallow the NaN (payoff 0), so such inputs are answered on the host.
-// T < 0 is the same case one step later: sqrt(dt) is NaN in the reference (gbm_numpy.py:37) and so is every price.
-bool poisoned(double S, double K, double T, double r, double sigma, double q) {
-    return std::isnan(S + K + T + r + sigma + q) || S < 0.0 || T < 0.0;
-}
-
-// ln of a barrier LEVEL the reference compares in price space (exotic_options.py:455-480): a level <= 0 lies below
-// every price, so `S_t >= level` always holds and `S_t < level` never does -- which is what -inf gives in log space
-// (log() itself would answer NaN for a negative level and every comparison would be false).
-double log_level(double level) {
-    return level > 0.0 ? std::log(level) : (std::isnan(level) ? level : -INFINITY);
-}
-
-void nan_stats(int64_t n, olmc_stats* out) {
-    const double nan = std::nan("");
-    out->sum = nan; out->sumsq = nan; out->n = n; out->price = nan; out->std_error = nan;
-}
+// make_contract, group_contracts, finish_stats, poisoned, log_level, nan_stats, GreeksSet, cv_finish and the moment combiners are
+// pure host arithmetic: olmc_host_math.h (compiled on its own, under sanitizers, by tests/test_host_math_sanitizers.py).
 
 int check_paths(int64_t path_offset, int64_t n_local, int32_t n_steps) {
     if (n_local < 1) return fail(OLMC_ERR_ARG, "n_paths must be >= 1");
@@ -785,14 +777,6 @@ int run_batch(const olmc_option* opts, int32_t k, int64_t path_offset, int64_t n
     return OLMC_OK;
 }
 
-olmc_option make_option(double S, double K, double T, double r, double sigma, double q, int is_call) {
-    olmc_option o;
-    o.S = S; o.K = K; o.T = T; o.r = r; o.sigma = sigma; o.q = q;
-    o.is_call = is_call ? 1 : 0;
-    o.reserved = 0;
-    return o;
-}
-
 }  // namespace
 
 namespace { void multi_gpu_release(); }      // the multi-GPU engine's streams, buffers and communicators (defined with it)
@@ -815,19 +799,19 @@ extern "C" int olmc_init(int device) {
     }();
     (void)env_read;
     if (device < 0 || device >= kMaxDevices) return fail(OLMC_ERR_ARG, "device index out of range");
-    if (!g_pool[device]) {
+    if (!g_pool[device].load(std::memory_order_acquire)) {
         DeviceCtx* c = nullptr;
         int rc = ctx_create(device, &c);            // the first context of the device: a device that cannot be used fails HERE, loudly
         if (rc) return rc;
         DevicePool* pool = new DevicePool();
         pool->device = device;
         pool->all.push_back(c);
-        g_pool[device] = pool;
+        g_pool[device].store(pool, std::memory_order_release);
     } else {
         HIP_TRY(hipSetDevice(device));
     }
     t_device = device;
-    if (g_default_device < 0) g_default_device = device;
+    if (g_default_device.load() < 0) g_default_device.store(device, std::memory_order_release);
     return OLMC_OK;
 }
 
@@ -835,7 +819,7 @@ extern "C" int olmc_shutdown(void) {
     std::lock_guard<std::mutex> lock(g_mu);
     multi_gpu_release();
     for (int d = 0; d < kMaxDevices; ++d) {         // the caller's contract: no call is in flight on any thread
-        DevicePool* pool = g_pool[d];
+        DevicePool* pool = g_pool[d].load();
         if (!pool) continue;
         const bool usable = hipSetDevice(d) == hipSuccess;
         for (DeviceCtx* c : pool->all) {
@@ -843,9 +827,9 @@ extern "C" int olmc_shutdown(void) {
             else delete c;
         }
         delete pool;
-        g_pool[d] = nullptr;
+        g_pool[d].store(nullptr);
     }
-    g_default_device = -1;
+    g_default_device.store(-1);
     t_device = -1;
     return OLMC_OK;
 }
@@ -934,15 +918,7 @@ extern "C" int olmc_european_batch(const olmc_option* opts, int32_t k, int64_t p
 
 extern "C" int olmc_combine_stats(const olmc_stats* parts, int32_t n_parts, double r, double T, olmc_stats* out) {
     if (!parts || !out || n_parts < 1) return fail(OLMC_ERR_ARG, "bad arguments");
-    double sum = 0.0, sumsq = 0.0;
-    int64_t n = 0;
-    for (int i = 0; i < n_parts; ++i) {   // fixed rank order => bitwise stable
-        sum += parts[i].sum;
-        sumsq += parts[i].sumsq;
-        n += parts[i].n;
-    }
-    if (n < 1) return fail(OLMC_ERR_ARG, "no samples");
-    finish_stats(sum, sumsq, n, r, T, out);
+    if (!combine_stats(parts, n_parts, r, T, out)) return fail(OLMC_ERR_ARG, "no samples");     // fixed rank order => bitwise stable
     return OLMC_OK;
 }
 
@@ -1039,20 +1015,7 @@ extern "C" int olmc_contract_layout(const olmc_option* opts, int32_t k, int32_t 
     if (!opts || !nsets_out || !pos || !base_mask || !upper_continues_slot0 || !scale16) return fail(OLMC_ERR_ARG, "null pointer");
     if (k < 2 || k > OLMC_MAX_BATCH) return fail(OLMC_ERR_ARG, "a set has 2 .. OLMC_MAX_BATCH contracts");
     if (n_steps < 1) return fail(OLMC_ERR_ARG, "n_steps must be >= 1");
-    int p[OLMC_MAX_BATCH];
-    for (int i = 0; i < OLMC_MAX_BATCH; ++i) scale16[i] = 0.0;
-    if (k <= 8) {
-        ContractSet<8> cs;
-        group_contracts<8>(opts, k, n_steps, &cs, p);
-        *nsets_out = 8; *base_mask = cs.base_mask; *upper_continues_slot0 = static_cast<int32_t>(cs.upper_continues_slot0);
-        for (int i = 0; i < 8; ++i) scale16[i] = cs.c[i].scale;
-    } else {
-        ContractSet<16> cs;
-        group_contracts<16>(opts, k, n_steps, &cs, p);
-        *nsets_out = 16; *base_mask = cs.base_mask; *upper_continues_slot0 = static_cast<int32_t>(cs.upper_continues_slot0);
-        for (int i = 0; i < 16; ++i) scale16[i] = cs.c[i].scale;
-    }
-    for (int i = 0; i < k; ++i) pos[i] = p[i];
+    contract_layout(opts, k, n_steps, nsets_out, pos, base_mask, upper_continues_slot0, scale16);
     return OLMC_OK;
 }
 
@@ -1069,59 +1032,8 @@ extern "C" int olmc_multi_capacity(int64_t* out2) {
 }
 
 // ================================================== finite-difference Greeks ====
-namespace {
-// The evaluations of compute_greeks_unified (unified_greeks.py:274-277, 295-358) in the reference's get_price() call order, and
-// the finite differences over their prices.  Shared by the pseudo-random and the Sobol form: only the pricing of the set differs.
-struct GreeksSet {
-    olmc_option o[OLMC_MAX_BATCH];
-    int k = 0;
-    double h_S, h_v, h_r, h_T;
-    bool has_T, second;
-    int i_mid, i_su, i_sd, i_vu, i_vd, i_td, i_ru, i_rd, i_uu = -1, i_ud = -1, i_du = -1, i_dd = -1, i_ut = -1, i_dt = -1;
-
-    GreeksSet(double S, double K, double T, double r, double sigma, double q, int is_call, int second_order) {
-        h_S = std::max(1e-4, 0.01 * S);                             // :274-277
-        h_v = std::max(1e-4, 0.01);
-        h_r = 1e-4;
-        h_T = 1 / 365.0;
-        has_T = T > h_T;                                            // :310
-        second = second_order != 0;
-        auto add = [&](double S_, double T_, double r_, double v_) { o[k] = make_option(S_, K, T_, r_, v_, q, is_call); return k++; };
-        i_mid = add(S, T, r, sigma);
-        i_su = add(S + h_S, T, r, sigma); i_sd = add(S - h_S, T, r, sigma);
-        i_vu = add(S, T, r, sigma + h_v); i_vd = add(S, T, r, sigma - h_v);
-        i_td = has_T ? add(S, T - h_T, r, sigma) : -1;
-        i_ru = add(S, T, r + h_r, sigma); i_rd = add(S, T, r - h_r, sigma);
-        if (second) {
-            i_uu = add(S + h_S, T, r, sigma + h_v); i_ud = add(S + h_S, T, r, sigma - h_v);
-            i_du = add(S - h_S, T, r, sigma + h_v); i_dd = add(S - h_S, T, r, sigma - h_v);
-            if (has_T) { i_ut = add(S + h_S, T - h_T, r, sigma); i_dt = add(S - h_S, T - h_T, r, sigma); }
-        }
-    }
-
-    void finish(const olmc_stats* st, double T, double* out9, olmc_stats* evals) const {
-        auto P = [&](int i) { return st[i].price; };
-        const double mid = P(i_mid);
-        const double delta = (P(i_su) - P(i_sd)) / (2 * h_S);                       // :301
-        out9[0] = mid;
-        out9[1] = delta;
-        out9[2] = (P(i_su) - 2 * mid + P(i_sd)) / (h_S * h_S);                       // :302
-        out9[3] = (P(i_vu) - P(i_vd)) / (2 * h_v);                                   // :307
-        out9[4] = has_T ? (P(i_td) - mid) / h_T : -mid / std::max(T, 1e-6);          // :310-314
-        out9[5] = (P(i_ru) - P(i_rd)) / (2 * h_r);                                   // :319
-        if (second) {
-            out9[6] = (P(i_uu) - P(i_ud) - P(i_du) + P(i_dd)) / (4 * h_S * h_v);    // :343-345
-            out9[7] = has_T ? ((P(i_ut) - P(i_dt)) / (2 * h_S) - delta) / h_T : 0.0; // :348-354
-            out9[8] = (P(i_vu) - 2 * mid + P(i_vd)) / (h_v * h_v);                   // :357
-        }
-        if (evals) {
-            for (int i = 0; i < k; ++i) evals[i] = st[i];
-            for (int i = k; i < 14; ++i) std::memset(&evals[i], 0, sizeof(olmc_stats));
-        }
-    }
-};
-}  // namespace
-
+// GreeksSet (olmc_host_math.h): the evaluations of compute_greeks_unified (unified_greeks.py:274-277, 295-358) in the reference's
+// get_price() call order, and the finite differences over their prices.
 extern "C" int olmc_european_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call,
                                        int64_t n_paths, int32_t n_steps, uint64_t seed, int second_order,
                                        double* out9, olmc_stats* evals) {
@@ -1156,26 +1068,10 @@ extern "C" int olmc_european_terminal(double S, double T, double r, double sigma
     ReduceWs ws{};   // unused in kTerminal mode
     launch_european<1, kTerminal>(antithetic != 0, grid, c->stream, pr, cs, ws, static_cast<double*>(c->d_bulk));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out_host, c->d_bulk, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return OLMC_OK;
+    return copy_to_host(c, out_host, c->d_bulk, bytes);
 }
 
 // =========================================================== control variate ====
-namespace {
-// beta, forward and the estimate from the five (already discounted) moments: monte_carlo.py:175-184
-void cv_finish(double S, double T, double r, double q, olmc_cv_moments* m) {
-    const double n = static_cast<double>(m->n);
-    const double mean_d = m->sum_d / n, mean_s = m->sum_s / n;
-    // np.cov default ddof = 1 (monte_carlo.py:181); the n-1 cancels in beta but not in the 1e-10 guard
-    const double cov_ds = (m->sum_ds - n * mean_d * mean_s) / (n - 1.0);
-    const double var_s = (m->sum_ss - n * mean_s * mean_s) / (n - 1.0);
-    const double beta = (n > 1.0 && var_s > 1e-10) ? cov_ds / var_s : 0.0;        // :182
-    const double forward = S * std::exp((r - q) * T);                              // :179
-    m->value = mean_d - beta * (mean_s - forward);                                 // :184
-}
-}  // namespace
-
 extern "C" int olmc_european_cv_shard(double S, double K, double T, double r, double sigma, double q, int is_call,
                                       int64_t path_offset, int64_t n_local, int32_t n_steps, uint64_t seed, int antithetic,
                                       olmc_cv_moments* out) {
@@ -1199,16 +1095,7 @@ extern "C" int olmc_european_cv_shard(double S, double K, double T, double r, do
     if (rc) return rc;
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
-    // device moments are of the UNdiscounted payoff x; d = disc * x (monte_carlo.py:175)
-    const double disc = std::exp(-r * T);
-    const double sx = c->h_result[0], ss = c->h_result[1], sxx = c->h_result[2], sss = c->h_result[3], sxs = c->h_result[4];
-    out->sum_d = disc * sx;
-    out->sum_s = ss;
-    out->sum_dd = disc * disc * sxx;
-    out->sum_ss = sss;
-    out->sum_ds = disc * sxs;
-    out->n = n_local * (antithetic ? 2 : 1);
-    cv_finish(S, T, r, q, out);
+    cv_from_device(c->h_result, n_local * (antithetic ? 2 : 1), S, T, r, q, out);       // d = disc * x (monte_carlo.py:175)
     if (poisoned(S, K, T, r, sigma, q)) out->value = std::nan("");
     return OLMC_OK;
 }
@@ -1222,14 +1109,7 @@ extern "C" int olmc_european_cv(double S, double K, double T, double r, double s
 extern "C" int olmc_combine_cv(const olmc_cv_moments* parts, int32_t n_parts, double S, double T, double r, double q,
                                olmc_cv_moments* out) {
     if (!parts || !out || n_parts < 1) return fail(OLMC_ERR_ARG, "bad arguments");
-    olmc_cv_moments m{};
-    for (int i = 0; i < n_parts; ++i) {   // fixed rank order => bitwise stable
-        m.sum_d += parts[i].sum_d;  m.sum_s += parts[i].sum_s;  m.sum_dd += parts[i].sum_dd;
-        m.sum_ss += parts[i].sum_ss;  m.sum_ds += parts[i].sum_ds;  m.n += parts[i].n;
-    }
-    if (m.n < 1) return fail(OLMC_ERR_ARG, "no samples");
-    cv_finish(S, T, r, q, &m);
-    *out = m;
+    if (!combine_cv(parts, n_parts, S, T, r, q, out)) return fail(OLMC_ERR_ARG, "no samples");     // fixed rank order => bitwise stable
     return OLMC_OK;
 }
 
@@ -1291,55 +1171,10 @@ extern "C" int olmc_asian_greeks_fd(double S, double K, double T, double r, doub
     int rc = check_paths(0, n_paths, n_steps);
     if (rc) return rc;
     const GreeksSet gs(S, K, T, r, sigma, q, is_call, second_order);
-    AsianGreeksSet as{};
-    // Recursions: contracts that share (drift, vol) per step share one (a spot bump only scales the average).  Geometric: up to six, all
-    // alike.  Arithmetic: slots 0..3 are recursions of their own; a contract whose vol is slot 0's and whose drift is not (the r bumps)
-    // rides on slot 0 through a per-date factor (slots 4..5, rate_step = its drift - slot 0's).
-    const int real_slots = geo ? kAsianGroups : kAsianRealGroups;
-    int n_groups = 0, n_riders = 0;
-    double rider_drift[kAsianGroups - kAsianRealGroups] = {0.0, 0.0};
-    auto same = [](const double& a, const double& b) { return std::memcmp(&a, &b, sizeof a) == 0; };
-    for (int i = 0; i < gs.k; ++i) {
-        const olmc_option& o = gs.o[i];
-        const double dt = o.T / n_steps;                             // exotic_options.py:54-56, as olmc_asian
-        const double drift = (o.r - o.q - 0.5 * o.sigma * o.sigma) * dt, vol = o.sigma * std::sqrt(dt);
-        as.s0[i] = o.S;
-        as.log_s0[i] = std::log(o.S);
-        if (!geo && n_groups > 0 && same(as.vol[0], vol) && !same(as.drift[0], drift)) {
-            int d = 0;
-            while (d < n_riders && !same(rider_drift[d], drift)) ++d;
-            if (d == n_riders) {
-                if (n_riders == kAsianGroups - kAsianRealGroups) return fail(OLMC_ERR_STATE, "more drift-only bumps than the fused Asian Greeks kernel carries");
-                rider_drift[d] = drift;
-                as.rate_step[d] = drift - as.drift[0];
-                ++n_riders;
-            }
-            as.group[i] = kAsianRealGroups + d;
-            continue;
-        }
-        int g = 0;
-        while (g < n_groups && !(same(as.drift[g], drift) && same(as.vol[g], vol))) ++g;
-        if (g == n_groups) {
-            if (n_groups == real_slots) return fail(OLMC_ERR_STATE, "more distinct path recursions than the fused Asian Greeks kernel carries");
-            as.drift[g] = drift;
-            as.vol[g] = vol;
-            ++n_groups;
-        }
-        as.group[i] = g;
-    }
-    for (int g = n_groups; g < kAsianGroups; ++g) { as.drift[g] = as.drift[0]; as.vol[g] = as.vol[0]; }
-    {   // into the units the kernel sums in, by the very products the one-contract kernels form on the device: arithmetic (asian_exp64_kernel)
-        // drift * kUnit, vol * kZScale * kUnit; geometric (asian_kernel<., true>) drift * 1.0, vol * kZScale * 1.0
-        constexpr double kLog2e = 1.4426950408889634;
-        const double kUnit = geo ? 1.0 : (OLMC_EXP2_TABLE ? kExp2Entries * kLog2e : kLog2e);
-        for (int g = 0; g < kAsianGroups; ++g) {
-            as.drift[g] = as.drift[g] * kUnit;
-            as.vol[g] = as.vol[g] * kZScale * kUnit;
-        }
-    }
-    as.strike = K;
-    as.sign = is_call ? 1.0 : -1.0;
-    as.inv_steps = 1.0 / n_steps;
+    AsianGreeksSet as;
+    constexpr double kLog2e = 1.4426950408889634;
+    const double unit = geo ? 1.0 : (OLMC_EXP2_TABLE ? kExp2Entries * kLog2e : kLog2e);     // what each kernel's exponential counts in
+    if (const char* bad = asian_greeks_layout(gs, n_steps, geo, unit, K, is_call, &as)) return fail(OLMC_ERR_STATE, bad);
     CtxLease lease;
     rc = ctx_lease(&lease);
     if (rc) return rc;
@@ -1449,28 +1284,8 @@ extern "C" int olmc_extrema_greeks_fd(double S, double K, double T, double r, do
     if (rc) return rc;
     if (n_paths > static_cast<int64_t>(kMaxGrid) * kBlock) return fail(OLMC_ERR_ARG, "n_paths beyond one launch of the fused Greeks kernel (2^26)");
     const GreeksSet gs(S, K, T, r, sigma, q, is_call, second_order);
-    ExtremaGreeksSet es{};
-    int n_groups = 0;
-    for (int i = 0; i < gs.k; ++i) {
-        const olmc_option& o = gs.o[i];
-        const double dt = o.T / n_steps;                             // exotic_options.py:54-56, as run_extrema
-        const double drift = (o.r - o.q - 0.5 * o.sigma * o.sigma) * dt, vol = o.sigma * std::sqrt(dt) * kZScale;
-        int g = 0;
-        while (g < n_groups && !(std::memcmp(&es.drift[g], &drift, sizeof drift) == 0 && std::memcmp(&es.vol[g], &vol, sizeof vol) == 0)) ++g;
-        if (g == n_groups) {
-            if (n_groups == kAsianGroups) return fail(OLMC_ERR_STATE, "more distinct path recursions than the fused Greeks kernel carries");
-            es.drift[g] = drift;
-            es.vol[g] = vol;
-            ++n_groups;
-        }
-        es.group[i] = g;
-        es.s0[i] = o.S;
-        es.log_barrier_rel[i] = is_barrier ? std::log(barrier / o.S) : 0.0;
-    }
-    for (int g = n_groups; g < kAsianGroups; ++g) { es.drift[g] = es.drift[0]; es.vol[g] = es.vol[0]; }
-    es.strike = K;
-    es.sign = is_call ? 1.0 : -1.0;
-    es.payoff = payoff;
+    ExtremaGreeksSet es;
+    if (const char* bad = extrema_greeks_layout(gs, n_steps, payoff, barrier, K, is_call, &es)) return fail(OLMC_ERR_STATE, bad);
     CtxLease lease;
     rc = ctx_lease(&lease);
     if (rc) return rc;
@@ -1610,9 +1425,7 @@ extern "C" int olmc_gbm_paths(double S, double T, double r, double sigma, double
     if (path_major) hipLaunchKernelGGL((lsm_paths_kernel<true>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, lc, static_cast<double*>(c->d_bulk));
     else hipLaunchKernelGGL((lsm_paths_kernel<false>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, lc, static_cast<double*>(c->d_bulk));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out_host, c->d_bulk, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return OLMC_OK;
+    return copy_to_host(c, out_host, c->d_bulk, static_cast<size_t>(bytes));
 }
 
 extern "C" int olmc_exercise_boundary(double S, double K, double T, double r, double sigma, double q, int is_call,
@@ -1800,10 +1613,9 @@ extern "C" int olmc_heston_paths(double S, double T, double r, double q, double 
     if (path_major) hipLaunchKernelGGL((heston_paths_kernel<true>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, hc, S, d_spot, d_var);
     else hipLaunchKernelGGL((heston_paths_kernel<false>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, hc, S, d_spot, d_var);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(spot_host, d_spot, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(var_host, d_var, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return OLMC_OK;
+    rc = copy_to_host(c, spot_host, d_spot, static_cast<size_t>(bytes));
+    if (rc) return rc;
+    return copy_to_host(c, var_host, d_var, static_cast<size_t>(bytes));
 }
 
 extern "C" int olmc_heston(double S, double K, double T, double r, double q, int is_call, double kappa, double theta,
@@ -1911,9 +1723,7 @@ extern "C" int olmc_jump_paths(double S, double T, double r, double sigma, doubl
     else hipLaunchKernelGGL((jump_paths_kernel<false>), dim3(grid_for(n_paths)), dim3(kBlock), 0, c->stream, pr, jc, S,
                             static_cast<double*>(c->d_bulk));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out_host, c->d_bulk, static_cast<size_t>(bytes), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return OLMC_OK;
+    return copy_to_host(c, out_host, c->d_bulk, static_cast<size_t>(bytes));
 }
 
 // ======================================================================= QMC ====
@@ -1921,7 +1731,8 @@ namespace {
 // The scrambled direction matrix and digital shift on the device: [dims x 30 | dims] words.  The table travels only when it
 // differs from the one already there (compared word for word: 31 KB at 252 dims, ~1 us, against two pageable uploads): the
 // 8 / 14 pricings of literal FD Greeks and every repeated pricing share one upload.  The caller holds the context's lease.
-int qmc_table(DeviceCtx* c, const uint32_t* sv, const uint32_t* shift, int32_t dims) {
+int qmc_table(DeviceCtx* c, const uint32_t* sv, const uint32_t* shift, int32_t dims, bool* uploaded = nullptr) {
+    if (uploaded) *uploaded = false;
     const size_t sv_words = static_cast<size_t>(dims) * kSobolBits, table_words = sv_words + dims;
     const bool same = c->sobol_host.size() == table_words && std::memcmp(c->sobol_host.data(), sv, sizeof(uint32_t) * sv_words) == 0 &&
                       std::memcmp(c->sobol_host.data() + sv_words, shift, sizeof(uint32_t) * dims) == 0;
@@ -1939,6 +1750,7 @@ int qmc_table(DeviceCtx* c, const uint32_t* sv, const uint32_t* shift, int32_t d
     HIP_TRY(hipMemcpyAsync(c->d_sobol + sv_words, shift, sizeof(uint32_t) * dims, hipMemcpyHostToDevice, c->stream));
     c->sobol_host.assign(sv, sv + sv_words);
     c->sobol_host.insert(c->sobol_host.end(), shift, shift + dims);
+    if (uploaded) *uploaded = true;
     return OLMC_OK;
 }
 
@@ -1973,7 +1785,9 @@ QmcShape qmc_shape(int64_t point_offset, int64_t n_paths, int32_t dims) {
 
 int run_qmc(double S, double K, double T, double r, double sigma, double q, int is_call, int64_t point_offset,
             int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
-            olmc_stats* out, double* terminal_host, int mirror = 0, olmc_cv_moments* cv = nullptr) {
+            olmc_stats* out, double* terminal_host, int mirror = 0, olmc_cv_moments* cv = nullptr,
+            double* d_triple = nullptr /* a shard of a multi-GPU call: {sum, sumsq, n} are LEFT here, on `shard_stream`, nothing is waited for */,
+            hipStream_t shard_stream = nullptr) {
     int rc = qmc_check(sv, shift, bits, dims, point_offset, n_paths);
     if (rc) return rc;
     CtxLease lease;
@@ -1986,8 +1800,10 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
         rc = bulk_reserve(c, term_bytes);
         if (rc) return rc;
     }
-    rc = qmc_table(c, sv, shift, dims);
+    bool uploaded = false;
+    rc = qmc_table(c, sv, shift, dims, &uploaded);
     if (rc) return rc;
+    if (d_triple && uploaded) HIP_TRY(hipStreamSynchronize(c->stream));      // the table travelled on the context's stream, the kernel runs on the rank's
     uint32_t* d_sv = c->d_sobol;
     uint32_t* d_shift = d_sv + sv_words;
     double* d_term = terminal_host ? static_cast<double*>(c->d_bulk) : nullptr;
@@ -2024,13 +1840,15 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
         else if (sh.split) launch_timed(european_qmc_kernel<kControlVariate, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
         else launch_timed(european_qmc_kernel<kControlVariate, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
     } else if (!terminal_host) {
-        rc = make_ws(c, c->stream, grid, 2, c->d_result, -1.0, &ws);
+        hipStream_t s = d_triple ? shard_stream : c->stream;
+        rc = make_ws(c, s, grid, 2, d_triple ? d_triple : c->d_result, d_triple ? static_cast<double>(n_paths) : -1.0, &ws);
         if (rc) return rc;
         rc = prof_pair(c, &ep, &timed);
         if (rc) return rc;
-        if (blocks) launch_timed(european_qmc_block_kernel<kReduce>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
-        else if (sh.split) launch_timed(european_qmc_kernel<kReduce, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
-        else launch_timed(european_qmc_kernel<kReduce, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        if (blocks) launch_timed(european_qmc_block_kernel<kReduce>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else if (sh.split) launch_timed(european_qmc_kernel<kReduce, true>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else launch_timed(european_qmc_kernel<kReduce, false>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        if (d_triple) return after_launch(c, s);
     } else {
         if (blocks) hipLaunchKernelGGL((european_qmc_block_kernel<kTerminal>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
         else if (sh.split) hipLaunchKernelGGL((european_qmc_kernel<kTerminal, true>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
@@ -2038,22 +1856,15 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
     }
     if (terminal_host) {            // no reduction workspace was handed out: only the launch status matters
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(terminal_host, d_term, term_bytes, hipMemcpyDeviceToHost, c->stream));
-        return sync_or_recover(c, c->stream);
+        c->armed = 0;
+        return copy_to_host(c, terminal_host, d_term, term_bytes);
     }
     rc = after_launch(c, c->stream);
     if (rc) return rc;
     rc = sync_or_recover(c, c->stream);
     if (rc) return rc;
     if (cv) {       // device moments are of the UNdiscounted payoff x; d = disc * x (monte_carlo.py:175)
-        const double disc = std::exp(-r * T);
-        cv->sum_d = disc * c->h_result[0];
-        cv->sum_s = c->h_result[1];
-        cv->sum_dd = disc * disc * c->h_result[2];
-        cv->sum_ss = c->h_result[3];
-        cv->sum_ds = disc * c->h_result[4];
-        cv->n = n_paths;
-        cv_finish(S, T, r, q, cv);
+        cv_from_device(c->h_result, n_paths, S, T, r, q, cv);
         if (poisoned(S, K, T, r, sigma, q)) cv->value = std::nan("");
         return OLMC_OK;
     }
@@ -2176,12 +1987,20 @@ extern "C" int olmc_european_qmc_greeks_fd(double S, double K, double T, double 
 // librccl is resolved lazily (dlopen) so single-GPU users never load it; the TYPES and ENUM VALUES come from
 // <rccl/rccl.h> at compile time, so a header / library mismatch is a build-time matter, not a guessed constant.
 //
-// One process, n ranks (rank d = device d), ONE host thread -- the caller's.  Per rank the engine owns a stream and a send / receive
-// buffer (never a pricing context: the shard launches lease one like any other call and use the rank's stream as a caller stream).
-// A call queues every rank's path kernel, then ONE grouped all-reduce of `count` doubles (3 for a price, 2 nsets + 1 for
-// finite-difference Greeks, 6 for the control variate: SURVEY §8e) before it waits for anything; the reduced values come home
-// through rank 0's polled completion word (olmc_fetch_dev), the other ranks hold the same values and are drained before the
-// call returns.
+// One process, n ranks (rank d = device d).  An ENGINE exists per list of devices: per rank a stream, a send / receive buffer and a
+// LAUNCHER THREAD bound to the rank's device at birth (one hipSetDevice, ever -- SURVEY §8e: "one host thread per device +
+// ncclCommInitAll"), plus the list's communicators.  Never a pricing context: a shard launch leases one like any other call and uses
+// the rank's stream as a caller stream.  A call
+//   1. posts the launch job: every launcher queues its rank's path kernel at once (round 4 queued them one after the other from the
+//      calling thread: rank 7's kernel started seven enqueues late);
+//   2. queues ONE grouped all-reduce of `count` doubles from the calling thread (3 for a price, 2 nsets + 1 for finite-difference
+//      Greeks, 6 for the control variate: SURVEY §8e) -- only after every rank has launched, so a rank that failed leaves no peer
+//      waiting inside a collective;
+//   3. posts the drain job (launchers 1 .. n-1 wait for their streams) and meanwhile takes the reduced values home through rank 0's
+//      polled completion word (olmc_fetch_dev); every rank holds the same values.
+// Calls on device lists that share no device run concurrently; lists that share one queue behind that device's mutex (two
+// communicators driven at once on one device may deadlock inside RCCL).  OLMC_TUNE_MULTI_LAUNCH = -1 keeps round 4's serial form
+// (everything from the calling thread) for A/B; both forms give the same bits.
 namespace {
 struct Rccl {
     void* lib = nullptr;
@@ -2193,8 +2012,10 @@ struct Rccl {
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 Rccl g_rccl;
+std::mutex g_rccl_mu;
 
 int rccl_load() {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
     if (g_rccl.lib) return OLMC_OK;
     void* h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -2214,15 +2035,25 @@ int rccl_load() {
     return OLMC_OK;
 }
 
-#define RCCL_TRY(expr)                                                                                   \
-    do {                                                                                                 \
-        ncclResult_t r_ = (expr);                                                                        \
-        if (r_ != ncclSuccess)                                                                           \
-            return fail(OLMC_ERR_RCCL, std::string(#expr) + ": " +                                       \
-                                           (g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error")); \
+std::string rccl_message(const char* what, ncclResult_t r) {
+    return std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "rccl error");
+}
+
+#define RCCL_TRY(expr)                                                                \
+    do {                                                                              \
+        ncclResult_t r_ = (expr);                                                     \
+        if (r_ != ncclSuccess) return fail(OLMC_ERR_RCCL, rccl_message(#expr, r_));   \
     } while (0)
 
 constexpr int kMultiValues = kMaxNV + 1;            // the widest payload: 2 x 16 sums + n
+
+// A word threads sleep on (futex): the launchers wait for the engine's job number to move.
+inline long futex_call(std::atomic<uint32_t>* word, int op, uint32_t value) {
+    static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "futex word");
+    return syscall(SYS_futex, reinterpret_cast<uint32_t*>(word), op, value, nullptr, nullptr, 0);
+}
+
+struct MultiEngine;
 
 struct MultiRank {
     int device = -1;
@@ -2230,21 +2061,87 @@ struct MultiRank {
     double* d_send = nullptr;                       // [kMultiValues] this rank's sums (written by its path kernel's last workgroup)
     double* d_recv = nullptr;                       // [kMultiValues] the reduced sums
     hipEvent_t queued = nullptr;                    // rehearsal only: the rank's path kernel is queued behind this
+    std::thread launcher;                           // bound to `device`; runs the engine's jobs for this rank
+    int rc = OLMC_OK;                               // of the job it ran last (read by the caller behind the job's completion count)
+    std::string error;
 };
 
 struct MultiEngine {
-    std::mutex mu;                                  // one multi-GPU call at a time
-    std::vector<MultiRank> ranks;
+    std::vector<MultiRank> ranks;                   // sized once, before the launchers start
     std::vector<int> devices;                       // device of every rank: what `ranks` and `comms` were built for
     std::vector<ncclComm_t> comms;                  // empty in a rehearsal
     bool rehearsal = false;
+    // job board: written by the caller, then `job_no` moves (release) and the launchers wake
+    std::atomic<uint32_t> job_no{0};
+    std::atomic<int> sleepers{0};                   // launchers inside futex_wait (the caller skips the wake syscall when none)
+    std::atomic<int> remaining{0};                  // launchers that have not finished the posted job yet
+    const std::function<int(int)>* work = nullptr;  // work(rank); nullptr = leave
+    int first_rank = 0;                             // ranks below take no part in the posted job
 };
-MultiEngine g_multi;
+
+std::mutex g_engines_mu;                            // guards g_engines (never held while a call runs)
+std::vector<MultiEngine*> g_engines;                // one per (device list, rehearsal) asked for since the last olmc_shutdown
+std::mutex g_multi_dev_mu[kMaxDevices];             // a multi-GPU call holds the mutex of every device of its list (ascending order)
+int g_multi_launch = 0;                             // OLMC_TUNE_MULTI_LAUNCH: 0 = launcher threads from two ranks on (default), -1 = serial
+thread_local double t_multi_spans[5] = {0, 0, 0, 0, 0};
+
+constexpr int64_t kLauncherSpinUs = 200;            // a launcher that finished a job spins this long for the next one before it sleeps
+
+void launcher_main(MultiEngine* e, int d, uint32_t seen) {
+    MultiRank& rk = e->ranks[d];
+    (void)hipSetDevice(rk.device);                  // once: every launch of this thread goes to this device
+    t_device = rk.device;
+    using clock = std::chrono::steady_clock;
+    for (;;) {
+        auto t0 = clock::now();
+        uint32_t now;
+        for (uint32_t spins = 0; (now = e->job_no.load(std::memory_order_acquire)) == seen; ++spins) {
+            if ((spins & 0x3F) != 0x3F || clock::now() - t0 < std::chrono::microseconds(kLauncherSpinUs)) {
+                __builtin_ia32_pause();
+                continue;
+            }
+            e->sleepers.fetch_add(1, std::memory_order_seq_cst);
+            if (e->job_no.load(std::memory_order_seq_cst) == seen) futex_call(&e->job_no, FUTEX_WAIT_PRIVATE, seen);
+            e->sleepers.fetch_sub(1, std::memory_order_seq_cst);
+            t0 = clock::now();
+        }
+        seen = now;
+        const std::function<int(int)>* work = e->work;
+        if (!work) return;
+        if (d < e->first_rank) continue;
+        rk.rc = (*work)(d);
+        if (rk.rc) rk.error = t_error;
+        e->remaining.fetch_sub(1, std::memory_order_release);
+    }
+}
+
+void engine_post(MultiEngine* e, const std::function<int(int)>* work, int first_rank) {
+    e->work = work;
+    e->first_rank = first_rank;
+    e->remaining.store(static_cast<int>(e->ranks.size()) - first_rank, std::memory_order_relaxed);
+    e->job_no.fetch_add(1, std::memory_order_seq_cst);
+    if (e->sleepers.load(std::memory_order_seq_cst) > 0) futex_call(&e->job_no, FUTEX_WAKE_PRIVATE, INT_MAX);
+}
+
+// Waits for the posted job; the first failing rank's status and message become the caller's.
+int engine_wait(MultiEngine* e) {
+    using clock = std::chrono::steady_clock;
+    const auto t0 = clock::now();
+    for (uint32_t spins = 0; e->remaining.load(std::memory_order_acquire) > 0; ++spins) {
+        if ((spins & 0x3F) == 0x3F && clock::now() - t0 >= std::chrono::microseconds(kSpinUs)) sched_yield();
+        else __builtin_ia32_pause();
+    }
+    for (size_t d = static_cast<size_t>(e->first_rank); d < e->ranks.size(); ++d)
+        if (e->ranks[d].rc) return fail(e->ranks[d].rc, "rank " + std::to_string(d) + ": " + e->ranks[d].error);
+    return OLMC_OK;
+}
 
 // A rank stream is about to be destroyed: the workspace slots it claimed in the contexts of its device are handed back (a later
-// stream may get the same handle value; and a slot whose owner is gone would otherwise stay taken for good).
+// stream may get the same handle value; and a slot whose owner is gone would otherwise stay taken for good -- the host fault of round 4,
+// with every slot claimed by a dead stream, the next caller stream went down the slot-sharing path, which drained the
+// slot's "owner" with hipStreamSynchronize on a destroyed handle).
 void pool_forget_stream(int dev, hipStream_t stream) {
-    DevicePool* pool = g_pool[dev];
+    DevicePool* pool = g_pool[dev].load(std::memory_order_acquire);
     if (!pool) return;
     std::unique_lock<std::mutex> lock(pool->mu);
     pool->idle.wait(lock, [&] { return std::none_of(pool->all.begin(), pool->all.end(), [](const DeviceCtx* c) { return c->busy; }); });
@@ -2253,54 +2150,103 @@ void pool_forget_stream(int dev, hipStream_t stream) {
             DeviceCtx::WsSlot& sl = c->slots[i];
             if (sl.claimed && !sl.shared && sl.owner == stream) { sl.claimed = false; sl.owner = nullptr; sl.used = false; }
         }
+    lock.unlock();
+    pool->idle.notify_all();                        // lease waiters share the condition variable with this wait
 }
 
-void multi_gpu_release() {
-    for (ncclComm_t cm : g_multi.comms)
+void engine_destroy(MultiEngine* e) {
+    if (!e->ranks.empty() && e->ranks[0].launcher.joinable()) {
+        engine_post(e, nullptr, 0);                 // work == nullptr: leave
+        for (MultiRank& rk : e->ranks)
+            if (rk.launcher.joinable()) rk.launcher.join();
+    }
+    for (ncclComm_t cm : e->comms)
         if (cm && g_rccl.CommDestroy) g_rccl.CommDestroy(cm);
-    g_multi.comms.clear();
-    for (MultiRank& rk : g_multi.ranks) {
-        if (hipSetDevice(rk.device) != hipSuccess) continue;
+    for (MultiRank& rk : e->ranks) {
+        if (rk.device < 0 || hipSetDevice(rk.device) != hipSuccess) continue;
         if (rk.stream) { (void)hipStreamSynchronize(rk.stream); pool_forget_stream(rk.device, rk.stream); (void)hipStreamDestroy(rk.stream); }
         if (rk.d_send) (void)hipFree(rk.d_send);
         if (rk.queued) (void)hipEventDestroy(rk.queued);
     }
-    g_multi.ranks.clear();
-    g_multi.devices.clear();
     (void)hipGetLastError();
+    delete e;
 }
 
-// Streams, buffers and communicators for exactly this list of devices (cached on the LIST, not its length).
-int multi_prepare(const std::vector<int>& devs, bool rehearsal) {
-    if (g_multi.devices == devs && g_multi.rehearsal == rehearsal && !g_multi.ranks.empty()) return OLMC_OK;
-    multi_gpu_release();
-    g_multi.rehearsal = rehearsal;
-    g_multi.ranks.resize(devs.size());
+// olmc_shutdown: the caller's contract is that no call is in flight.
+void multi_gpu_release() {
+    std::vector<MultiEngine*> all;
+    {
+        std::lock_guard<std::mutex> lock(g_engines_mu);
+        all.swap(g_engines);
+    }
+    for (MultiEngine* e : all) engine_destroy(e);
+}
+
+// Streams, buffers, launchers and communicators for exactly this list of devices.  Called with the devices' mutexes held.
+int engine_build(const std::vector<int>& devs, bool rehearsal, MultiEngine** out) {
+    MultiEngine* e = new MultiEngine();
+    e->rehearsal = rehearsal;
+    e->devices = devs;
+    e->ranks.resize(devs.size());
+    auto bail = [&](int rc) { engine_destroy(e); return rc; };
     for (size_t d = 0; d < devs.size(); ++d) {
-        MultiRank& rk = g_multi.ranks[d];
-        rk.device = devs[d];
-        HIP_TRY(hipSetDevice(devs[d]));
-        HIP_TRY(hipStreamCreateWithFlags(&rk.stream, hipStreamNonBlocking));
+        MultiRank& rk = e->ranks[d];
+        hipError_t err = hipSetDevice(devs[d]);
+        if (err == hipSuccess) { rk.device = devs[d]; err = hipStreamCreateWithFlags(&rk.stream, hipStreamNonBlocking); }
         constexpr int kStride = 64;                  // doubles: the receive buffer starts on its own 512-byte boundary (the collective's vector accesses)
         static_assert(kStride >= kMultiValues, "rank buffers hold the widest payload");
-        HIP_TRY(hipMalloc(&rk.d_send, sizeof(double) * 2 * kStride));
-        rk.d_recv = rk.d_send + kStride;
-        HIP_TRY(hipEventCreateWithFlags(&rk.queued, hipEventDisableTiming));
+        if (err == hipSuccess) err = hipMalloc(&rk.d_send, sizeof(double) * 2 * kStride);
+        if (err == hipSuccess) { rk.d_recv = rk.d_send + kStride; err = hipEventCreateWithFlags(&rk.queued, hipEventDisableTiming); }
+        if (err != hipSuccess) return bail(fail(OLMC_ERR_HIP, std::string("multi-GPU engine, rank ") + std::to_string(d) + ": " + hipGetErrorString(err)));
     }
     if (!rehearsal) {
         int rc = rccl_load();
-        if (rc) return rc;
-        g_multi.comms.assign(devs.size(), nullptr);
+        if (rc) return bail(rc);
+        e->comms.assign(devs.size(), nullptr);
         std::vector<int> list = devs;
-        RCCL_TRY(g_rccl.CommInitAll(g_multi.comms.data(), static_cast<int>(list.size()), list.data()));
+        const ncclResult_t r = g_rccl.CommInitAll(e->comms.data(), static_cast<int>(list.size()), list.data());
+        if (r != ncclSuccess) return bail(fail(OLMC_ERR_RCCL, rccl_message("ncclCommInitAll", r)));
     }
-    g_multi.devices = devs;
+    if (devs.size() > 1)                             // one rank needs no launcher: the calling thread is as good
+        for (size_t d = 0; d < devs.size(); ++d) e->ranks[d].launcher = std::thread(launcher_main, e, static_cast<int>(d), e->job_no.load());
+    *out = e;
+    return OLMC_OK;
+}
+
+int engine_for(const std::vector<int>& devs, bool rehearsal, MultiEngine** out) {
+    {
+        std::lock_guard<std::mutex> lock(g_engines_mu);
+        for (MultiEngine* e : g_engines)
+            if (e->devices == devs && e->rehearsal == rehearsal) { *out = e; return OLMC_OK; }
+    }
+    // A caller that keeps changing its device list (a rehearsal sweeping 1 .. 12 ranks on one device) must not pile up streams and
+    // parked launchers for ever: beyond kMaxEngines the oldest engines go -- but only engines ALL of whose devices this call has
+    // locked (nobody can be inside them), oldest first.
+    constexpr size_t kMaxEngines = 4;
+    std::vector<MultiEngine*> evicted;
+    {
+        std::lock_guard<std::mutex> lock(g_engines_mu);
+        for (size_t i = 0; i < g_engines.size() && g_engines.size() >= kMaxEngines;) {
+            const std::vector<int>& theirs = g_engines[i]->devices;
+            const bool ours = std::all_of(theirs.begin(), theirs.end(), [&](int d) { return std::find(devs.begin(), devs.end(), d) != devs.end(); });
+            if (!ours) { ++i; continue; }
+            evicted.push_back(g_engines[i]);
+            g_engines.erase(g_engines.begin() + static_cast<std::ptrdiff_t>(i));
+        }
+    }
+    for (MultiEngine* old : evicted) engine_destroy(old);      // joins its launchers, hands its streams' workspace slots back, destroys them
+    MultiEngine* e = nullptr;
+    const int rc = engine_build(devs, rehearsal, &e);      // the devices' mutexes are held: nobody else builds this list meanwhile
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(g_engines_mu);
+    g_engines.push_back(e);
+    *out = e;
     return OLMC_OK;
 }
 
 // After a stream of a failed call could not be drained: the self-resetting counters of that device's workspaces may be dirty.
 void pool_recover(int dev) {
-    DevicePool* pool = g_pool[dev];
+    DevicePool* pool = g_pool[dev].load(std::memory_order_acquire);
     if (!pool) return;
     std::lock_guard<std::mutex> lock(pool->mu);
     for (DeviceCtx* c : pool->all) ws_recover(c);
@@ -2308,21 +2254,46 @@ void pool_recover(int dev) {
 
 // Whatever way a multi-GPU call leaves (any of its error returns included), the calling thread gets back the library device and
 // the HIP current device it came in with, and every rank stream a kernel was already queued on has been drained, so no launch of
-// a failed call is still running behind the caller's next one.
+// a failed call is still running behind the caller's next one.  It also holds the device mutexes of the call.
 struct MultiGpuScope {
     int saved_lib_device, saved_hip_device = -1;
+    MultiEngine* engine = nullptr;
     std::vector<int> launched;          // ranks with work queued by this call
+    std::vector<int> locked;            // devices whose multi-GPU mutex this call holds
     explicit MultiGpuScope(int lib_device) : saved_lib_device(lib_device) { (void)hipGetDevice(&saved_hip_device); }
+    void lock_devices(const std::vector<int>& devs) {
+        locked = devs;
+        std::sort(locked.begin(), locked.end());
+        locked.erase(std::unique(locked.begin(), locked.end()), locked.end());
+        for (int d : locked) g_multi_dev_mu[d].lock();
+    }
     ~MultiGpuScope() {
-        for (int d : launched) {
-            const MultiRank& rk = g_multi.ranks[d];
-            if (hipSetDevice(rk.device) == hipSuccess && hipStreamSynchronize(rk.stream) != hipSuccess) pool_recover(rk.device);
-        }
+        if (engine)
+            for (int d : launched) {
+                const MultiRank& rk = engine->ranks[d];
+                if (hipSetDevice(rk.device) == hipSuccess && hipStreamSynchronize(rk.stream) != hipSuccess) pool_recover(rk.device);
+            }
+        for (auto it = locked.rbegin(); it != locked.rend(); ++it) g_multi_dev_mu[*it].unlock();
         t_device = saved_lib_device;
         if (saved_hip_device >= 0) (void)hipSetDevice(saved_hip_device);
         (void)hipGetLastError();
     }
 };
+
+// The grouped all-reduce of `count` doubles, one per rank stream.  The group is CLOSED on every path out (an error between
+// ncclGroupStart and ncclGroupEnd would otherwise leave the calling thread inside an open group for good).
+int grouped_allreduce(MultiEngine* e, int count) {
+    RCCL_TRY(g_rccl.GroupStart());
+    ncclResult_t bad = ncclSuccess;
+    for (size_t d = 0; d < e->ranks.size() && bad == ncclSuccess; ++d) {
+        const MultiRank& rk = e->ranks[d];
+        bad = g_rccl.AllReduce(rk.d_send, rk.d_recv, static_cast<size_t>(count), ncclFloat64, ncclSum, e->comms[d], rk.stream);
+    }
+    const ncclResult_t end = g_rccl.GroupEnd();
+    if (bad != ncclSuccess) return fail(OLMC_ERR_RCCL, rccl_message("ncclAllReduce", bad));
+    if (end != ncclSuccess) return fail(OLMC_ERR_RCCL, rccl_message("ncclGroupEnd", end));
+    return OLMC_OK;
+}
 
 #ifdef OLMC_WITH_PROBES
 // The instrumented build's stand-in for the collective when n ranks are REHEARSED on one device (RCCL refuses two ranks on one
@@ -2337,10 +2308,27 @@ __global__ void rehearsal_allreduce_kernel(RankBuffers in, int n_ranks, int coun
     for (int r = 0; r < n_ranks; ++r) sum += in.send[r][t];
     recv[t] = sum;
 }
+
+int rehearsal_allreduce(MultiEngine* e, int count) {
+    const int n = static_cast<int>(e->ranks.size());
+    RankBuffers in{};
+    for (int d = 0; d < n; ++d) {
+        in.send[d] = e->ranks[d].d_send;
+        HIP_TRY(hipEventRecord(e->ranks[d].queued, e->ranks[d].stream));
+    }
+    for (int d = 0; d < n; ++d) {
+        for (int o = 0; o < n; ++o)
+            if (o != d) HIP_TRY(hipStreamWaitEvent(e->ranks[d].stream, e->ranks[o].queued, 0));
+        hipLaunchKernelGGL(rehearsal_allreduce_kernel, dim3(1), dim3(kWave), 0, e->ranks[d].stream, in, n, count, e->ranks[d].d_recv);
+        HIP_TRY(hipGetLastError());
+    }
+    return OLMC_OK;
+}
 #endif
 
 // The skeleton every multi-GPU entry point shares.  launch(rank, lo, n_local, stream, d_send) queues rank's path kernel on ITS
-// stream (the calling thread's library device is the rank's) and must leave `count` doubles at d_send; host receives their sums.
+// stream (the thread it runs on has the rank's device as its library device) and must leave `count` doubles at d_send; host
+// receives their sums.  `launch` runs on the launcher threads, one rank each, at the same time: it must not write shared state.
 template <typename Launch>
 int multi_gpu_run(int n_gpus, int64_t n_paths, int32_t n_steps, int count, Launch launch, double* host) {
     if (n_gpus < 1 || n_gpus > kMaxDevices) return fail(OLMC_ERR_ARG, "n_gpus out of range");
@@ -2356,68 +2344,89 @@ int multi_gpu_run(int n_gpus, int64_t n_paths, int32_t n_steps, int count, Launc
     hipError_t e = hipGetDeviceCount(&visible);
     if (e != hipSuccess || visible < (rehearsal ? 1 : n_gpus))
         return fail(OLMC_ERR_HIP, "requested " + std::to_string(n_gpus) + " GPUs, " + std::to_string(visible) + " visible");
-    std::lock_guard<std::mutex> lock(g_multi.mu);
-    const int home = t_device >= 0 ? t_device : (g_default_device >= 0 ? g_default_device : 0);
+    using clock = std::chrono::steady_clock;
+    const int home = t_device >= 0 ? t_device : (g_default_device.load() >= 0 ? g_default_device.load() : 0);
     MultiGpuScope scope(home);
     std::vector<int> devs(n_gpus);
     for (int d = 0; d < n_gpus; ++d) devs[d] = rehearsal ? home : d;
-    for (int d = 0; d < n_gpus; ++d) { rc = olmc_init(devs[d]); if (rc) return rc; }      // olmc_init moves t_device: the guard puts it back
-    rc = multi_prepare(devs, rehearsal);
+    if (home >= kMaxDevices) return fail(OLMC_ERR_ARG, "device index out of range");
+    scope.lock_devices(devs);
+    for (int d = 0; d < n_gpus; ++d)
+        if (!g_pool[devs[d]].load(std::memory_order_acquire)) { rc = olmc_init(devs[d]); if (rc) return rc; }      // olmc_init moves t_device: the guard puts it back
+    MultiEngine* eng = nullptr;
+    rc = engine_for(devs, rehearsal, &eng);
     if (rc) return rc;
-    // contiguous global path ranges: rank d owns [d*N/P, (d+1)*N/P)  
-    for (int d = 0; d < n_gpus; ++d) {
-        const MultiRank& rk = g_multi.ranks[d];
-        HIP_TRY(hipSetDevice(rk.device));
-        t_device = rk.device;
-        const int64_t lo = n_paths * d / n_gpus, hi = n_paths * (d + 1) / n_gpus;
+    scope.engine = eng;
+    const bool threaded = n_gpus > 1 && g_multi_launch >= 0;
+    const auto t0 = clock::now();
+    // 1. every rank's path kernel: contiguous global path ranges, rank d owns [d N / P, (d + 1) N / P)  
+    const std::function<int(int)> launch_rank = [&](int d) -> int {
+        const MultiRank& rk = eng->ranks[d];
+        int64_t lo, n_local;
+        shard_range(n_paths, d, n_gpus, &lo, &n_local);
 #ifdef OLMC_WITH_PROBES
         if (g_fault_shard == d + 1) return fail(OLMC_ERR_HIP, "injected shard failure (OLMC_PROBE_TUNE_FAULT_SHARD)");
 #endif
-        scope.launched.push_back(d);
-        rc = launch(d, lo, hi - lo, rk.stream, rk.d_send);
+        return launch(d, lo, n_local, rk.stream, rk.d_send);
+    };
+    if (threaded) {
+        for (int d = 0; d < n_gpus; ++d) scope.launched.push_back(d);       // any of them may have queued work by the time one fails
+        engine_post(eng, &launch_rank, 0);
+        rc = engine_wait(eng);
         if (rc) return rc;
-    }
-    if (!rehearsal) {
-        RCCL_TRY(g_rccl.GroupStart());
+    } else {
         for (int d = 0; d < n_gpus; ++d) {
-            const MultiRank& rk = g_multi.ranks[d];
-            RCCL_TRY(g_rccl.AllReduce(rk.d_send, rk.d_recv, static_cast<size_t>(count), ncclFloat64, ncclSum, g_multi.comms[d], rk.stream));
+            HIP_TRY(hipSetDevice(eng->ranks[d].device));
+            t_device = eng->ranks[d].device;
+            scope.launched.push_back(d);
+            rc = launch_rank(d);
+            if (rc) return rc;
         }
-        RCCL_TRY(g_rccl.GroupEnd());
+    }
+    const auto t1 = clock::now();
+    // 2. the collective: queued on every rank stream before the first wait
+    if (!rehearsal) {
+        rc = grouped_allreduce(eng, count);
+        if (rc) return rc;
     } else {
 #ifdef OLMC_WITH_PROBES
-        RankBuffers in{};
-        for (int d = 0; d < n_gpus; ++d) {
-            in.send[d] = g_multi.ranks[d].d_send;
-            HIP_TRY(hipEventRecord(g_multi.ranks[d].queued, g_multi.ranks[d].stream));
-        }
-        for (int d = 0; d < n_gpus; ++d) {
-            for (int o = 0; o < n_gpus; ++o)
-                if (o != d) HIP_TRY(hipStreamWaitEvent(g_multi.ranks[d].stream, g_multi.ranks[o].queued, 0));
-            hipLaunchKernelGGL(rehearsal_allreduce_kernel, dim3(1), dim3(kWave), 0, g_multi.ranks[d].stream, in, n_gpus, count, g_multi.ranks[d].d_recv);
-            HIP_TRY(hipGetLastError());
-        }
+        rc = rehearsal_allreduce(eng, count);
+        if (rc) return rc;
 #endif
     }
-    // Every launch and the collective are queued on every rank before the first wait (the calls above only enqueue).  The sums come
-    // home the way every blocking pricing's result does: a one-wave kernel behind the all-reduce on rank 0 writes them into a pinned
-    // buffer and raises the completion word the host polls (olmc_fetch_dev); the other ranks hold the same sums and are drained
-    // afterwards -- they finish with the same collective.
-    const MultiRank& first = g_multi.ranks[0];
+    const auto t2 = clock::now();
+    // 3. The sums come home the way every blocking pricing's result does: a one-wave kernel behind the all-reduce on rank 0 writes
+    // them into a pinned buffer and raises the completion word the host polls (olmc_fetch_dev); the other ranks hold the same sums
+    // and finish with the same collective -- their launchers wait for their streams meanwhile.
+    const std::function<int(int)> drain_rank = [&](int d) -> int {
+        const hipError_t err = hipStreamSynchronize(eng->ranks[d].stream);
+        return err == hipSuccess ? OLMC_OK : fail(OLMC_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(err));
+    };
+    if (threaded) engine_post(eng, &drain_rank, 1);
+    const MultiRank& first = eng->ranks[0];
     HIP_TRY(hipSetDevice(first.device));
     t_device = first.device;
     rc = olmc_fetch_dev(first.d_recv, count, first.stream, host);
-    if (rc) return rc;
-    for (int d = n_gpus - 1; d >= 1; --d) {
-        HIP_TRY(hipSetDevice(g_multi.ranks[d].device));
-        HIP_TRY(hipStreamSynchronize(g_multi.ranks[d].stream));
+    const auto t3 = clock::now();
+    if (threaded) {
+        const int rc_drain = engine_wait(eng);          // always: the job refers to this frame
+        if (!rc) rc = rc_drain;
+    } else if (!rc) {
+        for (int d = n_gpus - 1; d >= 1 && !rc; --d) {
+            HIP_TRY(hipSetDevice(eng->ranks[d].device));
+            rc = drain_rank(d);
+        }
     }
+    if (rc) return rc;
+    const auto t4 = clock::now();
+    auto us = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    t_multi_spans[0] = us(t0, t1); t_multi_spans[1] = us(t1, t2); t_multi_spans[2] = us(t2, t3); t_multi_spans[3] = us(t3, t4); t_multi_spans[4] = us(t0, t4);
 #ifdef OLMC_WITH_PROBES
     // instrumented build: every rank must hold rank 0's bits (identical finalisation on every rank)
     for (int d = 1; d < n_gpus; ++d) {
         double other[kMultiValues];
-        HIP_TRY(hipSetDevice(g_multi.ranks[d].device));
-        HIP_TRY(hipMemcpy(other, g_multi.ranks[d].d_recv, sizeof(double) * count, hipMemcpyDeviceToHost));
+        HIP_TRY(hipSetDevice(eng->ranks[d].device));
+        HIP_TRY(hipMemcpy(other, eng->ranks[d].d_recv, sizeof(double) * count, hipMemcpyDeviceToHost));
         if (std::memcmp(other, host, sizeof(double) * count) != 0) return fail(OLMC_ERR_STATE, "rank " + std::to_string(d) + " holds other sums than rank 0");
     }
 #endif
@@ -2477,8 +2486,9 @@ extern "C" int olmc_multi_gpu_greeks_fd(double S, double K, double T, double r, 
     const int nsets = gs.k <= 8 ? 8 : 16;
     int pos[OLMC_MAX_BATCH] = {};
     double host[kMultiValues] = {};
-    const int rc = multi_gpu_run(n_gpus, n_paths, n_steps, 2 * nsets + 1, [&](int, int64_t lo, int64_t n_local, hipStream_t s, double* d_send) {
-        return batch_shard_dev(gs.o, gs.k, lo, n_local, n_steps, seed, 1, d_send, s, pos);      // every rank lays the set out alike
+    const int rc = multi_gpu_run(n_gpus, n_paths, n_steps, 2 * nsets + 1, [&](int rank, int64_t lo, int64_t n_local, hipStream_t s, double* d_send) {
+        int other[OLMC_MAX_BATCH];                                                               // every rank lays the set out alike: rank 0's
+        return batch_shard_dev(gs.o, gs.k, lo, n_local, n_steps, seed, 1, d_send, s, rank == 0 ? pos : other);      // layout is the one kept
     }, host);
     if (rc) return rc;
     const int64_t n = static_cast<int64_t>(host[2 * nsets]);
@@ -2510,6 +2520,33 @@ extern "C" int olmc_multi_gpu_european_cv(double S, double K, double T, double r
     out->n = static_cast<int64_t>(host[5]);
     cv_finish(S, T, r, q, out);
     if (poisoned(S, K, T, r, sigma, q)) out->value = std::nan("");
+    return OLMC_OK;
+}
+
+// Scrambled-Sobol pricing over n_gpus devices (gbm_qmc.py:14-46): rank d prices POINTS [d N / P, (d + 1) N / P) of the one sequence
+// through the point offset every Sobol kernel already takes, the ranks' {sum, sumsq, n} meet in the same all-reduce (count 3).  The
+// same points as the one-device call, another association of the sums.
+extern "C" int olmc_multi_gpu_european_qmc(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                           int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
+                                           int n_gpus, olmc_stats* out) {
+    if (!out) return fail(OLMC_ERR_ARG, "null pointer");
+    int rc = qmc_check(sv, shift, bits, dims, 0, n_paths);
+    if (rc) return rc;
+    double host[3] = {0, 0, 0};
+    rc = multi_gpu_run(n_gpus, n_paths, dims, 3, [&](int, int64_t lo, int64_t n_local, hipStream_t s, double* d_send) {
+        return run_qmc(S, K, T, r, sigma, q, is_call, lo, n_local, dims, sv, shift, bits, nullptr, nullptr, 0, nullptr, d_send, s);
+    }, host);
+    if (rc) return rc;
+    finish_stats(host[0], host[1], static_cast<int64_t>(host[2]), r, T, out);
+    if (poisoned(S, K, T, r, sigma, q)) nan_stats(out->n, out);
+    return OLMC_OK;
+}
+
+// Host microseconds of the calling thread's last multi-GPU call: {launch phase (first rank's launch begun -> every rank's kernel
+// queued), collective queued, result fetched (includes the kernels' run time), other ranks drained, total}.
+extern "C" int olmc_multi_gpu_spans(double* out5) {
+    if (!out5) return fail(OLMC_ERR_ARG, "null pointer");
+    for (int i = 0; i < 5; ++i) out5[i] = t_multi_spans[i];
     return OLMC_OK;
 }
 
@@ -2562,6 +2599,8 @@ extern "C" int olmc_tune(int knob, int value) {
     if (knob == OLMC_TUNE_POLL && value >= -1 && value <= 0) { g_poll = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_SPLIT_TAIL && value >= -1 && value <= 0) { g_split_tail = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_SPLIT_SAT && value >= 0 && value <= 16) { g_split_sat = value; return OLMC_OK; }
+    if (knob == OLMC_TUNE_MULTI_LAUNCH && value >= -1 && value <= 0) { g_multi_launch = value; return OLMC_OK; }
+    if (knob == OLMC_TUNE_STAGED_COPY && value >= -1 && value <= 0) { g_staged_copy = value; return OLMC_OK; }
     return fail(OLMC_ERR_ARG, "unknown tuning knob or value");
 }
 
@@ -2569,13 +2608,13 @@ namespace {
 // Runs fn on EVERY context of the calling thread's device, each taken out of circulation first (waits for the calls in flight).
 template <typename Fn>
 int with_all_contexts(Fn fn) {
-    int dev = t_device >= 0 ? t_device : g_default_device;
+    int dev = t_device >= 0 ? t_device : g_default_device.load(std::memory_order_acquire);
     if (dev < 0) {
         int rc = olmc_init(0);
         if (rc) return rc;
         dev = t_device;
     }
-    DevicePool* pool = g_pool[dev];
+    DevicePool* pool = g_pool[dev].load(std::memory_order_acquire);
     if (!pool) return fail(OLMC_ERR_STATE, "device not initialised (call olmc_init)");
     HIP_TRY(hipSetDevice(dev));
     std::vector<DeviceCtx*> mine;
@@ -2601,7 +2640,7 @@ int with_all_contexts(Fn fn) {
 
 extern "C" int olmc_profile_enable(int on) {
     g_profile = on != 0;
-    if (g_profile && (t_device >= 0 || g_default_device >= 0)) {
+    if (g_profile && (t_device >= 0 || g_default_device.load() >= 0)) {
         // pre-create the event pairs a measurement pass will consume, so that no hipEventCreate lands inside a timed call
         // (context 0 is the one a single-threaded measurement runs on; the others create theirs on demand)
         CtxLease lease;

@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "olmc_host_math.h"   // Contract, ContractSet, the fused-Greeks argument structs and their constants (plain C++, shared with the CPU-only test build)
+
 namespace olmc {
 
 constexpr int kBlock = 256;          // 4 wavefronts of 64
@@ -107,7 +109,7 @@ __device__ __forceinline__ Words4 philox4x32_10_pinned(uint32_t c0, uint32_t c1,
 // with the RAW normals z' = sqrt(-log2 u_a) * {cos, sin}(2 pi u_b) and apply the constant
 // kZScale = sqrt(2 ln 2) once per path (to sum z') or once per thread (to vol): two
 // multiplies fewer per pair, and the negation is a free source modifier of v_sqrt_f32.
-constexpr double kZScale = 1.1774100225154747;     // sqrt(2 ln 2)
+// kZScale = sqrt(2 ln 2): olmc_host_math.h
 constexpr float kZScaleF = 1.17741002f;
 
 __device__ __forceinline__ void box_muller_raw(uint32_t xa, uint32_t xb, float& z_cos, float& z_sin) {
@@ -266,15 +268,23 @@ __device__ __forceinline__ void signal_done(const ReduceWs& ws) {
     if (threadIdx.x == 0) __hip_atomic_store(ws.done_flag, ws.done_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// What the workgroup that took the last ticket does before it loads the rows the others stored.  Every row is stored write-through
-// (`sc1`) and drained (`s_waitcnt vmcnt(0)`) by its writer before that writer's ticket; the counter is an agent-scope atomic; and EVERY
-// load of a row in the consumer is an `sc1` load to registers (load_sc1: `global_load_dwordx2 ... sc1`, L2-served, bypassing this CU's
-// L1).  That is the hand-off for which cdna_hip_programming.md Guideline 16 says the agent-scope acquire -- `s_waitcnt vmcnt(0);
-// buffer_inv sc1`, an L1 invalidate nobody reads through, ~1 us at the head of the last workgroup's work -- is replaced by a
-// wavefront-scope fence: no instruction, it only keeps the compiler from moving the loads above the ticket.  Rounds 1-3 paid the
-// invalidate at every level of every launch (two levels from 65,537 paths on).  -DOLMC_AGENT_ACQUIRE=1 restores it (A/B).
+// What the workgroup that took the last ticket does before it loads the rows the others stored: an AGENT-scope acquire
+// (`s_waitcnt vmcnt(0); buffer_inv sc1`).  Every row is also stored write-through (`sc1`) and drained (`s_waitcnt vmcnt(0)`) by its
+// writer before that writer's ticket, the counter is an agent-scope atomic, and every load of a row in the consumer is an `sc1` load
+// to registers (load_sc1, L2-served) -- the hand-off for which cdna_hip_programming.md Guideline 16 allows a wavefront-scope fence in
+// place of the acquire, but ONLY for launches of one workgroup per CU (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads in
+// place of the acquire": a hand-off must match one row of that table in every cell).  The launches here run up to 7 workgroups per
+// CU plus split workgroups, outside that envelope: round 4 shipped the relaxed form everywhere and nothing ever failed, but a stale
+// 16-byte row at 1M paths would move a price by 0.25 sigma, invisible to every statistical gate.  So the acquire is back (round 5).
+// Its price, measured (profiles/r04_ab_kernels.txt, r05_ab_acquire.txt): within run-to-run noise at every size (1M x 252: 100.80
+// vs 100.73 us) -- the 16 us the relaxed form once saved were in the American option's per-date tickets, which no longer exist
+// (lsm_step_kernel sums the previous date's rows across a kernel boundary).  -DOLMC_AGENT_ACQUIRE=0 builds the relaxed form (A/B
+// only; refused on any target but gfx942 / gfx950, whose cache behaviour it leans on).
 #ifndef OLMC_AGENT_ACQUIRE
-#define OLMC_AGENT_ACQUIRE 0
+#define OLMC_AGENT_ACQUIRE 1
+#endif
+#if !OLMC_AGENT_ACQUIRE && defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx942__) && !defined(__gfx950__)
+#error "OLMC_AGENT_ACQUIRE=0 relies on gfx942 / gfx950 cache behaviour (sc1 rows are L2-served): build this target with the acquire"
 #endif
 __device__ __forceinline__ void acquire_rows() {
 #if OLMC_AGENT_ACQUIRE
@@ -717,7 +727,8 @@ __constant__ double kExp2Tab[256] = {
     1.978456026387951, 1.9838201648502194, 1.9891988469672663, 1.9945921121709402,
 };
 
-constexpr int kExp2Entries = 256;          // table entries = workgroup size: one entry per thread on the way to LDS
+// kExp2Entries (olmc_host_math.h) = table entries = workgroup size: one entry per thread on the way to LDS
+static_assert(kExp2Entries == kBlock, "one table entry per thread");
 constexpr int kExp2Shift = 8;
 
 __device__ __forceinline__ void exp2_table_to_lds(double* tab /* LDS [kExp2Entries] */) {
@@ -741,32 +752,7 @@ __device__ __forceinline__ double exp2_f64_tab(double c, const double* tab /* LD
 #define OLMC_EXP2_TABLE 1           // 0 builds the degree-11 polynomial into asian_exp64_kernel (A/B measurements)
 #endif
 
-// ------------------------------------------------------------- contracts ----
-// Host-precomputed per-contract constants, in the reference's own arithmetic
-// order (gbm_numpy.py:35-39): a = ln S + (r - q - sigma^2/2) dt * M, vol = sigma sqrt(dt).
-struct Contract {
-    double a;        // log_S0 + total_drift
-    double vol;      // sigma * sqrt(dt)
-    double strike;
-    double sign;     // +1 call, -1 put : payoff = max(sign * (S_T - K), 0)
-    double scale;    // a BASE contract (ContractSet::base_mask) evaluates its own exp(a +- vol z) and carries scale = 1.  Any other
-                     // shares vol with the nearest base before it in its half of the set and S_T = scale * S_T(base), scale =
-                     // exp(a - a_base): the S- and r-bumped contracts of a Greeks batch cost a multiply instead of two fp64 exps
-    double neg_sign_strike;   // -sign * K: payoff = max(fma(sign, S_T, -sign K), 0) -- the same bits as sign * (S_T - K) for sign = +-1
-                              // (one rounding of +-(S_T - K) either way), one instruction fewer per sample
-    double sign_scale;        // sign * scale (exact): the fused-Greeks epilogue forms max(fma(sign_scale, S_T(base), -sign K), 0) -- for a
-                              // base (scale 1) the very same bits as above, for a scaled contract one rounding fewer and one multiply fewer
-};
-
-template <int NSETS>
-struct ContractSet {
-    Contract c[NSETS];
-    uint32_t base_mask;   // bit s set <=> contract s is a base: it evaluates its own exponentials.  An integer test on the scalar
-                          // unit (s_bitcmp) where round 2 compared Contract::scale with 0.0 on the vector unit, once per contract
-    uint32_t upper_continues_slot0;   // != 0: slot NSETS/2 is not a base -- it and the non-base slots behind it belong to the group of
-                                      // slot 0 (the group straddles the middle: first-order Greeks' {mid, S+, S-, r+, r-}); see european_payoffs_folded
-};
-
+// Contract, ContractSet<NSETS>: olmc_host_math.h
 struct PathRange {
     uint64_t first;    // global index of local path 0
     int64_t count;     // paths in this launch
@@ -1230,20 +1216,6 @@ __global__ __launch_bounds__(kBlock) void asian_exp64_kernel(PathRange pr, Asian
 // launches.  Each recursion is asian_exp64_kernel's own arithmetic (same scaling of drift and vol into exponent units, same
 // exp2_f64_tab, same S_0 (run / M)), so a contract's payoffs are the bits its own launch produces; only the association of the sums
 // differs (16 / 32 values per workgroup row).
-constexpr int kAsianGroups = 6;
-constexpr int kAsianRealGroups = 4;                     // arithmetic kernel: slots 0..3 are recursions of their own, 4..5 ride on slot 0
-
-struct AsianGreeksSet {
-    double drift[kAsianGroups], vol[kAsianGroups];      // per step, in the exponential's units: AsianContract's drift x kUnit, vol x kZScale x kUnit
-                                                        // (host side: the two products asian_exp64_kernel forms; unused groups repeat group 0).
-                                                        // Geometric: unit 1 (drift, vol x kZScale), as asian_kernel<., true>
-    double s0[16];                                      // spot of contract s (0 for an unused slot)
-    double log_s0[16];                                  // geometric: ln of it
-    double strike, sign, inv_steps;
-    double rate_step[kAsianGroups - kAsianRealGroups];  // arithmetic kernel: slot 4 + d is slot 0 with the per-step drift moved by this much
-                                                        // (natural units; 0 for an unused slot)
-    int32_t group[16];                                  // recursion of contract s
-};
 
 template <bool ANTI, int NSETS>
 __global__ __launch_bounds__(kBlock) void asian_exp64_greeks_kernel(PathRange pr, AsianGreeksSet gs, ReduceWs ws) {
@@ -1444,10 +1416,6 @@ __global__ __launch_bounds__(kBlock) void asian_geometric_greeks_kernel(PathRang
 //            knock-out pays if !crossed, knock-in if crossed; payoff max(+-(S_T - K), 0).
 //   lookback (exotic_options.py:359-401):  floating call S_T - S_min, floating put S_max - S_T,
 //            fixed call max(S_max - K, 0), fixed put max(K - S_min, 0).
-enum ExtremaPayoff : int {
-    kBarrierUpOut = 0, kBarrierUpIn = 1, kBarrierDownOut = 2, kBarrierDownIn = 3,
-    kLookbackFloating = 4, kLookbackFixed = 5
-};
 
 struct ExtremaContract {
     double s0, log_barrier_rel;   // ln(B / S0)
@@ -1524,20 +1492,12 @@ __global__ __launch_bounds__(kBlock) void extrema_kernel(PathRange pr, ExtremaCo
 // (asian_exp64_greeks_kernel) a contract enters the step loop only through its drift and vol per step: the 8 / 14 contracts are at most
 // six recursions of (cumulative log-return, its running max, its running min); spot, strike and the barrier's level relative to the
 // spot act in the epilogue.  Each recursion is extrema_kernel's own arithmetic, each payoff extrema_payoff's.
-struct ExtremaGreeksSet {
-    double drift[kAsianGroups], vol[kAsianGroups];      // per step; vol already x kZScale (host: extrema_kernel's product)
-    double s0[16], log_barrier_rel[16];                 // contract s: spot, ln(B / S_s) (0 for lookbacks and unused slots)
-    double strike, sign;
-    int32_t group[16];
-    int32_t payoff, pad;
-};
 
 template <bool ANTI, int NSETS>
 __global__ __launch_bounds__(kBlock) void extrema_greeks_kernel(PathRange pr, ExtremaGreeksSet gs, ReduceWs ws) {
     constexpr int NV = 2 * NSETS, G = kAsianGroups, LEGS = ANTI ? 2 : 1;
-    double acc[NV];                                     // the grid covers every path (host guarantee): born after the step loop
     const RoundKeys rk = pin_round_keys(pr.key0, pr.key1);
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;       // the grid covers every path (host guarantee)
     const uint64_t gp = pr.first + static_cast<uint64_t>(i < pr.count ? i : 0);
     const uint32_t g_lo = static_cast<uint32_t>(gp), g_hi = static_cast<uint32_t>(gp >> 32);
     double cum[LEGS][G], mx[LEGS][G], mn[LEGS][G];
@@ -1560,7 +1520,8 @@ __global__ __launch_bounds__(kBlock) void extrema_greeks_kernel(PathRange pr, Ex
                     mn[1][g] = fmin(mn[1][g], cum[1][g]);
                 }
             }
-        }
+            if constexpr (ANTI) __builtin_amdgcn_sched_barrier(0);       // a date at a time: twelve chains already fill the pipeline, and
+        }                                                                  // four dates in flight at once cost 40 more registers
     };
     const int32_t full = pr.n_steps >> 2, rem = pr.n_steps & 3;
     float z[4];
@@ -1568,12 +1529,20 @@ __global__ __launch_bounds__(kBlock) void extrema_greeks_kernel(PathRange pr, Ex
         raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(b), 0u, rk, z);
         dates(z, std::integral_constant<int, 4>{});
     }
-    if (rem) {
-        raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(full), 0u, rk, z);
-        if (rem == 1) dates(z, std::integral_constant<int, 1>{});
-        else if (rem == 2) dates(z, std::integral_constant<int, 2>{});
-        else dates(z, std::integral_constant<int, 3>{});
+    if (rem) {                                          // the last one to three dates: ONE copy of the date body in a real loop (three
+        raw_normals4_pinned(g_lo, g_hi, static_cast<uint32_t>(full), 0u, rk, z);       // unrolled variants were where the register count peaked)
+#pragma unroll 1
+        for (int32_t j = 0; j < rem; ++j) {
+            const float one[4] = {j == 0 ? z[0] : (j == 1 ? z[1] : z[2]), 0.f, 0.f, 0.f};
+            dates(one, std::integral_constant<int, 1>{});
+        }
     }
+    // Epilogue, a contract at a time.  Round 4 kept every contract's {sum, sumsq} in registers until one transpose-reduce at the end:
+    // 32 doubles beside the 36 of the recursions -- 172 VGPRs for the antithetic second-order kernel, two waves per SIMD.  Here a
+    // contract's two values are folded over the wave as soon as they exist (wave_sum: fixed order) and parked in LDS; the workgroup
+    // row is the four waves' entries added in wave order, as in block_then_grid_reduce.  Nothing but the recursions stays live.
+    __shared__ double stage[kWavesPerBlock][NV];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const bool alive = i < pr.count;
 #pragma unroll 1
     for (int s = 0; s < NSETS; ++s) {                   // a real loop: the payoff holds up to three library exponentials
@@ -1595,12 +1564,17 @@ __global__ __launch_bounds__(kBlock) void extrema_greeks_kernel(PathRange pr, Ex
             sum += x;
             sumsq += x * x;
         }
-        // acc[] is indexed by the loop variable: keep it in registers by writing through a compile-time switch
-#pragma unroll
-        for (int k = 0; k < NSETS; ++k)
-            if (k == s) { acc[2 * k] = sum; acc[2 * k + 1] = sumsq; }
+        const double wave_total = wave_sum(sum), wave_total_sq = wave_sum(sumsq);       // valid in lane 0
+        if (lane == 0) { stage[wave][2 * s] = wave_total; stage[wave][2 * s + 1] = wave_total_sq; }
     }
-    block_then_grid_reduce<NV>(acc, ws);
+    __syncthreads();
+    double row = 0.0;
+    if (threadIdx.x < NV) {
+        row = stage[0][threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < kWavesPerBlock; ++k) row += stage[k][threadIdx.x];
+    }
+    grid_reduce_workgroup<NV>(row, ws);
 }
 
 // Structured products on the step loop, observation dates counted down in a scalar register.

@@ -26,6 +26,22 @@ SOBOL_VALIDATED_SCIPY = "1.15.3"  # the SciPy whose private Sobol tables (_sv, _
 _sobol_cache: "OrderedDict[tuple, tuple]" = OrderedDict()
 
 
+class SobolDirections(np.ndarray):
+    """The (dims, 30) uint32 direction matrix with the number of its columns that are KNOWN: tables derived from the engine's
+    public behaviour hold only the columns the requested points can select (the others are zero), so a point index at or beyond
+    2**valid_bits would silently repeat points.  `_hip.european_qmc*` refuses such a range (ValueError)."""
+
+    valid_bits: int = 30
+
+    def __new__(cls, sv: np.ndarray, valid_bits: int = 30):
+        obj = np.ascontiguousarray(sv, dtype=np.uint32).view(cls)
+        obj.valid_bits = int(valid_bits)
+        return obj
+
+    def __array_finalize__(self, obj):
+        self.valid_bits = getattr(obj, "valid_bits", 30)
+
+
 def sobol_tables(n_steps: int, seed: int, n_points: int = 1 << 20):
     """(sv, shift) of scipy.stats.qmc.Sobol(d=min(n_steps, 21201), scramble=True, seed=seed):
     the scrambled direction matrix and digital shift the device expands into the very same
@@ -56,7 +72,7 @@ def sobol_tables(n_steps: int, seed: int, n_points: int = 1 << 20):
         try:
             cand = (np.ascontiguousarray(eng._sv, dtype=np.uint32), np.ascontiguousarray(eng._shift, dtype=np.uint32))
             _check_sobol_tables(cand, eng, d)
-            val = (cand[0], cand[1], 30)
+            val = (SobolDirections(cand[0], 30), cand[1], 30)
         except AccelerationError as e:
             private_failure = e
     else:
@@ -65,10 +81,10 @@ def sobol_tables(n_steps: int, seed: int, n_points: int = 1 << 20):
     if val is None:
         try:
             sv, shift = _derive_sobol_tables(qmc.Sobol, d, seed, need_bits)
-        except (AttributeError, TypeError, ValueError, AssertionError) as e:
+        except (AttributeError, TypeError, ValueError) as e:
             raise AccelerationError(f"{private_failure}; and the tables cannot be derived from the engine's public behaviour either "
                                     f"({type(e).__name__}: {e}); MCMethod.QMC is unavailable", backend="hip") from e
-        val = (sv, shift, need_bits)
+        val = (SobolDirections(sv, need_bits), shift, need_bits)
     _sobol_cache[key] = val
     while len(_sobol_cache) > 8:
         _sobol_cache.popitem(last=False)
@@ -79,17 +95,27 @@ def _derive_sobol_tables(engine_class, d: int, seed: int, bits: int):
     """(sv, shift) from the PUBLIC behaviour of the engine: point 0 is the digital shift, and consecutive points of a Gray-code Sobol
     sequence differ by exactly one column of the direction matrix -- x_i = x_{i-1} ^ sv[:, ctz(i)] -- so points 2^c - 1 and 2^c give
     column c.  .fast_forward() skips the points in between (O(2^bits * d) inside SciPy: 0.3 s for 2^20 points x 252 dimensions; the
-    columns beyond `bits` stay zero and are never selected by a point index below 2^bits).  The result must reproduce the engine's own
-    points at the head of the sequence AND across the last derived column, or it is refused."""
+    columns beyond `bits` stay zero and are never selected by a point index below 2^bits: the caller records `bits` with the table,
+    SobolDirections.valid_bits).  The result must reproduce the engine's own points at the head of the sequence AND across the last
+    derived column, or it is refused (ValueError -- explicit raises, not `assert`: `python -O` must not skip the checks)."""
+    import warnings
+
     bits = min(max(int(bits), 4), 30)
     eng = engine_class(d=d, scramble=True, seed=seed)
 
+    def draw(engine, n):                  # SciPy warns about every n that is not a power of two; these draws are bookkeeping, not a sample
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", UserWarning)
+            return engine.random(n)
+
     def as_int(u):
-        x = np.rint(np.asarray(u, dtype=np.float64) * 2.0 ** 30)
-        assert np.array_equal(x * 2.0 ** -30, u) and x.min() >= 0 and x.max() < 2.0 ** 30, "points are not multiples of 2^-30"
+        u = np.asarray(u, dtype=np.float64)
+        x = np.rint(u * 2.0 ** 30)
+        if not (np.array_equal(x * 2.0 ** -30, u) and x.min() >= 0 and x.max() < 2.0 ** 30):
+            raise ValueError("the engine's points are not multiples of 2^-30")
         return x.astype(np.uint32)
 
-    shift = as_int(eng.random(1)[0])
+    shift = as_int(draw(eng, 1)[0])
     sv = np.zeros((d, 30), dtype=np.uint32)
     last_idx, last_x = 0, shift
     for c in range(bits):
@@ -98,17 +124,19 @@ def _derive_sobol_tables(engine_class, d: int, seed: int, bits: int):
             skip = t - 1 - (last_idx + 1)
             if skip:
                 eng.fast_forward(skip)
-            two = eng.random(2)
+            two = draw(eng, 2)
             before, at = as_int(two[0]), as_int(two[1])
         else:
-            before, at = last_x, as_int(eng.random(1)[0])
+            before, at = last_x, as_int(draw(eng, 1)[0])
         sv[:, c] = before ^ at
         last_idx, last_x = t, at
     check = engine_class(d=d, scramble=True, seed=seed)
-    assert np.array_equal(expand_sobol_points(sv, shift, 0, 8), np.asarray(check.random(8), dtype=np.float64)), "head of the sequence"
+    if not np.array_equal(expand_sobol_points(sv, shift, 0, 8), np.asarray(draw(check, 8), dtype=np.float64)):
+        raise ValueError("derived tables do not reproduce the head of the engine's sequence")
     far = (1 << bits) - 5
     check.fast_forward(far - 8)
-    assert np.array_equal(expand_sobol_points(sv, shift, far, 4), np.asarray(check.random(4), dtype=np.float64)), "end of the derived range"
+    if not np.array_equal(expand_sobol_points(sv, shift, far, 4), np.asarray(draw(check, 4), dtype=np.float64)):
+        raise ValueError("derived tables do not reproduce the end of the derived range")
     return sv, shift
 
 
@@ -176,7 +204,8 @@ class MonteCarloPricer:
     """monte_carlo.py:46-186 on the device.  Additive: `n_gpus` (keyword only, default 1) -- with n_gpus > 1 the pseudo-random
     price(), greeks() and price_with_control_variate() shard `num_simulations` over the first n_gpus devices of THIS process
     (contiguous global path ranges, one launch per device, ONE RCCL all-reduce of the sums over xGMI: olmc_multi_gpu_*, no
-    torch); the paths, hence the results up to the association of the sums, do not depend on n_gpus."""
+    torch); the paths, hence the results up to the association of the sums, do not depend on n_gpus.  MCMethod.QMC shards its
+    price() the same way (contiguous blocks of Sobol POINTS); its Greeks, control variate and terminal array stay on one device."""
 
     __slots__ = ("num_simulations", "num_steps", "seed", "method", "_use_numba", "n_gpus")
 
@@ -186,8 +215,6 @@ class MonteCarloPricer:
             raise ValueError("num_simulations must be >= 1")
         if n_gpus < 1:
             raise ValueError("n_gpus must be >= 1")
-        if n_gpus > 1 and method == MCMethod.QMC:
-            raise ValueError("MCMethod.QMC prices on one device (shard its points with olmc_european_qmc's point_offset)")
         self.n_gpus = int(n_gpus)
         self.num_simulations = num_simulations
         self.num_steps = num_steps
@@ -222,7 +249,10 @@ class MonteCarloPricer:
         actual_seed = seed if seed is not None else self.seed
         if self.method == MCMethod.QMC:
             sv, shift = sobol_tables(self._steps(), actual_seed, self.num_simulations)
-            st = _hip.european_qmc(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift)
+            if self.n_gpus > 1:
+                st = _hip.multi_gpu_european_qmc(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift, self.n_gpus)
+            else:
+                st = _hip.european_qmc(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift)
         elif self.n_gpus > 1:
             st = _hip.multi_gpu_european(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(), actual_seed, True,
                                          self.n_gpus)

@@ -1,0 +1,310 @@
+// CPU-only harness over optionslab_amd/csrc/olmc_host_math.h -- the pure-host arithmetic that feeds every fused and every multi-GPU
+// call of libolmc.so (contract layouts, the 8 / 14 evaluations of compute_greeks_unified, moment combiners, shard ranges).  Built by
+// tests/test_host_math_sanitizers.py with g++ -fsanitize=address,undefined; no HIP, no device.
+//
+//   harness self                                  property checks over a parameter sweep; prints "ok <count>" or aborts
+//   harness greeks S K T r sigma q is_call second prints k and the k evaluation tuples, reads k prices from stdin, prints out9
+//   harness layout n_steps k  (then k lines "S K T r sigma q is_call" on stdin)   prints nsets, base_mask, upper, pos[], scale[]
+#include "olmc_host_math.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+using namespace olmc;
+
+#define REQUIRE(cond)                                                                     \
+    do {                                                                                  \
+        if (!(cond)) {                                                                    \
+            std::fprintf(stderr, "%s:%d: requirement failed: %s\n", __FILE__, __LINE__, #cond); \
+            std::abort();                                                                 \
+        }                                                                                 \
+    } while (0)
+
+static long g_checks = 0;
+
+template <int NSETS>
+static void check_layout(const olmc_option* opts, int k, int n_steps) {
+    ContractSet<NSETS> cs;
+    int pos[OLMC_MAX_BATCH];
+    for (int i = 0; i < OLMC_MAX_BATCH; ++i) pos[i] = -1;
+    group_contracts<NSETS>(opts, k, n_steps, &cs, pos);
+    bool taken[NSETS] = {};
+    for (int i = 0; i < k; ++i) {                                  // pos is an injection into the slots
+        REQUIRE(pos[i] >= 0 && pos[i] < NSETS);
+        REQUIRE(!taken[pos[i]]);
+        taken[pos[i]] = true;
+        const Contract own = make_contract(opts[i], n_steps);
+        const Contract& got = cs.c[pos[i]];
+        REQUIRE(same_bits(own.a, got.a) && same_bits(own.vol, got.vol) && same_bits(own.strike, got.strike) && same_bits(own.sign, got.sign));
+        REQUIRE(same_bits(got.sign_scale, got.sign * got.scale));
+    }
+    REQUIRE(cs.base_mask & 1u);                                    // slot 0 opens a group
+    if (NSETS > 1) REQUIRE((cs.base_mask >> (NSETS / 2) & 1u) || cs.upper_continues_slot0);     // the second stream has a base, or slot 0's
+    REQUIRE((cs.base_mask >> NSETS) == 0);
+    // every non-base slot refers to the nearest base before it IN ITS HALF (or to slot 0 across the middle): same vol, scale = exp(a - a_base)
+    for (int half = 0; half < (NSETS > 1 ? 2 : 1); ++half) {
+        int base = (half == 1 && cs.upper_continues_slot0) ? 0 : -1;
+        const int lo = half * (NSETS / 2), hi = NSETS == 1 ? 1 : lo + NSETS / 2;
+        for (int s = lo; s < hi; ++s) {
+            if (cs.base_mask >> s & 1u) { base = s; REQUIRE(cs.c[s].scale == 1.0); continue; }
+            REQUIRE(base >= 0);
+            bool is_padding = true;
+            for (int i = 0; i < k; ++i) is_padding = is_padding && pos[i] != s;
+            if (is_padding) { REQUIRE(cs.c[s].scale == 1.0); continue; }
+            REQUIRE(same_bits(cs.c[s].vol, cs.c[base].vol));
+            const double want = std::exp(cs.c[s].a - cs.c[base].a);
+            REQUIRE(same_bits(cs.c[s].scale, want));
+        }
+    }
+    // olmc_contract_layout reports exactly this
+    if (k >= 2 && ((k <= 8) == (NSETS == 8))) {
+        int32_t nsets = 0, p2[OLMC_MAX_BATCH], upper = 0;
+        uint32_t mask = 0;
+        double scale[OLMC_MAX_BATCH];
+        contract_layout(opts, k, n_steps, &nsets, p2, &mask, &upper, scale);
+        REQUIRE(nsets == NSETS && mask == cs.base_mask && static_cast<uint32_t>(upper) == cs.upper_continues_slot0);
+        for (int i = 0; i < k; ++i) REQUIRE(p2[i] == pos[i]);
+        for (int s = 0; s < NSETS; ++s) REQUIRE(same_bits(scale[s], cs.c[s].scale));
+    }
+    ++g_checks;
+}
+
+static void check_greeks_set(double S, double K, double T, double r, double v, double q, int is_call, int second, int n_steps) {
+    const GreeksSet gs(S, K, T, r, v, q, is_call, second);
+    const int expect = (gs.has_T ? 8 : 7) + (second ? (gs.has_T ? 6 : 4) : 0);
+    REQUIRE(gs.k == expect && gs.k <= OLMC_MAX_BATCH && gs.k <= GreeksSet::kEvalSlots);
+    REQUIRE(gs.nsets() >= gs.k);
+    const int idx[] = {gs.i_mid, gs.i_su, gs.i_sd, gs.i_vu, gs.i_vd, gs.i_td, gs.i_ru, gs.i_rd, gs.i_uu, gs.i_ud, gs.i_du, gs.i_dd, gs.i_ut, gs.i_dt};
+    bool seen[OLMC_MAX_BATCH] = {};
+    int live = 0;
+    for (int i : idx) {
+        if (i < 0) continue;
+        REQUIRE(i < gs.k && !seen[i]);
+        seen[i] = true;
+        ++live;
+    }
+    REQUIRE(live == gs.k);
+    // the finite differences are exact on a quadratic price surface
+    auto f = [&](const olmc_option& o) {
+        return 3.0 + 0.5 * o.S + 0.01 * o.S * o.S + 7.0 * o.sigma + 11.0 * o.sigma * o.sigma + 0.3 * o.S * o.sigma + 13.0 * o.r + 2.0 * o.T + 0.05 * o.S * o.T;
+    };
+    olmc_stats st[OLMC_MAX_BATCH];
+    for (int i = 0; i < gs.k; ++i) { std::memset(&st[i], 0, sizeof st[i]); st[i].price = f(gs.o[i]); }
+    double out9[9] = {0};
+    olmc_stats evals[GreeksSet::kEvalSlots];
+    gs.finish(st, T, out9, evals);
+    const double scale = 1.0 + std::fabs(f(gs.o[0]));
+    auto near = [&](double a, double b, double amp) { return std::fabs(a - b) <= 1e-12 * scale * amp + 1e-9 * std::fabs(b); };
+    REQUIRE(out9[0] == f(gs.o[0]));
+    REQUIRE(near(out9[1], 0.5 + 0.02 * S + 0.3 * v + 0.05 * T, 1.0 / gs.h_S));
+    REQUIRE(near(out9[2], 0.02, 4.0 / (gs.h_S * gs.h_S)));
+    REQUIRE(near(out9[3], 7.0 + 22.0 * v + 0.3 * S, 1.0 / gs.h_v));
+    if (gs.has_T) REQUIRE(near(out9[4], -(2.0 + 0.05 * S), 2.0 / gs.h_T));          // theta = (P(T - h) - P(T)) / h
+    else REQUIRE(same_bits(out9[4], -out9[0] / std::max(T, 1e-6)));
+    REQUIRE(near(out9[5], 13.0, 1.0 / gs.h_r));
+    if (second) {
+        REQUIRE(near(out9[6], 0.3, 1.0 / (gs.h_S * gs.h_v)));
+        if (gs.has_T) REQUIRE(near(out9[7], -0.05, 4.0 / (gs.h_S * gs.h_T)));         // charm = (delta(T - h) - delta(T)) / h
+        else REQUIRE(out9[7] == 0.0);
+        REQUIRE(near(out9[8], 22.0, 4.0 / (gs.h_v * gs.h_v)));
+    }
+    for (int i = 0; i < gs.k; ++i) REQUIRE(evals[i].price == st[i].price);
+    for (int i = gs.k; i < GreeksSet::kEvalSlots; ++i) REQUIRE(evals[i].n == 0 && evals[i].price == 0.0);
+    gs.finish(st, T, out9, nullptr);                                                 // no evaluations asked for: evals == NULL is legal
+    // the European layout of the set
+    if (gs.k <= 8) check_layout<8>(gs.o, gs.k, n_steps);
+    check_layout<16>(gs.o, gs.k, n_steps);
+    // the exotic layouts: every contract's recursion carries the contract's own per-step drift and vol
+    for (int payoff = kBarrierUpOut; payoff <= kLookbackFixed; ++payoff) {
+        ExtremaGreeksSet es;
+        const char* bad = extrema_greeks_layout(gs, n_steps, payoff, 1.2 * S, K, is_call, &es);
+        REQUIRE(bad == nullptr);
+        for (int i = 0; i < gs.k; ++i) {
+            const olmc_option& o = gs.o[i];
+            const double dt = o.T / n_steps, drift = (o.r - o.q - 0.5 * o.sigma * o.sigma) * dt, vol = o.sigma * std::sqrt(dt) * kZScale;
+            REQUIRE(es.group[i] >= 0 && es.group[i] < kAsianGroups);
+            REQUIRE(same_bits(es.drift[es.group[i]], drift) && same_bits(es.vol[es.group[i]], vol));
+            REQUIRE(es.s0[i] == o.S);
+            if (payoff <= kBarrierDownIn) REQUIRE(same_bits(es.log_barrier_rel[i], std::log(1.2 * S / o.S)));
+            else REQUIRE(es.log_barrier_rel[i] == 0.0);
+        }
+        for (int i = gs.k; i < 16; ++i) REQUIRE(es.group[i] == 0 && es.s0[i] == 0.0);
+    }
+    for (int geo = 0; geo < 2; ++geo) {
+        AsianGreeksSet as;
+        const double unit = geo ? 1.0 : 256.0 * 1.4426950408889634;
+        const char* bad = asian_greeks_layout(gs, n_steps, geo != 0, unit, K, is_call, &as);
+        REQUIRE(bad == nullptr);
+        for (int i = 0; i < gs.k; ++i) {
+            const olmc_option& o = gs.o[i];
+            const double dt = o.T / n_steps, drift = (o.r - o.q - 0.5 * o.sigma * o.sigma) * dt, vol = o.sigma * std::sqrt(dt);
+            const int g = as.group[i];
+            REQUIRE(g >= 0 && g < kAsianGroups);
+            if (!geo && g >= kAsianRealGroups) {                   // a rider: slot 0's vol, its own drift as a step off slot 0's
+                REQUIRE(same_bits(as.vol[0], vol * kZScale * unit));
+                const int g0 = as.group[0];
+                REQUIRE(g0 == 0);
+                const olmc_option& m = gs.o[0];
+                const double drift0 = (m.r - m.q - 0.5 * m.sigma * m.sigma) * (m.T / n_steps);
+                REQUIRE(same_bits(as.rate_step[g - kAsianRealGroups], drift - drift0));
+            } else {
+                REQUIRE(same_bits(as.drift[g], drift * unit) && same_bits(as.vol[g], vol * kZScale * unit));
+            }
+            REQUIRE(as.s0[i] == o.S && same_bits(as.log_s0[i], std::log(o.S)));
+        }
+        REQUIRE(same_bits(as.inv_steps, 1.0 / n_steps));
+    }
+    ++g_checks;
+}
+
+static void check_combiners() {
+    // any partition of the shard sums, added in rank order, finishes like the sums themselves
+    std::vector<olmc_stats> parts;
+    double sum = 0, sumsq = 0;
+    int64_t n = 0;
+    for (int i = 0; i < 13; ++i) {
+        olmc_stats p{};
+        p.sum = 1000.0 + 37.5 * i; p.sumsq = 90000.0 + 1111.0 * i; p.n = 1000 + i;
+        parts.push_back(p);
+        sum += p.sum; sumsq += p.sumsq; n += p.n;
+        olmc_stats got{}, want{};
+        REQUIRE(combine_stats(parts.data(), static_cast<int32_t>(parts.size()), 0.05, 1.0, &got));
+        finish_stats(sum, sumsq, n, 0.05, 1.0, &want);
+        REQUIRE(std::memcmp(&got, &want, sizeof got) == 0);
+        REQUIRE(got.std_error >= 0.0 && got.price > 0.0);
+    }
+    olmc_stats none{};
+    olmc_stats out{};
+    REQUIRE(!combine_stats(&none, 1, 0.05, 1.0, &out));              // n == 0: refused, not a division by zero
+    olmc_stats neg{};
+    finish_stats(10.0, 9.0, 10, 0.0, 1.0, &neg);                     // sumsq / n < mean^2 by rounding: variance clamps at 0
+    REQUIRE(neg.std_error == 0.0);
+    // control variate: a perfectly linear payoff is priced exactly whatever the shards are
+    std::vector<olmc_cv_moments> cv;
+    olmc_cv_moments all{};
+    const double S = 100, T = 1, r = 0.05, q = 0.01, fwd = S * std::exp((r - q) * T);
+    for (int k = 0; k < 5; ++k) {
+        olmc_cv_moments m{};
+        for (int j = 0; j < 200; ++j) {
+            const double st = fwd * (0.5 + 0.005 * (k * 200 + j)), d = 2.0 * st + 1.0;
+            m.sum_d += d; m.sum_s += st; m.sum_dd += d * d; m.sum_ss += st * st; m.sum_ds += d * st; m.n += 1;
+        }
+        cv.push_back(m);
+        olmc_cv_moments got{};
+        REQUIRE(combine_cv(cv.data(), static_cast<int32_t>(cv.size()), S, T, r, q, &got));
+        REQUIRE(std::fabs(got.value - (2.0 * fwd + 1.0)) < 1e-9 * fwd);
+        all = got;
+    }
+    REQUIRE(all.n == 1000);
+    olmc_cv_moments one{};
+    one.n = 1; one.sum_d = 3; one.sum_s = 100; one.sum_dd = 9; one.sum_ss = 1e4; one.sum_ds = 300;
+    cv_finish(S, T, r, q, &one);                                     // n == 1: ddof = 1 divides by zero in the reference too; beta = 0
+    REQUIRE(one.value == 3.0);
+    double raw5[5] = {10, 1000, 30, 1.1e5, 1200};
+    olmc_cv_moments dev{};
+    cv_from_device(raw5, 10, S, T, r, q, &dev);
+    REQUIRE(same_bits(dev.sum_d, std::exp(-r * T) * 10.0) && dev.n == 10);
+    ++g_checks;
+}
+
+static void check_shards() {
+    const int64_t sizes[] = {1, 2, 7, 16, 1000, 300001, 8000000, (int64_t(1) << 40) + 12345};
+    for (int64_t n : sizes)
+        for (int p = 1; p <= 16; ++p) {
+            if (n < p) continue;
+            int64_t next = 0;
+            for (int d = 0; d < p; ++d) {
+                int64_t lo, count;
+                shard_range(n, d, p, &lo, &count);
+                REQUIRE(lo == next && count >= 1 && count <= n / p + 1);
+                next = lo + count;
+            }
+            REQUIRE(next == n);
+            ++g_checks;
+        }
+}
+
+static int self_test() {
+    const double spots[] = {0.01, 1.0, 37.5, 100.0, 4321.0}, vols[] = {0.011, 0.2, 1.5}, rates[] = {-0.02, 0.0, 0.05}, mats[] = {1.0 / 366.0, 1.0 / 365.0, 0.003, 0.25, 1.0, 30.0};
+    const int steps[] = {1, 3, 50, 252, 1024};
+    for (double S : spots)
+        for (double v : vols)
+            for (double r : rates)
+                for (double T : mats)
+                    for (int second = 0; second < 2; ++second)
+                        for (int m : steps) check_greeks_set(S, 1.1 * S, T, r, v, 0.01, (m & 1), second, m);
+    // batches that are not Greeks sets: duplicates, shared vols in any order, poisoned members, every size
+    uint64_t lcg = 12345;
+    auto rnd = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return static_cast<double>(lcg >> 11) * 0x1p-53; };
+    for (int trial = 0; trial < 4000; ++trial) {
+        const int k = 1 + static_cast<int>(rnd() * 16) % 16;
+        olmc_option opts[OLMC_MAX_BATCH];
+        const double vol_pool[3] = {0.1 + rnd(), 0.1 + rnd(), 0.1 + rnd()};
+        for (int i = 0; i < k; ++i) {
+            const double pick = rnd();
+            opts[i] = make_option(50 + 100 * rnd(), 50 + 100 * rnd(), 0.1 + 2 * rnd(), 0.1 * rnd() - 0.02, vol_pool[static_cast<int>(3 * rnd()) % 3], 0.03 * rnd(), rnd() < 0.5);
+            if (pick < 0.03) opts[i].S = -1.0;                      // poisoned: NaN constants must not break the layout
+            else if (pick < 0.06) opts[i].sigma = std::nan("");
+            else if (pick < 0.09) opts[i].S = 0.0;                  // ln 0 = -inf
+            else if (pick < 0.2 && i > 0) opts[i] = opts[i - 1];    // exact duplicate
+        }
+        const int n_steps = 1 + static_cast<int>(rnd() * 300);
+        if (k == 1) check_layout<1>(opts, 1, n_steps);
+        if (k <= 8) check_layout<8>(opts, k, n_steps);
+        check_layout<16>(opts, k, n_steps);
+    }
+    check_combiners();
+    check_shards();
+    REQUIRE(poisoned(-1, 1, 1, 0, 0.2, 0) && poisoned(1, 1, -1, 0, 0.2, 0) && poisoned(1, std::nan(""), 1, 0, 0.2, 0) && !poisoned(1, 1, 1, -0.1, 0.2, 0));
+    REQUIRE(log_level(0.0) == -INFINITY && log_level(-5.0) == -INFINITY && std::isnan(log_level(std::nan(""))) && log_level(1.0) == 0.0);
+    olmc_stats st{};
+    nan_stats(7, &st);
+    REQUIRE(st.n == 7 && std::isnan(st.price) && std::isnan(st.std_error));
+    std::printf("ok %ld\n", g_checks);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    const std::string mode = argc > 1 ? argv[1] : "self";
+    if (mode == "self") return self_test();
+    if (mode == "greeks" && argc == 10) {
+        const GreeksSet gs(std::atof(argv[2]), std::atof(argv[3]), std::atof(argv[4]), std::atof(argv[5]), std::atof(argv[6]), std::atof(argv[7]),
+                           std::atoi(argv[8]), std::atoi(argv[9]));
+        std::printf("%d\n", gs.k);
+        for (int i = 0; i < gs.k; ++i)
+            std::printf("%.17g %.17g %.17g %.17g %.17g %.17g %d\n", gs.o[i].S, gs.o[i].K, gs.o[i].T, gs.o[i].r, gs.o[i].sigma, gs.o[i].q, gs.o[i].is_call);
+        std::fflush(stdout);
+        olmc_stats st[OLMC_MAX_BATCH];
+        for (int i = 0; i < gs.k; ++i) {
+            std::memset(&st[i], 0, sizeof st[i]);
+            if (std::scanf("%lf", &st[i].price) != 1) return 3;
+        }
+        double out9[9] = {0};
+        gs.finish(st, std::atof(argv[4]), out9, nullptr);
+        for (int i = 0; i < 9; ++i) std::printf("%.17g%c", out9[i], i == 8 ? '\n' : ' ');
+        return 0;
+    }
+    if (mode == "layout" && argc == 4) {
+        const int n_steps = std::atoi(argv[2]), k = std::atoi(argv[3]);
+        if (k < 2 || k > OLMC_MAX_BATCH) return 2;
+        olmc_option opts[OLMC_MAX_BATCH];
+        for (int i = 0; i < k; ++i) {
+            double S, K, T, r, v, q;
+            int c;
+            if (std::scanf("%lf %lf %lf %lf %lf %lf %d", &S, &K, &T, &r, &v, &q, &c) != 7) return 3;
+            opts[i] = make_option(S, K, T, r, v, q, c);
+        }
+        int32_t nsets = 0, pos[OLMC_MAX_BATCH], upper = 0;
+        uint32_t mask = 0;
+        double scale[OLMC_MAX_BATCH];
+        contract_layout(opts, k, n_steps, &nsets, pos, &mask, &upper, scale);
+        std::printf("%d %u %d\n", nsets, mask, upper);
+        for (int i = 0; i < k; ++i) std::printf("%d%c", pos[i], i == k - 1 ? '\n' : ' ');
+        for (int i = 0; i < nsets; ++i) std::printf("%.17g%c", scale[i], i == nsets - 1 ? '\n' : ' ');
+        return 0;
+    }
+    std::fprintf(stderr, "usage: harness self | greeks S K T r sigma q is_call second | layout n_steps k\n");
+    return 2;
+}

@@ -125,6 +125,86 @@ def test_the_pricer_with_n_gpus_prices_what_the_one_gpu_pricer_prices(rehearsal,
         assert ol.compute_greeks_unified(many, *ATM, "call", include_second_order=second) == g5
 
 
+@pytest.mark.parametrize("n_ranks", [2, 8])
+def test_launcher_threads_and_the_serial_form_give_the_same_bits(rehearsal, n_ranks):
+    """Round 5: each rank's kernel is queued by a launcher thread bound to the rank's device (all at once); OLMC_TUNE_MULTI_LAUNCH = -1
+    keeps round 4's form (the calling thread queues them one after the other).  Same partition, same kernels, same rank-ordered
+    collective: every payload must come back bit for bit the same, and the spans of the call are reported."""
+    S, K, T, r, v = ATM
+    N, M, seed = 700_001, 24, 11
+    sv, shift = ol.monte_carlo.sobol_tables(16, 42, 1 << 18)
+    def everything():
+        a = hip.multi_gpu_european(S, K, T, r, v, 0.0, True, N, M, seed, True, n_ranks)
+        spans = hip.multi_gpu_spans()
+        g, ev = hip.multi_gpu_greeks_fd(S, K, T, r, v, 0.0, True, N, M, seed, True, n_ranks, want_evals=True)
+        c = hip.multi_gpu_european_cv(S, K, T, r, v, 0.01, False, N, M, seed, True, n_ranks)
+        q = hip.multi_gpu_european_qmc(S, K, T, r, v, 0.0, True, 1 << 18, sv, shift, n_ranks)
+        return ((a.sum, a.sumsq, a.n), tuple(g), tuple((e.sum, e.sumsq) for e in ev), (c.sum_d, c.sum_s, c.sum_dd, c.sum_ss, c.sum_ds, c.value),
+                (q.sum, q.sumsq, q.n)), spans
+    threaded, spans_t = everything()
+    hip.tune(hip.TUNE_MULTI_LAUNCH, -1)
+    try:
+        serial, spans_s = everything()
+    finally:
+        hip.tune(hip.TUNE_MULTI_LAUNCH, 0)
+    assert threaded == serial
+    again, _ = everything()
+    assert again == threaded
+    for spans in (spans_t, spans_s):
+        assert 0.0 < spans["launch_us"] < 5e4 and spans["total_us"] >= spans["launch_us"] + spans["collective_us"]
+
+
+@pytest.mark.parametrize("n_ranks", [1, 2, 5, 8])
+def test_n_rank_sobol_price_is_the_one_device_sobol_price(rehearsal, n_ranks):
+    """olmc_multi_gpu_european_qmc (gbm_qmc.py:14-46 over several devices): rank d prices POINTS [d N / P, (d + 1) N / P) of the one
+    scrambled sequence through the kernels' point offset -- the same points as the one-device call, the sums in another association
+    (1e-13), and exactly the rank-ordered sum of the shards priced one by one through olmc_european_qmc(point_offset=...)."""
+    S, K, T, r, v = ATM
+    for n, dims in ((1 << 14, 16), (300_001, 64), (1 << 20, 16)):            # split workgroups / one point per thread / eight per thread
+        sv, shift = ol.monte_carlo.sobol_tables(dims, 42, n)
+        whole = hip.european_qmc(S, K, T, r, v, 0.0, True, n, sv, shift)
+        got = hip.multi_gpu_european_qmc(S, K, T, r, v, 0.0, True, n, sv, shift, n_ranks)
+        assert got.n == whole.n == n
+        assert got.sum == pytest.approx(whole.sum, rel=1e-13) and got.sumsq == pytest.approx(whole.sumsq, rel=1e-13)
+        assert got.price == pytest.approx(whole.price, rel=1e-13)
+        parts = []
+        for d in range(n_ranks):
+            lo, hi = n * d // n_ranks, n * (d + 1) // n_ranks
+            st = hip.european_qmc(S, K, T, r, v, 0.0, True, hi - lo, sv, shift, point_offset=lo)
+            parts.append((st.sum, st.sumsq, st.n))
+        want = hip.combine_stats(parts, r, T)
+        assert (got.sum, got.sumsq, got.n, got.price, got.std_error) == (want.sum, want.sumsq, want.n, want.price, want.std_error)
+
+
+def test_the_qmc_pricer_with_n_gpus_prices_what_the_one_gpu_qmc_pricer_prices(rehearsal, monkeypatch):
+    monkeypatch.setattr(ol.monte_carlo, "_hip", hip)
+    one = ol.MonteCarloPricer(1 << 15, 32, 42, ol.MCMethod.QMC)
+    many = ol.MonteCarloPricer(1 << 15, 32, 42, ol.MCMethod.QMC, n_gpus=3)
+    a, b = one.price(*ATM, "call", return_error=True), many.price(*ATM, "call", return_error=True)
+    assert b.n_paths == a.n_paths == 1 << 15 and b.price == pytest.approx(a.price, rel=1e-13) and b.std_error == pytest.approx(a.std_error, rel=1e-10)
+
+
+def test_engines_come_and_go_without_touching_dead_streams(rehearsal):
+    """The host fault of round 4 (gpurun_out/r04d: SIGSEGV inside olmc_multi_gpu_greeks_fd).  Cause: the engine was
+    rebuilt whenever the rank count changed, which DESTROYED the old rank streams while the workspace slots they had claimed in the
+    device's contexts still named them as owners; once all eight slots of a context belonged to dead streams, the next rank stream
+    went down the slot-sharing path, which drained the slot's owner with hipStreamSynchronize(dead handle) -- a use-after-free inside
+    the HIP runtime, not an error code.  Fixed in b0df7f4: slots are handed back before a rank stream dies (pool_forget_stream), and a
+    shared slot's previous owner is drained with hipDeviceSynchronize, never through its handle.  This test walks that road on
+    purpose: more rank counts than the engine cache keeps (engines are evicted and their streams destroyed), more ranks than a
+    context has slots, twice over; every price must stay the one-device price."""
+    S, K, T, r, v = ATM
+    N, M, seed = 200_003, 12, 3
+    whole = hip.european(S, K, T, r, v, 0.0, True, N, M, seed, True)
+    for _ in range(2):
+        for n_ranks in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 9, 2, 12):
+            got = hip.multi_gpu_european(S, K, T, r, v, 0.0, True, N, M, seed, True, n_ranks)
+            assert got.n == whole.n and got.sum == pytest.approx(whole.sum, rel=1e-13)
+            g, _ = hip.multi_gpu_greeks_fd(S, K, T, r, v, 0.0, True, N, M, seed, bool(n_ranks & 1), n_ranks, want_evals=False)
+            assert g[0] == pytest.approx(whole.price, rel=1e-12)
+    assert hip.device_info()["device"] == 0
+
+
 def test_a_failing_rank_in_the_middle_leaves_the_thread_and_the_library_usable(rehearsal):
     """Error returns of the multi-GPU calls go through a scope guard: the ranks already queued are drained, the thread's library
     device and HIP device restored.  Rank 2 of 4 is made to fail by the fault-injection knob: ranks 0 and 1 have kernels in flight."""

@@ -36,8 +36,7 @@ def test_n_gpus_is_additive_and_keyword_only():
         ol.MonteCarloPricer(5000, 100, 123, ol.MCMethod.NUMPY, 8)          # not a fifth positional argument
     with pytest.raises(ValueError):
         ol.MonteCarloPricer(5000, n_gpus=0)
-    with pytest.raises(ValueError):
-        ol.MonteCarloPricer(5000, 16, 1, ol.MCMethod.QMC, n_gpus=2)
+    assert ol.MonteCarloPricer(5000, 16, 1, ol.MCMethod.QMC, n_gpus=2).n_gpus == 2       # round 5: the Sobol price shards its points too
     assert ol.MonteCarloPricer(1000, 10, 1, n_gpus=4).price(120, 100, 0.0, 0.05, 0.2, "call") == 20     # T <= 0: no device, whatever n_gpus
 
 
@@ -272,9 +271,18 @@ def test_sobol_tables_are_derived_from_public_behaviour_when_the_privates_fail(m
     sv2, _ = mc.sobol_tables(12, 5, n_points=1 << 15)
     assert np.array_equal(sv2[:, :15], np.asarray(truth._sv, dtype=np.uint32)[:, :15]) and not sv2[:, 15:].any()
     assert mc.sobol_tables(12, 5, n_points=100)[0] is sv2        # fewer points: the cached tables serve
+    # the tables know how many columns they hold: a point range that reaches beyond them is refused before any launch,
+    # instead of silently repeating points (the zero columns select nothing)
+    assert sv.valid_bits == 12 and sv2.valid_bits == 15
+    from optionslab_amd import _hip
+    with pytest.raises(ValueError, match="beyond the 2\\*\\*12 points"):
+        _hip.european_qmc(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, True, 4000, sv, shift, point_offset=200)
+    with pytest.raises(ValueError, match="beyond the 2\\*\\*15 points"):
+        _hip.european_qmc_greeks_fd(100.0, 100.0, 1.0, 0.05, 0.2, 0.0, True, (1 << 15) + 1, sv2, shift, True)
     monkeypatch.setattr(qmc, "Sobol", real)
     mc._sobol_cache.clear()
-    assert np.array_equal(mc.sobol_tables(12, 5)[0], np.asarray(truth._sv, dtype=np.uint32))       # the private tables, all 30 columns
+    full = mc.sobol_tables(12, 5)[0]
+    assert np.array_equal(full, np.asarray(truth._sv, dtype=np.uint32)) and full.valid_bits == 30       # the private tables, all 30 columns
 
 
 @pytest.mark.parametrize("breakage", ["no_tables", "wrong_bits", "reordered_columns", "wrong_shape"])

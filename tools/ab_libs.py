@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B of whole libolmc builds: one subprocess per (library, round), each timing the
 European path kernel with HIP events (olmc_kernel_time).  Usage (GPU box):
-    python tools/ab_libs.py libA.so libB.so ... [--n 1000000] [--m 252] [--rounds 7] [--case european|greeks8|greeks14|greeks8_lean|greeks14_lean|asian|asian_fast|asian_fast_anti|asian_anti|asian_geo|barrier|heston|merton|kou|autocall[_anti]|cliquet[_anti]|american|asian_greeks8|asian_greeks14[_rho]|qmc|qmc_cv|qmc_greeks8|qmc_greeks14]"""
+    python tools/ab_libs.py libA.so libB.so ... [--n 1000000] [--m 252] [--rounds 7] [--case european|greeks8|greeks14|greeks8_lean|greeks14_lean|asian|asian_fast|asian_fast_anti|asian_anti|asian_geo|barrier|heston|merton|kou|autocall[_anti]|cliquet[_anti]|american|{barrier,lookback}_greeks{8,14}[_anti]|asian_greeks8|asian_greeks14[_rho]|qmc|qmc_cv|qmc_greeks8|qmc_greeks14]"""
 import argparse
 import json
 import os
@@ -43,6 +43,11 @@ CASES["asian_greeks8"] = lambda s: _hip.asian_greeks_fd(*P, True, N, M, s, False
 CASES["asian_greeks14"] = lambda s: _hip.asian_greeks_fd(*P, True, N, M, s, False, True)[1][0]
 CASES["asian_greeks14_rho"] = lambda s: _hip.asian_greeks_fd(*P, True, N, M, s, False, True)[1][6]       # the r + h evaluation
 CASES["american"] = lambda s: _hip.american_lsm(*P, False, N, M, 3, s)
+# round 5: the fused barrier / lookback Greeks (payoff 0 = up-and-out barrier at 120, 4 = floating lookback), 8 / 14 contracts, +- antithetic
+for _name, _payoff, _level in (("barrier", 0, 120.0), ("lookback", 4, 0.0)):
+    for _k, _second in ((8, False), (14, True)):
+        for _anti in (False, True):
+            CASES[f"{_name}_greeks{_k}" + ("_anti" if _anti else "")] = (lambda s, p=_payoff, l=_level, a=_anti, o=_second: _hip.extrema_greeks_fd(*P, True, p, l, N, M, s, a, o)[1][0])
 if sys.argv[3].startswith("qmc"):
     import numpy as np
     from optionslab_amd.monte_carlo import sobol_tables

@@ -122,6 +122,16 @@ def main():
                lambda: ol.compute_greeks_unified(ad, *ATM, "call", include_second_order=True), lambda g: dict(greeks={k: float(v) for k, v in g.items()}), reps=5)
         report(f"ExoticAdapter Greeks, Asian {name}, 1M x 1024, second order: the 14 launches of bump-and-reprice", 14 * N * MA,
                lambda: ol.compute_greeks_unified(ad, *ATM, "call", include_second_order=True, fused=False), lambda g: dict(greeks={k: float(v) for k, v in g.items()}), reps=3)
+    # the fused barrier / lookback Greeks where the kernel, not the launch, is what is timed (VERDICT r4 "missing" 2): 1M x 252
+    for name, opt, kw in (("barrier up-and-out", ol.BarrierOption(*ATM, barrier=120.0, seed=42), dict(barrier_type="up-and-out")),
+                          ("lookback floating", ol.LookbackOption(*ATM, seed=42), dict(lookback_type="floating"))):
+        for anti in (False, True):
+            ad = ol.ExoticAdapter(opt, n_paths=N, n_steps=M, antithetic=anti, **kw)
+            tag = ", antithetic" if anti else ""
+            report(f"ExoticAdapter Greeks, {name}{tag}, 1M x 252, second order: one launch", N * M,
+                   lambda: ol.compute_greeks_unified(ad, *ATM, "call", include_second_order=True), lambda g: dict(greeks={k: float(v) for k, v in g.items()}), reps=10)
+            report(f"ExoticAdapter Greeks, {name}{tag}, 1M x 252, second order: the 14 launches of bump-and-reprice", 14 * N * M,
+                   lambda: ol.compute_greeks_unified(ad, *ATM, "call", include_second_order=True, fused=False), lambda g: dict(greeks={k: float(v) for k, v in g.items()}), reps=3)
     mj = ol.MertonJumpDiffusion(0.5, -0.1, 0.2)
     report("Merton jump diffusion 1M x 252", N * M, lambda: mj.price_monte_carlo(*ATM, "call", 0.0, N, M, 42, return_error=True),
            lambda r: dict(price=float(r[0]), std_error=r[1], series=float(mj.price(*ATM, "call"))), reps=10)
@@ -132,6 +142,15 @@ def main():
            lambda: ol.simulate_gbm_paths_hip(100.0, 1.0, 0.05, 0.2, 0.0, 100_000, M, 42), lambda a: dict(mean_terminal=float(a[:, -1].mean())), reps=5)
     report("HestonPricer.simulate_paths 100k x 252 -> 2 x (100k, 253) fp64 on host", 100_000 * M,
            lambda: hes.simulate_paths(100.0, 1.0, 0.05, 0.0, 100_000, M, 42), lambda a: dict(mean_terminal=float(a[0][:, -1].mean())), reps=5)
+    _hip.tune(_hip.TUNE_STAGED_COPY, -1)                    # round 4's form beside it: ONE hipMemcpyAsync into the fresh pageable buffer
+    report("simulate_gbm_paths 100k x 252, direct copy (OLMC_TUNE_STAGED_COPY = -1)", 100_000 * M,
+           lambda: ol.simulate_gbm_paths_hip(100.0, 1.0, 0.05, 0.2, 0.0, 100_000, M, 42), lambda a: dict(mean_terminal=float(a[:, -1].mean())), reps=5)
+    report("HestonPricer.simulate_paths 100k x 252, direct copy (OLMC_TUNE_STAGED_COPY = -1)", 100_000 * M,
+           lambda: hes.simulate_paths(100.0, 1.0, 0.05, 0.0, 100_000, M, 42), lambda a: dict(mean_terminal=float(a[0][:, -1].mean())), reps=5)
+    _hip.tune(_hip.TUNE_STAGED_COPY, 0)
+    p64t = ol.MonteCarloPricer(32_000_000, M, 42)
+    report("terminal array 32M x 252 -> 64M fp64 on host (512 MB D2H into a fresh buffer, staged)", 32_000_000 * M,
+           lambda: p64t._simulate(100.0, 1.0, 0.05, 0.2, 0.0), lambda a: dict(mean_terminal=float(a[::4096].mean())), reps=3)
     report("AmericanOption.early_exercise_boundary 10k x 50 (reference defaults)", 10_000 * 50,
            lambda: ol.AmericanOption(*ATM, seed=42).early_exercise_boundary(10_000, 50, "put"), lambda r: dict(boundary_T=float(r[1][-1])), reps=10)
     report("AmericanOption.early_exercise_boundary 1M x 50", N * 50,

@@ -415,9 +415,10 @@ int olmc_multi_gpu_european_cv(double S, double K, double T, double r, double si
 int olmc_multi_gpu_european_qmc(double S, double K, double T, double r, double sigma, double q, int is_call,
                                 int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
                                 int n_gpus, olmc_stats* out);
-/* Host microseconds of the calling thread's last multi-GPU call: out5 = {launch phase (first rank's launch begun -> every rank's
- * kernel queued), collective queued, result fetched (contains the kernels' run time), other ranks drained, total}. */
-int olmc_multi_gpu_spans(double* out5);
+/* Host microseconds of the calling thread's last multi-GPU call: out8 = {launch phase (launch job posted -> every rank's kernel
+ * queued), collective queued, result fetched (contains the kernels' run time), other ranks drained, total, the latest launcher's start
+ * after the post (wake latency; 0 in the serial form), the longest and the shortest single rank's own launch}. */
+int olmc_multi_gpu_spans(double* out8);
 
 /* Blocking fetch of n (1..33) doubles that work ALREADY QUEUED on hip_stream leaves at d_src -- the triple after the caller's RCCL
  * all-reduce in the one-process-per-GPU form: a one-wave kernel behind that work hands them over through the library's pinned
@@ -468,8 +469,10 @@ int olmc_profile_enable(int on);
 enum { OLMC_TUNE_GRID_CAP = 2, OLMC_TUNE_QMC_BLOCK = 4, OLMC_TUNE_SPLIT_TAIL = 7, OLMC_TUNE_POLL = 8, OLMC_TUNE_SPLIT_SAT = 9,
        OLMC_TUNE_MULTI_LAUNCH = 10, OLMC_TUNE_STAGED_COPY = 11 };
 int olmc_tune(int knob, int value);
-/* The two behavioural knobs can also be switched off from the environment, read once by the first olmc_init:
- * OLMC_POLL=0 (as OLMC_TUNE_POLL = -1) and OLMC_SPLIT_TAIL=0 (as OLMC_TUNE_SPLIT_TAIL = -1). */
+/* The behavioural knobs can also be switched off from the environment, read once by the first olmc_init:
+ * OLMC_POLL=0 (as OLMC_TUNE_POLL = -1), OLMC_SPLIT_TAIL=0 (as OLMC_TUNE_SPLIT_TAIL = -1), OLMC_MULTI_LAUNCH=serial (as
+ * OLMC_TUNE_MULTI_LAUNCH = -1), OLMC_STAGED_COPY=0 (as OLMC_TUNE_STAGED_COPY = -1).  OLMC_TRACE_COPY=1 prints the phases of every
+ * staged copy to stderr. */
 int olmc_profile_reset(void);
 int olmc_kernel_time(int64_t* launches, double* total_ms);
 

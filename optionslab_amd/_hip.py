@@ -562,9 +562,9 @@ def multi_gpu_european_qmc(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv
 
 def multi_gpu_spans() -> dict:
     """Host microseconds of this thread's last multi-GPU call (olmc_multi_gpu_spans)."""
-    out = (C.c_double * 5)()
+    out = (C.c_double * 8)()
     _check(lib().olmc_multi_gpu_spans(out))
-    return dict(zip(("launch_us", "collective_us", "fetch_us", "drain_us", "total_us"), out))
+    return dict(zip(("launch_us", "collective_us", "fetch_us", "drain_us", "total_us", "wake_us_max", "rank_launch_us_max", "rank_launch_us_min"), out))
 
 
 def combine_stats(parts: Sequence[Tuple[float, float, int]], r: float, T: float) -> Stats:

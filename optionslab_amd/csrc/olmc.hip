@@ -313,28 +313,47 @@ int copy_to_host(DeviceCtx* c, void* dst, const void* d_src, size_t bytes) {
             copied[i & 1].fetch_add(1, std::memory_order_release);
         }
     };
+    static const bool trace = std::getenv("OLMC_TRACE_COPY") != nullptr;
+    using clock = std::chrono::steady_clock;
+    auto us_since = [](clock::time_point t) { return std::chrono::duration<double, std::micro>(clock::now() - t).count(); };
+    const auto t_begin = clock::now();
+    double us_spawn = 0, us_first = 0, us_events = 0, us_workers = 0;
     std::vector<std::thread> threads;
     threads.reserve(n_threads);
     for (int w = 0; w < n_threads; ++w) threads.emplace_back(worker, w);
+    us_spawn = us_since(t_begin);
     hipError_t err = hipSuccess;
     for (int64_t i = 0; i < n_chunks && err == hipSuccess; ++i) {
         const int slot = static_cast<int>(i & 1);
         if (i >= 2) {                               // the chunk that sat in this buffer has been copied out by every thread
+            const auto t = clock::now();
             for (uint32_t spins = 0; copied[slot].load(std::memory_order_acquire) < n_threads; ++spins)
                 if ((spins & 0xFF) == 0xFF) sched_yield(); else __builtin_ia32_pause();
             copied[slot].store(0, std::memory_order_relaxed);
+            us_workers += us_since(t);
         }
         err = hipMemcpyAsync(c->h_stage[slot], static_cast<const char*>(d_src) + static_cast<size_t>(i) * kStageBytes, chunk_len(i), hipMemcpyDeviceToHost, c->stream);
         if (err == hipSuccess) err = hipEventRecord(c->stage_landed[slot], c->stream);
         if (err == hipSuccess && i >= 1) {
+            const auto t = clock::now();
             err = hipEventSynchronize(c->stage_landed[slot ^ 1]);
+            if (i == 1) us_first = us_since(t); else us_events += us_since(t);
             if (err == hipSuccess) landed.store(i, std::memory_order_release);
         }
     }
-    if (err == hipSuccess) err = hipEventSynchronize(c->stage_landed[(n_chunks - 1) & 1]);
+    {
+        const auto t = clock::now();
+        if (err == hipSuccess) err = hipEventSynchronize(c->stage_landed[(n_chunks - 1) & 1]);
+        us_events += us_since(t);
+    }
     if (err == hipSuccess) landed.store(n_chunks, std::memory_order_release);
     else give_up.store(true);
+    const auto t_join = clock::now();
     for (std::thread& t : threads) t.join();
+    if (trace)
+        std::fprintf(stderr, "[olmc copy_to_host] %.1f MB, %lld chunks, %d threads: spawn %.0f us, first chunk landed (kernel + DMA) %.0f us, later event waits %.0f us, "
+                             "waits for the copy threads %.0f us, last chunk out + join %.0f us, total %.0f us\n", bytes / 1e6, static_cast<long long>(n_chunks), n_threads,
+                     us_spawn, us_first, us_events, us_workers, us_since(t_join), us_since(t_begin));
     if (err != hipSuccess) {
         (void)hipStreamSynchronize(c->stream);
         (void)hipGetLastError();
@@ -344,6 +363,7 @@ int copy_to_host(DeviceCtx* c, void* dst, const void* d_src, size_t bytes) {
 }
 
 // Tuning knob (olmc_tune): 0 = automatic.
+int g_multi_launch = 0;      // OLMC_TUNE_MULTI_LAUNCH: 0 = multi-GPU calls queue their ranks from one launcher thread per device (default), -1 = serial
 int g_grid_cap = 0;          // OLMC_TUNE_GRID_CAP: max workgroups per launch (0 = kMaxGrid)
 int g_qmc_block = 0;         // OLMC_TUNE_QMC_BLOCK: 0 = by size, 1 = always eight points per thread, -1 = never
 int g_poll = 0;              // OLMC_TUNE_POLL: 0 = blocking calls poll a host-mapped flag for completion (default), -1 = hipStreamSynchronize
@@ -795,6 +815,10 @@ extern "C" int olmc_init(int device) {
         if (p && p[0] == '0') g_poll = -1;
         const char* t = std::getenv("OLMC_SPLIT_TAIL");
         if (t && t[0] == '0') g_split_tail = -1;
+        const char* m = std::getenv("OLMC_MULTI_LAUNCH");          // "serial": the multi-GPU entry points queue their ranks from the calling thread
+        if (m && m[0] == 's') g_multi_launch = -1;
+        const char* sc = std::getenv("OLMC_STAGED_COPY");          // "0": large results come home by one hipMemcpyAsync
+        if (sc && sc[0] == '0') g_staged_copy = -1;
         return true;
     }();
     (void)env_read;
@@ -2064,6 +2088,7 @@ struct MultiRank {
     std::thread launcher;                           // bound to `device`; runs the engine's jobs for this rank
     int rc = OLMC_OK;                               // of the job it ran last (read by the caller behind the job's completion count)
     std::string error;
+    std::chrono::steady_clock::time_point began, ended;     // of that job, on the launcher's clock (olmc_multi_gpu_spans: wake latency, own time)
 };
 
 struct MultiEngine {
@@ -2082,8 +2107,7 @@ struct MultiEngine {
 std::mutex g_engines_mu;                            // guards g_engines (never held while a call runs)
 std::vector<MultiEngine*> g_engines;                // one per (device list, rehearsal) asked for since the last olmc_shutdown
 std::mutex g_multi_dev_mu[kMaxDevices];             // a multi-GPU call holds the mutex of every device of its list (ascending order)
-int g_multi_launch = 0;                             // OLMC_TUNE_MULTI_LAUNCH: 0 = launcher threads from two ranks on (default), -1 = serial
-thread_local double t_multi_spans[5] = {0, 0, 0, 0, 0};
+thread_local double t_multi_spans[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 constexpr int64_t kLauncherSpinUs = 200;            // a launcher that finished a job spins this long for the next one before it sleeps
 
@@ -2109,8 +2133,10 @@ void launcher_main(MultiEngine* e, int d, uint32_t seen) {
         const std::function<int(int)>* work = e->work;
         if (!work) return;
         if (d < e->first_rank) continue;
+        rk.began = clock::now();
         rk.rc = (*work)(d);
         if (rk.rc) rk.error = t_error;
+        rk.ended = clock::now();
         e->remaining.fetch_sub(1, std::memory_order_release);
     }
 }
@@ -2384,6 +2410,18 @@ int multi_gpu_run(int n_gpus, int64_t n_paths, int32_t n_steps, int count, Launc
         }
     }
     const auto t1 = clock::now();
+    auto us = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    double wake_max = 0.0, own_max = 0.0, own_min = 0.0;      // launcher threads: how late the slowest one began, how long a rank's own launch took
+    if (threaded) {
+        own_min = 1e30;
+        for (const MultiRank& rk : eng->ranks) {
+            wake_max = std::max(wake_max, us(t0, rk.began));
+            own_max = std::max(own_max, us(rk.began, rk.ended));
+            own_min = std::min(own_min, us(rk.began, rk.ended));
+        }
+    } else {
+        own_max = own_min = us(t0, t1) / n_gpus;
+    }
     // 2. the collective: queued on every rank stream before the first wait
     if (!rehearsal) {
         rc = grouped_allreduce(eng, count);
@@ -2402,7 +2440,7 @@ int multi_gpu_run(int n_gpus, int64_t n_paths, int32_t n_steps, int count, Launc
         const hipError_t err = hipStreamSynchronize(eng->ranks[d].stream);
         return err == hipSuccess ? OLMC_OK : fail(OLMC_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(err));
     };
-    if (threaded) engine_post(eng, &drain_rank, 1);
+    if (threaded) engine_post(eng, &drain_rank, 0);     // rank 0's launcher too: every launcher ends the call awake, and spins for the next
     const MultiRank& first = eng->ranks[0];
     HIP_TRY(hipSetDevice(first.device));
     t_device = first.device;
@@ -2419,7 +2457,7 @@ int multi_gpu_run(int n_gpus, int64_t n_paths, int32_t n_steps, int count, Launc
     }
     if (rc) return rc;
     const auto t4 = clock::now();
-    auto us = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    t_multi_spans[5] = wake_max; t_multi_spans[6] = own_max; t_multi_spans[7] = own_min;
     t_multi_spans[0] = us(t0, t1); t_multi_spans[1] = us(t1, t2); t_multi_spans[2] = us(t2, t3); t_multi_spans[3] = us(t3, t4); t_multi_spans[4] = us(t0, t4);
 #ifdef OLMC_WITH_PROBES
     // instrumented build: every rank must hold rank 0's bits (identical finalisation on every rank)
@@ -2542,11 +2580,12 @@ extern "C" int olmc_multi_gpu_european_qmc(double S, double K, double T, double 
     return OLMC_OK;
 }
 
-// Host microseconds of the calling thread's last multi-GPU call: {launch phase (first rank's launch begun -> every rank's kernel
-// queued), collective queued, result fetched (includes the kernels' run time), other ranks drained, total}.
-extern "C" int olmc_multi_gpu_spans(double* out5) {
-    if (!out5) return fail(OLMC_ERR_ARG, "null pointer");
-    for (int i = 0; i < 5; ++i) out5[i] = t_multi_spans[i];
+// Host microseconds of the calling thread's last multi-GPU call: {launch phase (launch job posted -> every rank's kernel queued),
+// collective queued, result fetched (includes the kernels' run time), other ranks drained, total, the latest launcher's start after the
+// post (wake latency), the longest and the shortest single rank's own launch}.
+extern "C" int olmc_multi_gpu_spans(double* out8) {
+    if (!out8) return fail(OLMC_ERR_ARG, "null pointer");
+    for (int i = 0; i < 8; ++i) out8[i] = t_multi_spans[i];
     return OLMC_OK;
 }
 

@@ -1935,8 +1935,20 @@ struct LsmFit {
         for (int col = 0; col <= D; ++col) {
             // no pivot search: the moment matrix of the standardised regressor is symmetric positive definite with a modest condition
             // number, for which elimination in the natural order is stable (it is the Cholesky order)
-            const double p = lane_bcast(e, col * 8 + col);
-            if (!(fabs(p) > 1e-280)) ok = false;
+            // ... as long as the matrix IS definite.  Few distinct in-the-money prices (near-duplicate paths, a count of exactly
+            // degree + 2, a width clamped at 1e-6 of the mean) make it numerically singular: the pivot -- the part of sum z^(2 col) that
+            // the lower monomials do not explain -- is then rounding noise, and dividing by it would hand the next date arbitrary
+            // coefficients with `valid` = 1.  A pivot below 1e-11 of its own diagonal entry pins that unknown to zero
+            // instead (its row and column become the identity; the remaining monomials are fitted), a rule the checker restates.  The
+            // reference's lstsq returns the minimum-norm solution there: not the same numbers -- per-seed parity of the American
+            // option is statistical (olmc.h), and these cases are where it cannot be anything else.
+            double p = lane_bcast(e, col * 8 + col);
+            const bool pin = !(fabs(p) > 1e-11 * fabs(lane_bcast(total, 2 * col)));       // wave-uniform
+            if (pin) {
+                if (row == col) e = l == col ? 1.0 : 0.0;
+                else if (l == col) e = 0.0;
+                p = 1.0;
+            }
             const double inv = 1.0 / p;
             const double f = __shfl(e, row * 8 + col, kWave) * inv;
             const double pr = __shfl(e, col * 8 + l, kWave);

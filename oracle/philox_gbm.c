@@ -356,7 +356,7 @@ void ol_cliquet_moments(double S, double T, double r, double sigma, double q, do
 }
 
 /* American LSM (exotic_options.py:237-305) on the device's paths; regression in x = S/K by the
- * normal equations (long double Gaussian elimination with partial pivoting), degree <= 4.
+ * normal equations (long double Gaussian elimination in the natural order, singular directions pinned), degree <= 4.
  * moments[0..1] = sum, sum of squares of the time-0 cash flows. */
 static int lsm_solve(const long double* mom, const long double* rhs, int degree, double* beta) {
     int n = degree + 1;
@@ -365,12 +365,15 @@ static int lsm_solve(const long double* mom, const long double* rhs, int degree,
         for (int l = 0; l < n; ++l) a[k][l] = mom[k + l];
         a[k][n] = rhs[k];
     }
+    /* Natural order, as the device (olmc_kernels.h LsmFit): the moment matrix of the standardised regressor is symmetric positive
+     * definite.  Where it is numerically singular -- the pivot below 1e-11 of its own diagonal entry sum z^(2 col): few distinct
+     * in-the-money prices -- that unknown is pinned to zero and the remaining monomials are fitted (the device's rule; the reference's
+     * lstsq gives the minimum-norm solution there, so per-seed parity with the reference is statistical for the American option). */
     for (int col = 0; col < n; ++col) {
-        int piv = col;
-        for (int row = col + 1; row < n; ++row)
-            if (fabsl(a[row][col]) > fabsl(a[piv][col])) piv = row;
-        if (!(fabsl(a[piv][col]) > 1e-280L)) return 0;
-        for (int l = 0; l <= n; ++l) { long double tmp = a[piv][l]; a[piv][l] = a[col][l]; a[col][l] = tmp; }
+        if (!(fabsl(a[col][col]) > 1e-11L * fabsl(mom[2 * col]))) {
+            for (int l = 0; l <= n; ++l) a[col][l] = l == col ? 1.0L : 0.0L;
+            for (int row = 0; row < n; ++row) if (row != col) a[row][col] = 0.0L;
+        }
         for (int row = col + 1; row < n; ++row) {
             long double f = a[row][col] / a[col][col];
             for (int l = col; l <= n; ++l) a[row][l] -= f * a[col][l];

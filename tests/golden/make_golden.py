@@ -181,6 +181,70 @@ def main():
     g = cgu(ad, 100.0, 100.0, 1.0, 0.05, 0.2, "call", 0.0, include_second_order=False)
     doc["asian_greeks"] = dict(n_paths=20000, n_steps=64, seed=42, values={k: float(x) for k, x in g.items()})
 
+    # -- ExoticAdapter Greeks of the payoffs the device prices in ONE fused launch (unified_greeks.py:177-227 over exotic_options.py:97-131,
+    #    163-224, 347-401), each Greek with a standard error from the reference's OWN per-path payoffs, so that the device -- at many
+    #    more paths -- is held to 3 sigma of the reference run instead of to a guessed absolute tolerance.  The payoffs are not restated
+    #    here: every exotic price() ends in `np.exp(-r T) * np.mean(payoffs)`, and the array that last, axis-free np.mean receives IS the
+    #    per-path payoff vector (asserted: its discounted mean is the returned price, bit for bit).  All bumps of one option walk the same
+    #    normals (legacy np.random.seed(self.seed) in _generate_paths), so the per-path finite differences are the CRN differences.
+    class PayoffSpy:
+        def __enter__(self):
+            self.real, self.last = np.mean, None
+
+            def spy(a, *args, **kw):
+                if not args and not kw and getattr(a, "ndim", 0) == 1:
+                    self.last = np.array(a, dtype=np.float64)
+                return self.real(a, *args, **kw)
+            np.mean = spy
+            return self
+
+        def __exit__(self, *exc):
+            np.mean = self.real
+
+    def adapter_greeks_with_errors(make_option, n_paths, n_steps, typ, second, **kw):
+        S, K, T, r, v, q = 100.0, 100.0, 1.0, 0.05, 0.2, 0.0
+        ad = ref["ExoticAdapter"](make_option(), n_paths=n_paths, n_steps=n_steps, **kw)
+        g = cgu(ad, S, K, T, r, v, typ, q, include_second_order=second)
+        h_S, h_v, h_r, h_T = max(1e-4, 0.01 * S), 0.01, 1e-4, 1 / 365.0            # unified_greeks.py:274-277
+
+        def pv(S_=S, T_=T, r_=r, v_=v):                                               # discounted per-path payoffs of one evaluation
+            with PayoffSpy() as spy:
+                price = ad.price(S_, K, T_, r_, v_, typ, q)
+            assert spy.last is not None and len(spy.last) == n_paths and float(np.exp(-r_ * T_) * spy.real(spy.last)) == float(price)
+            return np.exp(-r_ * T_) * spy.last
+
+        mid, su, sd = pv(), pv(S_=S + h_S), pv(S_=S - h_S)
+        vu, vd, td, ru, rd = pv(v_=v + h_v), pv(v_=v - h_v), pv(T_=T - h_T), pv(r_=r + h_r), pv(r_=r - h_r)
+        per_path = {"price": mid, "delta": (su - sd) / (2 * h_S), "gamma": (su - 2 * mid + sd) / h_S**2, "vega": (vu - vd) / (2 * h_v),
+                    "theta": (td - mid) / h_T, "rho": (ru - rd) / (2 * h_r)}
+        if second:
+            uu, ud = pv(S_=S + h_S, v_=v + h_v), pv(S_=S + h_S, v_=v - h_v)
+            du, dd = pv(S_=S - h_S, v_=v + h_v), pv(S_=S - h_S, v_=v - h_v)
+            ut, dt = pv(S_=S + h_S, T_=T - h_T), pv(S_=S - h_S, T_=T - h_T)
+            per_path["vanna"] = (uu - ud - du + dd) / (4 * h_S * h_v)
+            per_path["charm"] = ((ut - dt) / (2 * h_S) - per_path["delta"]) / h_T
+            per_path["vomma"] = (vu - 2 * mid + vd) / h_v**2
+        for k_, x in per_path.items():          # the per-path differences average to the reference's own Greeks (another association of the same sums)
+            assert abs(float(x.mean()) - float(g[k_])) <= 1e-9 * max(1.0, abs(float(g[k_]))) + 1e-7 * float(x.std()), (k_, float(x.mean()), float(g[k_]))
+        return dict(n_paths=n_paths, n_steps=n_steps, seed=42, option_type=typ, include_second_order=second, kwargs=kw, keys=list(g.keys()),
+                    values={k_: float(x) for k_, x in g.items()},
+                    std_errors={k_: float(per_path[k_].std() / np.sqrt(n_paths)) for k_ in g.keys()})
+
+    doc["exotic_adapter_greeks"] = []
+    for name, make, typ, second, kw in [
+            ("asian", lambda: A(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, seed=42), "call", False, dict(avg_type="arithmetic")),
+            ("asian", lambda: A(S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, seed=42), "put", True, dict(avg_type="geometric")),
+            ("barrier", lambda: ref["BarrierOption"](S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, barrier=120.0, seed=42), "call", True, dict(barrier_type="up-and-out")),
+            ("barrier", lambda: ref["BarrierOption"](S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, barrier=85.0, seed=42), "put", False, dict(barrier_type="down-and-in")),
+            ("lookback", lambda: ref["LookbackOption"](S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, seed=42), "call", True, dict(lookback_type="floating")),
+            ("lookback", lambda: ref["LookbackOption"](S=100.0, K=100.0, T=1.0, r=0.05, sigma=0.2, seed=42), "put", False, dict(lookback_type="fixed"))]:
+        entry = adapter_greeks_with_errors(make, 20000, 64, typ, second, **kw)
+        entry["option"] = name
+        if name == "barrier":
+            entry["barrier"] = float(make().barrier)
+        doc["exotic_adapter_greeks"].append(entry)
+    assert doc["exotic_adapter_greeks"][0]["values"] == doc["asian_greeks"]["values"]      # the case the fixture has held since round 1
+
     # -- barrier / lookback (exotic_options.py:163-224, 347-401) -------------------------
     doc["barrier"], doc["lookback"] = [], []
     B, L = ref["BarrierOption"], ref["LookbackOption"]

@@ -38,7 +38,11 @@ def test_isa_mix_covers_every_kernel_the_bench_prices(bench):
         elif key == "f_heston":                                              # two normals per step
             assert m["steps_per_trip"] == m["by_class"]["v_log_f32"] == 2
         else:
-            assert m["steps_per_trip"] in (4, 16) and m["by_class"]["v_log_f32"] * 2 == m["steps_per_trip"]        # one Box-Muller log per two normals
+            assert m["steps_per_trip"] in (4, 8, 16) and m["by_class"]["v_log_f32"] * 2 == m["steps_per_trip"]        # one Box-Muller log per two normals
+    # round 5's entries: the fused barrier / lookback Greeks carry six recursions (x 2 legs) of {fma + add, max, min} per date, and fit four waves per SIMD
+    eg, ega = mix["f_extrema_greeks14"], mix["f_extrema_greeks14_anti"]
+    assert eg["by_class"]["v_fma_f64"] == 24 and ega["by_class"]["v_fma_f64"] == 48 and eg["vgprs"] <= 128 and ega["vgprs"] <= 128
+    assert mix["f_cv"]["by_class"]["v_mad_u64_u32"] == 68           # the control-variate shape runs the headline step loop
     # the headline loop: 17 multiplies and 19 XOR3 per Philox block, all but two of the XOR3 on three VGPRs (pinned round keys)
     c2 = mix["c2_european"]["by_class"]
     assert c2["v_mad_u64_u32"] == 68 and c2["v_bitop3_b32(v,v,v)"] + c2["v_bitop3_b32"] == 76 and c2["v_bitop3_b32"] <= 8
@@ -82,7 +86,7 @@ def test_a_mix_of_other_device_sources_is_refused(bench, tmp_path, monkeypatch):
     import shutil
     fake = tmp_path / "repo"
     (fake / "optionslab_amd" / "csrc").mkdir(parents=True)
-    for name in ("olmc.hip", "olmc_kernels.h"):
+    for name in ("olmc.hip", "olmc_kernels.h", "olmc_host_math.h"):
         shutil.copy(os.path.join(ROOT, "optionslab_amd", "csrc", name), fake / "optionslab_amd" / "csrc" / name)
     shutil.copy(os.path.join(ROOT, "optionslab_amd", "isa_mix.json"), fake / "optionslab_amd" / "isa_mix.json")
     monkeypatch.setattr(bench, "ROOT", str(fake))

@@ -416,6 +416,28 @@ def test_american_where_the_regression_is_ill_conditioned(S, K, T, r, v, call, N
     assert st.price >= max(K - S, 0.0) - 3 * st.std_error if not call else st.price >= max(S - K, 0.0) - 3 * st.std_error
 
 
+def test_american_where_the_moment_matrix_is_singular():
+    """a numerically singular moment matrix -- a handful of in-the-money paths (count = degree + 2: the fit interpolates),
+    in-the-money prices that all but coincide (vol 1e-7: the regressor's width is clamped) -- must not hand the next date
+    coefficients that are rounding noise divided by rounding noise.  A pivot below 1e-11 of its own diagonal entry pins that unknown
+    to zero (olmc_kernels.h LsmFit; restated in the checker).  Device = checker on the same paths wherever the decisions are robust,
+    every price finite and between the European value's neighbourhood and the strike."""
+    for N in (5, 6, 7, 9, 12):                                  # a few paths: some dates have exactly degree + 2 of them in the money
+        for deg in (3, 4):
+            for seed in range(12):
+                st = _hip.american_lsm(100.0, 110.0, 1.0, 0.05, 0.2, 0.0, False, N, 6, deg, seed)
+                sx, sxx, n = po.american_lsm(100.0, 110.0, 1.0, 0.05, 0.2, 0.0, False, N, 6, deg, seed)
+                assert st.n == n == N and math.isfinite(st.price) and 0.0 <= st.price <= 110.0
+                assert st.sum == pytest.approx(sx, rel=1e-5, abs=1e-9), (N, deg, seed, st.sum, sx)
+    for v in (1e-7, 1e-5):                                      # the in-the-money prices of a date differ in the 8th / 6th digit
+        st = _hip.american_lsm(90.0, 100.0, 1.0, 0.03, v, 0.0, False, 20_000, 10, 4, 3)
+        sx, sxx, n = po.american_lsm(90.0, 100.0, 1.0, 0.03, v, 0.0, False, 20_000, 10, 4, 3)
+        assert math.isfinite(st.price) and st.sum == pytest.approx(sx, rel=1e-6)
+        # no uncertainty left: the first exercise date (t = dt; time 0 is not one, exotic_options.py:262-296) beats every later one --
+        # K e^{-r k dt} - S falls with k -- whatever the (constant) continuation estimate the pinned fit makes of the later dates
+        assert st.price == pytest.approx(100.0 * math.exp(-0.03 * 0.1) - 90.0, abs=2e-3)
+
+
 _BIAS_CASES = {
     # name: (device price of seed s, the reference's algorithm -- oracle/numpy_reference.py, pinned bitwise to the reference -- on ITS normals of seed s)
     "asian arithmetic call": (lambda s: _hip.asian(100.0, 100.0, 1.0, 0.05, 0.2, 0.01, True, False, 40_000, 64, s).price,
@@ -671,6 +693,41 @@ def test_fused_barrier_and_lookback_greeks_equal_the_literal_bump_and_reprice(ki
     for k in fused:
         assert fused[k] == pytest.approx(literal[k], rel=1e-8, abs=1e-8), (kind, k)
     assert fused["price"] > 0 and isinstance(fused["vega"], np.float64)
+
+
+def test_fused_exotic_greeks_meet_the_reference_run(golden):
+    """The fused Asian / barrier / lookback Greeks against the REFERENCE, not only against their own literal launches:
+    compute_greeks_unified(ExoticAdapter(option, 20,000 x 64), ...) as the reference computes it (unified_greeks.py:177-358 over
+    exotic_options.py:97-131, 163-224, 347-401), each Greek with the standard error of the reference run (from its own per-path
+    payoffs under common random numbers, tests/golden/make_golden.py).  The device runs 100 x the paths in ONE launch per case: its
+    error is a tenth of the fixture's, the gate 3 sqrt(1 + 1/100) sigma."""
+    cases = golden["exotic_adapter_greeks"]
+    assert {c["option"] for c in cases} == {"asian", "barrier", "lookback"} and any(c["include_second_order"] for c in cases)
+    ratio = 100
+    worst = 0.0
+    for c in cases:
+        S, K, T, r, v, q = 100.0, 100.0, 1.0, 0.05, 0.2, 0.0
+        if c["option"] == "asian":
+            opt = ol.AsianOption(S, K, T, r, v, seed=42)
+        elif c["option"] == "barrier":
+            opt = ol.BarrierOption(S, K, T, r, v, seed=42, barrier=c["barrier"])
+        else:
+            opt = ol.LookbackOption(S, K, T, r, v, seed=42)
+        ad = ol.ExoticAdapter(opt, n_paths=ratio * c["n_paths"], n_steps=c["n_steps"], **c["kwargs"])
+        assert ad._can_fuse({})                                    # one launch: the kernels under test
+        g = ol.compute_greeks_unified(ad, S, K, T, r, v, c["option_type"], q, include_second_order=c["include_second_order"])
+        assert list(g) == c["keys"]
+        h_S, h_v, h_r, h_T = 1.0, 0.01, 1e-4, 1 / 365.0
+        amp = dict(price=1.0, delta=1 / h_S, gamma=4 / h_S**2, vega=1 / h_v, theta=2 / h_T, rho=1 / h_r, vanna=1 / (h_S * h_v), charm=4 / (h_S * h_T), vomma=4 / h_v**2)
+        for k in c["keys"]:
+            se = c["std_errors"][k] * math.sqrt(1.0 + 1.0 / ratio)
+            # a Greek that vanishes path by path (the floating lookback is homogeneous of degree one in S: its gamma is rounding noise
+            # in both runs, "standard error" 1e-14) is held to the rounding of the prices it is a difference of, amplified by its divisor
+            floor = 1e-11 * abs(c["values"]["price"]) * amp[k]
+            z = abs(g[k] - c["values"][k]) / (se + floor / 3.0)
+            worst = max(worst, z)
+            assert z <= 3.0, (c["option"], c["kwargs"], c["option_type"], k, g[k], c["values"][k], c["std_errors"][k])
+    assert 0.5 < worst <= 3.0                                      # the gate is neither vacuous nor crossed
 
 
 def test_the_exotic_page_greeks_take_one_launch_each():

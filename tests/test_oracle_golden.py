@@ -124,6 +124,31 @@ def test_asian_greeks_via_adapter(golden):
         assert float(g[k]) == x, k
 
 
+def test_exotic_adapter_greeks_of_every_fused_payoff(golden):
+    """compute_greeks_unified over ExoticAdapter(Asian | Barrier | Lookback) at 20,000 x 64 (unified_greeks.py:177-358 over
+    exotic_options.py:97-131, 163-224, 347-401): the restatement reproduces every Greek of the reference's runs bit for bit.  (The
+    fixture's standard errors come from the reference's own per-path payoffs; the restatement has no counterpart to pin there --
+    they are positive and of the size 1 / sqrt(n) predicts.)"""
+    cases = golden["exotic_adapter_greeks"]
+    assert len(cases) == 6
+    for c in cases:
+        n, m, seed, kw = c["n_paths"], c["n_steps"], c["seed"], c["kwargs"]
+
+        def price(S, K, T, r, v, typ, q=0.0):
+            if c["option"] == "asian":
+                return orc.asian_price(S, K, T, r, v, q, seed, n, m, kw["avg_type"], typ)
+            if c["option"] == "barrier":
+                return orc.barrier_price(S, K, T, r, v, c["barrier"], q, seed, n, m, kw["barrier_type"], typ)
+            return orc.lookback_price(S, K, T, r, v, q, seed, n, m, kw["lookback_type"], typ)
+
+        g = orc.fd_greeks(price, 100.0, 100.0, 1.0, 0.05, 0.2, c["option_type"], 0.0, include_second_order=c["include_second_order"])
+        assert list(g) == c["keys"]
+        for k in c["keys"]:
+            assert float(g[k]) == c["values"][k], (c["option"], kw, k)
+            assert c["std_errors"][k] >= 0.0
+        assert 0.0 < c["std_errors"]["price"] < 0.02 * abs(c["values"]["price"]) + 0.1
+
+
 def test_unified_pricer(golden):
     g = golden["uni"]
     N, M, seed = g["ctor"]

@@ -21,12 +21,15 @@ def timeit(fn, reps=20, warm=3):
     while n < warm or time.perf_counter() < t_end:
         fn()
         n += 1
-    ts = []
+    ts, frees, out = [], [], None
     for _ in range(reps):
+        t0 = time.perf_counter()
+        out = None                              # the previous result is released BEFORE the call is timed: handing 200 MB back to the kernel
+        frees.append(time.perf_counter() - t0)  # (munmap) costs the caller milliseconds that are NumPy's and the OS's, not the call's
         t0 = time.perf_counter()
         out = fn()
         ts.append(time.perf_counter() - t0)
-    return statistics.median(ts), min(ts), out
+    return statistics.median(ts), min(ts), out, statistics.median(frees[1:] or frees)
 
 
 def kernel_us(fn, reps=10):
@@ -40,10 +43,16 @@ def kernel_us(fn, reps=10):
 
 
 def report(name, path_steps, fn, extra=None, reps=20):
-    med, best, out = timeit(fn, reps)
+    med, best, out, free = timeit(fn, reps)
     kus, launches = kernel_us(fn)
     row = dict(config=name, path_steps=path_steps, wall_ms_median=med * 1e3, wall_ms_min=best * 1e3,
                path_steps_per_s=path_steps / med, kernel_us=kus, kernel_launches_per_call=launches)
+    if free > 1e-4:
+        row["release_previous_result_ms"] = free * 1e3
+    nbytes = sum(getattr(x, "nbytes", 0) for x in (out if isinstance(out, tuple) else (out,)))
+    if nbytes >= 1 << 24:
+        row["result_mb"] = nbytes / 1e6
+        row["result_gb_per_s_end_to_end"] = nbytes / med / 1e9
     if extra:
         row.update(extra(out))
     print(json.dumps(row), flush=True)

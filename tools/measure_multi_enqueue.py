@@ -46,6 +46,7 @@ def main():
                 print(json.dumps({"ranks": n_ranks, "paths_per_rank": per_rank, "n_steps": 252, "form": form, "calls": len(spans),
                                   "launch_us": round(med["launch_us"], 2), "launch_us_p90": round(p90, 2), "collective_us": round(med["collective_us"], 2),
                                   "fetch_us": round(med["fetch_us"], 2), "drain_us": round(med["drain_us"], 2), "total_us": round(med["total_us"], 2),
+                                  "wake_us_max": round(med["wake_us_max"], 2), "rank_launch_us_max": round(med["rank_launch_us_max"], 2), "rank_launch_us_min": round(med["rank_launch_us_min"], 2),
                                   "wall_us_python": round(statistics.median(wall), 2), "device": info["name"], "rehearsal": True}), flush=True)
     hip.tune(hip.TUNE_MULTI_LAUNCH, 0)
     probe.tune(probe.TUNE_MULTI_REHEARSAL, 0)

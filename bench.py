@@ -318,13 +318,14 @@ def roofline_for(pmc, key, avg_kernel_s, n_steps, n_paths, costs=None, mixes=Non
         path_waves = n_paths / 64.0                     # whole-path wave equivalents (a split workgroup's four waves share 64 paths)
         rest = max(c["SQ_INSTS_VALU"] - path_waves * trips * mix["loop_valu_instructions"], 0.0)      # instructions outside the hot loop, per launch
         loop_cycles = sum(n * ISSUE_PASSES[cls] for cls, n in mix["by_class"].items())
-        need = path_waves * trips * loop_cycles + rest * OUTSIDE_LOOP_PASSES                          # issue cycles per launch, all SIMDs
+        rest_passes = mix.get("rest_passes", OUTSIDE_LOOP_PASSES)   # a two-path loop (isa_mix.py MIN_PATH) prices what exceeds its cheapest trip at the minimum
+        need = path_waves * trips * loop_cycles + rest * rest_passes                                  # issue cycles per launch, all SIMDs
         r.update({"achieved": need / avg_kernel_s / 1e9, "frac": need / avg_kernel_s / peak,
                   "issue_cycles_needed_per_launch": need, "speed_of_light_kernel_ms": need / peak * 1e3,
                   "issue_model": {"loop_trips_per_path": trips, "loop_valu_instructions": mix["loop_valu_instructions"], "loop_mix": mix["by_class"],
                                   "loop_issue_cycles_per_trip": loop_cycles, "issue_passes": ISSUE_PASSES,
                                   "valu_instructions_in_the_loop_per_launch": path_waves * trips * mix["loop_valu_instructions"],
-                                  "valu_instructions_outside_the_loop_per_launch": rest, "outside_the_loop_passes": OUTSIDE_LOOP_PASSES}})
+                                  "valu_instructions_outside_the_loop_per_launch": rest, "outside_the_loop_passes": rest_passes}})
         if costs:
             loop_ns = sum(n * costs.get(cls, costs["v_fmamk_f32"]) for cls, n in mix["by_class"].items())
             model_s = (path_waves * trips * loop_ns + rest * costs["v_fma_f64"]) / N_SIMD * 1e-9

@@ -382,7 +382,7 @@ int g_multi_rehearsal = 0;   // OLMC_PROBE_TUNE_MULTI_REHEARSAL: != 0 runs the n
 // Short paths (n_steps <= 128, the reference's default is ONE step) are bounded by per-workgroup costs
 // (dispatch, row store, ticket), not by the step loop: there 16 workgroups per CU that grid-stride beat
 // one workgroup per 256 paths (8M x 4: 63 -> 43 us, 8M x 32: 143 -> 125 us; equal from 128 steps on,
-// tools/history/single_step_probe.py).
+// a one-off probe of round 3, profiles/HISTORY.md).
 constexpr int32_t kShortPathSteps = 128, kShortPathGrid = 4096;
 
 int32_t grid_for(int64_t n_paths, int32_t n_steps = INT32_MAX) {
@@ -417,7 +417,7 @@ int resident_workgroups(Kernel kernel) {
 // F = floor(W / C) C: every CU gets the same number of whole workgroups, the remainder is spread in quarter-length units.
 // Round 3 asked whether a THIN last round of whole workgroups (1M paths = 15 per CU = 7 + 7 + 1 at 7 resident per CU) should be
 // split too, on the theory that a lone wave per SIMD issues slowly.  It does not: exactly k C whole workgroups take
-// 9.4 + 6.03 k us for every k from 1 to 28 (tools/history/occupancy_probe.py, profiles/r03_occupancy_probe.jsonl) -- one wave per SIMD
+// 9.4 + 6.03 k us for every k from 1 to 28 (profiles/r03_occupancy_probe.jsonl) -- one wave per SIMD
 // already issues at the full rate (four interleaved Philox blocks are enough ILP), the SIMD serves its waves oldest-first
 // rather than in rounds (first workgroup of a 7-per-CU launch done after 9 us, last after 48: profiles/r03_phase_stamps.jsonl),
 // and OLMC_TUNE_SPLIT_SAT at 2 / 5 / 7 left the 1M x 252 kernel at 100.35 us +- 0.1 (profiles/r03_ab_kernels.txt).  The knob
@@ -1114,7 +1114,11 @@ extern "C" int olmc_european_cv_shard(double S, double K, double T, double r, do
     ReduceWs ws;
     rc = make_ws(c, c->stream, grid, 5, c->d_result, -1.0, &ws);
     if (rc) return rc;
-    launch_european<1, kControlVariate>(antithetic != 0, grid, c->stream, pr, cs, ws, nullptr);
+    EventPair ep{};
+    const EventPair* timed = nullptr;
+    rc = prof_pair(c, &ep, &timed);
+    if (rc) return rc;
+    launch_european<1, kControlVariate>(antithetic != 0, grid, c->stream, pr, cs, ws, nullptr, timed);
     rc = after_launch(c, c->stream);
     if (rc) return rc;
     rc = sync_or_recover(c, c->stream);

@@ -1616,6 +1616,7 @@ __global__ __launch_bounds__(kBlock) void autocall_kernel(PathRange pr, Autocall
             if (until_obs > 4 && 4 * b + 4 <= pr.n_steps) {
                 // no observation date among these four steps (16 of 21 blocks at monthly observation): only the
                 // cumulative return and its running minimum move -- branch-free, the four dates schedule together
+                asm volatile("; olmc_fast_trip");       // no instruction: a label in the assembly by which tools/isa_mix.py finds the fast path of this loop
                 until_obs -= 4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1696,6 +1697,7 @@ __global__ __launch_bounds__(kBlock) void cliquet_kernel(PathRange pr, CliquetCo
         const int32_t blocks = (used_steps + 3) >> 2;
         for (int32_t b = 0; b < blocks; ++b) {
             if (until_reset > 4) {                      // no period end among these four steps (and all four are used)
+                asm volatile("; olmc_fast_trip");       // (tools/isa_mix.py: the fast path of this loop)
                 until_reset -= 4;
                 part = raw_block_sum_of_words(part, philox4x32_10_pinned(g_lo, g_hi, static_cast<uint32_t>(b), 0u, rk));
                 if (++part_blocks == kGroup) { psum += static_cast<double>(part); part = 0.0f; part_blocks = 0; }

@@ -43,6 +43,13 @@ def test_isa_mix_covers_every_kernel_the_bench_prices(bench):
     eg, ega = mix["f_extrema_greeks14"], mix["f_extrema_greeks14_anti"]
     assert eg["by_class"]["v_fma_f64"] == 24 and ega["by_class"]["v_fma_f64"] == 48 and eg["vgprs"] <= 128 and ega["vgprs"] <= 128
     assert mix["f_cv"]["by_class"]["v_mad_u64_u32"] == 68           # the control-variate shape runs the headline step loop
+    # two-path loops (autocallable, cliquet): the trip is the marked fast path, one Philox block of four dates; what the slow trips add is
+    # priced at the minimum (rest_passes 2), so the fraction stays a bound
+    for key in ("f_autocall", "f_cliquet"):
+        assert mix[key]["steps_per_trip"] == 4 and mix[key]["by_class"]["v_mad_u64_u32"] == 17 and mix[key]["rest_passes"] == 2
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_mix
+    assert isa_mix._PASSES == bench.ISSUE_PASSES                    # the path search prices blocks with bench.py's own table
     # the headline loop: 17 multiplies and 19 XOR3 per Philox block, all but two of the XOR3 on three VGPRs (pinned round keys)
     c2 = mix["c2_european"]["by_class"]
     assert c2["v_mad_u64_u32"] == 68 and c2["v_bitop3_b32(v,v,v)"] + c2["v_bitop3_b32"] == 76 and c2["v_bitop3_b32"] <= 8

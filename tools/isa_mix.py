@@ -113,6 +113,68 @@ def hot_loop(body):
     return members[max(steps or inner, key=count)]
 
 
+# Kernels whose step loop holds a FAST path (Philox blocks without an observation / reset date) and a slow one behind wave-uniform
+# branches: the loop's blocks together are not what one trip executes.  The kernel source marks its fast path with an assembly
+# comment (`; olmc_fast_trip`, no instruction); a trip is priced along the cheapest path from the loop header THROUGH the marked
+# block to the back edge -- what the fast trips execute.  A slow trip executes more; that reaches the model through the counters
+# (SQ_INSTS_VALU minus trips x this path) at the 2-cycle minimum, so the fraction stays a bound (bench.py: "rest_passes").
+MIN_PATH = {"f_autocall", "f_cliquet"}
+FAST_MARK = "olmc_fast_trip"
+_PASSES = {"v_mad_u64_u32": 4, "v_bitop3_b32": 4, "v_bitop3_b32(v,v,v)": 2, "v_cvt_f32_u32": 4, "v_fmamk_f32": 2, "v_and_or_b32": 4,
+           "v_log_f32": 8, "v_sqrt_f32": 8, "v_sin_f32": 8, "v_cos_f32": 8, "v_exp_f32": 8, "v_add_f32": 2, "v_fma_f32": 2,
+           "v_cvt_f64_f32": 4, "v_add_f64": 4, "v_fma_f64": 4, "v_rndne_f64": 4, "v_ldexp_f64": 4, "v_cvt_i32_f64": 4, "other": 2}     # = bench.ISSUE_PASSES (tests/test_bench_roofline.py)
+
+
+def cheapest_trip(body, blocks):
+    """Blocks of the loop on the path of least issue cycles header -> marked block -> back edge (Dijkstra over the loop's own CFG:
+    `s_cbranch_* L` -> {L, fall-through}, `s_branch L` -> {L}, else fall-through)."""
+    import heapq
+    label_of = {b[2]: k for k, b in enumerate(blocks) if b[2]}
+    header = blocks[0][2]
+    marked = [k for k, (first, end, *_r) in enumerate(blocks) if any(FAST_MARK in l for l in body[first:end])]
+    if len(marked) != 1:
+        raise RuntimeError(f"expected one block marked `; {FAST_MARK}` in the loop, found {len(marked)}")
+    cost, succ = [], []
+    for k, (first, end, *_rest) in enumerate(blocks):
+        _ops, classes, _cold = mix_of(body, [blocks[k]])
+        cost.append(sum(n * _PASSES[c] for c, n in classes.items()))
+        out, falls = [], True
+        for l in body[first:end]:
+            m = re.match(r"^\s+(s_cbranch_\w+|s_branch)\s+\.L(BB[0-9_]+)", l)
+            if m:
+                out.append(m.group(2))
+                if m.group(1) == "s_branch":
+                    falls = False
+        if falls and k + 1 < len(blocks):
+            out.append(k + 1)
+        succ.append([("back" if t == header else label_of.get(t)) if isinstance(t, str) else t for t in out])
+
+    def shortest(src, dst):
+        best, heap, done = {src: (cost[src], [src])}, [(cost[src], src)], set()
+        while heap:
+            d, k = heapq.heappop(heap)
+            if k in done:
+                continue
+            done.add(k)
+            if k == dst:
+                return best[k][1]
+            for j in succ[k]:
+                if j == "back":
+                    if dst == "back":
+                        return best[k][1]
+                    continue
+                if j is None:
+                    continue
+                nd = d + cost[j]
+                if j not in best or nd < best[j][0]:
+                    best[j] = (nd, best[k][1] + [j])
+                    heapq.heappush(heap, (nd, j))
+        raise RuntimeError("no such path in the loop")
+
+    path = shortest(0, marked[0]) + shortest(marked[0], "back")[1:]
+    return [blocks[i] for i in path]
+
+
 def mix_of(body, blocks):
     """VALU instructions of the loop's blocks by mnemonic and by probe class.  A block that holds an fp64 square root is COLD: it is the
     tail of the inverse normal (0.1 % of the Sobol points, olmc_kernels.h ndtri_tail), skipped by a branch in nearly every wave."""
@@ -161,12 +223,17 @@ def main():
             print(f"{key:28s} NO KERNEL MATCHES {pat}", file=sys.stderr)
             continue
         span = hot_loop(body)
+        if key in MIN_PATH:
+            span = cheapest_trip(body, span)
         ops, classes, n_cold = mix_of(body, span)
         vgprs = next((int(m.group(1)) for l in lines[lines.index(body[0]):] if (m := re.match(r"^; NumVgprs: (\d+)", l))), None)
         steps = STEPS_PER_TRIP[key](ops) if key in STEPS_PER_TRIP else 2 * ops.get("v_log_f32", 0)
         result[key] = {"loop_valu_instructions": sum(ops.values()), "steps_per_trip": steps, "by_class": dict(sorted(classes.items())), "by_mnemonic": dict(sorted(ops.items())),
                        "unclassified_priced_as_" + OTHER: sum(n for op, n in ops.items() if op not in CLASS_OF and not re.search(r"_f64$|_f64_", op)),
                        "cold_lines_skipped": n_cold, "vgprs": vgprs}
+        if key in MIN_PATH:
+            result[key]["rest_passes"] = 2
+            result[key]["trip"] = "cheapest path through the loop (the fast trips); slower trips reach the model through SQ_INSTS_VALU at 2 cycles an instruction"
         print(f"{key:28s} loop {sum(ops.values()):4d} VALU instr, {vgprs} VGPRs: {dict(classes)}", file=sys.stderr)
     result["_sources_sha256"] = source_digest()
     with open(OUT, "w") as f:

@@ -40,7 +40,7 @@ def test_isa_mix_covers_every_kernel_the_bench_prices(bench):
         else:
             assert m["steps_per_trip"] in (4, 8, 16) and m["by_class"]["v_log_f32"] * 2 == m["steps_per_trip"]        # one Box-Muller log per two normals
     # round 5's entries: the fused barrier / lookback Greeks carry six recursions (x 2 legs) of {fma + add, max, min} per date, and fit four waves per SIMD
-    eg, ega = mix["f_extrema_greeks14"], mix["f_extrema_greeks14_anti"]
+    eg, ega = mix["f_extrema_greeks14"], mix["f_extrema_greeks14a"]
     assert eg["by_class"]["v_fma_f64"] == 24 and ega["by_class"]["v_fma_f64"] == 48 and eg["vgprs"] <= 128 and ega["vgprs"] <= 128
     assert mix["f_cv"]["by_class"]["v_mad_u64_u32"] == 68           # the control-variate shape runs the headline step loop
     # two-path loops (autocallable, cliquet): the trip is the marked fast path, one Philox block of four dates; what the slow trips add is

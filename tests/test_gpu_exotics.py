@@ -360,6 +360,32 @@ def test_path_matrix_layouts_agree_bitwise():
             assert j1.shape == (N, M + 1) and np.array_equal(j1, _hip.jump_paths(100.0, 1.0, 0.05, 0.2, 0.01, kou, *mdl, N, M, 9).T)
 
 
+def test_large_results_come_home_bit_identical_through_the_staged_copy():
+    """Results of 32 MB and more leave the device in 16 MB chunks through two pinned staging buffers while host threads copy the
+    previous chunk into the caller's buffer (olmc.hip copy_to_host; 41 GB/s end to end where one hipMemcpy into a fresh pageable
+    buffer made 17).  Bytes are copied, never interpreted: the arrays must equal the single-copy form's (OLMC_TUNE_STAGED_COPY = -1)
+    bit for bit -- sizes that are not a multiple of a chunk, of a page or of the thread count, both layouts, both Heston matrices,
+    a terminal array, twice over (the staging buffers are reused)."""
+    def grab():
+        out = []
+        for N, M, pm in ((30_011, 252, True), (17_000, 251, False), (262_144, 15, True)):          # 60.8 / 34.3 / 33.6 MB
+            out.append(_hip.gbm_paths(100.0, 1.0, 0.05, 0.2, 0.01, N, M, 9, path_major=pm))
+        out.extend(_hip.heston_paths(100.0, 1.0, 0.05, 0.01, 2.0, 0.04, 0.3, -0.7, 0.04, 45_001, 101, 9, path_major=True))
+        out.append(_hip.european_terminal(100.0, 1.0, 0.05, 0.2, 0.0, 3_000_001, 16, 5, True))      # 48 MB [pos | neg]
+        return out
+    staged = grab()
+    again = grab()
+    _hip.tune(_hip.TUNE_STAGED_COPY, -1)
+    try:
+        direct = grab()
+    finally:
+        _hip.tune(_hip.TUNE_STAGED_COPY, 0)
+    assert all(a.nbytes >= 32 << 20 for a in staged)
+    for a, b, c in zip(staged, again, direct):
+        assert a.shape == c.shape and a.tobytes() == c.tobytes() and b.tobytes() == c.tobytes()
+        assert np.isfinite(a).all() and (a >= 0).all()          # (Heston's variance touches 0 under full truncation)
+
+
 def _heston_call_characteristic_function(S, K, T, r, q, kappa, theta, sv, rho, v0):
     """Heston (1993) call by the P1/P2 integrals in the branch-cut-safe ("little trap") form -- a test-only analytic
     anchor, written from the published formula.  (The reference's own price_european, heston.py:131-182, is mirrored

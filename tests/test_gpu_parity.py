@@ -743,6 +743,47 @@ def test_concurrent_callers_get_bit_identical_results_on_contexts_of_their_own()
     assert [f() for f in calls(3)] == want[3]               # and single-threaded again afterwards
 
 
+def test_one_seed_gives_one_pair_of_sums_thousands_of_times_under_load():
+    """`price1 == price2` for equal seeds (the reference's tests/test_monte_carlo.py:153-158) rests on the grid reduction: every
+    workgroup's row stored write-through and drained, a ticket, and the LAST workgroup reading ALL rows (agent-scope acquire since round
+    5; olmc_kernels.h acquire_rows).  A stale 16-byte row at 1M paths would move the price by 0.25 sigma -- invisible to every 3-sigma
+    gate.  So: the same pricing thousands of times (the headline 1M x 252: 3,907 rows in two levels; 8M x 252: 31,250 rows; the
+    14-contract Greeks: 32-wide rows summed by a whole workgroup; 10k x 50: one level), while seven other threads keep seven other
+    contexts of the device busy with launches of other sizes -- ONE distinct (sum, sumsq) each.  OLMC_REPRO_SCALE multiplies the counts
+    (10 = the 20,000 pricings VERDICT r4 asked for)."""
+    import threading
+    scale = float(os.environ.get("OLMC_REPRO_SCALE", "1"))
+    stop, errs = threading.Event(), []
+
+    def load(k):
+        try:
+            sizes = [(10_000, 50), (100_000, 100), (300_001, 7), (65_537, 33), (1_000_000, 16), (257, 1), (2_000_000, 4)]
+            N, M = sizes[k % len(sizes)]
+            first = None
+            while not stop.is_set():
+                st = _hip.european(*ATM, 0.0, True, N, M, 1000 + k, True)
+                first = first or (st.sum, st.sumsq)
+                if (st.sum, st.sumsq) != first:
+                    raise AssertionError(f"load thread {k}: other bits on a repeat")
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=load, args=(k,)) for k in range(7)]
+    [t.start() for t in ts]
+    try:
+        for what, reps, fn in (
+                ("1M x 252", int(2000 * scale), lambda: (lambda st: (st.sum, st.sumsq))(_hip.european(*ATM, 0.0, True, 1_000_000, 252, 42, True))),
+                ("8M x 252", int(150 * scale), lambda: (lambda st: (st.sum, st.sumsq))(_hip.european(*ATM, 0.0, True, 8_000_000, 252, 42, True))),
+                ("10k x 50", int(3000 * scale), lambda: (lambda st: (st.sum, st.sumsq))(_hip.european(*ATM, 0.0, True, 10_000, 50, 42, True))),
+                ("greeks14 1M x 64", int(500 * scale), lambda: tuple(_hip.european_greeks_fd(*ATM, 0.0, True, 1_000_000, 64, 42, True, want_evals=False)[0]))):
+            seen = {fn() for _ in range(reps)}
+            assert len(seen) == 1, (what, len(seen), sorted(seen)[:3])
+    finally:
+        stop.set()
+        [t.join() for t in ts]
+    assert not errs, errs[:2]
+
+
 def test_concurrent_calls_from_threads_are_serialised_correctly():
     import threading
     p = ol.MonteCarloPricer(50_000, 16, 7)

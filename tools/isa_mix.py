@@ -39,8 +39,8 @@ KERNELS = {      # key in bench.py's JSON -> mangled-name regex
     "f_qmc_block": r"^_ZN4olmc25european_qmc_block_kernelILi0EEE",
     # round 5: round 4's new kernels (VERDICT r4 "missing" 2) and the control-variate shape of the headline kernel
     "f_extrema_greeks14": r"^_ZN4olmc21extrema_greeks_kernelILb0ELi16EEE",
-    "f_extrema_greeks14_anti": r"^_ZN4olmc21extrema_greeks_kernelILb1ELi16EEE",
-    "f_asian_geo_greeks14": r"^_ZN4olmc29asian_geometric_greeks_kernelILb0ELi16EEE",
+    "f_extrema_greeks14a": r"^_ZN4olmc21extrema_greeks_kernelILb1ELi16EEE",
+    "f_geo_greeks14": r"^_ZN4olmc29asian_geometric_greeks_kernelILb0ELi16EEE",
     "f_autocall": r"^_ZN4olmc15autocall_kernelILb0EEE",
     "f_cliquet": r"^_ZN4olmc14cliquet_kernelILb0EEE",
     "f_cv": r"^_ZN4olmc20european_path_kernelILi1ELb1ELi2ELb0EEE",

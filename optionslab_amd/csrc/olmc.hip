@@ -26,6 +26,7 @@
 #include <functional>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 #include <linux/futex.h>
@@ -320,7 +321,15 @@ int copy_to_host(DeviceCtx* c, void* dst, const void* d_src, size_t bytes) {
     double us_spawn = 0, us_first = 0, us_events = 0, us_workers = 0;
     std::vector<std::thread> threads;
     threads.reserve(n_threads);
-    for (int w = 0; w < n_threads; ++w) threads.emplace_back(worker, w);
+    try {
+        for (int w = 0; w < n_threads; ++w) threads.emplace_back(worker, w);
+    } catch (const std::system_error&) {             // no thread to be had: the single copy still works
+        give_up.store(true);
+        for (std::thread& t : threads) t.join();
+        HIP_TRY(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return OLMC_OK;
+    }
     us_spawn = us_since(t_begin);
     hipError_t err = hipSuccess;
     for (int64_t i = 0; i < n_chunks && err == hipSuccess; ++i) {
@@ -2185,7 +2194,7 @@ void pool_forget_stream(int dev, hipStream_t stream) {
 }
 
 void engine_destroy(MultiEngine* e) {
-    if (!e->ranks.empty() && e->ranks[0].launcher.joinable()) {
+    if (std::any_of(e->ranks.begin(), e->ranks.end(), [](const MultiRank& rk) { return rk.launcher.joinable(); })) {
         engine_post(e, nullptr, 0);                 // work == nullptr: leave
         for (MultiRank& rk : e->ranks)
             if (rk.launcher.joinable()) rk.launcher.join();
@@ -2237,8 +2246,13 @@ int engine_build(const std::vector<int>& devs, bool rehearsal, MultiEngine** out
         const ncclResult_t r = g_rccl.CommInitAll(e->comms.data(), static_cast<int>(list.size()), list.data());
         if (r != ncclSuccess) return bail(fail(OLMC_ERR_RCCL, rccl_message("ncclCommInitAll", r)));
     }
-    if (devs.size() > 1)                             // one rank needs no launcher: the calling thread is as good
-        for (size_t d = 0; d < devs.size(); ++d) e->ranks[d].launcher = std::thread(launcher_main, e, static_cast<int>(d), e->job_no.load());
+    if (devs.size() > 1) {                           // one rank needs no launcher: the calling thread is as good
+        try {
+            for (size_t d = 0; d < devs.size(); ++d) e->ranks[d].launcher = std::thread(launcher_main, e, static_cast<int>(d), e->job_no.load());
+        } catch (const std::system_error& err) {
+            return bail(fail(OLMC_ERR_STATE, std::string("multi-GPU engine: cannot start a launcher thread: ") + err.what()));
+        }
+    }
     *out = e;
     return OLMC_OK;
 }

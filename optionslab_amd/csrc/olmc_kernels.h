@@ -1438,6 +1438,23 @@ __device__ __forceinline__ double extrema_payoff(const ExtremaContract& c, doubl
     return c.sign > 0.0 ? fmax(c.s0 * exp(mx) - c.strike, 0.0) : fmax(c.strike - c.s0 * exp(mn), 0.0);
 }
 
+// Running extrema: v_max_f64 / v_min_f64 as single instructions.  fmax() / fmin() reach the same instruction, but the compiler
+// first CANONICALISES any operand it cannot prove quiet (`v_max_f64 x, x, x`) -- and a running extremum carried around a loop is such
+// an operand at the head of every trip: two extra fp64 instructions per recursion per Philox block (a third of the max / min work of
+// the barrier / lookback kernels: 6 v_max + 4 v_min where 4 + 4 are needed).  The hardware instruction quiets a signalling NaN by
+// itself (IEEE mode), both operands here are sums of finite terms or earlier extrema, and NaN parameters never reach a kernel
+// (olmc_host_math.h poisoned()).  Same bits as fmax / fmin for every non-NaN input.
+__device__ __forceinline__ double max_f64(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double min_f64(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <bool ANTI, int LIVE>
 __device__ __forceinline__ void extrema_block(const float (&z)[4], double drift, double vol, double& cum_u, double& mx_u,
                                               double& mn_u, double& cum_d, double& mx_d, double& mn_d) {
@@ -1445,12 +1462,12 @@ __device__ __forceinline__ void extrema_block(const float (&z)[4], double drift,
     for (int j = 0; j < LIVE; ++j) {
         const double zj = static_cast<double>(z[j]);
         cum_u += __builtin_fma(vol, zj, drift);
-        mx_u = fmax(mx_u, cum_u);
-        mn_u = fmin(mn_u, cum_u);
+        mx_u = max_f64(mx_u, cum_u);
+        mn_u = min_f64(mn_u, cum_u);
         if constexpr (ANTI) {
             cum_d += __builtin_fma(-vol, zj, drift);
-            mx_d = fmax(mx_d, cum_d);
-            mn_d = fmin(mn_d, cum_d);
+            mx_d = max_f64(mx_d, cum_d);
+            mn_d = min_f64(mn_d, cum_d);
         }
     }
 }
@@ -1512,12 +1529,12 @@ __global__ __launch_bounds__(kBlock) void extrema_greeks_kernel(PathRange pr, Ex
 #pragma unroll
             for (int g = 0; g < G; ++g) {
                 cum[0][g] += __builtin_fma(gs.vol[g], zj, gs.drift[g]);
-                mx[0][g] = fmax(mx[0][g], cum[0][g]);
-                mn[0][g] = fmin(mn[0][g], cum[0][g]);
+                mx[0][g] = max_f64(mx[0][g], cum[0][g]);
+                mn[0][g] = min_f64(mn[0][g], cum[0][g]);
                 if constexpr (ANTI) {
                     cum[1][g] += __builtin_fma(-gs.vol[g], zj, gs.drift[g]);
-                    mx[1][g] = fmax(mx[1][g], cum[1][g]);
-                    mn[1][g] = fmin(mn[1][g], cum[1][g]);
+                    mx[1][g] = max_f64(mx[1][g], cum[1][g]);
+                    mn[1][g] = min_f64(mn[1][g], cum[1][g]);
                 }
             }
             if constexpr (ANTI) __builtin_amdgcn_sched_barrier(0);       // a date at a time: twelve chains already fill the pipeline, and
@@ -1624,7 +1641,7 @@ __global__ __launch_bounds__(kBlock) void autocall_kernel(PathRange pr, Autocall
 #pragma unroll
                     for (int leg = 0; leg < LEGS; ++leg) {
                         cum[leg] += __builtin_fma(leg ? -vol : vol, zj, c.drift);
-                        mn[leg] = fmin(mn[leg], cum[leg]);
+                        mn[leg] = min_f64(mn[leg], cum[leg]);
                     }
                 }
                 continue;
@@ -1644,7 +1661,7 @@ __global__ __launch_bounds__(kBlock) void autocall_kernel(PathRange pr, Autocall
 #pragma unroll
                     for (int leg = 0; leg < LEGS; ++leg) {
                         cum[leg] += __builtin_fma(leg ? -vol : vol, zj, c.drift);
-                        mn[leg] = fmin(mn[leg], cum[leg]);
+                        mn[leg] = min_f64(mn[leg], cum[leg]);
                         const bool call_now = observe && !redeemed[leg] && cum[leg] >= c.log_autocall;
                         pay[leg] = call_now ? redemption : pay[leg];
                         redeemed[leg] = redeemed[leg] || call_now;

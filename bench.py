@@ -1164,6 +1164,26 @@ def single_process_child(args):
            "what": "olmc_multi_gpu_european: one process, a launcher thread and a stream per device (every rank's kernel queued at once), ONE grouped "
                    "RCCL all-reduce of (sum, sumsq, n) per blocking pricing, result by rank 0's polled completion word; no torch.  enqueue_us = host "
                    "time from posting the launch to the last rank's kernel being queued"}
+    # the serial form of the launch phase beside it (round 4's: the calling thread queues the ranks one after the other), so that the
+    # first run on real multi-GPU hardware carries its own A/B; with one rank the two forms are the same code
+    if n_gpus > 1:
+        try:
+            _hip.tune(_hip.TUNE_MULTI_LAUNCH, -1)
+            for k in range(10):
+                step(2000 + k)
+            sp, ssp = [], []
+            for p_ in range(5):
+                t0 = time.perf_counter()
+                for k in range(args.steps):
+                    step(3000 + p_ * args.steps + k)
+                sp.append(time.perf_counter() - t0)
+                ssp.append(_hip.multi_gpu_spans())
+            out["serial_launch_form"] = {"ms_per_step": statistics.median(sp) / args.steps * 1e3,
+                                         "spans_us": {k: round(statistics.median(x[k] for x in ssp), 2) for k in ssp[0]}}
+        except Exception as e:
+            out["serial_launch_form"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            _hip.tune(_hip.TUNE_MULTI_LAUNCH, 0)
     # the other two payloads of the same engine (count 33 and 6), at 1M paths per GPU
     try:
         g = lambda: _hip.multi_gpu_greeks_fd(S, K, T, r, sigma, q, True, PATHS_PER_GPU * n_gpus, N_STEPS, SEED, True, n_gpus, want_evals=False)

@@ -2458,10 +2458,11 @@ int multi_gpu_run(int n_gpus, int64_t n_paths, int32_t n_steps, int count, Launc
         const hipError_t err = hipStreamSynchronize(eng->ranks[d].stream);
         return err == hipSuccess ? OLMC_OK : fail(OLMC_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(err));
     };
-    if (threaded) engine_post(eng, &drain_rank, 0);     // rank 0's launcher too: every launcher ends the call awake, and spins for the next
     const MultiRank& first = eng->ranks[0];
     HIP_TRY(hipSetDevice(first.device));
     t_device = first.device;
+    // from the post to the wait below NOTHING may return: the job refers to this frame
+    if (threaded) engine_post(eng, &drain_rank, 0);     // rank 0's launcher too: every launcher ends the call awake, and spins for the next
     rc = olmc_fetch_dev(first.d_recv, count, first.stream, host);
     const auto t3 = clock::now();
     if (threaded) {

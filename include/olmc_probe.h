@@ -72,9 +72,11 @@ int olmc_launch_gap_probe(int32_t n, double* us_per_launch);
  *   OLMC_PROBE_TUNE_MULTI_REHEARSAL  1: the n ranks of olmc_multi_gpu_* all run on the caller's ONE device, each with its own
  *                                    stream and buffers, and the RCCL all-reduce (which refuses two ranks on one GPU) is replaced by
  *                                    a kernel per rank that adds the n send buffers in rank order behind every rank's path kernel.
- *                                    Partitioning, queueing order, payload layout, the hand-over by rank 0's completion word, the
- *                                    drain of ranks >= 1 and the restoration of the thread's device run exactly as with n devices;
- *                                    the call also checks that every rank ended with rank 0's bits. */
+ *                                    The engine with its launcher thread per rank, partitioning, payload layout, the hand-over by rank
+ *                                    0's completion word, the drain of the ranks and the restoration of the thread's device run
+ *                                    exactly as with n devices (except that n launchers then queue on ONE device's runtime locks: the
+ *                                    launch phase is no faster than the serial form's there); the call also checks that every rank
+ *                                    ended with rank 0's bits. */
 enum { OLMC_PROBE_TUNE_FAULT_SHARD = 5, OLMC_PROBE_TUNE_FORCE_NV = 6, OLMC_PROBE_TUNE_MULTI_REHEARSAL = 11 };
 int olmc_probe_tune(int knob, int value);
 

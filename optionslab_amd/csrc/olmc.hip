@@ -2182,15 +2182,27 @@ int engine_wait(MultiEngine* e) {
 void pool_forget_stream(int dev, hipStream_t stream) {
     DevicePool* pool = g_pool[dev].load(std::memory_order_acquire);
     if (!pool) return;
-    std::unique_lock<std::mutex> lock(pool->mu);
-    pool->idle.wait(lock, [&] { return std::none_of(pool->all.begin(), pool->all.end(), [](const DeviceCtx* c) { return c->busy; }); });
-    for (DeviceCtx* c : pool->all)
-        for (int i = 0; i < DeviceCtx::kSlots; ++i) {
-            DeviceCtx::WsSlot& sl = c->slots[i];
+    // context by context: each is taken out of circulation for the moment its slots are looked at (a wait bounded by one call's
+    // duration).  Waiting for ALL contexts to be idle at once could starve behind two busy callers that never pause together.
+    for (size_t i = 0;; ++i) {
+        DeviceCtx* c = nullptr;
+        {
+            std::unique_lock<std::mutex> lock(pool->mu);
+            if (i >= pool->all.size()) break;
+            c = pool->all[i];
+            pool->idle.wait(lock, [&] { return !c->busy; });
+            c->busy = true;
+        }
+        for (int k = 0; k < DeviceCtx::kSlots; ++k) {
+            DeviceCtx::WsSlot& sl = c->slots[k];
             if (sl.claimed && !sl.shared && sl.owner == stream) { sl.claimed = false; sl.owner = nullptr; sl.used = false; }
         }
-    lock.unlock();
-    pool->idle.notify_all();                        // lease waiters share the condition variable with this wait
+        {
+            std::lock_guard<std::mutex> lock(pool->mu);
+            c->busy = false;
+        }
+        pool->idle.notify_all();                    // lease waiters share the condition variable with this wait
+    }
 }
 
 void engine_destroy(MultiEngine* e) {

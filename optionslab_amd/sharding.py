@@ -6,6 +6,7 @@
     control_variate_sharded     the five moments + n                                        count = 6
     price_sharded               any entry point that takes (path_offset, n_local): Asian, barrier, lookback,
                                 autocallable, cliquet, Heston, jump diffusion               count = 3
+    qmc_sharded                 MCMethod.QMC: contiguous blocks of Sobol POINTS (gbm_qmc.py:14-46)        count = 3
 
 Global path index g in [0, N); rank k of P owns the contiguous block
 [k*N/P, (k+1)*N/P).  The Philox counter carries g, so every path's normals are
@@ -108,6 +109,19 @@ def price_sharded(shard_fn, n_paths_global: int, r_discount: float, T: float, gr
     s, ss, n = _allreduce_list([st.sum, st.sumsq, float(st.n)], group)
     price, se = finalize(s, ss, int(n), r_discount, T)
     return price, se, int(n)
+
+
+def qmc_sharded(S, K, T, r, sigma, option_type, q, n_points_global: int, n_steps: int, seed: int, group=None, shard_fn=None):
+    """MonteCarloPricer(method=MCMethod.QMC).price over sharded POINTS (src/simulation/gbm_qmc.py:14-46): rank k prices points
+    [k N / P, (k + 1) N / P) of the one scrambled Sobol sequence through the kernels' point offset -- the same points whatever P is --
+    and the ranks' (sum, sumsq, n) meet in one all-reduce.  `shard_fn(lo, n_local)` -> an object with (.sum, .sumsq, .n) defaults to
+    the device kernel (tests inject the oracle).  The single-process form is olmc_multi_gpu_european_qmc."""
+    if shard_fn is None:
+        from .monte_carlo import sobol_tables
+
+        sv, shift = sobol_tables(n_steps, seed, n_points_global)
+        shard_fn = lambda lo, n: _hip.european_qmc(S, K, T, r, sigma, q, option_type == "call", n, sv, shift, point_offset=lo)   # noqa: E731
+    return price_sharded(shard_fn, n_points_global, r, T, group)
 
 
 class _Recorder:

@@ -896,6 +896,9 @@ def test_sharded_price_through_process_group_single_rank():
                                                 300_000, ATM[3], ATM[2])
         want = _hip.asian(*ATM, 0.0, True, False, 300_000, 21, 11, False)
         assert (ap, an) == (want.price, want.n) and ase == pytest.approx(want.std_error, rel=1e-12)
+        qp, qse, qn = ol.sharding.qmc_sharded(*ATM, "call", 0.0, 1 << 15, 16, 42)          # Sobol points through the same helpers (device kernel)
+        qwant = ol.MonteCarloPricer(1 << 15, 16, 42, ol.MCMethod.QMC).price(*ATM, "call", return_error=True)
+        assert (qp, qn) == (qwant.price, qwant.n_paths) and qse == pytest.approx(qwant.std_error, rel=1e-12)
     finally:
         dist.destroy_process_group()
 

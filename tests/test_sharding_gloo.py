@@ -44,6 +44,22 @@ def _checker_cv(lo, n_local):
     return types.SimpleNamespace(sum_d=disc * sx, sum_s=ss, sum_dd=disc * disc * sxx, sum_ss=sss, sum_ds=disc * sxs, n=n)
 
 
+QMC_N, QMC_M = 1000, 5             # not a power of two: ragged blocks of the sequence
+
+
+def _oracle_qmc_shard(lo, n_local):
+    import warnings
+
+    import numpy as np
+
+    from oracle import numpy_reference as orc
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        st = orc.terminal_sobol(ARGS["S"], ARGS["T"], ARGS["r"], ARGS["sigma"], ARGS["q"], QMC_N, QMC_M, SEED)[lo:lo + n_local]
+    x = np.maximum(st - ARGS["K"], 0.0)
+    return _Triple(float(x.sum()), float((x * x).sum()), n_local)
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     import torch
@@ -69,8 +85,12 @@ def _worker(rank, world, port, out_dir):
     asian = sharding.price_sharded(lambda lo_, n_: _Triple(*po.asian_moments(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"],
                                                                              ARGS["q"], True, False, n_, M, SEED, False, lo_)),
                                    N, ARGS["r"], ARGS["T"])
+    # Sobol points shard like paths (gbm_qmc.py:14-46): rank k takes points [k N / P, (k + 1) N / P) of the one sequence (the NumPy
+    # oracle -- SciPy's own engine -- stands in for the device kernel's point offset)
+    qmc = sharding.qmc_sharded(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], "call", ARGS["q"], QMC_N, QMC_M, SEED,
+                               shard_fn=_oracle_qmc_shard)
     with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
-        f.write(repr((lo, hi, price, se, int(t[2].item()), dict(greeks), cv, asian)))
+        f.write(repr((lo, hi, price, se, int(t[2].item()), dict(greeks), cv, asian, qmc)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -122,6 +142,10 @@ def test_two_rank_gloo_allreduce_reproduces_unsharded_price(tmp_path):
     am = po.asian_moments(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], ARGS["q"], True, False, N, M, SEED, False, 0)
     ap, ase = po.price_and_error(am[0], am[1], am[2], ARGS["r"], ARGS["T"])
     assert got[0][7][0] == pytest.approx(ap, rel=1e-13) and got[0][7][1] == pytest.approx(ase, rel=1e-10) and got[0][7][2] == N
+    whole_qmc = sharding.qmc_sharded(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], "call", ARGS["q"], QMC_N, QMC_M, SEED,
+                                     shard_fn=_oracle_qmc_shard)                  # world = 1: the whole sequence in one block
+    assert got[0][8][2] == whole_qmc[2] == QMC_N and got[0][8][0] == pytest.approx(whole_qmc[0], rel=1e-13) and got[0][8][1] == pytest.approx(whole_qmc[1], rel=1e-10)
+    assert abs(whole_qmc[0] - 10.450583572185565) < 0.5
 
 
 def test_finalize_matches_reference_formula():

@@ -1803,18 +1803,24 @@ int qmc_check(const uint32_t* sv, const uint32_t* shift, int32_t bits, int32_t d
 
 // gbm_qmc.py:38-44 as an olmc_option -> Contract: dt = T / dims, a = ln S + drift dims, vol = sigma sqrt(dt) = make_contract(o, dims)
 // Launch shape of a Sobol kernel.  From 2^20 points on (measured crossover between 2^19 and 2^20) a thread takes an aligned block of
-// eight consecutive points; up to 2^18 points (the interactive sizes: 2,048 waves of one-point threads at 2^17 points leave the vector
-// unit idle 30 % of the time) a workgroup takes 64 points and each of its four waves a quarter of the dimensions; between the two, one
-// point per thread.  OLMC_TUNE_QMC_BLOCK: 1 = always eight points per thread, -1 = never eight and never split (one point per thread).
+// eight consecutive points; below, a workgroup takes 64 points and each of its four waves a quarter of the dimensions (from 16
+// dimensions on; round 4 drew that line at 2^18 points and ran one point per thread in between).  OLMC_TUNE_QMC_BLOCK: 1 = always
+// eight points per thread, -1 = never eight and never split (one point per thread).
 struct QmcShape {
-    bool blocks, split;
+    bool blocks, split, aligned;
     int64_t units;       // threads' worth of work: blocks of eight, or points
     int32_t grid;
 };
 QmcShape qmc_shape(int64_t point_offset, int64_t n_paths, int32_t dims) {
     QmcShape sh;
+    // split workgroups whose 64 lanes are a 64-ALIGNED block of points form the high Gray bits' XOR on the scalar unit and keep the
+    // inverse normal's coefficients in vector registers (olmc_kernels.h qmc_point_sum<true>): 2^17 x 252 119 -> 100 us.  The
+    // coefficients' load is a fixed cost per wave: it pays from 64 dimensions on (16 per wave; 2^14 x 32: 10.5 -> 10.8 us, 2^16 x 64:
+    // 24.1 -> 22.0).  With it the split form beats one point per thread up to where eight points per thread take over (2^19 x 252:
+    // 451 -> 353 us, 2^19 x 64: 122 -> 104), so the one-point form is left to launches of fewer than 16 dimensions and to the knob
+    sh.aligned = (point_offset & 63) == 0 && dims >= 64;
     sh.blocks = g_qmc_block > 0 ? true : (g_qmc_block < 0 ? false : n_paths >= (int64_t(1) << 20));
-    sh.split = !sh.blocks && g_qmc_block == 0 && n_paths <= (int64_t(1) << 18) && dims >= 16;
+    sh.split = !sh.blocks && g_qmc_block == 0 && dims >= 16;     // every launch below 2^20 points (round 4: up to 2^18; the aligned form moved the crossover)
     sh.units = sh.blocks ? (point_offset + n_paths + kQmcBlock - 1) / kQmcBlock - point_offset / kQmcBlock : n_paths;
     sh.grid = sh.split ? static_cast<int32_t>((n_paths + kWave - 1) / kWave) : grid_for(sh.units);
     return sh;
@@ -1874,6 +1880,7 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
         rc = prof_pair(c, &ep, &timed);
         if (rc) return rc;
         if (blocks) launch_timed(european_qmc_block_kernel<kControlVariate>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else if (sh.split && sh.aligned) launch_timed(european_qmc_kernel<kControlVariate, true, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
         else if (sh.split) launch_timed(european_qmc_kernel<kControlVariate, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
         else launch_timed(european_qmc_kernel<kControlVariate, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
     } else if (!terminal_host) {
@@ -1883,11 +1890,13 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
         rc = prof_pair(c, &ep, &timed);
         if (rc) return rc;
         if (blocks) launch_timed(european_qmc_block_kernel<kReduce>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
-        else if (sh.split) launch_timed(european_qmc_kernel<kReduce, true>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
-        else launch_timed(european_qmc_kernel<kReduce, false>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else if (sh.split && sh.aligned) launch_timed(european_qmc_kernel<kReduce, true, true>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else if (sh.split) launch_timed(european_qmc_kernel<kReduce, true, false>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else launch_timed(european_qmc_kernel<kReduce, false, false>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
         if (d_triple) return after_launch(c, s);
     } else {
         if (blocks) hipLaunchKernelGGL((european_qmc_block_kernel<kTerminal>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
+        else if (sh.split && sh.aligned) hipLaunchKernelGGL((european_qmc_kernel<kTerminal, true, true>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
         else if (sh.split) hipLaunchKernelGGL((european_qmc_kernel<kTerminal, true>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
         else hipLaunchKernelGGL((european_qmc_kernel<kTerminal, false>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
     }
@@ -1981,12 +1990,14 @@ int run_qmc_batch(const olmc_option* opts, int32_t k, int64_t point_offset, int6
         ContractSet<8> cs;
         group_contracts<8>(opts, k, dims, &cs, pos);
         if (blocks) launch_timed(european_qmc_batch_kernel<8, true, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+        else if (sh.split && sh.aligned) launch_timed(european_qmc_batch_kernel<8, false, true, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
         else if (sh.split) launch_timed(european_qmc_batch_kernel<8, false, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
         else launch_timed(european_qmc_batch_kernel<8, false, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
     } else {
         ContractSet<16> cs;
         group_contracts<16>(opts, k, dims, &cs, pos);
         if (blocks) launch_timed(european_qmc_batch_kernel<16, true, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+        else if (sh.split && sh.aligned) launch_timed(european_qmc_batch_kernel<16, false, true, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
         else if (sh.split) launch_timed(european_qmc_batch_kernel<16, false, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
         else launch_timed(european_qmc_batch_kernel<16, false, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
     }

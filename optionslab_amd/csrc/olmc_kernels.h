@@ -2441,6 +2441,54 @@ __device__ __forceinline__ double ndtri_w(double p, int z_tail = 0) {
     return 1.4142135623730951 * x * f;
 }
 
+// The main branch's coefficients held in VECTOR registers by the caller (the aligned one-point Sobol kernels, whose 24 fewer lane
+// masks leave the room): every fma then reads three VGPRs -- no scalar-operand limit, no coefficient spilled to lanes and fetched
+// back by v_readlane_b32.  Same operations in the same order as ndtri_w: the same bits.
+struct NdtriRegs {
+    double a[25], q[7];
+    __device__ __forceinline__ void load() {
+#pragma unroll
+        for (int k = 0; k < 25; ++k) { a[k] = kNdtriA[k]; asm volatile("" : "+v"(a[k])); }
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { q[k] = kLogQ[k]; asm volatile("" : "+v"(q[k])); }
+    }
+};
+
+__device__ __forceinline__ double ndtri_w_regs(double p, const NdtriRegs& c, int z_tail) {
+    const double x = 2.0 * p - 1.0;
+    const double t4 = 4.0 * p * (1.0 - p);
+    // neg_log_unit(t4) with its seven coefficients from registers
+    double m = __builtin_amdgcn_frexp_mant(t4);
+    int e = __builtin_amdgcn_frexp_exp(t4);
+    const bool low = m < 0.70710678118654752;
+    m = low ? m + m : m;
+    e = low ? e - 1 : e;
+    const double num = m - 1.0, den = m + 1.0;
+    double r = __builtin_amdgcn_rcp(den);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    double s = num * r;
+    s = __builtin_fma(__builtin_fma(-den, s, num), r, s);
+    const double u = s * s;
+    double q = c.q[6];
+#pragma unroll
+    for (int k = 5; k >= 0; --k) q = __builtin_fma(q, u, c.q[k]);
+    const double ln_m = __builtin_fma(s * u, q, s + s);
+    const double ed = static_cast<double>(e);
+    const double w = -__builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, ln_m));
+    double f;
+    if (w < kNdtriSplit) {
+        const double t = w - kNdtriCentreA;
+        f = c.a[24];
+#pragma unroll
+        for (int k = 23; k >= 0; --k) f = __builtin_fma(f, t, c.a[k]);
+    } else {
+        asm volatile("");
+        f = ndtri_tail(w, z_tail);
+    }
+    return 1.4142135623730951 * x * f;
+}
+
 // fma(a, b, c) with the addend taken straight from a scalar register pair (VOP3).  Left to itself hipcc copies a freshly s_load-ed
 // coefficient into a VGPR pair (two v_mov_b32) so that it can use the two-address v_fmac_f64.
 __device__ __forceinline__ double fma_scalar_addend(double a, double b, double c_uniform) {
@@ -2507,14 +2555,44 @@ __device__ __forceinline__ int32_t qmc_quarter_begin(int32_t dims, int w) {
 }
 
 // Sum of the inverse normals of one Sobol point over the dimensions [t0, t1).
+//
+// UNIFORM_HI (round 5): the 64 lanes of the wave hold the 64 CONSECUTIVE points of a 64-aligned block, so bits 6 .. 29 of their
+// Gray codes are the same in every lane (gray bit b = k_b ^ k_{b+1}).  The XOR of the direction numbers those bits select is then one
+// number per wave and dimension -- formed on the SCALAR unit from the scalar-loaded row (`gray_hi` comes from v_readfirstlane), next
+// to the digital shift, which is scalar anyway -- and only the six low bits are left to the vector unit: 6 + 1 v_bitop3_b32 per
+// point and dimension instead of 30 (each with an SGPR operand: 4 issue cycles), and 6 lane masks in registers instead of 30.
+template <bool UNIFORM_HI = false>
 __device__ __forceinline__ double qmc_point_sum(const uint32_t (&mask)[kSobolBits], int32_t t0, int32_t t1, const uint32_t* __restrict__ sv,
-                                                const uint32_t* __restrict__ shift) {
+                                                const uint32_t* __restrict__ shift, uint32_t gray_hi = 0u /* wave-uniform; UNIFORM_HI only */,
+                                                const NdtriRegs* regs = nullptr /* UNIFORM_HI only */) {
     double q = 0.0;
+    uint64_t hi_pairs[12] = {};
+    if constexpr (UNIFORM_HI) {
+#pragma unroll
+        for (int j = 0; j < 12; ++j)
+            hi_pairs[j] = static_cast<uint64_t>(0u - ((gray_hi >> (6 + 2 * j)) & 1u)) | (static_cast<uint64_t>(0u - ((gray_hi >> (7 + 2 * j)) & 1u)) << 32);
+    }
     for (int32_t t = t0; t < t1; ++t) {
         const uint32_t* __restrict__ row = sv + static_cast<size_t>(t) * kSobolBits;
         uint32_t x = shift[t];
+        if constexpr (UNIFORM_HI) {
+            // scalar unit, two direction numbers at a time: rows 6 .. 29 are twelve 8-byte-aligned pairs (a row starts 120 t + 24 bytes
+            // into the table), the wave's pair masks were formed once (hi_pairs)
+            const uint64_t* __restrict__ row64 = reinterpret_cast<const uint64_t*>(row + 6);
+            uint64_t acc = 0;
 #pragma unroll
-        for (int b = 0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);   // x ^ (row & mask), one v_bitop3_b32
+            for (int j = 0; j < 12; ++j) acc ^= row64[j] & hi_pairs[j];
+            x ^= static_cast<uint32_t>(acc) ^ static_cast<uint32_t>(acc >> 32);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);
+            double u = static_cast<double>(x) * 9.313225746154785e-10;      // 2^-30
+            u = fmin(fmax(u, 1e-10), 1.0 - 1e-10);
+            q += ndtri_w_regs(u, *regs, opaque_zero());
+            continue;
+        } else {
+#pragma unroll
+            for (int b = 0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);   // x ^ (row & mask), one v_bitop3_b32
+        }
         double u = static_cast<double>(x) * 9.313225746154785e-10;      // 2^-30
         u = fmin(fmax(u, 1e-10), 1.0 - 1e-10);
         q += ndtri_w(u, opaque_zero());
@@ -2524,12 +2602,18 @@ __device__ __forceinline__ double qmc_point_sum(const uint32_t (&mask)[kSobolBit
 
 // Contract::a = ln S + drift * dims, Contract::vol = sigma sqrt(T / dims) (gbm_qmc.py:38-44).
 //
-// SPLIT (round 4; launches of at most 2^18 points, the sizes an interactive caller uses): a workgroup owns 64 points and each of
+// SPLIT (round 4: launches of at most 2^18 points; round 5: every launch below 2^20 points): a workgroup owns 64 points and each of
 // its four waves walks a QUARTER of the dimensions -- the split workgroups of the pseudo-random kernel.  A 2^17-point launch is
 // 2,048 waves of one-point threads, two per SIMD, each a serial chain of ~45 dependent fp64 operations per dimension: the vector
 // unit idles 30 % of the time (`frac_valu_active_pmc` 0.70, profiles/r04_bench_detail.json).  Split, the same launch is 8,192 waves
 // of a quarter of the length.  The quarter sums meet in LDS, wave 0 adds them in the canonical order and prices the point.
-template <int MODE, bool SPLIT = false>
+// ALIGNED (round 5; SPLIT launches whose point offset is a multiple of 64, from 64 dimensions on): qmc_point_sum<true> -- the wave's
+// lanes are an aligned block of 64 points, the direction numbers of Gray bits 6 .. 29 are folded on the scalar unit (twelve 64-bit
+// and / xor pairs per dimension), six v_bitop3_b32 are left per point and dimension, and with 24 lane masks fewer the inverse
+// normal's 32 coefficients live in vector registers (no v_readlane spill traffic): 110 -> 75 vector instructions per point and
+// dimension, 63 -> 102 VGPRs.  2^17 x 252: 119 -> 100 us; the 14-contract Greeks 132 -> 109; same bits.  The one-point form
+// (SPLIT = false) keeps its 30 lane masks: its aligned variant needed 191 VGPRs and lost.
+template <int MODE, bool SPLIT = false, bool ALIGNED = false /* qr.first is a multiple of 64: a wave's lanes are an aligned block of points */>
 __global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contract c, const uint32_t* __restrict__ sv,
                                                               const uint32_t* __restrict__ shift, ReduceWs ws,
                                                               double* __restrict__ terminal) {
@@ -2548,12 +2632,16 @@ __global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contr
         __shared__ double quarter_sum[kWavesPerBlock][kWave];
         const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / kWave), lane = threadIdx.x & (kWave - 1);
         const int64_t i = static_cast<int64_t>(blockIdx.x) * kWave + lane;             // the grid covers every point (host guarantee)
-        const uint64_t k = qr.first + static_cast<uint64_t>(i < qr.count ? i : 0);
+        // a dead lane of the last workgroup keeps ITS index in the aligned form (its sum is never used; the wave's high bits stay uniform)
+        const uint64_t k = qr.first + static_cast<uint64_t>((ALIGNED || i < qr.count) ? i : 0);
         const uint32_t gray = static_cast<uint32_t>(k ^ (k >> 1));
         uint32_t mask[kSobolBits];
 #pragma unroll
         for (int b = 0; b < kSobolBits; ++b) mask[b] = 0u - ((gray >> b) & 1u);
-        quarter_sum[wave][lane] = qmc_point_sum(mask, qmc_quarter_begin(qr.dims, wave), qmc_quarter_begin(qr.dims, wave + 1), sv, shift);
+        const uint32_t gray_hi = ALIGNED ? static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gray))) : 0u;
+        NdtriRegs regs;
+        if constexpr (ALIGNED) regs.load();
+        quarter_sum[wave][lane] = qmc_point_sum<ALIGNED>(mask, qmc_quarter_begin(qr.dims, wave), qmc_quarter_begin(qr.dims, wave + 1), sv, shift, gray_hi, &regs);
         __syncthreads();
         if (wave == 0 && i < qr.count)
             price_point(i, ((quarter_sum[0][lane] + quarter_sum[1][lane]) + quarter_sum[2][lane]) + quarter_sum[3][lane]);
@@ -2565,9 +2653,12 @@ __global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contr
             uint32_t mask[kSobolBits];
 #pragma unroll
             for (int b = 0; b < kSobolBits; ++b) mask[b] = 0u - ((gray >> b) & 1u);
+            const uint32_t gray_hi = ALIGNED ? static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gray))) : 0u;
+            NdtriRegs regs;
+            if constexpr (ALIGNED) regs.load();
             double zsum = 0.0;
 #pragma unroll 1
-            for (int w = 0; w < 4; ++w) zsum += qmc_point_sum(mask, qmc_quarter_begin(qr.dims, w), qmc_quarter_begin(qr.dims, w + 1), sv, shift);
+            for (int w = 0; w < 4; ++w) zsum += qmc_point_sum<ALIGNED>(mask, qmc_quarter_begin(qr.dims, w), qmc_quarter_begin(qr.dims, w + 1), sv, shift, gray_hi, &regs);
             price_point(i, zsum);
         }
     }
@@ -2665,23 +2756,29 @@ __global__ __launch_bounds__(kBlock) void european_qmc_block_kernel(QmcRange qr,
 // does for it alone; a contract that shares its vol with a base takes scale * S_T(base) (2-3 ulp from its own exp).
 // BLOCK8 = the eight-points-per-thread expansion of european_qmc_block_kernel.  The grid covers every point / block (host
 // guarantee), so the 2 NSETS sums are born after the dimension loop.
-template <int NSETS, bool BLOCK8, bool SPLIT = false>
+template <int NSETS, bool BLOCK8, bool SPLIT = false, bool ALIGNED = false /* SPLIT only: qr.first is a multiple of 64 (qmc_point_sum<true>) */>
 __global__ __launch_bounds__(kBlock) void european_qmc_batch_kernel(QmcRange qr, ContractSet<NSETS> cs, const uint32_t* __restrict__ sv,
                                                                     const uint32_t* __restrict__ shift, ReduceWs ws) {
     static_assert(!(BLOCK8 && SPLIT), "a thread either carries eight points or a quarter of one point's dimensions");
+    static_assert(SPLIT || !ALIGNED, "the aligned form exists for split workgroups");
     constexpr int NV = 2 * NSETS;
     double acc[NV];
     if constexpr (SPLIT) {
-        // 64 points per workgroup, a quarter of the dimensions per wave (european_qmc_kernel<., true>): launches of <= 2^18 points
+        // 64 points per workgroup, a quarter of the dimensions per wave (european_qmc_kernel<., true>): launches below 2^20 points
         __shared__ double quarter_sum[kWavesPerBlock][kWave];
         const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / kWave), lane = threadIdx.x & (kWave - 1);
         const int64_t i = static_cast<int64_t>(blockIdx.x) * kWave + lane;
-        const uint64_t k = qr.first + static_cast<uint64_t>(i < qr.count ? i : 0);
+        const uint64_t k = qr.first + static_cast<uint64_t>((ALIGNED || i < qr.count) ? i : 0);
         const uint32_t gray = static_cast<uint32_t>(k ^ (k >> 1));
         uint32_t mask[kSobolBits];
 #pragma unroll
         for (int b = 0; b < kSobolBits; ++b) mask[b] = 0u - ((gray >> b) & 1u);
-        quarter_sum[wave][lane] = qmc_point_sum(mask, qmc_quarter_begin(qr.dims, wave), qmc_quarter_begin(qr.dims, wave + 1), sv, shift);
+        const uint32_t gray_hi = ALIGNED ? static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gray))) : 0u;
+        {
+            NdtriRegs regs;             // dead after the dimension loop: the contracts' epilogue gets the registers back
+            if constexpr (ALIGNED) regs.load();
+            quarter_sum[wave][lane] = qmc_point_sum<ALIGNED>(mask, qmc_quarter_begin(qr.dims, wave), qmc_quarter_begin(qr.dims, wave + 1), sv, shift, gray_hi, &regs);
+        }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NV; ++j) acc[j] = 0.0;

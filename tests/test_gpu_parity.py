@@ -1021,14 +1021,18 @@ def test_qmc_eight_point_blocks_give_the_same_points():
 
 
 def test_qmc_split_workgroups_return_the_bits_of_one_point_threads():
-    """Round 4: launches of <= 2^18 Sobol points with >= 16 dimensions give 64 points to a workgroup and a quarter of the dimensions
-    to each of its four waves (european_qmc_kernel<., true>, european_qmc_batch_kernel<., false, true>).  Every Sobol kernel adds a
-    point's inverse normals in the same association (quarters), so the split form must return the one-point form's terminal prices bit
-    for bit -- ragged point counts around the 64-point workgroup, dimension counts that do not divide by four, point offsets -- and the
-    same sums to reduction-order rounding, for the price, the control variate and the fused Greeks."""
+    """Launches of fewer than 2^20 Sobol points (round 4: up to 2^18) with >= 16 dimensions give 64 points to a workgroup and a quarter
+    of the dimensions to each of its four waves (european_qmc_kernel<., true>, european_qmc_batch_kernel<., false, true>).  Every Sobol
+    kernel adds a point's inverse normals in the same association (quarters), so the split form must return the one-point form's
+    terminal prices bit for bit -- ragged point counts around the 64-point workgroup, dimension counts that do not divide by four,
+    point offsets -- and the same sums to reduction-order rounding, for the price, the control variate and the fused Greeks.
+    Round 5: where the point offset is a multiple of 64 and there are >= 64 dimensions, the ALIGNED form runs (the direction numbers of
+    Gray bits 6 .. 29 folded on the scalar unit, the inverse normal's coefficients in vector registers): the cases with offsets 0, 64,
+    640 and 1 << 20 and 64+ dimensions -- ragged last workgroups included (dead lanes keep their index) -- hold it to the same bits."""
     S, K, T, r, v = ATM
     try:
-        for N, M, off in ((1, 16, 0), (63, 17, 0), (64, 18, 5), (65, 19, 64), (1000, 33, 3), (4097, 252, 12345), (70_001, 63, 1), (1 << 18, 16, 0)):
+        for N, M, off in ((1, 16, 0), (63, 17, 0), (64, 18, 5), (65, 19, 64), (1000, 33, 3), (4097, 252, 12345), (70_001, 63, 1), (1 << 18, 16, 0),
+                          (1, 64, 0), (1000, 64, 0), (4097, 252, 0), (70_001, 65, 640), (300_000, 64, 64), ((1 << 19) + 17, 70, 1 << 20), (65, 100, 63)):
             tables = ol.monte_carlo.sobol_tables(M, 11)
             _hip.tune(_hip.TUNE_QMC_BLOCK, -1)                       # one point per thread, never split
             one = _hip.european_qmc_terminal(S, T, r, v, 0.01, N, *tables, point_offset=off)

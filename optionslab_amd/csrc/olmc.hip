@@ -1807,7 +1807,7 @@ int qmc_check(const uint32_t* sv, const uint32_t* shift, int32_t bits, int32_t d
 // dimensions on; round 4 drew that line at 2^18 points and ran one point per thread in between).  OLMC_TUNE_QMC_BLOCK: 1 = always
 // eight points per thread, -1 = never eight and never split (one point per thread).
 struct QmcShape {
-    bool blocks, split, aligned;
+    bool blocks, split, aligned, aligned8;
     int64_t units;       // threads' worth of work: blocks of eight, or points
     int32_t grid;
 };
@@ -1819,6 +1819,7 @@ QmcShape qmc_shape(int64_t point_offset, int64_t n_paths, int32_t dims) {
     // 24.1 -> 22.0).  With it the split form beats one point per thread up to where eight points per thread take over (2^19 x 252:
     // 451 -> 353 us, 2^19 x 64: 122 -> 104), so the one-point form is left to launches of fewer than 16 dimensions and to the knob
     sh.aligned = (point_offset & 63) == 0 && dims >= 64;
+    sh.aligned8 = (point_offset & 511) == 0;        // eight points per thread: a wave's 64 blocks start at a multiple of 512 points
     sh.blocks = g_qmc_block > 0 ? true : (g_qmc_block < 0 ? false : n_paths >= (int64_t(1) << 20));
     sh.split = !sh.blocks && g_qmc_block == 0 && dims >= 16;     // every launch below 2^20 points (round 4: up to 2^18; the aligned form moved the crossover)
     sh.units = sh.blocks ? (point_offset + n_paths + kQmcBlock - 1) / kQmcBlock - point_offset / kQmcBlock : n_paths;
@@ -1879,7 +1880,8 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
         if (rc) return rc;
         rc = prof_pair(c, &ep, &timed);
         if (rc) return rc;
-        if (blocks) launch_timed(european_qmc_block_kernel<kControlVariate>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        if (blocks && sh.aligned8) launch_timed(european_qmc_block_kernel<kControlVariate, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else if (blocks) launch_timed(european_qmc_block_kernel<kControlVariate, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
         else if (sh.split && sh.aligned) launch_timed(european_qmc_kernel<kControlVariate, true, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
         else if (sh.split) launch_timed(european_qmc_kernel<kControlVariate, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
         else launch_timed(european_qmc_kernel<kControlVariate, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
@@ -1889,13 +1891,15 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
         if (rc) return rc;
         rc = prof_pair(c, &ep, &timed);
         if (rc) return rc;
-        if (blocks) launch_timed(european_qmc_block_kernel<kReduce>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        if (blocks && sh.aligned8) launch_timed(european_qmc_block_kernel<kReduce, true>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else if (blocks) launch_timed(european_qmc_block_kernel<kReduce, false>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
         else if (sh.split && sh.aligned) launch_timed(european_qmc_kernel<kReduce, true, true>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
         else if (sh.split) launch_timed(european_qmc_kernel<kReduce, true, false>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
         else launch_timed(european_qmc_kernel<kReduce, false, false>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
         if (d_triple) return after_launch(c, s);
     } else {
-        if (blocks) hipLaunchKernelGGL((european_qmc_block_kernel<kTerminal>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
+        if (blocks && sh.aligned8) hipLaunchKernelGGL((european_qmc_block_kernel<kTerminal, true>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
+        else if (blocks) hipLaunchKernelGGL((european_qmc_block_kernel<kTerminal, false>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
         else if (sh.split && sh.aligned) hipLaunchKernelGGL((european_qmc_kernel<kTerminal, true, true>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
         else if (sh.split) hipLaunchKernelGGL((european_qmc_kernel<kTerminal, true>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
         else hipLaunchKernelGGL((european_qmc_kernel<kTerminal, false>), dim3(grid), dim3(kBlock), 0, c->stream, qr, ct, d_sv, d_shift, ws, d_term);
@@ -1989,14 +1993,16 @@ int run_qmc_batch(const olmc_option* opts, int32_t k, int64_t point_offset, int6
     if (nsets == 8) {
         ContractSet<8> cs;
         group_contracts<8>(opts, k, dims, &cs, pos);
-        if (blocks) launch_timed(european_qmc_batch_kernel<8, true, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+        if (blocks && sh.aligned8) launch_timed(european_qmc_batch_kernel<8, true, false, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+        else if (blocks) launch_timed(european_qmc_batch_kernel<8, true, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
         else if (sh.split && sh.aligned) launch_timed(european_qmc_batch_kernel<8, false, true, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
         else if (sh.split) launch_timed(european_qmc_batch_kernel<8, false, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
         else launch_timed(european_qmc_batch_kernel<8, false, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
     } else {
         ContractSet<16> cs;
         group_contracts<16>(opts, k, dims, &cs, pos);
-        if (blocks) launch_timed(european_qmc_batch_kernel<16, true, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+        if (blocks && sh.aligned8) launch_timed(european_qmc_batch_kernel<16, true, false, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+        else if (blocks) launch_timed(european_qmc_batch_kernel<16, true, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
         else if (sh.split && sh.aligned) launch_timed(european_qmc_batch_kernel<16, false, true, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
         else if (sh.split) launch_timed(european_qmc_batch_kernel<16, false, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
         else launch_timed(european_qmc_batch_kernel<16, false, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);

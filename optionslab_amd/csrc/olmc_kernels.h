@@ -2677,9 +2677,22 @@ constexpr int kQmcBlock = 8;
 // (its bits 0 and 1 are clear).  The running totals live in LDS between the quarters (each thread touches only its own column: no
 // barrier), so the dimension loop carries the eight quarter sums in registers and nothing else -- the epilogues walk the eight
 // points by a run-time index anyway, which registers do not offer.
-template <int B0>
+// UNIFORM_HI (round 5): the wave's 64 lanes carry 64 CONSECUTIVE blocks starting at a multiple of 512 points, so bits 9 .. 29 of
+// their first points' Gray codes are wave-uniform: those direction numbers are folded on the scalar unit (row 9 alone, rows 10 .. 29
+// as ten 8-byte-aligned pairs), bits 2 .. 8 stay vector work -- 7 + 7 v_bitop3_b32 / v_xor per dimension for eight points instead of
+// 28 + 7, and 21 lane masks fewer in registers.
+template <int B0, bool UNIFORM_HI = false>
 __device__ __forceinline__ void qmc_block_sums(const uint32_t (&mask)[kSobolBits], int32_t dims, const uint32_t* __restrict__ sv,
-                                               const uint32_t* __restrict__ shift, double (*zs)[kBlock]) {
+                                               const uint32_t* __restrict__ shift, double (*zs)[kBlock], uint32_t gray_hi = 0u) {
+    static_assert(!UNIFORM_HI || B0 == 2, "the scalar fold is laid out for blocks of eight");
+    uint64_t hi_pairs[10] = {};
+    uint32_t hi_9 = 0u;
+    if constexpr (UNIFORM_HI) {
+        hi_9 = 0u - ((gray_hi >> 9) & 1u);
+#pragma unroll
+        for (int j = 0; j < 10; ++j)
+            hi_pairs[j] = static_cast<uint64_t>(0u - ((gray_hi >> (10 + 2 * j)) & 1u)) | (static_cast<uint64_t>(0u - ((gray_hi >> (11 + 2 * j)) & 1u)) << 32);
+    }
 #pragma unroll
     for (int p = 0; p < kQmcBlock; ++p) zs[p][threadIdx.x] = 0.0;          // 0 + Q0 = Q0 exactly
 #pragma unroll 1
@@ -2692,8 +2705,18 @@ __device__ __forceinline__ void qmc_block_sums(const uint32_t (&mask)[kSobolBits
             const uint32_t* __restrict__ row = sv + static_cast<size_t>(t) * kSobolBits;
             uint32_t x = shift[t];
             const int z0 = opaque_zero();
+            if constexpr (UNIFORM_HI) {
+                const uint64_t* __restrict__ row64 = reinterpret_cast<const uint64_t*>(row + 10);     // 120 t + 40 bytes into the table: 8-byte aligned
+                uint64_t acc = 0;
 #pragma unroll
-            for (int b = B0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);
+                for (int j = 0; j < 10; ++j) acc ^= row64[j] & hi_pairs[j];
+                x ^= (row[9] & hi_9) ^ static_cast<uint32_t>(acc) ^ static_cast<uint32_t>(acc >> 32);
+#pragma unroll
+                for (int b = B0; b < 9; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);
+            } else {
+#pragma unroll
+                for (int b = B0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);
+            }
             double u[kQmcBlock], z[kQmcBlock];
 #pragma unroll
             for (int p = 0; p < kQmcBlock; ++p) {
@@ -2710,7 +2733,7 @@ __device__ __forceinline__ void qmc_block_sums(const uint32_t (&mask)[kSobolBits
     }
 }
 
-template <int MODE>
+template <int MODE, bool ALIGNED = false /* qr.first is a multiple of 512: a wave's lanes are 64 consecutive blocks of an aligned run */>
 __global__ __launch_bounds__(kBlock) void european_qmc_block_kernel(QmcRange qr, Contract c, const uint32_t* __restrict__ sv,
                                                                     const uint32_t* __restrict__ shift, ReduceWs ws,
                                                                     double* __restrict__ terminal) {
@@ -2729,7 +2752,7 @@ __global__ __launch_bounds__(kBlock) void european_qmc_block_kernel(QmcRange qr,
         // the eight exponentials one after the other (a real loop over the LDS-staged sums, as in european_qmc_batch_kernel): unrolled,
         // their interleaving set the kernel's register count
         __shared__ double zs[kQmcBlock][kBlock];
-        qmc_block_sums<2>(mask, qr.dims, sv, shift, zs);
+        qmc_block_sums<2, ALIGNED>(mask, qr.dims, sv, shift, zs, ALIGNED ? static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gray))) : 0u);
 #pragma unroll 1
         for (int p = 0; p < kQmcBlock; ++p) {
             const uint64_t k = k0 + static_cast<uint64_t>(p);
@@ -2756,11 +2779,11 @@ __global__ __launch_bounds__(kBlock) void european_qmc_block_kernel(QmcRange qr,
 // does for it alone; a contract that shares its vol with a base takes scale * S_T(base) (2-3 ulp from its own exp).
 // BLOCK8 = the eight-points-per-thread expansion of european_qmc_block_kernel.  The grid covers every point / block (host
 // guarantee), so the 2 NSETS sums are born after the dimension loop.
-template <int NSETS, bool BLOCK8, bool SPLIT = false, bool ALIGNED = false /* SPLIT only: qr.first is a multiple of 64 (qmc_point_sum<true>) */>
+template <int NSETS, bool BLOCK8, bool SPLIT = false, bool ALIGNED = false /* SPLIT: qr.first is a multiple of 64 (qmc_point_sum<true>); BLOCK8: of 512 (qmc_block_sums<2, true>) */>
 __global__ __launch_bounds__(kBlock) void european_qmc_batch_kernel(QmcRange qr, ContractSet<NSETS> cs, const uint32_t* __restrict__ sv,
                                                                     const uint32_t* __restrict__ shift, ReduceWs ws) {
     static_assert(!(BLOCK8 && SPLIT), "a thread either carries eight points or a quarter of one point's dimensions");
-    static_assert(SPLIT || !ALIGNED, "the aligned form exists for split workgroups");
+    static_assert(SPLIT || BLOCK8 || !ALIGNED, "the aligned forms exist for split workgroups and for blocks of eight");
     constexpr int NV = 2 * NSETS;
     double acc[NV];
     if constexpr (SPLIT) {
@@ -2792,13 +2815,13 @@ __global__ __launch_bounds__(kBlock) void european_qmc_batch_kernel(QmcRange qr,
         const uint64_t last = qr.first + static_cast<uint64_t>(qr.count);
         const int64_t n_units = static_cast<int64_t>((last + kQmcBlock - 1) / kQmcBlock - base);
         const bool unit_live = i < n_units;
-        const uint64_t k0 = (base + static_cast<uint64_t>(unit_live ? i : 0)) * kQmcBlock;
+        const uint64_t k0 = (base + static_cast<uint64_t>((ALIGNED || unit_live) ? i : 0)) * kQmcBlock;     // aligned: a dead lane keeps its index (uniform high bits)
         const uint32_t gray = static_cast<uint32_t>(k0 ^ (k0 >> 1));       // an aligned block of eight starts with gray bits 0 and 1 clear
         uint32_t mask[kSobolBits];
 #pragma unroll
         for (int b = 2; b < kSobolBits; ++b) mask[b] = 0u - ((gray >> b) & 1u);
         __shared__ double zs[kQmcBlock][kBlock];
-        qmc_block_sums<2>(mask, qr.dims, sv, shift, zs);
+        qmc_block_sums<2, ALIGNED>(mask, qr.dims, sv, shift, zs, ALIGNED ? static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(gray))) : 0u);
 #pragma unroll
         for (int j = 0; j < NV; ++j) acc[j] = 0.0;
         // The eight points of the thread are priced ONE AFTER THE OTHER by a real loop (round 4).  Unrolled, the compiler interleaved

@@ -35,7 +35,7 @@ KERNELS = {      # key in bench.py's JSON -> mangled-name regex
     "f_heston": r"^_ZN4olmc13heston_kernelILb0EEE",
     "f_multi": r"^_ZN4olmc21european_multi_kernelILb1EEE",
     "f_qmc": r"^_ZN4olmc19european_qmc_kernelILi0ELb1ELb1EEE",       # SPLIT, ALIGNED: what a launch below 2^20 points runs (bench.py's f_qmc workload: 2^17 x 252)
-    "f_qmc_block": r"^_ZN4olmc25european_qmc_block_kernelILi0EEE",
+    "f_qmc_block": r"^_ZN4olmc25european_qmc_block_kernelILi0ELb1EEE",
     # round 5: round 4's new kernels (VERDICT r4 "missing" 2) and the control-variate shape of the headline kernel
     "f_extrema_greeks14": r"^_ZN4olmc21extrema_greeks_kernelILb0ELi16EEE",
     "f_extrema_greeks14a": r"^_ZN4olmc21extrema_greeks_kernelILb1ELi16EEE",

@@ -2450,7 +2450,9 @@ struct NdtriRegs {
 #pragma unroll
         for (int k = 0; k < 25; ++k) { a[k] = kNdtriA[k]; asm volatile("" : "+v"(a[k])); }
 #pragma unroll
-        for (int k = 0; k < 7; ++k) { q[k] = kLogQ[k]; asm volatile("" : "+v"(q[k])); }
+        for (int k = 0; k < 7; ++k) q[k] = kLogQ[k];   // the logarithm's seven are left to the compiler (scalar where they fit):
+                                                        // 102 -> 88 VGPRs, one more wave per SIMD, 100 -> 97 us at 2^17 x 252.  Freeing
+                                                        // more of a[] (82, 69 VGPRs) brought the readlanes back and lost: r05_ab_kernels
     }
 };
 
@@ -2610,8 +2612,8 @@ __device__ __forceinline__ double qmc_point_sum(const uint32_t (&mask)[kSobolBit
 // ALIGNED (round 5; SPLIT launches whose point offset is a multiple of 64, from 64 dimensions on): qmc_point_sum<true> -- the wave's
 // lanes are an aligned block of 64 points, the direction numbers of Gray bits 6 .. 29 are folded on the scalar unit (twelve 64-bit
 // and / xor pairs per dimension), six v_bitop3_b32 are left per point and dimension, and with 24 lane masks fewer the inverse
-// normal's 32 coefficients live in vector registers (no v_readlane spill traffic): 110 -> 75 vector instructions per point and
-// dimension, 63 -> 102 VGPRs.  2^17 x 252: 119 -> 100 us; the 14-contract Greeks 132 -> 109; same bits.  The one-point form
+// normal's 25 main-branch coefficients live in vector registers (no v_readlane spill traffic): 110 -> 75 vector instructions per
+// point and dimension, 63 -> 88 VGPRs.  2^17 x 252: 119 -> 97 us; the 14-contract Greeks 132 -> 104; same bits.  The one-point form
 // (SPLIT = false) keeps its 30 lane masks: its aligned variant needed 191 VGPRs and lost.
 template <int MODE, bool SPLIT = false, bool ALIGNED = false /* qr.first is a multiple of 64: a wave's lanes are an aligned block of points */>
 __global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contract c, const uint32_t* __restrict__ sv,

@@ -21,6 +21,11 @@ int olmc_exp2_probe(const double* x_host, int64_t n, double* y_host);
 /* Either form the sources carry: form 0 = rint + degree-11 polynomial (round 2; <= 1.5 ulp), form 1 = 256-entry table of 2^(k/256)
  * in LDS + degree-4 correction (1 + r q(r), q cubic; <= 1.1 ulp measured) -- the one OLMC_AVG_ARITHMETIC uses. */
 int olmc_exp2_probe_form(const double* x_host, int64_t n, double* y_host, int form);
+/* The Sobol kernels' inverse normal (ndtri_w and its register / lockstep forms, olmc_kernels.h) on a host array of probabilities
+ * in [1e-10, 1 - 1e-10] (the clip of gbm_qmc.py:36): z[i] = Phi^-1(p[i]).  form 0 = one point, 1 = coefficients in registers,
+ * 2 = two in lockstep, 3 = eight in lockstep: the four must agree bit for bit (the Sobol kernels' sums do not depend on the launch
+ * shape because of it). */
+int olmc_ndtri_probe(const double* p_host, int64_t n, double* z_host, int form);
 /* Power sums of the normal stream: out4[m-1] = sum over paths and steps of z^m, m = 1..4 (fp64). */
 int olmc_normal_moments(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps, double* out4);
 

@@ -2392,11 +2392,25 @@ __device__ __forceinline__ int opaque_zero() {
 // The one-point-per-thread kernels (european_qmc_kernel, european_qmc_batch_kernel<., false>) call ndtri_w once per dimension: the
 // compiler keeps the 55 coefficients in scalar registers across the dimension loop (what does not fit next to the dimension's 30
 // direction numbers comes back through a few v_readlane_b32).
+// 2 m for m in [0.5, 1) where `twice`, else m: the exponent field plus one, on the high word alone (one 32-bit add and ONE select
+// where `low ? m + m : m` is an fp64 add and two selects).  Exact either way: the same bits.
+__device__ __forceinline__ double twice_if(double m, bool twice) {
+    const uint64_t b = static_cast<uint64_t>(__double_as_longlong(m));
+    const uint32_t hi = static_cast<uint32_t>(b >> 32) + (twice ? 0x00100000u : 0u);
+    return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | static_cast<uint32_t>(b)));
+}
+
+// A Sobol integer x < 2^30 as the reference's clipped uniform: clip(x 2^-30, 1e-10, 1 - 1e-10) (gbm_qmc.py:36).  The upper clip
+// can never bind -- the largest uniform is 1 - 2^-30 = 1 - 9.3e-10 -- so it is not computed; the lower one binds for x = 0 alone.
+__device__ __forceinline__ double sobol_uniform(uint32_t x) {
+    return fmax(static_cast<double>(x) * 9.313225746154785e-10, 1e-10);      // x 2^-30
+}
+
 __device__ __forceinline__ double neg_log_unit(double t) {
     double m = __builtin_amdgcn_frexp_mant(t);          // t = m 2^e, m in [0.5, 1)
     int e = __builtin_amdgcn_frexp_exp(t);
     const bool low = m < 0.70710678118654752;
-    m = low ? m + m : m;
+    m = twice_if(m, low);
     e = low ? e - 1 : e;
     const double num = m - 1.0, den = m + 1.0;
     double r = __builtin_amdgcn_rcp(den);
@@ -2423,7 +2437,7 @@ __device__ __forceinline__ double ndtri_tail(double w, int z = 0 /* see ndtri_lo
 }
 
 __device__ __forceinline__ double ndtri_w(double p, int z_tail = 0) {
-    const double x = 2.0 * p - 1.0;                    // exact for p = k 2^-30
+    const double x = __builtin_fma(p, 2.0, -1.0);      // = 2.0 * p - 1.0 bit for bit (2 p is exact), one instruction
     const double w = neg_log_unit(4.0 * p * (1.0 - p));        // p (1 - p) straight from p: no cancellation at either end
     double f;
     if (w < kNdtriSplit) {
@@ -2446,24 +2460,27 @@ __device__ __forceinline__ double ndtri_w(double p, int z_tail = 0) {
 // back by v_readlane_b32.  Same operations in the same order as ndtri_w: the same bits.
 struct NdtriRegs {
     double a[25], q[7];
+    // Which coefficients are pinned to vector registers (the rest is left to the compiler: scalar registers, rebuilt by s_mov
+    // where they do not fit): the two LEADING ones -- an fma takes one scalar operand, so a scalar leading coefficient next to a
+    // scalar addend costs a v_mov_b64 per point -- and the main polynomial's first kPinned.  All 25 pinned: 95 VGPRs; 12: 71 VGPRs,
+    // seven waves per SIMD, the fastest by 0.3 .. 1.5 % (profiles/r05_ab_kernels.txt: 25 / 16 / 12 / 8).
+    static constexpr int kPinned = 12;
     __device__ __forceinline__ void load() {
 #pragma unroll
-        for (int k = 0; k < 25; ++k) { a[k] = kNdtriA[k]; asm volatile("" : "+v"(a[k])); }
+        for (int k = 0; k < 25; ++k) { a[k] = kNdtriA[k]; if (k < kPinned || k == 24) asm volatile("" : "+v"(a[k])); }
 #pragma unroll
-        for (int k = 0; k < 7; ++k) q[k] = kLogQ[k];   // the logarithm's seven are left to the compiler (scalar where they fit):
-                                                        // 102 -> 88 VGPRs, one more wave per SIMD, 100 -> 97 us at 2^17 x 252.  Freeing
-                                                        // more of a[] (82, 69 VGPRs) brought the readlanes back and lost: r05_ab_kernels
+        for (int k = 0; k < 7; ++k) { q[k] = kLogQ[k]; if (k == 6) asm volatile("" : "+v"(q[k])); }
     }
 };
 
 __device__ __forceinline__ double ndtri_w_regs(double p, const NdtriRegs& c, int z_tail) {
-    const double x = 2.0 * p - 1.0;
+    const double x = __builtin_fma(p, 2.0, -1.0);
     const double t4 = 4.0 * p * (1.0 - p);
     // neg_log_unit(t4) with its seven coefficients from registers
     double m = __builtin_amdgcn_frexp_mant(t4);
     int e = __builtin_amdgcn_frexp_exp(t4);
     const bool low = m < 0.70710678118654752;
-    m = low ? m + m : m;
+    m = twice_if(m, low);
     e = low ? e - 1 : e;
     const double num = m - 1.0, den = m + 1.0;
     double r = __builtin_amdgcn_rcp(den);
@@ -2489,6 +2506,52 @@ __device__ __forceinline__ double ndtri_w_regs(double p, const NdtriRegs& c, int
         f = ndtri_tail(w, z_tail);
     }
     return 1.4142135623730951 * x * f;
+}
+
+// TWO inverse normals in lockstep from the same register-held coefficients (round 5: two consecutive dimensions of one point in the
+// aligned one-point Sobol kernels).  One point per thread left a wave a single chain of ~60 dependent fp64 operations per dimension,
+// and at five waves per SIMD the chains, not the issue port, set the pace.  Both logarithms and both main polynomials run as one
+// basic block here; a tail point is repaired afterwards behind a branch the wave almost always skips (as in ndtri_lockstep below).
+// Every point sees exactly the operations of ndtri_w: the same bits.
+__device__ __forceinline__ void ndtri_w_regs_pair(const double (&p)[2], double (&out)[2], const NdtriRegs& c, int z_tail) {
+    double w[2], f[2], t[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const double t4 = 4.0 * p[j] * (1.0 - p[j]);
+        double m = __builtin_amdgcn_frexp_mant(t4);
+        int e = __builtin_amdgcn_frexp_exp(t4);
+        const bool low = m < 0.70710678118654752;
+        m = twice_if(m, low);
+        e = low ? e - 1 : e;
+        const double num = m - 1.0, den = m + 1.0;
+        double r = __builtin_amdgcn_rcp(den);
+        r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+        r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+        double s = num * r;
+        s = __builtin_fma(__builtin_fma(-den, s, num), r, s);
+        const double u = s * s;
+        double q = c.q[6];
+#pragma unroll
+        for (int k = 5; k >= 0; --k) q = __builtin_fma(q, u, c.q[k]);
+        const double ln_m = __builtin_fma(s * u, q, s + s);
+        const double ed = static_cast<double>(e);
+        w[j] = -__builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, ln_m));
+        t[j] = w[j] - kNdtriCentreA;
+        f[j] = c.a[24];
+    }
+#pragma unroll
+    for (int k = 23; k >= 0; --k) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) f[j] = __builtin_fma(f[j], t[j], c.a[k]);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        if (!(w[j] < kNdtriSplit)) {
+            asm volatile("");                           // a real branch (see ndtri_w)
+            f[j] = ndtri_tail(w[j], z_tail);
+        }
+        out[j] = 1.4142135623730951 * __builtin_fma(p[j], 2.0, -1.0) * f[j];
+    }
 }
 
 // fma(a, b, c) with the addend taken straight from a scalar register pair (VOP3).  Left to itself hipcc copies a freshly s_load-ed
@@ -2538,7 +2601,7 @@ __device__ __forceinline__ void ndtri_lockstep(const double (&p)[NP], double (&o
             asm volatile("");                           // a real branch (see ndtri_w)
             f[j] = ndtri_tail(w[j], z);
         }
-        out[j] = 1.4142135623730951 * (2.0 * p[j] - 1.0) * f[j];
+        out[j] = 1.4142135623730951 * __builtin_fma(p[j], 2.0, -1.0) * f[j];
     }
 }
 
@@ -2568,35 +2631,72 @@ __device__ __forceinline__ double qmc_point_sum(const uint32_t (&mask)[kSobolBit
                                                 const uint32_t* __restrict__ shift, uint32_t gray_hi = 0u /* wave-uniform; UNIFORM_HI only */,
                                                 const NdtriRegs* regs = nullptr /* UNIFORM_HI only */) {
     double q = 0.0;
-    uint64_t hi_pairs[12] = {};
     if constexpr (UNIFORM_HI) {
+        // Lane-per-dimension fold (round 5, second form): for 64 dimensions at a time, lane l XORs rows 6 .. 29 of dimension c0 + l
+        // under the wave's Gray bits -- and the digital shift -- into ONE word: 24 vector and-xors per 64 dimensions where the
+        // scalar unit spent 24 and / xor per dimension behind a scalar load it had to wait for.  The dimension loop fetches only
+        // the six low rows, one trip AHEAD (s_load, no wait in front of its use).
+        const int lane = static_cast<int>(threadIdx.x) & (kWave - 1);
+        for (int32_t c0 = t0; c0 < t1; c0 += kWave) {
+            const int32_t cn = __builtin_amdgcn_readfirstlane(t1 - c0 < kWave ? t1 - c0 : kWave);
+            const int32_t tl = c0 + lane < t1 ? c0 + lane : t1 - 1;
+            const uint32_t* __restrict__ mine = sv + static_cast<size_t>(tl) * kSobolBits;
+            uint32_t fold = shift[tl];
 #pragma unroll
-        for (int j = 0; j < 12; ++j)
-            hi_pairs[j] = static_cast<uint64_t>(0u - ((gray_hi >> (6 + 2 * j)) & 1u)) | (static_cast<uint64_t>(0u - ((gray_hi >> (7 + 2 * j)) & 1u)) << 32);
+            for (int b = 6; b < kSobolBits; ++b) fold ^= mine[b] & (0u - ((gray_hi >> b) & 1u));
+            // two dimensions per trip (their inverse normals in lockstep: ndtri_w_regs_pair), added to q in dimension order.  A
+            // dimension's folded word reaches every lane through ds_bpermute_b32 (a broadcast of lane j, issued one trip ahead: no
+            // vector-unit instruction, where v_readlane_b32 + the v_mov_b32 its scalar result forced on the first row cost two).
+            int hop = 0;                                                            // byte address of lane j for ds_bpermute_b32
+            asm volatile("" : "+v"(hop));
+            uint32_t lo[2][6];
+            int xf[2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const uint32_t* __restrict__ row = sv + static_cast<size_t>(c0 + d < t1 ? c0 + d : c0) * kSobolBits;
+#pragma unroll
+                for (int b = 0; b < 6; ++b) lo[d][b] = row[b];
+                xf[d] = __builtin_amdgcn_ds_bpermute(hop + 4 * d, static_cast<int>(fold));
+            }
+            int32_t j = 0;
+            for (; j + 2 <= cn; j += 2) {
+                double u[2], z[2];
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    uint32_t x = static_cast<uint32_t>(xf[d]);
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) x = __builtin_amdgcn_bitop3_b32(x, lo[d][b], mask[b], 0x78);
+                    u[d] = sobol_uniform(x);
+                }
+                // the next trip's words and low rows, fetched now (lane indices wrap, dimensions are clamped: unused past the end)
+                hop += 8;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    xf[d] = __builtin_amdgcn_ds_bpermute(hop + 4 * d, static_cast<int>(fold));
+                    const int32_t tn = c0 + j + 2 + d < t1 ? c0 + j + 2 + d : t1 - 1;
+                    const uint32_t* __restrict__ next = sv + static_cast<size_t>(tn) * kSobolBits;
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) lo[d][b] = next[b];
+                }
+                ndtri_w_regs_pair(u, z, *regs, opaque_zero());
+                q += z[0];
+                q += z[1];
+            }
+            if (j < cn) {                                                           // an odd dimension left (xf[0], lo[0] are its)
+                uint32_t x = static_cast<uint32_t>(xf[0]);
+#pragma unroll
+                for (int b = 0; b < 6; ++b) x = __builtin_amdgcn_bitop3_b32(x, lo[0][b], mask[b], 0x78);
+                q += ndtri_w_regs(sobol_uniform(x), *regs, opaque_zero());
+            }
+        }
+        return q;
     }
     for (int32_t t = t0; t < t1; ++t) {
         const uint32_t* __restrict__ row = sv + static_cast<size_t>(t) * kSobolBits;
         uint32_t x = shift[t];
-        if constexpr (UNIFORM_HI) {
-            // scalar unit, two direction numbers at a time: rows 6 .. 29 are twelve 8-byte-aligned pairs (a row starts 120 t + 24 bytes
-            // into the table), the wave's pair masks were formed once (hi_pairs)
-            const uint64_t* __restrict__ row64 = reinterpret_cast<const uint64_t*>(row + 6);
-            uint64_t acc = 0;
 #pragma unroll
-            for (int j = 0; j < 12; ++j) acc ^= row64[j] & hi_pairs[j];
-            x ^= static_cast<uint32_t>(acc) ^ static_cast<uint32_t>(acc >> 32);
-#pragma unroll
-            for (int b = 0; b < 6; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);
-            double u = static_cast<double>(x) * 9.313225746154785e-10;      // 2^-30
-            u = fmin(fmax(u, 1e-10), 1.0 - 1e-10);
-            q += ndtri_w_regs(u, *regs, opaque_zero());
-            continue;
-        } else {
-#pragma unroll
-            for (int b = 0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);   // x ^ (row & mask), one v_bitop3_b32
-        }
-        double u = static_cast<double>(x) * 9.313225746154785e-10;      // 2^-30
-        u = fmin(fmax(u, 1e-10), 1.0 - 1e-10);
+        for (int b = 0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);   // x ^ (row & mask), one v_bitop3_b32
+        const double u = sobol_uniform(x);
         q += ndtri_w(u, opaque_zero());
     }
     return q;
@@ -2723,8 +2823,7 @@ __device__ __forceinline__ void qmc_block_sums(const uint32_t (&mask)[kSobolBits
 #pragma unroll
             for (int p = 0; p < kQmcBlock; ++p) {
                 if (p) x ^= row[__builtin_ctz(static_cast<unsigned>(p))];          // gray(k + 1) = gray(k) ^ (1 << ctz(k + 1))
-                u[p] = static_cast<double>(x) * 9.313225746154785e-10;          // 2^-30
-                u[p] = fmin(fmax(u[p], 1e-10), 1.0 - 1e-10);
+                u[p] = sobol_uniform(x);
             }
             ndtri_lockstep<kQmcBlock>(u, z, z0);
 #pragma unroll

@@ -56,7 +56,7 @@ def test_measurement_code_is_not_in_the_product_library():
     build_probe_library()
     product, instrumented = exported_symbols(LIBRARY), exported_symbols(PROBE_LIBRARY)
     only_probe = set(declared_symbols(PROBE_HEADER))
-    assert only_probe == set(probe.PROBE_PROTOTYPES) and len(only_probe) == 9
+    assert only_probe == set(probe.PROBE_PROTOTYPES) and len(only_probe) == 10
     assert not (only_probe & product)
     assert not [n for n in product if any(w in n for w in ("probe", "stamp", "clock", "moments"))]
     assert instrumented == product | only_probe

@@ -5,7 +5,7 @@ binding bound to that library, so `probe.hip.european(...)` runs the same code `
   * the multi-GPU engine REHEARSED with several ranks on the one GPU of the box (hand-over order, drain of ranks >= 1,
     restoration of the thread's device, every payload: price 3, Greeks 17 / 33, control variate 6 doubles);
   * the error paths behind fault injection (failing rank, device-side row-capacity guard);
-  * the exp2 and normal-moment taps.
+  * the exp2, inverse-normal and normal-moment taps.
 """
 import math
 
@@ -284,6 +284,42 @@ def test_device_exp2_f64_is_within_two_ulp_of_libm_everywhere(form):
     # documented limit of the domain: an INFINITE argument answers NaN (inf - rint(inf)), where exp2() says inf / 0.  A
     # cumulative log-return is infinite only for infinite parameters, for which the reference's own path is NaN as well.
     assert np.isnan(special[7:]).all()
+
+
+def test_the_sobol_kernels_inverse_normal_is_scipy_class_in_every_form():
+    """ndtri_w and its three other forms (coefficients in registers, two in lockstep, eight in lockstep: olmc_kernels.h) through the
+    instrumented build's tap, on Sobol-shaped probabilities k 2^-30: the clip's ends, the centre, both sides of the seam between
+    the two fits (w = -ln 4p(1-p) = 6.25), the 2,000 smallest and largest uniforms and 200,000 random ones.
+
+      * the four forms agree BIT FOR BIT (why a Sobol price does not depend on the launch shape);
+      * against mpmath (40 digits) on 5,000 of them: within 2.5 x 2^-52 of the value (measured: 1.8; mean 0.49) -- SciPy's own
+        ndtri, the reference's inverse normal (gbm_qmc.py:37), measures 1.56e-15 absolute on the same sample, ours 1.59e-15;
+      * against SciPy on all of them: 2e-15 max(1, |z|)."""
+    mp = pytest.importorskip("mpmath")
+    from scipy.special import ndtri
+    mp.mp.dps = 40
+    rng = np.random.default_rng(7)
+    seam = 0.5 * (1 - np.sqrt(1 - np.exp(-6.25)))
+    edges = np.array([1e-10, 2.0 ** -30, 2.0 ** -29, 3 * 2.0 ** -30, 0.5, 0.5 - 2.0 ** -30, 0.5 + 2.0 ** -30, 1 - 2.0 ** -30, 1 - 2.0 ** -29, 0.25, 0.75])
+    near = np.round((seam * (1 + np.linspace(-1e-3, 1e-3, 401))) * 2.0 ** 30) * 2.0 ** -30
+    tails = np.arange(1, 2001) * 2.0 ** -30
+    p = np.concatenate([edges, near, 1 - near, tails, 1 - tails, rng.integers(1, 1 << 30, size=200_000) * 2.0 ** -30])
+    z = probe.ndtri_probe(p, 0)
+    for form in (1, 2, 3):
+        assert np.array_equal(z, probe.ndtri_probe(p, form)), form
+    assert z[4] == 0.0 and np.array_equal(z[:4] < 0, np.ones(4, bool))
+    want = ndtri(p)
+    assert (np.abs(z - want) <= 2e-15 * np.maximum(1.0, np.abs(want))).all()
+    fixed = edges.size + 2 * near.size
+    sample = np.concatenate([np.arange(fixed), fixed + np.arange(0, 4000, 20), rng.integers(0, p.size, 4000)])
+    worst = 0.0
+    for i in sample:
+        exact = mp.sqrt(2) * mp.erfinv(2 * mp.mpf(float(p[i])) - 1)
+        if exact != 0:
+            worst = max(worst, float(abs(mp.mpf(float(z[i])) - exact) / (abs(exact) * mp.mpf(2) ** -52)))
+    assert worst <= 2.5, worst
+    with pytest.raises(ol.AccelerationError):
+        probe.ndtri_probe(np.array([0.0, 0.5]), 0)
 
 
 def test_normal_moments_tap_agrees_with_the_normals_tap():

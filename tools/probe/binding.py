@@ -36,6 +36,7 @@ def _second_binding():
     mod.PROTOTYPES.update({
         "olmc_exp2_probe": (_I, [C.POINTER(_D), _I64, C.POINTER(_D)]),
         "olmc_exp2_probe_form": (_I, [C.POINTER(_D), _I64, C.POINTER(_D), _I]),
+        "olmc_ndtri_probe": (_I, [C.POINTER(_D), _I64, C.POINTER(_D), _I]),
         "olmc_normal_moments": (_I, [_U64T, _I64, _I64, _I32, C.POINTER(_D)]),
         "olmc_phase_stamps": (_I, [_I64, _I32, _U64T, _I32, C.POINTER(C.c_uint64), _I64, C.POINTER(_I64)]),
         "olmc_clock_probe": (_I, [_I64, _I32, _U64T, C.POINTER(_D)]),
@@ -48,7 +49,7 @@ def _second_binding():
 
 
 hip = _second_binding()
-PROBE_PROTOTYPES = ("olmc_exp2_probe", "olmc_exp2_probe_form", "olmc_normal_moments", "olmc_phase_stamps", "olmc_clock_probe",
+PROBE_PROTOTYPES = ("olmc_exp2_probe", "olmc_exp2_probe_form", "olmc_ndtri_probe", "olmc_normal_moments", "olmc_phase_stamps", "olmc_clock_probe",
                     "olmc_issue_probe", "olmc_probe_tune", "olmc_european_f64_normals", "olmc_launch_gap_probe")
 _check, lib, seed64 = hip._check, hip.lib, hip.seed64
 
@@ -72,6 +73,14 @@ def exp2_probe(x: np.ndarray, form: Optional[int] = None) -> np.ndarray:
     else:
         _check(lib().olmc_exp2_probe_form(px, x.size, py, int(form)))
     return y
+
+
+def ndtri_probe(p: np.ndarray, form: int = 0) -> np.ndarray:
+    """Phi^-1(p) by the Sobol kernels' inverse normal: form 0 one point, 1 coefficients in registers, 2 two in lockstep, 3 eight."""
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    z = np.empty_like(p)
+    _check(lib().olmc_ndtri_probe(p.ctypes.data_as(C.POINTER(C.c_double)), p.size, z.ctypes.data_as(C.POINTER(C.c_double)), int(form)))
+    return z
 
 
 def normal_moments(seed: int, n_paths: int, n_steps: int, path_offset: int = 0):

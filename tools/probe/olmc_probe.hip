@@ -37,6 +37,29 @@ extern "C" int olmc_exp2_probe(const double* x_host, int64_t n, double* y_host) 
     return olmc_exp2_probe_form(x_host, n, y_host, OLMC_EXP2_TABLE ? 1 : 0);
 }
 
+extern "C" int olmc_ndtri_probe(const double* p_host, int64_t n, double* z_host, int form) {
+    if (!p_host || !z_host || n < 1) return fail(OLMC_ERR_ARG, "bad arguments");
+    if (form < 0 || form > 3) return fail(OLMC_ERR_ARG, "form must be 0 .. 3");
+    for (int64_t i = 0; i < n; ++i)
+        if (!(p_host[i] >= 1e-10 && p_host[i] <= 1.0 - 1e-10)) return fail(OLMC_ERR_ARG, "a probability outside [1e-10, 1 - 1e-10]");
+    CtxLease lease;
+    int rc = ctx_lease(&lease);
+    if (rc) return rc;
+    DeviceCtx* const c = lease.c;
+    const size_t bytes = sizeof(double) * static_cast<size_t>(n);
+    rc = bulk_reserve(c, 2 * bytes);
+    if (rc) return rc;
+    double* d_p = static_cast<double*>(c->d_bulk);
+    double* d_z = d_p + n;
+    HIP_TRY(hipMemcpyAsync(d_p, p_host, bytes, hipMemcpyHostToDevice, c->stream));
+    const int grid = static_cast<int>(std::min<int64_t>((n + 255) / 256, 4096));
+    hipLaunchKernelGGL(ndtri_probe_kernel, dim3(grid), dim3(256), 0, c->stream, d_p, n, d_z, form);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(z_host, d_z, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return OLMC_OK;
+}
+
 extern "C" int olmc_normal_moments(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_steps, double* out4) {
     if (!out4) return fail(OLMC_ERR_ARG, "null pointer");
     olmc_stats dummy;

@@ -2348,38 +2348,43 @@ __global__ __launch_bounds__(kBlock) void jump_paths_kernel(PathRange pr, JumpCo
 // antithetic mirror in the pricer (gbm_qmc.py:14-46); QmcRange.mirror serves simulate_gbm_qmc_antithetic (:49-76).
 constexpr int kSobolBits = 30;      // SciPy's default `bits`
 
-// Inverse normal CDF for p in [1e-10, 1 - 1e-10], 1 ulp-class (max |z - mpmath| 8.9e-16, the same as SciPy's ndtri):
-//   z = sqrt(2) x f(w),   x = 2p - 1,   w = -ln(4 p (1 - p)) = -ln(1 - x^2),   f = erfinv(x) / x,
+// Inverse normal CDF for p in [1e-10, 1 - 1e-10], 1 ulp-class (against mpmath on Sobol-shaped probabilities: within 1.5 x 2^-52
+// of the value, 1.40e-15 absolute; SciPy's ndtri, the reference's: 1.56e-15 -- tests/test_gpu_instrumented.py):
+//   z = x f(w),   x = 2p - 1,   w = -ln(4 p (1 - p)) = -ln(1 - x^2),   f = sqrt(2) erfinv(x) / x,
 // with f a degree-24 polynomial in (w - 3.125) for w < 6.25 (|x| < 0.99903: 99.9 % of the points, so a wave almost
 // never runs the other branch) and a degree-22 polynomial in (sqrt(w) - 3.6) beyond (the form of Giles, "Approximating
 // the erfinv function"; the coefficients are our own Chebyshev fits in 50-digit arithmetic, tools/fit_ndtri.py).  The
 // coefficients sit in constant memory so that they reach the fma as SGPR pairs (as literals each needs a v_mov_b64 and
-// the kernel 187 VGPRs).  One 33-instruction log + 24 fma on the main path, against ~280 instructions of the two-region
-// rational AS241 (whose tail, 15 % of the points, made nearly every wave execute both branches).
+// the kernel 187 VGPRs).  One 24-instruction log + 24 fma on the main path (round 4: 33 + 24), against ~280 instructions of the
+// two-region rational AS241 (whose tail, 15 % of the points, made nearly every wave execute both branches).
 constexpr double kNdtriSplit = 6.25, kNdtriCentreA = 3.125, kNdtriCentreB = 3.6;
 __constant__ double kNdtriA[25] = {
-    1.6536545626831027, 0.24015818242558834, -0.006033670871426851,
-    -0.0007407025341546431, 0.00018673420801981186, -1.3882523393957483e-05,
-    -1.3654691758785656e-06, 4.23478816822246e-07, -2.907039127564132e-08,
-    -4.1126604371632185e-09, 1.051223377050429e-09, -5.414303283919504e-11,
-    -1.2978805369932565e-11, 2.6305268312595183e-12, -8.07192593899004e-14,
-    -4.0020031087558496e-14, 6.521333511502239e-15, -3.94018812230432e-17,
-    -1.2215637192404172e-16, 1.5510787009902526e-17, 6.075050702072414e-19,
-    -3.4734793888538036e-19, 1.999259988861535e-20, 3.194015548136271e-21,
-    -3.5932028927020693e-22};
+    2.338620710026593, 0.3396349587011389, -0.008532899177267343,
+    -0.001047511569485617, 0.00026408204954061674, -1.9632852863696442e-05,
+    -1.931065027529881e-06, 5.988894861277318e-07, -4.111174160550445e-08,
+    -5.8161801676714855e-09, 1.4866543569083624e-09, -7.65698113492015e-11,
+    -1.8354802577559388e-11, 3.7201267209535326e-12, -1.1415427137390895e-13,
+    -5.659687073061811e-14, 9.222558296724625e-15, -5.57226748086415e-17,
+    -1.7275519790527177e-16, 2.1935565352484576e-17, 8.591419094975e-19,
+    -4.912241660340459e-19, 2.8273805909578654e-20, 4.51702010660485e-21,
+    -5.081556263217504e-22};
 __constant__ double kNdtriB[23] = {
-    3.4362534068011823, 1.0079663489656199, 0.0027173235759475095,
-    -0.0016859071965492362, 0.0008108055595869524, -0.0004643688234153306,
-    0.00029446662482508865, -0.00016564226708733703, 6.88768166250667e-05,
-    -1.432355652527823e-05, -4.919733756599446e-06, 6.028709084915152e-06,
-    -2.649609589349179e-06, 4.028386034223256e-07, 2.3426178285459596e-07,
-    -1.8359599682240365e-07, 5.6435684203616095e-08, -2.4148392054837038e-09,
-    -7.067895448044831e-09, 4.403960698499458e-09, -8.643938352702886e-10,
-    -3.63258949542749e-10, 1.57703474090927e-10};
+    4.859596171648984, 1.4254796811228716, 0.003842875854461125,
+    -0.0023842328222623333, 0.0011466522188153746, -0.0006567166880171974,
+    0.0004164386944938703, -0.00023425354061713856, 9.740652820425401e-05,
+    -2.0256567899466118e-05, -6.957554201847671e-06, 8.5258821514889e-06,
+    -3.747113816251416e-06, 5.696998164072895e-07, 3.3129619045867057e-07,
+    -2.596439487036509e-07, 7.981211000255892e-08, -3.4150983553453232e-09,
+    -9.995513600060063e-09, 6.228140947976023e-09, -1.2224374850709372e-09,
+    -5.137257330967595e-10, 2.2302639189274297e-10};
 
-// -ln t for t in (2^-1000, 1]: frexp, m in [sqrt(1/2), sqrt(2)), ln m = 2 atanh(s) with s = (m - 1)/(m + 1) as 2s + s^3 Q(s^2),
-// Q of degree 6 (5.6e-17 absolute on ln m; tools/fit_ndtri.py), the division by a v_rcp_f64 seed with two Newton rounds and a
-// residual correction, e ln 2 in two pieces: ~33 instructions where the library's correctly rounded log spends ~75.
+// w = -ln(4 t) for t = p (1 - p) in [1e-10, 1/4] (neg_log_quad).  t = m 2^e with m in [0.7071066, 1.4142132) -- split on the HIGH
+// WORD as the C libraries do (add 0x3ff00000 - 0x3fe6a09e, shift for e, mask and add back for m: four 32-bit integer operations
+// where frexp + compare + selects took six, two of them fp64) -- ln m = 2 atanh(s) with s = (m - 1)/(m + 1) as 2s + s^3 Q(s^2), Q of
+// degree 6 (5.6e-17 absolute on ln m; tools/fit_ndtri.py), the division by a v_rcp_f64 seed (2^-23) with ONE Newton round (2^-46)
+// and a residual correction of the quotient (which squares what is left: below 2^-53), (e + 2) ln 2 in two pieces: 24 instructions
+// where the library's correctly rounded log spends ~75.  Round 5 (new bits, the same accuracy: tests/test_gpu_instrumented.py pins
+// all forms to mpmath): t by one fma (ndtri_pt), the factor 4 in the exponent, one Newton round instead of two, the integer split.
 __constant__ double kLogQ[7] = {0.666666666666667, 0.39999999999886615, 0.28571428631764334, 0.2222221019926421, 0.18182956608063458, 0.15329500754204178, 0.14643628601909797};
 
 // A zero the optimiser cannot see through (see ndtri_lockstep): a table indexed [k + opaque_zero()] is loaded where it is used.
@@ -2389,39 +2394,32 @@ __device__ __forceinline__ int opaque_zero() {
     return z;
 }
 
-// The one-point-per-thread kernels (european_qmc_kernel, european_qmc_batch_kernel<., false>) call ndtri_w once per dimension: the
-// compiler keeps the 55 coefficients in scalar registers across the dimension loop (what does not fit next to the dimension's 30
-// direction numbers comes back through a few v_readlane_b32).
-// 2 m for m in [0.5, 1) where `twice`, else m: the exponent field plus one, on the high word alone (one 32-bit add and ONE select
-// where `low ? m + m : m` is an fp64 add and two selects).  Exact either way: the same bits.
-__device__ __forceinline__ double twice_if(double m, bool twice) {
-    const uint64_t b = static_cast<uint64_t>(__double_as_longlong(m));
-    const uint32_t hi = static_cast<uint32_t>(b >> 32) + (twice ? 0x00100000u : 0u);
-    return __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(hi) << 32) | static_cast<uint32_t>(b)));
-}
-
 // A Sobol integer x < 2^30 as the reference's clipped uniform: clip(x 2^-30, 1e-10, 1 - 1e-10) (gbm_qmc.py:36).  The upper clip
 // can never bind -- the largest uniform is 1 - 2^-30 = 1 - 9.3e-10 -- so it is not computed; the lower one binds for x = 0 alone.
 __device__ __forceinline__ double sobol_uniform(uint32_t x) {
     return fmax(static_cast<double>(x) * 9.313225746154785e-10, 1e-10);      // x 2^-30
 }
 
-__device__ __forceinline__ double neg_log_unit(double t) {
-    double m = __builtin_amdgcn_frexp_mant(t);          // t = m 2^e, m in [0.5, 1)
-    int e = __builtin_amdgcn_frexp_exp(t);
-    const bool low = m < 0.70710678118654752;
-    m = twice_if(m, low);
-    e = low ? e - 1 : e;
+// p (1 - p) = p - p^2 with ONE rounding (and no cancellation at either end: the fma sees the exact difference).
+__device__ __forceinline__ double ndtri_pt(double p) { return __builtin_fma(-p, p, p); }
+
+template <class Q /* q[0 .. 6]: kLogQ, or the caller's registers */>
+__device__ __forceinline__ double neg_log_quad(double t, const Q& lq) {
+    const uint64_t bits = static_cast<uint64_t>(__double_as_longlong(t));
+    // the exponent counted from 1/4 (so that 4 t costs nothing), the mantissa's high word re-based to [sqrt(1/2), sqrt(2))
+    const int32_t k = static_cast<int32_t>(static_cast<uint32_t>(bits >> 32) + (0x3ff00000u - 0x3fe6a09eu) - (1021u << 20));
+    const int32_t e = k >> 20;                                                                  // arithmetic: floor
+    const uint32_t mh = (static_cast<uint32_t>(k) & 0x000fffffu) + 0x3fe6a09eu;
+    const double m = __longlong_as_double(static_cast<long long>((static_cast<uint64_t>(mh) << 32) | static_cast<uint32_t>(bits)));
     const double num = m - 1.0, den = m + 1.0;
     double r = __builtin_amdgcn_rcp(den);
-    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
     double s = num * r;
     s = __builtin_fma(__builtin_fma(-den, s, num), r, s);
     const double u = s * s;
-    double q = kLogQ[6];
+    double q = lq[6];
 #pragma unroll
-    for (int k = 5; k >= 0; --k) q = __builtin_fma(q, u, kLogQ[k]);
+    for (int j = 5; j >= 0; --j) q = __builtin_fma(q, u, lq[j]);
     const double ln_m = __builtin_fma(s * u, q, s + s);
     const double ed = static_cast<double>(e);
     return -__builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, ln_m));
@@ -2436,9 +2434,16 @@ __device__ __forceinline__ double ndtri_tail(double w, int z = 0 /* see ndtri_lo
     return f;
 }
 
-__device__ __forceinline__ double ndtri_w(double p, int z_tail = 0) {
-    const double x = __builtin_fma(p, 2.0, -1.0);      // = 2.0 * p - 1.0 bit for bit (2 p is exact), one instruction
-    const double w = neg_log_unit(4.0 * p * (1.0 - p));        // p (1 - p) straight from p: no cancellation at either end
+// Every form below ADDS a point's inverse normal to a running sum:  acc + Phi^-1(p) = fma(x, f(w), acc),  x = 2p - 1 (one fma, exact),
+// the sqrt(2) inside f's coefficients -- one instruction where z = sqrt(2) * x * f, acc += z were three.  The Sobol kernels only ever
+// sum a point's normals; a lone Phi^-1(p) is the same call with acc = 0.
+//
+// The one-point-per-thread kernels (european_qmc_kernel, european_qmc_batch_kernel<., false>) call ndtri_w_add once per dimension:
+// the compiler keeps the 55 coefficients in scalar registers across the dimension loop (what does not fit next to the dimension's
+// 30 direction numbers comes back through a few v_readlane_b32).
+__device__ __forceinline__ double ndtri_w_add(double acc, double p, int z_tail = 0) {
+    const double x = __builtin_fma(p, 2.0, -1.0);
+    const double w = neg_log_quad(ndtri_pt(p), kLogQ);
     double f;
     if (w < kNdtriSplit) {
         const double t = w - kNdtriCentreA;
@@ -2452,12 +2457,12 @@ __device__ __forceinline__ double ndtri_w(double p, int z_tail = 0) {
         asm volatile("");
         f = ndtri_tail(w, z_tail);
     }
-    return 1.4142135623730951 * x * f;
+    return __builtin_fma(x, f, acc);
 }
 
 // The main branch's coefficients held in VECTOR registers by the caller (the aligned one-point Sobol kernels, whose 24 fewer lane
 // masks leave the room): every fma then reads three VGPRs -- no scalar-operand limit, no coefficient spilled to lanes and fetched
-// back by v_readlane_b32.  Same operations in the same order as ndtri_w: the same bits.
+// back by v_readlane_b32.  Same operations in the same order as ndtri_w_add: the same bits.
 struct NdtriRegs {
     double a[25], q[7];
     // Which coefficients are pinned to vector registers (the rest is left to the compiler: scalar registers, rebuilt by s_mov
@@ -2473,28 +2478,9 @@ struct NdtriRegs {
     }
 };
 
-__device__ __forceinline__ double ndtri_w_regs(double p, const NdtriRegs& c, int z_tail) {
+__device__ __forceinline__ double ndtri_w_regs_add(double acc, double p, const NdtriRegs& c, int z_tail) {
     const double x = __builtin_fma(p, 2.0, -1.0);
-    const double t4 = 4.0 * p * (1.0 - p);
-    // neg_log_unit(t4) with its seven coefficients from registers
-    double m = __builtin_amdgcn_frexp_mant(t4);
-    int e = __builtin_amdgcn_frexp_exp(t4);
-    const bool low = m < 0.70710678118654752;
-    m = twice_if(m, low);
-    e = low ? e - 1 : e;
-    const double num = m - 1.0, den = m + 1.0;
-    double r = __builtin_amdgcn_rcp(den);
-    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
-    double s = num * r;
-    s = __builtin_fma(__builtin_fma(-den, s, num), r, s);
-    const double u = s * s;
-    double q = c.q[6];
-#pragma unroll
-    for (int k = 5; k >= 0; --k) q = __builtin_fma(q, u, c.q[k]);
-    const double ln_m = __builtin_fma(s * u, q, s + s);
-    const double ed = static_cast<double>(e);
-    const double w = -__builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, ln_m));
+    const double w = neg_log_quad(ndtri_pt(p), c.q);
     double f;
     if (w < kNdtriSplit) {
         const double t = w - kNdtriCentreA;
@@ -2505,37 +2491,19 @@ __device__ __forceinline__ double ndtri_w_regs(double p, const NdtriRegs& c, int
         asm volatile("");
         f = ndtri_tail(w, z_tail);
     }
-    return 1.4142135623730951 * x * f;
+    return __builtin_fma(x, f, acc);
 }
 
 // TWO inverse normals in lockstep from the same register-held coefficients (round 5: two consecutive dimensions of one point in the
-// aligned one-point Sobol kernels).  One point per thread left a wave a single chain of ~60 dependent fp64 operations per dimension,
-// and at five waves per SIMD the chains, not the issue port, set the pace.  Both logarithms and both main polynomials run as one
-// basic block here; a tail point is repaired afterwards behind a branch the wave almost always skips (as in ndtri_lockstep below).
-// Every point sees exactly the operations of ndtri_w: the same bits.
-__device__ __forceinline__ void ndtri_w_regs_pair(const double (&p)[2], double (&out)[2], const NdtriRegs& c, int z_tail) {
+// aligned one-point Sobol kernels), added to acc in order: (acc + z0) + z1.  One point per thread left a wave a single chain of ~60
+// dependent fp64 operations per dimension.  Both logarithms and both main polynomials run as one basic block here; a tail point is
+// repaired afterwards behind a branch the wave almost always skips (as in ndtri_lockstep below).  Every point sees exactly the
+// operations of ndtri_w_add: the same bits.
+__device__ __forceinline__ double ndtri_w_regs_pair_add(double acc, const double (&p)[2], const NdtriRegs& c, int z_tail) {
     double w[2], f[2], t[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const double t4 = 4.0 * p[j] * (1.0 - p[j]);
-        double m = __builtin_amdgcn_frexp_mant(t4);
-        int e = __builtin_amdgcn_frexp_exp(t4);
-        const bool low = m < 0.70710678118654752;
-        m = twice_if(m, low);
-        e = low ? e - 1 : e;
-        const double num = m - 1.0, den = m + 1.0;
-        double r = __builtin_amdgcn_rcp(den);
-        r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
-        r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
-        double s = num * r;
-        s = __builtin_fma(__builtin_fma(-den, s, num), r, s);
-        const double u = s * s;
-        double q = c.q[6];
-#pragma unroll
-        for (int k = 5; k >= 0; --k) q = __builtin_fma(q, u, c.q[k]);
-        const double ln_m = __builtin_fma(s * u, q, s + s);
-        const double ed = static_cast<double>(e);
-        w[j] = -__builtin_fma(ed, 6.93147180369123816490e-01, __builtin_fma(ed, 1.90821492927058770002e-10, ln_m));
+        w[j] = neg_log_quad(ndtri_pt(p[j]), c.q);
         t[j] = w[j] - kNdtriCentreA;
         f[j] = c.a[24];
     }
@@ -2547,11 +2515,12 @@ __device__ __forceinline__ void ndtri_w_regs_pair(const double (&p)[2], double (
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (!(w[j] < kNdtriSplit)) {
-            asm volatile("");                           // a real branch (see ndtri_w)
+            asm volatile("");                           // a real branch (see ndtri_w_add)
             f[j] = ndtri_tail(w[j], z_tail);
         }
-        out[j] = 1.4142135623730951 * __builtin_fma(p[j], 2.0, -1.0) * f[j];
+        acc = __builtin_fma(__builtin_fma(p[j], 2.0, -1.0), f[j], acc);
     }
+    return acc;
 }
 
 // fma(a, b, c) with the addend taken straight from a scalar register pair (VOP3).  Left to itself hipcc copies a freshly s_load-ed
@@ -2562,12 +2531,12 @@ __device__ __forceinline__ double fma_scalar_addend(double a, double b, double c
     return d;
 }
 
-// EIGHT inverse normals per thread, in lockstep (round 4; the eight-points-per-thread kernels).  Round 3 called ndtri_w eight times
-// per dimension: eight basic blocks (each point has its own main / tail branch), so nothing of one point overlapped anything of
-// another -- a wave ran eight serial chains of ~45 dependent fp64 operations per dimension -- and the 55 coefficients, hoisted in
-// front of the dimension loop, overflowed the scalar registers next to the 28 direction numbers of the dimension: 511 v_readlane_b32
-// per trip of european_qmc_block_kernel's loop brought them back one by one (the 16-contract batch kernel's spill lanes and
-// accumulation registers took its VGPR count to 270).  Here
+// EIGHT inverse normals per thread, in lockstep (round 4; the eight-points-per-thread kernels), each added to its own running sum.
+// Round 3 called the one-point form eight times per dimension: eight basic blocks (each point has its own main / tail branch), so
+// nothing of one point overlapped anything of another -- a wave ran eight serial chains of ~45 dependent fp64 operations per
+// dimension -- and the 55 coefficients, hoisted in front of the dimension loop, overflowed the scalar registers next to the 28
+// direction numbers of the dimension: 511 v_readlane_b32 per trip of european_qmc_block_kernel's loop brought them back one by one
+// (the 16-contract batch kernel's spill lanes and accumulation registers took its VGPR count to 270).  Here
 //   * the eight logarithms run as one basic block (eight independent chains for the scheduler to interleave);
 //   * the main polynomial (99.9 % of the points) is evaluated for ALL eight points, coefficient by coefficient: one scalar load
 //     serves eight fma, the chains cover each other's latency;
@@ -2575,13 +2544,13 @@ __device__ __forceinline__ double fma_scalar_addend(double a, double b, double c
 //   * the tables are indexed [k + z] with z an OPAQUE ZERO the caller redefines once per dimension (opaque_zero()): the address is
 //     then not invariant in the dimension loop, so the coefficients are s_load-ed where they are used (440 bytes per trip from
 //     the scalar data cache) and occupy scalar registers only then.
-// Every point sees exactly the operations of ndtri_w: the same bits.
+// Every point sees exactly the operations of ndtri_w_add: the same bits.
 template <int NP>
-__device__ __forceinline__ void ndtri_lockstep(const double (&p)[NP], double (&out)[NP], int z) {
+__device__ __forceinline__ void ndtri_lockstep_add(double (&acc)[NP], const double (&p)[NP], int z) {
     double w[NP], f[NP], t[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        w[j] = neg_log_unit(4.0 * p[j] * (1.0 - p[j]));
+        w[j] = neg_log_quad(ndtri_pt(p[j]), kLogQ);
         t[j] = w[j] - kNdtriCentreA;
     }
     {
@@ -2598,10 +2567,10 @@ __device__ __forceinline__ void ndtri_lockstep(const double (&p)[NP], double (&o
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         if (!(w[j] < kNdtriSplit)) {
-            asm volatile("");                           // a real branch (see ndtri_w)
+            asm volatile("");                           // a real branch (see ndtri_w_add)
             f[j] = ndtri_tail(w[j], z);
         }
-        out[j] = 1.4142135623730951 * __builtin_fma(p[j], 2.0, -1.0) * f[j];
+        acc[j] = __builtin_fma(__builtin_fma(p[j], 2.0, -1.0), f[j], acc[j]);
     }
 }
 
@@ -2623,9 +2592,9 @@ __device__ __forceinline__ int32_t qmc_quarter_begin(int32_t dims, int w) {
 //
 // UNIFORM_HI (round 5): the 64 lanes of the wave hold the 64 CONSECUTIVE points of a 64-aligned block, so bits 6 .. 29 of their
 // Gray codes are the same in every lane (gray bit b = k_b ^ k_{b+1}).  The XOR of the direction numbers those bits select is then one
-// number per wave and dimension -- formed on the SCALAR unit from the scalar-loaded row (`gray_hi` comes from v_readfirstlane), next
-// to the digital shift, which is scalar anyway -- and only the six low bits are left to the vector unit: 6 + 1 v_bitop3_b32 per
-// point and dimension instead of 30 (each with an SGPR operand: 4 issue cycles), and 6 lane masks in registers instead of 30.
+// number per wave and dimension (`gray_hi` comes from v_readfirstlane; the digital shift goes into the same word) and only the six
+// low bits are left per point: 6 v_bitop3_b32 per point and dimension instead of 30 (each with an SGPR operand: 4 issue cycles),
+// and 6 lane masks in registers instead of 30.
 template <bool UNIFORM_HI = false>
 __device__ __forceinline__ double qmc_point_sum(const uint32_t (&mask)[kSobolBits], int32_t t0, int32_t t1, const uint32_t* __restrict__ sv,
                                                 const uint32_t* __restrict__ shift, uint32_t gray_hi = 0u /* wave-uniform; UNIFORM_HI only */,
@@ -2660,7 +2629,7 @@ __device__ __forceinline__ double qmc_point_sum(const uint32_t (&mask)[kSobolBit
             }
             int32_t j = 0;
             for (; j + 2 <= cn; j += 2) {
-                double u[2], z[2];
+                double u[2];
 #pragma unroll
                 for (int d = 0; d < 2; ++d) {
                     uint32_t x = static_cast<uint32_t>(xf[d]);
@@ -2678,15 +2647,13 @@ __device__ __forceinline__ double qmc_point_sum(const uint32_t (&mask)[kSobolBit
 #pragma unroll
                     for (int b = 0; b < 6; ++b) lo[d][b] = next[b];
                 }
-                ndtri_w_regs_pair(u, z, *regs, opaque_zero());
-                q += z[0];
-                q += z[1];
+                q = ndtri_w_regs_pair_add(q, u, *regs, opaque_zero());
             }
             if (j < cn) {                                                           // an odd dimension left (xf[0], lo[0] are its)
                 uint32_t x = static_cast<uint32_t>(xf[0]);
 #pragma unroll
                 for (int b = 0; b < 6; ++b) x = __builtin_amdgcn_bitop3_b32(x, lo[0][b], mask[b], 0x78);
-                q += ndtri_w_regs(sobol_uniform(x), *regs, opaque_zero());
+                q = ndtri_w_regs_add(q, sobol_uniform(x), *regs, opaque_zero());
             }
         }
         return q;
@@ -2697,7 +2664,7 @@ __device__ __forceinline__ double qmc_point_sum(const uint32_t (&mask)[kSobolBit
 #pragma unroll
         for (int b = 0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);   // x ^ (row & mask), one v_bitop3_b32
         const double u = sobol_uniform(x);
-        q += ndtri_w(u, opaque_zero());
+        q = ndtri_w_add(q, u, opaque_zero());
     }
     return q;
 }
@@ -2710,10 +2677,12 @@ __device__ __forceinline__ double qmc_point_sum(const uint32_t (&mask)[kSobolBit
 // unit idles 30 % of the time (`frac_valu_active_pmc` 0.70, profiles/r04_bench_detail.json).  Split, the same launch is 8,192 waves
 // of a quarter of the length.  The quarter sums meet in LDS, wave 0 adds them in the canonical order and prices the point.
 // ALIGNED (round 5; SPLIT launches whose point offset is a multiple of 64, from 64 dimensions on): qmc_point_sum<true> -- the wave's
-// lanes are an aligned block of 64 points, the direction numbers of Gray bits 6 .. 29 are folded on the scalar unit (twelve 64-bit
-// and / xor pairs per dimension), six v_bitop3_b32 are left per point and dimension, and with 24 lane masks fewer the inverse
-// normal's 25 main-branch coefficients live in vector registers (no v_readlane spill traffic): 110 -> 75 vector instructions per
-// point and dimension, 63 -> 88 VGPRs.  2^17 x 252: 119 -> 97 us; the 14-contract Greeks 132 -> 104; same bits.  The one-point form
+// lanes are an aligned block of 64 points, so the direction numbers of Gray bits 6 .. 29 fold into one word per wave and dimension
+// (first on the scalar unit, twelve 64-bit and / xor pairs per dimension behind a scalar load: 119 -> 97 us at 2^17 x 252; then
+// lane-per-dimension on the vector unit, 64 dimensions at a time, broadcast by ds_bpermute_b32: see qmc_point_sum), six
+// v_bitop3_b32 are left per point and dimension, two dimensions run in lockstep, and with 24 lane masks fewer the inverse normal's
+// coefficients sit in registers without v_readlane spill traffic: 110 -> 71 vector instructions per point and dimension with the
+// same bits (83 us), 64 with round 5's shorter inverse normal (76 us; round 4: 120).  63 -> 79 VGPRs.  The one-point form
 // (SPLIT = false) keeps its 30 lane masks: its aligned variant needed 191 VGPRs and lost.
 template <int MODE, bool SPLIT = false, bool ALIGNED = false /* qr.first is a multiple of 64: a wave's lanes are an aligned block of points */>
 __global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contract c, const uint32_t* __restrict__ sv,
@@ -2819,15 +2788,13 @@ __device__ __forceinline__ void qmc_block_sums(const uint32_t (&mask)[kSobolBits
 #pragma unroll
                 for (int b = B0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);
             }
-            double u[kQmcBlock], z[kQmcBlock];
+            double u[kQmcBlock];
 #pragma unroll
             for (int p = 0; p < kQmcBlock; ++p) {
                 if (p) x ^= row[__builtin_ctz(static_cast<unsigned>(p))];          // gray(k + 1) = gray(k) ^ (1 << ctz(k + 1))
                 u[p] = sobol_uniform(x);
             }
-            ndtri_lockstep<kQmcBlock>(u, z, z0);
-#pragma unroll
-            for (int p = 0; p < kQmcBlock; ++p) q[p] += z[p];
+            ndtri_lockstep_add<kQmcBlock>(q, u, z0);
         }
 #pragma unroll
         for (int p = 0; p < kQmcBlock; ++p) zs[p][threadIdx.x] += q[p];

@@ -292,8 +292,9 @@ def test_the_sobol_kernels_inverse_normal_is_scipy_class_in_every_form():
     the two fits (w = -ln 4p(1-p) = 6.25), the 2,000 smallest and largest uniforms and 200,000 random ones.
 
       * the four forms agree BIT FOR BIT (why a Sobol price does not depend on the launch shape);
-      * against mpmath (40 digits) on 5,000 of them: within 2.5 x 2^-52 of the value (measured: 1.8; mean 0.49) -- SciPy's own
-        ndtri, the reference's inverse normal (gbm_qmc.py:37), measures 1.56e-15 absolute on the same sample, ours 1.59e-15;
+      * against mpmath (40 digits) on 5,000 of them: within 2 x 2^-52 of the value (measured: 1.5, mean 0.34; before round 5's shorter
+        arithmetic: 1.8, 0.49) -- SciPy's own ndtri, the reference's inverse normal (gbm_qmc.py:37), measures 1.56e-15 absolute on the
+        same sample, ours 1.40e-15;
       * against SciPy on all of them: 2e-15 max(1, |z|)."""
     mp = pytest.importorskip("mpmath")
     from scipy.special import ndtri
@@ -317,7 +318,7 @@ def test_the_sobol_kernels_inverse_normal_is_scipy_class_in_every_form():
         exact = mp.sqrt(2) * mp.erfinv(2 * mp.mpf(float(p[i])) - 1)
         if exact != 0:
             worst = max(worst, float(abs(mp.mpf(float(z[i])) - exact) / (abs(exact) * mp.mpf(2) ** -52)))
-    assert worst <= 2.5, worst
+    assert worst <= 2.0, worst
     with pytest.raises(ol.AccelerationError):
         probe.ndtri_probe(np.array([0.0, 0.5]), 0)
 

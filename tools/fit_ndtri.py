@@ -1,14 +1,15 @@
 #!/usr/bin/env python3
 """Generates the coefficients of ndtri_w (optionslab_amd/csrc/olmc_kernels.h): Chebyshev interpolants of
-f(w) = erfinv(x)/x, x = sqrt(1 - e^-w), in 50-digit arithmetic (mpmath), converted to powers of (w - centre) and of
+f(w) = sqrt(2) erfinv(x)/x, x = sqrt(1 - e^-w)  (Phi^-1(p) = x f(w), x = 2p - 1, w = -ln 4p(1-p); the sqrt(2) sits in the
+coefficients since round 5: one multiplication fewer per point), in 50-digit arithmetic (mpmath), converted to powers of (w - centre) and of
 (sqrt(w) - centre), with the double-precision Horner error of every candidate degree.  CPU only: python tools/fit_ndtri.py [out.json]"""
 import mpmath as mp, numpy as np, json, sys
 mp.mp.dps = 50
 def f_of_w(w):
     w = mp.mpf(w)
-    if w == 0: return mp.sqrt(mp.pi)/2
+    if w == 0: return mp.sqrt(2) * mp.sqrt(mp.pi)/2
     x = mp.sqrt(1 - mp.e**(-w))
-    return mp.erfinv(x)/x
+    return mp.sqrt(2) * mp.erfinv(x)/x
 def cheb_fit(g, a, b, deg):
     # Chebyshev interpolation coefficients in mp, then monomial in t=(v-c) (unscaled centre c=(a+b)/2)
     n = deg + 1

@@ -45,8 +45,9 @@ KERNELS = {      # key in bench.py's JSON -> mangled-name regex
     "f_cv": r"^_ZN4olmc20european_path_kernelILi1ELb1ELi2ELb0EEE",
 }
 # steps (monitoring dates, Sobol dimensions) one trip of the hot loop advances a path by, where it is not "two per Box-Muller":
-# Heston consumes TWO normals per step; a Sobol kernel's trip is one dimension (of one point, or of a thread's eight points)
-STEPS_PER_TRIP = {"f_heston": lambda ops: ops.get("v_log_f32", 0), "f_qmc": lambda ops: 1, "f_qmc_block": lambda ops: 1}
+# Heston consumes TWO normals per step; a Sobol kernel's trip is one dimension of a thread's eight points, or -- the aligned one-point
+# kernel since round 5 -- TWO dimensions of one point (one v_rcp_f64 per inverse normal)
+STEPS_PER_TRIP = {"f_heston": lambda ops: ops.get("v_log_f32", 0), "f_qmc": lambda ops: ops.get("v_rcp_f64", 0), "f_qmc_block": lambda ops: 1}
 
 # mnemonic (encoding suffix stripped) -> probe class of optionslab_amd/_hip.py PROBE_CLASSES
 CLASS_OF = {

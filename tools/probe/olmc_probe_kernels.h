@@ -260,29 +260,29 @@ __global__ void exp2_probe_kernel(const double* __restrict__ x, int64_t n, doubl
 
 
 // The Sobol kernels' inverse normal on an array of probabilities: z[i] = 0 + (the term every Sobol kernel adds to a point's sum for
-// the uniform p[i]) -- form 0 = ndtri_w (one point), 1 = ndtri_w_regs (coefficients in registers), 2 = ndtri_w_regs_pair (two in
-// lockstep; element i is paired with element i ^ 1), 3 = ndtri_lockstep<8> (elements 8 j .. 8 j + 7).  All forms must agree bit for
-// bit; tests pin them to mpmath.
+// the uniform p[i]) -- form 0 = ndtri_w_add (one point), 1 = ndtri_w_regs_add (coefficients in registers), 2 = ndtri_w_regs_pair_add
+// (two in lockstep: element i rides in slot i & 1 next to p = 1/2, whose normal is an exact zero), 3 = ndtri_lockstep_add<8>
+// (elements 8 j .. 8 j + 7).  All forms must agree bit for bit; tests pin them to mpmath.
 __global__ void ndtri_probe_kernel(const double* __restrict__ p, int64_t n, double* __restrict__ z, int form) {
     NdtriRegs regs;
     regs.load();
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         if (form == 0) {
-            z[i] = ndtri_w(p[i], opaque_zero());
+            z[i] = ndtri_w_add(0.0, p[i], opaque_zero());
         } else if (form == 1) {
-            z[i] = ndtri_w_regs(p[i], regs, opaque_zero());
+            z[i] = ndtri_w_regs_add(0.0, p[i], regs, opaque_zero());
         } else if (form == 2) {
-            const int64_t mate = (i ^ 1) < n ? (i ^ 1) : i;
-            const double in[2] = {p[i], p[mate]};
-            double out[2];
-            ndtri_w_regs_pair(in, out, regs, opaque_zero());
-            z[i] = out[0];
+            const double in[2] = {(i & 1) ? 0.5 : p[i], (i & 1) ? p[i] : 0.5};
+            z[i] = ndtri_w_regs_pair_add(0.0, in, regs, opaque_zero());
         } else {
             const int64_t base = i & ~static_cast<int64_t>(7);
             double in[8], out[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) in[j] = p[base + j < n ? base + j : i];
-            ndtri_lockstep<8>(in, out, opaque_zero());
+            for (int j = 0; j < 8; ++j) {
+                in[j] = p[base + j < n ? base + j : i];
+                out[j] = 0.0;
+            }
+            ndtri_lockstep_add<8>(out, in, opaque_zero());
             z[i] = out[i & 7];
         }
     }

@@ -107,7 +107,7 @@ PMC_KERNELS = {         # substring of the demangled kernel name -> key in the J
     "extrema_kernel<false>": "f_extrema",
     "heston_kernel<false>": "f_heston",
     "european_multi_kernel<true>": "f_multi",
-    "european_qmc_kernel<0, true, true>": "f_qmc",         # split workgroups, aligned form: what every launch below 2^20 points runs (>= 64 dimensions, offset 0)
+    "european_qmc_kernel<0, true, true>": "f_qmc",         # split workgroups, aligned form: what every launch below 2^22 points runs (2^21 below 128 dimensions; >= 32 dimensions, offset 0)
     "european_qmc_block_kernel<0, true>": "f_qmc_block",   # eight points per thread, aligned form (offset 0)
     # round 5: the kernels round 4 added without a fraction (VERDICT r4 "missing" 2) and the control-variate shape of the headline kernel
     "extrema_greeks_kernel<false, 16>": "f_extrema_greeks14",
@@ -147,7 +147,7 @@ def f_workloads(ol, _hip):
                     "(monte_carlo_unified.py:562-631)", F_MULTI_CONTRACTS * F_MULTI_PATHS, F_MULTI_STEPS),
         "f_qmc": (lambda: _hip.european_qmc(*P, True, F_QMC_POINTS, sv1, sh1),
                   f"MCMethod.QMC price, 2^17 Sobol points x {F_QMC_DIMS} dims, 64 points per workgroup, a quarter of the dims per wave, high Gray bits "
-                  "on the scalar unit (gbm_qmc.py:14-46)", F_QMC_POINTS, F_QMC_DIMS),
+                  "folded once per wave and dim (gbm_qmc.py:14-46)", F_QMC_POINTS, F_QMC_DIMS),
         "f_qmc_block": (lambda: _hip.european_qmc(*P, True, F_QMC_BLOCK_POINTS, sv8, sh8),
                         f"MCMethod.QMC price, 2^22 Sobol points x {F_QMC_BLOCK_DIMS} dims, eight points per thread (gbm_qmc.py:14-46)",
                         F_QMC_BLOCK_POINTS // 8, F_QMC_BLOCK_DIMS),

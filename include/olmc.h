@@ -455,11 +455,12 @@ int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths, int32_t n_
 int olmc_profile_enable(int on);
 /* Tuning knob for A/B measurements (results never change, only the launch shape):
  *   OLMC_TUNE_GRID_CAP   max workgroups per launch, 0 = default (larger jobs grid-stride)
- *   OLMC_TUNE_QMC_BLOCK  Sobol kernels: 0 = by size (default): below 2^20 points (and from 16 dimensions on) a workgroup takes 64 points and
- *                        each of its four waves a quarter of the dimensions -- where the point offset is a multiple of 64 and there are
- *                        64 dimensions or more, with the high Gray-code bits' direction numbers folded on the scalar unit --; from 2^20
- *                        points on a thread takes eight consecutive points.  1 = always eight points per thread, -1 = always one point per
- *                        thread.  Every shape returns the same terminal prices bit for bit (one association of a point's normal sum)
+ *   OLMC_TUNE_QMC_BLOCK  Sobol kernels: 0 = by size (default): from 16 dimensions on a workgroup takes 64 points and each of its four waves
+ *                        a quarter of the dimensions -- where the point offset is a multiple of 64 and there are 32 dimensions or more,
+ *                        with the high Gray-code bits' direction numbers folded once per wave and dimension --; from 2^22 points on (2^21
+ *                        below 128 dimensions) a thread takes eight consecutive points.  1 = always eight points per thread, 2 = always
+ *                        split workgroups, -1 = always one point per thread.  Every shape returns the same terminal prices bit for bit
+ *                        (one association of a point's normal sum)
  *   OLMC_TUNE_POLL       blocking calls: 0 = wait by polling the host-mapped flag the kernel raises behind its results
  *                        (default), -1 = hipStreamSynchronize
  *   OLMC_TUNE_SPLIT_TAIL European launches: 0 = the paths beyond a whole number of workgroups per compute unit go to split

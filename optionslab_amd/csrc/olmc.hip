@@ -374,7 +374,7 @@ int copy_to_host(DeviceCtx* c, void* dst, const void* d_src, size_t bytes) {
 // Tuning knob (olmc_tune): 0 = automatic.
 int g_multi_launch = 0;      // OLMC_TUNE_MULTI_LAUNCH: 0 = multi-GPU calls queue their ranks from one launcher thread per device (default), -1 = serial
 int g_grid_cap = 0;          // OLMC_TUNE_GRID_CAP: max workgroups per launch (0 = kMaxGrid)
-int g_qmc_block = 0;         // OLMC_TUNE_QMC_BLOCK: 0 = by size, 1 = always eight points per thread, -1 = never
+int g_qmc_block = 0;         // OLMC_TUNE_QMC_BLOCK: 0 = by size, 1 = always eight points per thread, -1 = never (and never split), 2 = always split
 int g_poll = 0;              // OLMC_TUNE_POLL: 0 = blocking calls poll a host-mapped flag for completion (default), -1 = hipStreamSynchronize
 int g_split_tail = 0;        // OLMC_TUNE_SPLIT_TAIL: 0 = split workgroups for the remainder of a European launch (default), -1 = never
 int g_split_sat = 0;         // OLMC_TUNE_SPLIT_SAT: k > 0: a last round of fewer than k whole workgroups per CU is split too; 0 = never (default:
@@ -1802,10 +1802,12 @@ int qmc_check(const uint32_t* sv, const uint32_t* shift, int32_t bits, int32_t d
 }
 
 // gbm_qmc.py:38-44 as an olmc_option -> Contract: dt = T / dims, a = ln S + drift dims, vol = sigma sqrt(dt) = make_contract(o, dims)
-// Launch shape of a Sobol kernel.  From 2^20 points on (measured crossover between 2^19 and 2^20) a thread takes an aligned block of
-// eight consecutive points; below, a workgroup takes 64 points and each of its four waves a quarter of the dimensions (from 16
-// dimensions on; round 4 drew that line at 2^18 points and ran one point per thread in between).  OLMC_TUNE_QMC_BLOCK: 1 = always
-// eight points per thread, -1 = never eight and never split (one point per thread).
+// Launch shape of a Sobol kernel.  A workgroup takes 64 points and each of its four waves a quarter of the dimensions (from 16
+// dimensions on; round 4 drew that line at 2^18 points and ran one point per thread in between); from 2^22 points on -- from 2^21
+// below 128 dimensions -- a thread takes an aligned block of eight consecutive points instead (round 5 moved the crossover up from
+// 2^20 twice: the aligned split kernel got faster.  2^20 x 252: split 530 us, eight 638; 2^21 x 64: 310 / 293; 2^21 x 252: 1050 /
+// 1107; 2^22 x 64: 612 / 541; 2^22 x 252: 2106 / 2074 -- profiles/r05_ab_kernels.txt).  OLMC_TUNE_QMC_BLOCK: 1 = always eight points
+// per thread, 2 = always split, -1 = never eight and never split (one point per thread).
 struct QmcShape {
     bool blocks, split, aligned, aligned8;
     int64_t units;       // threads' worth of work: blocks of eight, or points
@@ -1813,15 +1815,15 @@ struct QmcShape {
 };
 QmcShape qmc_shape(int64_t point_offset, int64_t n_paths, int32_t dims) {
     QmcShape sh;
-    // split workgroups whose 64 lanes are a 64-ALIGNED block of points form the high Gray bits' XOR on the scalar unit and keep the
-    // inverse normal's coefficients in vector registers (olmc_kernels.h qmc_point_sum<true>): 2^17 x 252 119 -> 100 us.  The
-    // coefficients' load is a fixed cost per wave: it pays from 64 dimensions on (16 per wave; 2^14 x 32: 10.5 -> 10.8 us, 2^16 x 64:
-    // 24.1 -> 22.0).  With it the split form beats one point per thread up to where eight points per thread take over (2^19 x 252:
-    // 451 -> 353 us, 2^19 x 64: 122 -> 104), so the one-point form is left to launches of fewer than 16 dimensions and to the knob
-    sh.aligned = (point_offset & 63) == 0 && dims >= 64;
+    // split workgroups whose 64 lanes are a 64-ALIGNED block of points fold the high Gray bits' direction numbers once per wave and
+    // dimension and keep the inverse normal's coefficients in registers (olmc_kernels.h qmc_point_sum<true>).  The coefficients'
+    // load and the fold's prologue are a fixed cost per wave: it pays from 32 dimensions on (8 per wave; 2^17 x 32: 21.5 -> 19.9 us,
+    // 2^18 x 48: 44.6 -> 38.4, 2^14 x 32: even; 16 dimensions: 8.6 -> 8.9, 12.0 -> 12.3).  The one-point form is left to launches of
+    // fewer than 16 dimensions and to the knob
+    sh.aligned = (point_offset & 63) == 0 && dims >= 32;
     sh.aligned8 = (point_offset & 511) == 0;        // eight points per thread: a wave's 64 blocks start at a multiple of 512 points
-    sh.blocks = g_qmc_block > 0 ? true : (g_qmc_block < 0 ? false : n_paths >= (int64_t(1) << 20));
-    sh.split = !sh.blocks && g_qmc_block == 0 && dims >= 16;     // every launch below 2^20 points (round 4: up to 2^18; the aligned form moved the crossover)
+    sh.blocks = g_qmc_block == 1 ? true : (g_qmc_block != 0 ? false : n_paths >= (int64_t(1) << (dims < 128 ? 21 : 22)));
+    sh.split = !sh.blocks && (g_qmc_block == 0 || g_qmc_block == 2) && dims >= 16;
     sh.units = sh.blocks ? (point_offset + n_paths + kQmcBlock - 1) / kQmcBlock - point_offset / kQmcBlock : n_paths;
     sh.grid = sh.split ? static_cast<int32_t>((n_paths + kWave - 1) / kWave) : grid_for(sh.units);
     return sh;
@@ -2682,7 +2684,7 @@ extern "C" int olmc_normals(uint64_t seed, int64_t path_offset, int64_t n_paths,
 // ================================================================ measurement ====
 extern "C" int olmc_tune(int knob, int value) {
     if (knob == OLMC_TUNE_GRID_CAP && value >= 0) { g_grid_cap = value; return OLMC_OK; }
-    if (knob == OLMC_TUNE_QMC_BLOCK && value >= -1 && value <= 1) { g_qmc_block = value; return OLMC_OK; }
+    if (knob == OLMC_TUNE_QMC_BLOCK && value >= -1 && value <= 2) { g_qmc_block = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_POLL && value >= -1 && value <= 0) { g_poll = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_SPLIT_TAIL && value >= -1 && value <= 0) { g_split_tail = value; return OLMC_OK; }
     if (knob == OLMC_TUNE_SPLIT_SAT && value >= 0 && value <= 16) { g_split_sat = value; return OLMC_OK; }

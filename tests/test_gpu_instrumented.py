@@ -160,7 +160,7 @@ def test_n_rank_sobol_price_is_the_one_device_sobol_price(rehearsal, n_ranks):
     scrambled sequence through the kernels' point offset -- the same points as the one-device call, the sums in another association
     (1e-13), and exactly the rank-ordered sum of the shards priced one by one through olmc_european_qmc(point_offset=...)."""
     S, K, T, r, v = ATM
-    for n, dims in ((1 << 14, 16), (300_001, 64), (1 << 20, 16)):            # split workgroups / one point per thread / eight per thread
+    for n, dims in ((1 << 14, 16), (300_001, 64), (1 << 21, 16)):            # split workgroups (plain, aligned) / eight points per thread
         sv, shift = ol.monte_carlo.sobol_tables(dims, 42, n)
         whole = hip.european_qmc(S, K, T, r, v, 0.0, True, n, sv, shift)
         got = hip.multi_gpu_european_qmc(S, K, T, r, v, 0.0, True, n, sv, shift, n_ranks)

@@ -1017,25 +1017,28 @@ def test_qmc_eight_point_blocks_give_the_same_points():
             b = ol.MonteCarloPricer(N, M, 42, ol.MCMethod.QMC).price(*ATM, "call", return_error=True)
             assert b.price == pytest.approx(a.price, rel=1e-13) and b.std_error == pytest.approx(a.std_error, rel=1e-10) and b.n_paths == a.n_paths
         _hip.tune(_hip.TUNE_QMC_BLOCK, 0)
-        big = ol.MonteCarloPricer(2**20, 8, 42, ol.MCMethod.QMC).price(*ATM, "call", return_error=True)     # the size that switches by itself
+        big = ol.MonteCarloPricer(2**21, 8, 42, ol.MCMethod.QMC).price(*ATM, "call", return_error=True)     # the size that switches by itself (2^21 below 128 dimensions, else 2^22)
         assert abs(big.price - BS_CALL) < 2e-3
     finally:
         _hip.tune(_hip.TUNE_QMC_BLOCK, 0)
 
 
 def test_qmc_split_workgroups_return_the_bits_of_one_point_threads():
-    """Launches of fewer than 2^20 Sobol points (round 4: up to 2^18) with >= 16 dimensions give 64 points to a workgroup and a quarter
+    """Launches of fewer than 2^22 Sobol points (2^21 below 128 dimensions; round 4: up to 2^18) with >= 16 dimensions give 64 points to a workgroup and a quarter
     of the dimensions to each of its four waves (european_qmc_kernel<., true>, european_qmc_batch_kernel<., false, true>).  Every Sobol
     kernel adds a point's inverse normals in the same association (quarters), so the split form must return the one-point form's
     terminal prices bit for bit -- ragged point counts around the 64-point workgroup, dimension counts that do not divide by four,
     point offsets -- and the same sums to reduction-order rounding, for the price, the control variate and the fused Greeks.
-    Round 5: where the point offset is a multiple of 64 and there are >= 64 dimensions, the ALIGNED form runs (the direction numbers of
-    Gray bits 6 .. 29 folded on the scalar unit, the inverse normal's coefficients in vector registers): the cases with offsets 0, 64,
-    640 and 1 << 20 and 64+ dimensions -- ragged last workgroups included (dead lanes keep their index) -- hold it to the same bits."""
+    Round 5: where the point offset is a multiple of 64 and there are >= 32 dimensions, the ALIGNED form runs (the direction numbers of
+    Gray bits 6 .. 29 folded lane-per-dimension for 64 dimensions at a time and broadcast by ds_bpermute, two dimensions in lockstep,
+    the inverse normal's coefficients in registers): the cases with offsets 0, 64, 128, 640 and 1 << 20 and 32+ dimensions -- ragged
+    last workgroups (dead lanes keep their index), odd quarters, quarters longer than 64 dimensions (a second chunk) and a launch
+    above 2^20 points included -- hold it to the same bits."""
     S, K, T, r, v = ATM
     try:
         for N, M, off in ((1, 16, 0), (63, 17, 0), (64, 18, 5), (65, 19, 64), (1000, 33, 3), (4097, 252, 12345), (70_001, 63, 1), (1 << 18, 16, 0),
-                          (1, 64, 0), (1000, 64, 0), (4097, 252, 0), (70_001, 65, 640), (300_000, 64, 64), ((1 << 19) + 17, 70, 1 << 20), (65, 100, 63)):
+                          (1, 64, 0), (1000, 64, 0), (4097, 252, 0), (70_001, 65, 640), (300_000, 64, 64), ((1 << 19) + 17, 70, 1 << 20), (65, 100, 63),
+                          (1000, 32, 0), (70_001, 41, 128), (4097, 300, 64), (130, 1021, 0), ((1 << 20) + 3, 130, 0)):
             tables = ol.monte_carlo.sobol_tables(M, 11)
             _hip.tune(_hip.TUNE_QMC_BLOCK, -1)                       # one point per thread, never split
             one = _hip.european_qmc_terminal(S, T, r, v, 0.01, N, *tables, point_offset=off)

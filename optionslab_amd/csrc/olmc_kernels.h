@@ -2548,21 +2548,43 @@ __device__ __forceinline__ double fma_scalar_addend(double a, double b, double c
 template <int NP>
 __device__ __forceinline__ void ndtri_lockstep_add(double (&acc)[NP], const double (&p)[NP], int z) {
     double w[NP], f[NP], t[NP];
+    // the main polynomial's leading coefficient and first group are asked for BEFORE the logarithms (which do not need them)
+    constexpr int kGroup = 4;
+    double cur[kGroup], nxt[kGroup];
+    const double lead = kNdtriA[24 + z];
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) cur[i] = kNdtriA[23 - i + z];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         w[j] = neg_log_quad(ndtri_pt(p[j]), kLogQ);
         t[j] = w[j] - kNdtriCentreA;
     }
-    {
-        const double c = kNdtriA[24 + z];
+    // the main polynomial, its coefficients fetched a GROUP AHEAD of the fma that use them: scalar loads return out of order, so the
+    // wait in front of a group's first use is for everything outstanding -- issued right before its use (what the compiler does
+    // left alone: nine load-wait pairs per trip) a wave idles a scalar-cache latency each time; issued a group earlier, behind
+    // kGroup x NP fma of work, the wait finds the data there.  The scheduling barriers keep the order written here.
 #pragma unroll
-        for (int j = 0; j < NP; ++j) f[j] = c;
-    }
+    for (int j = 0; j < NP; ++j) f[j] = lead;
 #pragma unroll
-    for (int k = 23; k >= 0; --k) {
-        const double c = kNdtriA[k + z];
+    for (int g = 0; g < 24 / kGroup; ++g) {
+        // touch the group in hand FIRST: its wait (for everything outstanding) must come before the next group's loads are issued
 #pragma unroll
-        for (int j = 0; j < NP; ++j) f[j] = fma_scalar_addend(f[j], t[j], c);
+        for (int i = 0; i < kGroup; ++i) asm volatile("" : "+s"(cur[i]));
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 1 < 24 / kGroup) {
+#pragma unroll
+            for (int i = 0; i < kGroup; ++i) nxt[i] = kNdtriA[23 - kGroup * (g + 1) - i + z];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < kGroup; ++i) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) f[j] = fma_scalar_addend(f[j], t[j], cur[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < kGroup; ++i) cur[i] = nxt[i];
     }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -2749,52 +2771,79 @@ constexpr int kQmcBlock = 8;
 // barrier), so the dimension loop carries the eight quarter sums in registers and nothing else -- the epilogues walk the eight
 // points by a run-time index anyway, which registers do not offer.
 // UNIFORM_HI (round 5): the wave's 64 lanes carry 64 CONSECUTIVE blocks starting at a multiple of 512 points, so bits 9 .. 29 of
-// their first points' Gray codes are wave-uniform: those direction numbers are folded on the scalar unit (row 9 alone, rows 10 .. 29
-// as ten 8-byte-aligned pairs), bits 2 .. 8 stay vector work -- 7 + 7 v_bitop3_b32 / v_xor per dimension for eight points instead of
-// 28 + 7, and 21 lane masks fewer in registers.
+// their first points' Gray codes are wave-uniform: those direction numbers fold into one word per wave and dimension (first on the
+// scalar unit per dimension, then lane-per-dimension for 64 dimensions at a time), bits 2 .. 8 stay per-lane work -- 7 + 7
+// v_bitop3_b32 / v_xor per dimension for eight points instead of 28 + 7, and 21 lane masks fewer in registers.
 template <int B0, bool UNIFORM_HI = false>
 __device__ __forceinline__ void qmc_block_sums(const uint32_t (&mask)[kSobolBits], int32_t dims, const uint32_t* __restrict__ sv,
                                                const uint32_t* __restrict__ shift, double (*zs)[kBlock], uint32_t gray_hi = 0u) {
-    static_assert(!UNIFORM_HI || B0 == 2, "the scalar fold is laid out for blocks of eight");
-    uint64_t hi_pairs[10] = {};
-    uint32_t hi_9 = 0u;
-    if constexpr (UNIFORM_HI) {
-        hi_9 = 0u - ((gray_hi >> 9) & 1u);
-#pragma unroll
-        for (int j = 0; j < 10; ++j)
-            hi_pairs[j] = static_cast<uint64_t>(0u - ((gray_hi >> (10 + 2 * j)) & 1u)) | (static_cast<uint64_t>(0u - ((gray_hi >> (11 + 2 * j)) & 1u)) << 32);
-    }
+    static_assert(!UNIFORM_HI || B0 == 2, "the fold is laid out for blocks of eight");
 #pragma unroll
     for (int p = 0; p < kQmcBlock; ++p) zs[p][threadIdx.x] = 0.0;          // 0 + Q0 = Q0 exactly
+    const int lane = static_cast<int>(threadIdx.x) & (kWave - 1);
 #pragma unroll 1
     for (int w = 0; w < 4; ++w) {
         double q[kQmcBlock];
 #pragma unroll
         for (int p = 0; p < kQmcBlock; ++p) q[p] = 0.0;
-        const int32_t t1 = qmc_quarter_begin(dims, w + 1);
-        for (int32_t t = qmc_quarter_begin(dims, w); t < t1; ++t) {
-            const uint32_t* __restrict__ row = sv + static_cast<size_t>(t) * kSobolBits;
-            uint32_t x = shift[t];
-            const int z0 = opaque_zero();
-            if constexpr (UNIFORM_HI) {
-                const uint64_t* __restrict__ row64 = reinterpret_cast<const uint64_t*>(row + 10);     // 120 t + 40 bytes into the table: 8-byte aligned
-                uint64_t acc = 0;
+        const int32_t t0 = qmc_quarter_begin(dims, w), t1 = qmc_quarter_begin(dims, w + 1);
+        if constexpr (UNIFORM_HI) {
+            // as qmc_point_sum<true>: 64 dimensions at a time, lane l folds rows 9 .. 29 of dimension c0 + l under the wave's Gray
+            // bits (and the digital shift) into one word, ds_bpermute_b32 hands a dimension's word to every lane one trip ahead, and
+            // the nine low rows (2 .. 8 under lane masks, 0 .. 2 for the steps inside a block) come by s_load one trip ahead
+            for (int32_t c0 = t0; c0 < t1; c0 += kWave) {
+                const int32_t cn = __builtin_amdgcn_readfirstlane(t1 - c0 < kWave ? t1 - c0 : kWave);
+                const int32_t tl = c0 + lane < t1 ? c0 + lane : t1 - 1;
+                const uint32_t* __restrict__ mine = sv + static_cast<size_t>(tl) * kSobolBits;
+                uint32_t fold = shift[tl];
 #pragma unroll
-                for (int j = 0; j < 10; ++j) acc ^= row64[j] & hi_pairs[j];
-                x ^= (row[9] & hi_9) ^ static_cast<uint32_t>(acc) ^ static_cast<uint32_t>(acc >> 32);
+                for (int b = 9; b < kSobolBits; ++b) fold ^= mine[b] & (0u - ((gray_hi >> b) & 1u));
+                int hop = 0;
+                asm volatile("" : "+v"(hop));
+                uint32_t lo[9];
+                {
+                    const uint32_t* __restrict__ row = sv + static_cast<size_t>(c0) * kSobolBits;
 #pragma unroll
-                for (int b = B0; b < 9; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);
-            } else {
+                    for (int b = 0; b < 9; ++b) lo[b] = row[b];
+                }
+                int xf = __builtin_amdgcn_ds_bpermute(hop, static_cast<int>(fold));
+                for (int32_t j = 0; j < cn; ++j) {
+                    const int z0 = opaque_zero();
+                    uint32_t x = static_cast<uint32_t>(xf);
+#pragma unroll
+                    for (int b = B0; b < 9; ++b) x = __builtin_amdgcn_bitop3_b32(x, lo[b], mask[b], 0x78);
+                    double u[kQmcBlock];
+#pragma unroll
+                    for (int p = 0; p < kQmcBlock; ++p) {
+                        if (p) x ^= lo[__builtin_ctz(static_cast<unsigned>(p))];          // gray(k + 1) = gray(k) ^ (1 << ctz(k + 1))
+                        u[p] = sobol_uniform(x);
+                    }
+                    hop += 4;
+                    xf = __builtin_amdgcn_ds_bpermute(hop, static_cast<int>(fold));
+                    {
+                        const int32_t tn = c0 + j + 1 < t1 ? c0 + j + 1 : t1 - 1;
+                        const uint32_t* __restrict__ next = sv + static_cast<size_t>(tn) * kSobolBits;
+#pragma unroll
+                        for (int b = 0; b < 9; ++b) lo[b] = next[b];
+                    }
+                    ndtri_lockstep_add<kQmcBlock>(q, u, z0);
+                }
+            }
+        } else {
+            for (int32_t t = t0; t < t1; ++t) {
+                const uint32_t* __restrict__ row = sv + static_cast<size_t>(t) * kSobolBits;
+                uint32_t x = shift[t];
+                const int z0 = opaque_zero();
 #pragma unroll
                 for (int b = B0; b < kSobolBits; ++b) x = __builtin_amdgcn_bitop3_b32(x, row[b], mask[b], 0x78);
-            }
-            double u[kQmcBlock];
+                double u[kQmcBlock];
 #pragma unroll
-            for (int p = 0; p < kQmcBlock; ++p) {
-                if (p) x ^= row[__builtin_ctz(static_cast<unsigned>(p))];          // gray(k + 1) = gray(k) ^ (1 << ctz(k + 1))
-                u[p] = sobol_uniform(x);
+                for (int p = 0; p < kQmcBlock; ++p) {
+                    if (p) x ^= row[__builtin_ctz(static_cast<unsigned>(p))];          // gray(k + 1) = gray(k) ^ (1 << ctz(k + 1))
+                    u[p] = sobol_uniform(x);
+                }
+                ndtri_lockstep_add<kQmcBlock>(q, u, z0);
             }
-            ndtri_lockstep_add<kQmcBlock>(q, u, z0);
         }
 #pragma unroll
         for (int p = 0; p < kQmcBlock; ++p) zs[p][threadIdx.x] += q[p];
@@ -2802,7 +2851,7 @@ __device__ __forceinline__ void qmc_block_sums(const uint32_t (&mask)[kSobolBits
 }
 
 template <int MODE, bool ALIGNED = false /* qr.first is a multiple of 512: a wave's lanes are 64 consecutive blocks of an aligned run */>
-__global__ __launch_bounds__(kBlock) void european_qmc_block_kernel(QmcRange qr, Contract c, const uint32_t* __restrict__ sv,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ALIGNED ? 4 : 3, 8))) void european_qmc_block_kernel(QmcRange qr, Contract c, const uint32_t* __restrict__ sv,
                                                                     const uint32_t* __restrict__ shift, ReduceWs ws,
                                                                     double* __restrict__ terminal) {
     constexpr int NV = MODE == kControlVariate ? 5 : 2;
@@ -2811,7 +2860,11 @@ __global__ __launch_bounds__(kBlock) void european_qmc_block_kernel(QmcRange qr,
     const uint64_t last = qr.first + static_cast<uint64_t>(qr.count);             // one past the last point
     const int64_t n_blocks = static_cast<int64_t>((last + kQmcBlock - 1) / kQmcBlock - base);
     const int64_t stride = static_cast<int64_t>(gridDim.x) * kBlock;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n_blocks; i += stride) {
+    // ALIGNED: a wave stays whole while its FIRST lane has a block -- the lanes fold one another's dimensions (qmc_block_sums<2, true>:
+    // lane l serves dimension c0 + l), so a lane past the end keeps going with its own index (the wave's high Gray bits stay uniform)
+    // and its points, all >= last, are skipped below like any ragged end
+    const int64_t lane = ALIGNED ? static_cast<int64_t>(threadIdx.x & (kWave - 1)) : 0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i - lane < n_blocks; i += stride) {
         const uint64_t k0 = (base + static_cast<uint64_t>(i)) * kQmcBlock;
         const uint32_t gray = static_cast<uint32_t>(k0 ^ (k0 >> 1));              // bits 0 and 1 are zero for k0 = 8j
         uint32_t mask[kSobolBits];
@@ -2848,7 +2901,7 @@ __global__ __launch_bounds__(kBlock) void european_qmc_block_kernel(QmcRange qr,
 // BLOCK8 = the eight-points-per-thread expansion of european_qmc_block_kernel.  The grid covers every point / block (host
 // guarantee), so the 2 NSETS sums are born after the dimension loop.
 template <int NSETS, bool BLOCK8, bool SPLIT = false, bool ALIGNED = false /* SPLIT: qr.first is a multiple of 64 (qmc_point_sum<true>); BLOCK8: of 512 (qmc_block_sums<2, true>) */>
-__global__ __launch_bounds__(kBlock) void european_qmc_batch_kernel(QmcRange qr, ContractSet<NSETS> cs, const uint32_t* __restrict__ sv,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((BLOCK8 && ALIGNED) ? 4 : 1, 8))) void european_qmc_batch_kernel(QmcRange qr, ContractSet<NSETS> cs, const uint32_t* __restrict__ sv,
                                                                     const uint32_t* __restrict__ shift, ReduceWs ws) {
     static_assert(!(BLOCK8 && SPLIT), "a thread either carries eight points or a quarter of one point's dimensions");
     static_assert(SPLIT || BLOCK8 || !ALIGNED, "the aligned forms exist for split workgroups and for blocks of eight");

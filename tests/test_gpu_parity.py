@@ -999,10 +999,11 @@ def test_qmc_eight_point_blocks_give_the_same_points():
     """european_qmc_block_kernel (eight consecutive Sobol points per thread, Gray-code increments) against the one-point
     kernel: identical terminal prices bit for bit at ragged offsets and sizes, prices equal to reduction-order rounding.  Round 5: at
     point offsets that are multiples of 512 the ALIGNED form runs (Gray bits 9 .. 29 of a wave's 64 blocks are uniform: their direction
-    numbers are folded on the scalar unit) -- offsets 0, 512, 1 << 21, ragged counts and dead lanes included."""
+    numbers fold into one word per wave and dimension, lane l serving dimension c0 + l: a wave stays whole while its first lane has a
+    block) -- offsets 0, 512, 1 << 21, ragged counts, waves with one live lane and quarters longer than 64 dimensions included."""
     try:
         for N, M, off in ((1, 1, 0), (7, 3, 0), (8, 5, 8), (9, 2, 7), (1000, 16, 3), (4097, 64, 12345), (70_000, 7, 1),
-                          (513, 5, 512), (4097, 64, 1 << 21), (70_001, 17, 1024), (300_000, 3, 0)):
+                          (513, 5, 512), (4097, 64, 1 << 21), (70_001, 17, 1024), (300_000, 3, 0), (1, 9, 0), (4097, 300, 512), (520, 260, 0)):
             tables = ol.monte_carlo.sobol_tables(M, 11)
             _hip.tune(_hip.TUNE_QMC_BLOCK, -1)
             one = _hip.european_qmc_terminal(100.0, 1.0, 0.05, 0.2, 0.01, N, *tables, point_offset=off)

@@ -402,6 +402,8 @@ int olmc_european_qmc_terminal(double S, double T, double r, double sigma, doubl
  *                                {sum, sumsq} x 8 or 16 slots, n                   count = 17 / 33
  *   olmc_multi_gpu_european_cv   the five control-variate moments, n              count = 6
  *   olmc_multi_gpu_european_qmc  {sum, sumsq, n} of the rank's block of Sobol POINTS (src/simulation/gbm_qmc.py:14-46)   count = 3
+ *                                (inner boundaries on multiples of 512 points where a rank owns >= 4,096: every rank's point offset
+ *                                is one the aligned kernels take; sharding.qmc_shard_bounds cuts the same way)
  * Prices agree with the one-GPU entry points to the rounding of the sums' association (same paths whatever n_gpus is: the Philox
  * counter carries the global path index, the Sobol kernels take the global point index).
  *

@@ -2405,7 +2405,7 @@ int rehearsal_allreduce(MultiEngine* e, int count) {
 // stream (the thread it runs on has the rank's device as its library device) and must leave `count` doubles at d_send; host
 // receives their sums.  `launch` runs on the launcher threads, one rank each, at the same time: it must not write shared state.
 template <typename Launch>
-int multi_gpu_run(int n_gpus, int64_t n_paths, int32_t n_steps, int count, Launch launch, double* host) {
+int multi_gpu_run(int n_gpus, int64_t n_paths, int32_t n_steps, int count, Launch launch, double* host, bool sobol_points = false) {
     if (n_gpus < 1 || n_gpus > kMaxDevices) return fail(OLMC_ERR_ARG, "n_gpus out of range");
     int rc = check_paths(0, n_paths, n_steps);
     if (rc) return rc;
@@ -2438,7 +2438,8 @@ int multi_gpu_run(int n_gpus, int64_t n_paths, int32_t n_steps, int count, Launc
     const std::function<int(int)> launch_rank = [&](int d) -> int {
         const MultiRank& rk = eng->ranks[d];
         int64_t lo, n_local;
-        shard_range(n_paths, d, n_gpus, &lo, &n_local);
+        if (sobol_points) qmc_shard_range(n_paths, d, n_gpus, &lo, &n_local);
+        else shard_range(n_paths, d, n_gpus, &lo, &n_local);
 #ifdef OLMC_WITH_PROBES
         if (g_fault_shard == d + 1) return fail(OLMC_ERR_HIP, "injected shard failure (OLMC_PROBE_TUNE_FAULT_SHARD)");
 #endif
@@ -2611,8 +2612,9 @@ extern "C" int olmc_multi_gpu_european_cv(double S, double K, double T, double r
     return OLMC_OK;
 }
 
-// Scrambled-Sobol pricing over n_gpus devices (gbm_qmc.py:14-46): rank d prices POINTS [d N / P, (d + 1) N / P) of the one sequence
-// through the point offset every Sobol kernel already takes, the ranks' {sum, sumsq, n} meet in the same all-reduce (count 3).  The
+// Scrambled-Sobol pricing over n_gpus devices (gbm_qmc.py:14-46): rank d prices POINTS [d N / P, (d + 1) N / P) of the one sequence --
+// the inner boundaries rounded down to multiples of 512 points where a rank owns 4,096 or more (qmc_shard_range: every rank then
+// runs the aligned kernels) -- through the point offset every Sobol kernel already takes, the ranks' {sum, sumsq, n} meet in the same all-reduce (count 3).  The
 // same points as the one-device call, another association of the sums.
 extern "C" int olmc_multi_gpu_european_qmc(double S, double K, double T, double r, double sigma, double q, int is_call,
                                            int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
@@ -2623,7 +2625,7 @@ extern "C" int olmc_multi_gpu_european_qmc(double S, double K, double T, double 
     double host[3] = {0, 0, 0};
     rc = multi_gpu_run(n_gpus, n_paths, dims, 3, [&](int, int64_t lo, int64_t n_local, hipStream_t s, double* d_send) {
         return run_qmc(S, K, T, r, sigma, q, is_call, lo, n_local, dims, sv, shift, bits, nullptr, nullptr, 0, nullptr, d_send, s);
-    }, host);
+    }, host, true);
     if (rc) return rc;
     finish_stats(host[0], host[1], static_cast<int64_t>(host[2]), r, T, out);
     if (poisoned(S, K, T, r, sigma, q)) nan_stats(out->n, out);

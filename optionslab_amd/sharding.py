@@ -34,6 +34,19 @@ def shard_bounds(n_paths: int, rank: int, world: int) -> Tuple[int, int]:
     return n_paths * rank // world, n_paths * (rank + 1) // world
 
 
+QMC_SHARD_ALIGN, QMC_SHARD_MIN_POINTS = 512, 4096
+
+
+def qmc_shard_bounds(n_points: int, rank: int, world: int) -> Tuple[int, int]:
+    """[lo, hi) of rank `rank` over Sobol POINTS: shard_bounds with every inner boundary rounded down to a multiple of 512 points
+    where a rank then still owns 4,096 or more, so that every rank's point offset is one the aligned Sobol kernels take (an
+    unaligned offset costs a rank 1.5 x the time).  The cut olmc_multi_gpu_european_qmc makes (olmc_host_math.h qmc_shard_range)."""
+    lo, hi = shard_bounds(n_points, rank, world)
+    if n_points // world < QMC_SHARD_MIN_POINTS:
+        return lo, hi
+    return lo // QMC_SHARD_ALIGN * QMC_SHARD_ALIGN, (n_points if rank + 1 == world else hi // QMC_SHARD_ALIGN * QMC_SHARD_ALIGN)
+
+
 def finalize(sum_x: float, sum_xx: float, n: int, r: float, T: float) -> Tuple[float, float]:
     """(price, std_error) from the reduced triple; identical on every rank
     (formulae of src/pricing_models/monte_carlo.py:145-150)."""
@@ -98,13 +111,13 @@ def _allreduce_list(values, group=None):
     return t.cpu().tolist()
 
 
-def price_sharded(shard_fn, n_paths_global: int, r_discount: float, T: float, group=None):
+def price_sharded(shard_fn, n_paths_global: int, r_discount: float, T: float, group=None, bounds=shard_bounds):
     """Generic sharded pricing.  `shard_fn(path_offset, n_local)` prices this rank's block and returns an
     object with (.sum, .sumsq, .n) -- e.g. ``lambda lo, n: _hip.asian(S, K, T, r, v, q, True, False, n, M, seed,
     False, path_offset=lo)``.  Returns (price, std_error, n) identical on every rank; pass r_discount = 0 for
     payoffs that carry their own discounting (autocallable, American)."""
     rank, world = _group_info(group)
-    lo, hi = shard_bounds(n_paths_global, rank, world)
+    lo, hi = bounds(n_paths_global, rank, world)
     st = shard_fn(lo, hi - lo)
     s, ss, n = _allreduce_list([st.sum, st.sumsq, float(st.n)], group)
     price, se = finalize(s, ss, int(n), r_discount, T)
@@ -113,7 +126,8 @@ def price_sharded(shard_fn, n_paths_global: int, r_discount: float, T: float, gr
 
 def qmc_sharded(S, K, T, r, sigma, option_type, q, n_points_global: int, n_steps: int, seed: int, group=None, shard_fn=None):
     """MonteCarloPricer(method=MCMethod.QMC).price over sharded POINTS (src/simulation/gbm_qmc.py:14-46): rank k prices points
-    [k N / P, (k + 1) N / P) of the one scrambled Sobol sequence through the kernels' point offset -- the same points whatever P is --
+    [k N / P, (k + 1) N / P) of the one scrambled Sobol sequence (inner boundaries on multiples of 512 points: qmc_shard_bounds) through
+    the kernels' point offset -- the same points whatever P is --
     and the ranks' (sum, sumsq, n) meet in one all-reduce.  `shard_fn(lo, n_local)` -> an object with (.sum, .sumsq, .n) defaults to
     the device kernel (tests inject the oracle).  The single-process form is olmc_multi_gpu_european_qmc."""
     if shard_fn is None:
@@ -121,7 +135,7 @@ def qmc_sharded(S, K, T, r, sigma, option_type, q, n_points_global: int, n_steps
 
         sv, shift = sobol_tables(n_steps, seed, n_points_global)
         shard_fn = lambda lo, n: _hip.european_qmc(S, K, T, r, sigma, q, option_type == "call", n, sv, shift, point_offset=lo)   # noqa: E731
-    return price_sharded(shard_fn, n_points_global, r, T, group)
+    return price_sharded(shard_fn, n_points_global, r, T, group, bounds=qmc_shard_bounds)
 
 
 class _Recorder:

@@ -210,7 +210,7 @@ static void check_combiners() {
 }
 
 static void check_shards() {
-    const int64_t sizes[] = {1, 2, 7, 16, 1000, 300001, 8000000, (int64_t(1) << 40) + 12345};
+    const int64_t sizes[] = {1, 2, 7, 16, 1000, 4095, 4096, 32767, 32768, 65535, 100000, 300001, 1000000, 8000000, (int64_t(1) << 30), (int64_t(1) << 40) + 12345};
     for (int64_t n : sizes)
         for (int p = 1; p <= 16; ++p) {
             if (n < p) continue;
@@ -223,7 +223,30 @@ static void check_shards() {
             }
             REQUIRE(next == n);
             ++g_checks;
+            // Sobol points: the same tiling, inner boundaries on multiples of 512 where a rank keeps >= 4,096 points
+            next = 0;
+            for (int d = 0; d < p; ++d) {
+                int64_t lo, count, plain_lo, plain_count;
+                qmc_shard_range(n, d, p, &lo, &count);
+                shard_range(n, d, p, &plain_lo, &plain_count);
+                REQUIRE(lo == next && count >= 1);
+                if (n / p < kQmcShardMinPoints) REQUIRE(lo == plain_lo && count == plain_count);
+                else REQUIRE(lo % kQmcShardAlign == 0 && plain_lo - lo >= 0 && plain_lo - lo < kQmcShardAlign && count >= kQmcShardMinPoints - kQmcShardAlign);
+                next = lo + count;
+            }
+            REQUIRE(next == n);
+            ++g_checks;
         }
+}
+
+// "qmc-shards n p": the P ranges, one per line (the Python mirror is compared with them)
+static int print_qmc_shards(int64_t n, int p) {
+    for (int d = 0; d < p; ++d) {
+        int64_t lo, count;
+        qmc_shard_range(n, d, p, &lo, &count);
+        std::printf("%lld %lld\n", static_cast<long long>(lo), static_cast<long long>(lo + count));
+    }
+    return 0;
 }
 
 static int self_test() {
@@ -269,6 +292,7 @@ static int self_test() {
 int main(int argc, char** argv) {
     const std::string mode = argc > 1 ? argv[1] : "self";
     if (mode == "self") return self_test();
+    if (mode == "qmc-shards" && argc == 4) return print_qmc_shards(std::atoll(argv[2]), std::atoi(argv[3]));
     if (mode == "greeks" && argc == 10) {
         const GreeksSet gs(std::atof(argv[2]), std::atof(argv[3]), std::atof(argv[4]), std::atof(argv[5]), std::atof(argv[6]), std::atof(argv[7]),
                            std::atoi(argv[8]), std::atoi(argv[9]));

@@ -157,7 +157,7 @@ def test_launcher_threads_and_the_serial_form_give_the_same_bits(rehearsal, n_ra
 @pytest.mark.parametrize("n_ranks", [1, 2, 5, 8])
 def test_n_rank_sobol_price_is_the_one_device_sobol_price(rehearsal, n_ranks):
     """olmc_multi_gpu_european_qmc (gbm_qmc.py:14-46 over several devices): rank d prices POINTS [d N / P, (d + 1) N / P) of the one
-    scrambled sequence through the kernels' point offset -- the same points as the one-device call, the sums in another association
+    scrambled sequence (boundaries on multiples of 512: qmc_shard_bounds, every rank runs the aligned kernels) through the kernels' point offset -- the same points as the one-device call, the sums in another association
     (1e-13), and exactly the rank-ordered sum of the shards priced one by one through olmc_european_qmc(point_offset=...)."""
     S, K, T, r, v = ATM
     for n, dims in ((1 << 14, 16), (300_001, 64), (1 << 21, 16)):            # split workgroups (plain, aligned) / eight points per thread
@@ -169,7 +169,7 @@ def test_n_rank_sobol_price_is_the_one_device_sobol_price(rehearsal, n_ranks):
         assert got.price == pytest.approx(whole.price, rel=1e-13)
         parts = []
         for d in range(n_ranks):
-            lo, hi = n * d // n_ranks, n * (d + 1) // n_ranks
+            lo, hi = ol.sharding.qmc_shard_bounds(n, d, n_ranks)                    # inner boundaries on multiples of 512 points
             st = hip.european_qmc(S, K, T, r, v, 0.0, True, hi - lo, sv, shift, point_offset=lo)
             parts.append((st.sum, st.sumsq, st.n))
         want = hip.combine_stats(parts, r, T)

@@ -92,3 +92,20 @@ def test_layout_in_the_header_is_the_layout_the_library_reports(harness):
         scale = [float(x) for x in lines[2].split()]
         lib = _hip.contract_layout([(*o[:6], bool(o[6])) for o in opts], 252)
         assert (nsets, pos, mask, bool(upper), scale) == lib, name
+
+
+def test_sobol_shard_ranges_are_the_python_side_ranges(harness):
+    """qmc_shard_range (what olmc_multi_gpu_european_qmc cuts the sequence by) against optionslab_amd.sharding.qmc_shard_bounds (what
+    one process per GPU cuts it by): the same points on every rank whichever form runs -- inner boundaries on multiples of 512 where a
+    rank keeps 4,096 points, the plain ranges below."""
+    from optionslab_amd.sharding import qmc_shard_bounds, shard_bounds
+
+    for n, p in [(100_000, 8), (1_000_000, 8), (1 << 17, 3), (32_767, 8), (32_768, 8), (4096, 1), (300_001, 7), (1 << 30, 16), (20, 5)]:
+        got = [tuple(map(int, line.split())) for line in harness("qmc-shards", n, p).splitlines()]
+        want = [qmc_shard_bounds(n, k, p) for k in range(p)]
+        assert got == want, (n, p)
+        assert want[0][0] == 0 and want[-1][1] == n and all(a[1] == b[0] for a, b in zip(want, want[1:]))
+        if n // p >= 4096:
+            assert all(lo % 512 == 0 for lo, _ in want) and all(0 <= shard_bounds(n, k, p)[0] - want[k][0] < 512 for k in range(p))
+        else:
+            assert want == [shard_bounds(n, k, p) for k in range(p)]

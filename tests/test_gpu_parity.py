@@ -197,6 +197,29 @@ def test_qmc_points_far_into_the_sequence_equal_scipys(off, M):
     assert np.allclose(got, want, rtol=1e-11, atol=0)
 
 
+@pytest.mark.parametrize("knob,off,M", [(0, (1 << 24) + 64 * 5, 40), (0, (1 << 26) - 512, 33), (0, (1 << 29) + 64, 130), (1, (1 << 25) + 512 * 3, 9),
+                                        (1, (1 << 28) - 1024, 70), (2, (1 << 22) + 128, 300)])
+def test_aligned_qmc_kernels_far_into_the_sequence_equal_scipys(knob, off, M):
+    """The ALIGNED Sobol kernels (round 5: the wave's high Gray bits folded lane-per-dimension, olmc_kernels.h qmc_point_sum<true> /
+    qmc_block_sums<2, true>) where the high bits are not zero: 321 points from a 64- / 512-aligned index far into the sequence --
+    split workgroups (the default shape at this size, and forced: knob 2) and eight points per thread (knob 1), quarters of 8 .. 75
+    dimensions, a ragged last wave -- against SciPy's own engine fast-forwarded there, through the reference's pipeline
+    (gbm_qmc.py:32-46)."""
+    from scipy.stats import norm
+    from scipy.stats.qmc import Sobol
+    S, T, r, v, q, seed, N = 100.0, 1.0, 0.05, 0.2, 0.01, 13, 321
+    eng = Sobol(d=M, scramble=True, seed=seed)
+    eng.fast_forward(off)
+    z = norm.ppf(np.clip(eng.random(N), 1e-10, 1 - 1e-10))
+    want = np.exp(np.log(S) + (r - q - 0.5 * v * v) * (T / M) * M + v * np.sqrt(T / M) * np.sum(z, axis=1))
+    try:
+        _hip.tune(_hip.TUNE_QMC_BLOCK, knob)
+        got = _hip.european_qmc_terminal(S, T, r, v, q, N, *ol.monte_carlo.sobol_tables(M, seed), point_offset=off)
+    finally:
+        _hip.tune(_hip.TUNE_QMC_BLOCK, 0)
+    assert np.allclose(got, want, rtol=1e-11, atol=0)
+
+
 def test_qmc_prices_the_same_bits_from_tables_derived_without_scipys_privates(monkeypatch):
     """optionslab_amd.monte_carlo._derive_sobol_tables: a SciPy without `_sv` / `_shift` still prices on the same Sobol points -- the
     price, its Greeks and the terminal array from the derived tables are the bits the private tables give."""

@@ -40,6 +40,7 @@ def test_isa_mix_covers_every_kernel_the_bench_prices(bench):
             # an inverse normal: 24 + 6 polynomial fma, 2 + 2 for the quotient, 1 p - p^2, 1 x, 1 accumulate, 1 ln m, 2 e ln 2 = 40 fma; 64 / 59 in all
             assert m["by_mnemonic"]["v_rcp_f64"] == points and m["by_mnemonic"]["v_fma_f64"] + m["by_mnemonic"]["v_fmac_f64"] == 40 * points
             assert m["loop_valu_instructions"] <= (64 if key == "f_qmc" else 60) * points
+            assert m["vgprs"] <= (85 if key == "f_qmc" else 128)                               # six / four waves per SIMD
         elif key == "c4_asian_greeks14":                                     # four recursions per date (the two r bumps ride on the mid one): four table exponentials per normal
             assert m["steps_per_trip"] == 4 and m["by_class"]["v_ldexp_f64"] == 16 and m["by_class"]["v_rndne_f64"] == 16
         elif key == "f_heston":                                              # two normals per step

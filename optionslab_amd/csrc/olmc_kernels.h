@@ -2465,11 +2465,12 @@ __device__ __forceinline__ double ndtri_w_add(double acc, double p, int z_tail =
 // back by v_readlane_b32.  Same operations in the same order as ndtri_w_add: the same bits.
 struct NdtriRegs {
     double a[25], q[7];
-    // Which coefficients are pinned to vector registers (the rest is left to the compiler: scalar registers, rebuilt by s_mov
-    // where they do not fit): the two LEADING ones -- an fma takes one scalar operand, so a scalar leading coefficient next to a
-    // scalar addend costs a v_mov_b64 per point -- and the main polynomial's first kPinned.  All 25 pinned: 95 VGPRs; 12: 71 VGPRs,
-    // seven waves per SIMD, the fastest by 0.3 .. 1.5 % (profiles/r05_ab_kernels.txt: 25 / 16 / 12 / 8).
-    static constexpr int kPinned = 12;
+    // Which coefficients are pinned to vector registers: the two LEADING ones -- an fma takes one scalar operand, so a scalar leading
+    // coefficient next to a scalar addend costs a v_mov_b64 per point.  The rest is left to the compiler (scalar registers, rebuilt
+    // by s_mov where they do not fit).  Pinning the main polynomial's first 4 / 8 / 12 / 25 as well (63 / 71 / 79 / 95 VGPRs against
+    // 55) measured even to 1.5 % slower (profiles/r05_ab_kernels.txt): since the fold left the scalar unit, neither occupancy nor
+    // the operand kind is what limits the kernel.
+    static constexpr int kPinned = 0;
     __device__ __forceinline__ void load() {
 #pragma unroll
         for (int k = 0; k < 25; ++k) { a[k] = kNdtriA[k]; if (k < kPinned || k == 24) asm volatile("" : "+v"(a[k])); }
@@ -2704,7 +2705,7 @@ __device__ __forceinline__ double qmc_point_sum(const uint32_t (&mask)[kSobolBit
 // lane-per-dimension on the vector unit, 64 dimensions at a time, broadcast by ds_bpermute_b32: see qmc_point_sum), six
 // v_bitop3_b32 are left per point and dimension, two dimensions run in lockstep, and with 24 lane masks fewer the inverse normal's
 // coefficients sit in registers without v_readlane spill traffic: 110 -> 71 vector instructions per point and dimension with the
-// same bits (83 us), 64 with round 5's shorter inverse normal (76 us; round 4: 120).  63 -> 79 VGPRs.  The one-point form
+// same bits (83 us), 64 with round 5's shorter inverse normal (76 us; round 4: 120).  63 -> 55 VGPRs.  The one-point form
 // (SPLIT = false) keeps its 30 lane masks: its aligned variant needed 191 VGPRs and lost.
 template <int MODE, bool SPLIT = false, bool ALIGNED = false /* qr.first is a multiple of 64: a wave's lanes are an aligned block of points */>
 __global__ __launch_bounds__(kBlock) void european_qmc_kernel(QmcRange qr, Contract c, const uint32_t* __restrict__ sv,

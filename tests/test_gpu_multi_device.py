@@ -3,14 +3,20 @@ run with more than one rank; the rehearsed ranks of tests/test_gpu_instrumented.
 .so).  On a box with N >= 2 visible GPUs these tests compare olmc_multi_gpu_european / _greeks_fd / _european_cv / _european_qmc
 at n_gpus = 2 .. N with the one-GPU results (same paths, another association of the sums) and SKIP where only one GPU is visible
 -- the one-GPU boxes this build is developed on.  The n_gpus = 1 cases always run: one rank through the real ncclAllReduce.
+The multi-rank bodies run in a child process under a time limit (a hang or fault on hardware nobody has run them on must not end
+the whole GPU suite); `python tests/test_gpu_multi_device.py <body> <n,n,...>` runs one by hand.
 
 Also here: the regression test of round 4's host fault through the product's C ABI (caller streams that are destroyed)."""
 import ctypes as C
+import os
+import subprocess
+import sys
 
 import pytest
 
-import optionslab_amd as ol
-from optionslab_amd import _hip
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import optionslab_amd as ol  # noqa: E402
+from optionslab_amd import _hip  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -62,14 +68,14 @@ def test_one_rank_goes_through_the_real_all_reduce_for_every_payload():
     assert p == q0.price
 
 
-def test_n_devices_price_what_one_device_prices():
+def _child_n_devices_price_what_one_device_prices(rank_counts):
     S, K, T, r, v = ATM
     N, M, seed = 2_000_003, 64, 9
     whole = _hip.european(S, K, T, r, v, 0.0, True, N, M, seed, True)
     cv0 = _hip.european_cv(S, K, T, r, v, 0.01, False, N, M, seed, True)
     sv, shift = ol.monte_carlo.sobol_tables(32, 42, 1 << 20)
     q0 = _hip.european_qmc(S, K, T, r, v, 0.0, True, 1 << 20, sv, shift)
-    for n_gpus in _rank_counts():
+    for n_gpus in rank_counts:
         for launch in (0, -1):                          # launcher threads, then the serial form: the same bits
             _hip.tune(_hip.TUNE_MULTI_LAUNCH, launch)
             try:
@@ -99,8 +105,8 @@ def test_n_devices_price_what_one_device_prices():
     assert _hip.device_info()["device"] == 0            # the thread's library device came back
 
 
-def test_the_pricer_over_n_devices():
-    n = _rank_counts()[-1]
+def _child_the_pricer_over_n_devices(rank_counts):
+    n = rank_counts[-1]
     one, many = ol.MonteCarloPricer(1_000_000, 252, 42), ol.MonteCarloPricer(1_000_000, 252, 42, n_gpus=n)
     a, b = one.price(*ATM, "call", return_error=True), many.price(*ATM, "call", return_error=True)
     assert b.n_paths == a.n_paths and b.price == pytest.approx(a.price, rel=1e-13) and b.std_error == pytest.approx(a.std_error, rel=1e-10)
@@ -109,6 +115,24 @@ def test_the_pricer_over_n_devices():
     g1, gn = one.greeks(*ATM, "call"), many.greeks(*ATM, "call")
     for k in g1:
         assert gn[k] == pytest.approx(g1[k], rel=1e-7, abs=1e-7), k
+
+
+
+def _in_a_child(name: str, timeout_s: int = 900):
+    """The multi-rank branch has never run on hardware (one-GPU boxes only): it runs in a CHILD process under a time limit, so that a
+    hang or a fault in it is this test's failure and not the end of the whole GPU suite.  The child is killed by its PID on timeout."""
+    counts = _rank_counts()
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), name, ",".join(map(str, counts))], capture_output=True, text=True,
+                       timeout=timeout_s, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, f"child {name} rc {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}"
+
+
+def test_n_devices_price_what_one_device_prices():
+    _in_a_child("_child_n_devices_price_what_one_device_prices")
+
+
+def test_the_pricer_over_n_devices():
+    _in_a_child("_child_the_pricer_over_n_devices")
 
 
 def test_caller_streams_that_die_are_never_touched_again():
@@ -147,3 +171,8 @@ def test_caller_streams_that_die_are_never_touched_again():
         rt.hipFree(buf)
     again = _hip.european(S, K, T, r, v, 0.0, True, N, M, 7, True)
     assert again.n == 2 * N
+
+
+if __name__ == "__main__":              # child of _in_a_child: one body, the rank counts the parent found
+    globals()[sys.argv[1]]([int(x) for x in sys.argv[2].split(",")])
+    _hip.shutdown()

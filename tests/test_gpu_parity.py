@@ -1062,7 +1062,7 @@ def test_qmc_split_workgroups_return_the_bits_of_one_point_threads():
     try:
         for N, M, off in ((1, 16, 0), (63, 17, 0), (64, 18, 5), (65, 19, 64), (1000, 33, 3), (4097, 252, 12345), (70_001, 63, 1), (1 << 18, 16, 0),
                           (1, 64, 0), (1000, 64, 0), (4097, 252, 0), (70_001, 65, 640), (300_000, 64, 64), ((1 << 19) + 17, 70, 1 << 20), (65, 100, 63),
-                          (1000, 32, 0), (70_001, 41, 128), (4097, 300, 64), (130, 1021, 0), ((1 << 20) + 3, 130, 0)):
+                          (1000, 32, 0), (70_001, 41, 128), (4097, 300, 64), (130, 1021, 0), ((1 << 20) + 3, 130, 0), (1000, 260, 0), (77, 257, 64)):
             tables = ol.monte_carlo.sobol_tables(M, 11)
             _hip.tune(_hip.TUNE_QMC_BLOCK, -1)                       # one point per thread, never split
             one = _hip.european_qmc_terminal(S, T, r, v, 0.01, N, *tables, point_offset=off)

@@ -201,3 +201,29 @@ def test_bench_single_process_section_in_a_two_rank_job(tmp_path):
     r0, r1 = (eval(open(tmp_path / f"section{k}.txt").read()) for k in range(2))
     assert r0 == ({"value": 1.0e13, "ms_per_step": 1.6, "n_gpus": 2, "paths_per_gpu": 8000000}, "go\n")
     assert r1 == (None, None)                    # the other rank only waits on the barriers: it starts nothing and reports nothing
+
+
+def test_sobol_shard_bounds_tile_the_range_on_aligned_cuts():
+    """qmc_shard_bounds: the ranges of shard_bounds with every inner boundary rounded down to a multiple of 512 points where a rank
+    keeps at least 4,096 -- they tile [0, n) without gaps, no rank is empty, no boundary moves by 512 or more."""
+    from hypothesis import given, settings, strategies as st
+
+    from optionslab_amd.sharding import QMC_SHARD_ALIGN, QMC_SHARD_MIN_POINTS, qmc_shard_bounds, shard_bounds
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.integers(1, 1 << 30), st.integers(1, 16))
+    def check(n, world):
+        if n < world:
+            with pytest.raises(ValueError):
+                qmc_shard_bounds(n, 0, world)
+            return
+        cuts = [qmc_shard_bounds(n, k, world) for k in range(world)]
+        plain = [shard_bounds(n, k, world) for k in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        assert all(hi > lo for lo, hi in cuts)
+        if n // world >= QMC_SHARD_MIN_POINTS:
+            assert all(lo % QMC_SHARD_ALIGN == 0 and 0 <= p[0] - lo < QMC_SHARD_ALIGN for (lo, _), p in zip(cuts, plain))
+        else:
+            assert cuts == plain
+
+    check()

@@ -7,7 +7,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SOURCES = [os.path.join(PKG, "csrc", "olmc.hip")]
-HEADERS = [os.path.join(PKG, "csrc", "olmc_kernels.h"), os.path.join(PKG, "csrc", "olmc_host_math.h"), os.path.join(ROOT, "include", "olmc.h")]
+HEADERS = [os.path.join(PKG, "csrc", "olmc_kernels.h"), os.path.join(PKG, "csrc", "olmc_host_math.h"), os.path.join(PKG, "csrc", "olmc_job_board.h"),
+           os.path.join(ROOT, "include", "olmc.h")]
 LIBRARY = os.path.join(PKG, "libolmc.so")
 # the instrumented build (include/olmc_probe.h): the same translation unit with its test seams compiled in + the measurement kernels.
 # Test / measurement infrastructure: lives under tools/, loaded by tests, tools and bench.py's calibration, never by the package.

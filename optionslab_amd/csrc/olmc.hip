@@ -7,6 +7,7 @@
 // and fails loudly when no HIP device is usable -- there is no CPU fallback.
 #include "olmc.h"
 #include "olmc_kernels.h"
+#include "olmc_job_board.h"
 
 #include <dlfcn.h>
 #include <sched.h>
@@ -2103,12 +2104,6 @@ std::string rccl_message(const char* what, ncclResult_t r) {
 
 constexpr int kMultiValues = kMaxNV + 1;            // the widest payload: 2 x 16 sums + n
 
-// A word threads sleep on (futex): the launchers wait for the engine's job number to move.
-inline long futex_call(std::atomic<uint32_t>* word, int op, uint32_t value) {
-    static_assert(sizeof(std::atomic<uint32_t>) == sizeof(uint32_t), "futex word");
-    return syscall(SYS_futex, reinterpret_cast<uint32_t*>(word), op, value, nullptr, nullptr, 0);
-}
-
 struct MultiEngine;
 
 struct MultiRank {
@@ -2128,12 +2123,7 @@ struct MultiEngine {
     std::vector<int> devices;                       // device of every rank: what `ranks` and `comms` were built for
     std::vector<ncclComm_t> comms;                  // empty in a rehearsal
     bool rehearsal = false;
-    // job board: written by the caller, then `job_no` moves (release) and the launchers wake
-    std::atomic<uint32_t> job_no{0};
-    std::atomic<int> sleepers{0};                   // launchers inside futex_wait (the caller skips the wake syscall when none)
-    std::atomic<int> remaining{0};                  // launchers that have not finished the posted job yet
-    const std::function<int(int)>* work = nullptr;  // work(rank); nullptr = leave
-    int first_rank = 0;                             // ranks below take no part in the posted job
+    JobBoard board;                                 // the hand-over between the calling thread and the launchers (olmc_job_board.h)
 };
 
 std::mutex g_engines_mu;                            // guards g_engines (never held while a call runs)
@@ -2141,55 +2131,26 @@ std::vector<MultiEngine*> g_engines;                // one per (device list, reh
 std::mutex g_multi_dev_mu[kMaxDevices];             // a multi-GPU call holds the mutex of every device of its list (ascending order)
 thread_local double t_multi_spans[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-constexpr int64_t kLauncherSpinUs = 200;            // a launcher that finished a job spins this long for the next one before it sleeps
-
 void launcher_main(MultiEngine* e, int d, uint32_t seen) {
     MultiRank& rk = e->ranks[d];
     (void)hipSetDevice(rk.device);                  // once: every launch of this thread goes to this device
     t_device = rk.device;
     using clock = std::chrono::steady_clock;
-    for (;;) {
-        auto t0 = clock::now();
-        uint32_t now;
-        for (uint32_t spins = 0; (now = e->job_no.load(std::memory_order_acquire)) == seen; ++spins) {
-            if ((spins & 0x3F) != 0x3F || clock::now() - t0 < std::chrono::microseconds(kLauncherSpinUs)) {
-                __builtin_ia32_pause();
-                continue;
-            }
-            e->sleepers.fetch_add(1, std::memory_order_seq_cst);
-            if (e->job_no.load(std::memory_order_seq_cst) == seen) futex_call(&e->job_no, FUTEX_WAIT_PRIVATE, seen);
-            e->sleepers.fetch_sub(1, std::memory_order_seq_cst);
-            t0 = clock::now();
-        }
-        seen = now;
-        const std::function<int(int)>* work = e->work;
-        if (!work) return;
-        if (d < e->first_rank) continue;
+    while (const std::function<int(int)>* work = board_next(e->board, d, seen)) {
         rk.began = clock::now();
         rk.rc = (*work)(d);
         if (rk.rc) rk.error = t_error;
         rk.ended = clock::now();
-        e->remaining.fetch_sub(1, std::memory_order_release);
+        board_done(e->board);
     }
 }
 
-void engine_post(MultiEngine* e, const std::function<int(int)>* work, int first_rank) {
-    e->work = work;
-    e->first_rank = first_rank;
-    e->remaining.store(static_cast<int>(e->ranks.size()) - first_rank, std::memory_order_relaxed);
-    e->job_no.fetch_add(1, std::memory_order_seq_cst);
-    if (e->sleepers.load(std::memory_order_seq_cst) > 0) futex_call(&e->job_no, FUTEX_WAKE_PRIVATE, INT_MAX);
-}
+void engine_post(MultiEngine* e, const std::function<int(int)>* work, int first_rank) { board_post(e->board, work, first_rank); }
 
 // Waits for the posted job; the first failing rank's status and message become the caller's.
 int engine_wait(MultiEngine* e) {
-    using clock = std::chrono::steady_clock;
-    const auto t0 = clock::now();
-    for (uint32_t spins = 0; e->remaining.load(std::memory_order_acquire) > 0; ++spins) {
-        if ((spins & 0x3F) == 0x3F && clock::now() - t0 >= std::chrono::microseconds(kSpinUs)) sched_yield();
-        else __builtin_ia32_pause();
-    }
-    for (size_t d = static_cast<size_t>(e->first_rank); d < e->ranks.size(); ++d)
+    board_wait(e->board);
+    for (size_t d = static_cast<size_t>(e->board.first_rank); d < e->ranks.size(); ++d)
         if (e->ranks[d].rc) return fail(e->ranks[d].rc, "rank " + std::to_string(d) + ": " + e->ranks[d].error);
     return OLMC_OK;
 }
@@ -2278,8 +2239,9 @@ int engine_build(const std::vector<int>& devs, bool rehearsal, MultiEngine** out
         if (r != ncclSuccess) return bail(fail(OLMC_ERR_RCCL, rccl_message("ncclCommInitAll", r)));
     }
     if (devs.size() > 1) {                           // one rank needs no launcher: the calling thread is as good
+        e->board.n_ranks = static_cast<int>(devs.size());
         try {
-            for (size_t d = 0; d < devs.size(); ++d) e->ranks[d].launcher = std::thread(launcher_main, e, static_cast<int>(d), e->job_no.load());
+            for (size_t d = 0; d < devs.size(); ++d) e->ranks[d].launcher = std::thread(launcher_main, e, static_cast<int>(d), e->board.job_no.load());
         } catch (const std::system_error& err) {
             return bail(fail(OLMC_ERR_STATE, std::string("multi-GPU engine: cannot start a launcher thread: ") + err.what()));
         }

@@ -2387,7 +2387,7 @@ __constant__ double kNdtriB[23] = {
 // all forms to mpmath): t by one fma (ndtri_pt), the factor 4 in the exponent, one Newton round instead of two, the integer split.
 __constant__ double kLogQ[7] = {0.666666666666667, 0.39999999999886615, 0.28571428631764334, 0.2222221019926421, 0.18182956608063458, 0.15329500754204178, 0.14643628601909797};
 
-// A zero the optimiser cannot see through (see ndtri_lockstep): a table indexed [k + opaque_zero()] is loaded where it is used.
+// A zero the optimiser cannot see through (see ndtri_lockstep_add): a table indexed [k + opaque_zero()] is loaded where it is used.
 __device__ __forceinline__ int opaque_zero() {
     int z = 0;
     asm volatile("" : "+s"(z));
@@ -2426,7 +2426,7 @@ __device__ __forceinline__ double neg_log_quad(double t, const Q& lq) {
 }
 
 // The rare side of the inverse normal (w >= 6.25, 0.1 % of the points): degree 22 in sqrt(w) - 3.6.
-__device__ __forceinline__ double ndtri_tail(double w, int z = 0 /* see ndtri_lockstep */) {
+__device__ __forceinline__ double ndtri_tail(double w, int z = 0 /* see ndtri_lockstep_add */) {
     const double t = sqrt(w) - kNdtriCentreB;
     double f = kNdtriB[22 + z];
 #pragma unroll
@@ -2498,7 +2498,7 @@ __device__ __forceinline__ double ndtri_w_regs_add(double acc, double p, const N
 // TWO inverse normals in lockstep from the same register-held coefficients (round 5: two consecutive dimensions of one point in the
 // aligned one-point Sobol kernels), added to acc in order: (acc + z0) + z1.  One point per thread left a wave a single chain of ~60
 // dependent fp64 operations per dimension.  Both logarithms and both main polynomials run as one basic block here; a tail point is
-// repaired afterwards behind a branch the wave almost always skips (as in ndtri_lockstep below).  Every point sees exactly the
+// repaired afterwards behind a branch the wave almost always skips (as in ndtri_lockstep_add below).  Every point sees exactly the
 // operations of ndtri_w_add: the same bits.
 __device__ __forceinline__ double ndtri_w_regs_pair_add(double acc, const double (&p)[2], const NdtriRegs& c, int z_tail) {
     double w[2], f[2], t[2];
@@ -2636,7 +2636,7 @@ __device__ __forceinline__ double qmc_point_sum(const uint32_t (&mask)[kSobolBit
             uint32_t fold = shift[tl];
 #pragma unroll
             for (int b = 6; b < kSobolBits; ++b) fold ^= mine[b] & (0u - ((gray_hi >> b) & 1u));
-            // two dimensions per trip (their inverse normals in lockstep: ndtri_w_regs_pair), added to q in dimension order.  A
+            // two dimensions per trip (their inverse normals in lockstep: ndtri_w_regs_pair_add), added to q in dimension order.  A
             // dimension's folded word reaches every lane through ds_bpermute_b32 (a broadcast of lane j, issued one trip ahead: no
             // vector-unit instruction, where v_readlane_b32 + the v_mov_b32 its scalar result forced on the first row cost two).
             int hop = 0;                                                            // byte address of lane j for ds_bpermute_b32

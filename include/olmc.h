@@ -460,7 +460,7 @@ int olmc_profile_enable(int on);
  *   OLMC_TUNE_QMC_BLOCK  Sobol kernels: 0 = by size (default): from 16 dimensions on a workgroup takes 64 points and each of its four waves
  *                        a quarter of the dimensions -- where the point offset is a multiple of 64 and there are 32 dimensions or more,
  *                        with the high Gray-code bits' direction numbers folded once per wave and dimension --; from 2^22 points on (2^21
- *                        below 128 dimensions) a thread takes eight consecutive points.  1 = always eight points per thread, 2 = always
+ *                        below 128 dimensions, 2^20 below 64, 2^19 below 32) a thread takes eight consecutive points.  1 = always eight points per thread, 2 = always
  *                        split workgroups, -1 = always one point per thread.  Every shape returns the same terminal prices bit for bit
  *                        (one association of a point's normal sum)
  *   OLMC_TUNE_POLL       blocking calls: 0 = wait by polling the host-mapped flag the kernel raises behind its results

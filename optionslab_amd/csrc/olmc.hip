@@ -1804,11 +1804,13 @@ int qmc_check(const uint32_t* sv, const uint32_t* shift, int32_t bits, int32_t d
 
 // gbm_qmc.py:38-44 as an olmc_option -> Contract: dt = T / dims, a = ln S + drift dims, vol = sigma sqrt(dt) = make_contract(o, dims)
 // Launch shape of a Sobol kernel.  A workgroup takes 64 points and each of its four waves a quarter of the dimensions (from 16
-// dimensions on; round 4 drew that line at 2^18 points and ran one point per thread in between); from 2^22 points on -- from 2^21
-// below 128 dimensions -- a thread takes an aligned block of eight consecutive points instead (round 5 moved the crossover up from
-// 2^20 twice: the aligned split kernel got faster.  2^20 x 252: split 530 us, eight 638; 2^21 x 64: 310 / 293; 2^21 x 252: 1050 /
-// 1107; 2^22 x 64: 612 / 541; 2^22 x 252: 2106 / 2074 -- profiles/r05_ab_kernels.txt).  OLMC_TUNE_QMC_BLOCK: 1 = always eight points
-// per thread, 2 = always split, -1 = never eight and never split (one point per thread).
+// dimensions on; round 4 drew that line at 2^18 points and ran one point per thread in between); from 2^22 points on a thread takes
+// an aligned block of eight consecutive points instead -- from 2^21 below 128 dimensions, 2^20 below 64, 2^19 below 32: a split wave
+// has its fixed costs (masks, coefficients, the fold's prologue) to spread over a quarter of the dimensions.  Round 5 re-measured the
+// crossover as the aligned split kernel got faster (profiles/r05_ab_kernels.txt, profiles/r05_qmc_grid.txt; split / eight, us):
+// 2^19 x 16: 36 / 32, 2^20 x 16: 65 / 48, 2^19 x 32: 52 / 52, 2^20 x 32: 97 / 82, 2^19 x 48: 68 / 73, 2^20 x 48: 128 / 117, 2^20 x 64:
+// 158 / 171, 2^21 x 64: 310 / 293, 2^20 x 252: 530 / 638, 2^21 x 252: 1050 / 1107, 2^22 x 252: 2106 / 2074.  OLMC_TUNE_QMC_BLOCK:
+// 1 = always eight points per thread, 2 = always split, -1 = never eight and never split (one point per thread).
 struct QmcShape {
     bool blocks, split, aligned, aligned8;
     int64_t units;       // threads' worth of work: blocks of eight, or points
@@ -1823,7 +1825,8 @@ QmcShape qmc_shape(int64_t point_offset, int64_t n_paths, int32_t dims) {
     // fewer than 16 dimensions and to the knob
     sh.aligned = (point_offset & 63) == 0 && dims >= 32;
     sh.aligned8 = (point_offset & 511) == 0;        // eight points per thread: a wave's 64 blocks start at a multiple of 512 points
-    sh.blocks = g_qmc_block == 1 ? true : (g_qmc_block != 0 ? false : n_paths >= (int64_t(1) << (dims < 128 ? 21 : 22)));
+    const int blocks_from_log2 = dims < 32 ? 19 : dims < 64 ? 20 : dims < 128 ? 21 : 22;      // fewer dimensions: less for a split wave to spread its fixed costs over
+    sh.blocks = g_qmc_block == 1 ? true : (g_qmc_block != 0 ? false : n_paths >= (int64_t(1) << blocks_from_log2));
     sh.split = !sh.blocks && (g_qmc_block == 0 || g_qmc_block == 2) && dims >= 16;
     sh.units = sh.blocks ? (point_offset + n_paths + kQmcBlock - 1) / kQmcBlock - point_offset / kQmcBlock : n_paths;
     sh.grid = sh.split ? static_cast<int32_t>((n_paths + kWave - 1) / kWave) : grid_for(sh.units);

@@ -1041,14 +1041,14 @@ def test_qmc_eight_point_blocks_give_the_same_points():
             b = ol.MonteCarloPricer(N, M, 42, ol.MCMethod.QMC).price(*ATM, "call", return_error=True)
             assert b.price == pytest.approx(a.price, rel=1e-13) and b.std_error == pytest.approx(a.std_error, rel=1e-10) and b.n_paths == a.n_paths
         _hip.tune(_hip.TUNE_QMC_BLOCK, 0)
-        big = ol.MonteCarloPricer(2**21, 8, 42, ol.MCMethod.QMC).price(*ATM, "call", return_error=True)     # the size that switches by itself (2^21 below 128 dimensions, else 2^22)
+        big = ol.MonteCarloPricer(2**21, 8, 42, ol.MCMethod.QMC).price(*ATM, "call", return_error=True)     # a size that switches by itself (2^19 below 32 dimensions ... 2^22 from 128)
         assert abs(big.price - BS_CALL) < 2e-3
     finally:
         _hip.tune(_hip.TUNE_QMC_BLOCK, 0)
 
 
 def test_qmc_split_workgroups_return_the_bits_of_one_point_threads():
-    """Launches of fewer than 2^22 Sobol points (2^21 below 128 dimensions; round 4: up to 2^18) with >= 16 dimensions give 64 points to a workgroup and a quarter
+    """Launches of fewer than 2^22 Sobol points (2^21 below 128 dimensions, 2^20 below 64, 2^19 below 32; round 4: up to 2^18) with >= 16 dimensions give 64 points to a workgroup and a quarter
     of the dimensions to each of its four waves (european_qmc_kernel<., true>, european_qmc_batch_kernel<., false, true>).  Every Sobol
     kernel adds a point's inverse normals in the same association (quarters), so the split form must return the one-point form's
     terminal prices bit for bit -- ragged point counts around the 64-point workgroup, dimension counts that do not divide by four,

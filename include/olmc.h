@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define OLMC_ABI_VERSION 5   /* 2: olmc_asian avg_kind 0 is the fp64-exponent kernel (2 = the fp32 one); probes, tune knobs 5-8
+#define OLMC_ABI_VERSION 6   /* 2: olmc_asian avg_kind 0 is the fp64-exponent kernel (2 = the fp32 one); probes, tune knobs 5-8
                               * 3: additions only -- olmc_european_qmc_batch, olmc_european_qmc_greeks_fd, olmc_multi_capacity,
                               *    olmc_exp2_probe_form, olmc_phase_stamps, olmc_contract_layout, tune knob 9; every v2 entry point keeps its signature and meaning
                               * 4: the measurement entry points (olmc_*probe*, olmc_phase_stamps, olmc_clock_probe, olmc_normal_moments) and the
@@ -56,7 +56,8 @@ extern "C" {
                               *    entry points are now concurrent across threads (a context per caller, olmc.h "Threading")
                               * 5: additions only -- olmc_multi_gpu_european_qmc, olmc_multi_gpu_spans, tune knobs 10, 11 (OLMC_TUNE_MULTI_LAUNCH, OLMC_TUNE_STAGED_COPY); the multi-GPU
                               *    entry points launch their ranks from one launcher thread per device; the grid reduction's consumer side is an
-                              *    agent-scope acquire again (numbers unchanged) */
+                              *    agent-scope acquire again (numbers unchanged) 
+                              * 6: additions only -- olmc_multi_gpu_european_qmc_greeks_fd, olmc_multi_gpu_european_qmc_cv; OLMC_TUNE_QMC_BLOCK takes 2 */
 
 enum {
     OLMC_OK = 0,
@@ -404,6 +405,9 @@ int olmc_european_qmc_terminal(double S, double T, double r, double sigma, doubl
  *   olmc_multi_gpu_european_qmc  {sum, sumsq, n} of the rank's block of Sobol POINTS (src/simulation/gbm_qmc.py:14-46)   count = 3
  *                                (inner boundaries on multiples of 512 points where a rank owns >= 4,096: every rank's point offset
  *                                is one the aligned kernels take; sharding.qmc_shard_bounds cuts the same way)
+ *   olmc_multi_gpu_european_qmc_greeks_fd   the 8 / 14 bumped contracts of olmc_european_qmc_greeks_fd on the rank's block of the SAME
+ *                                Sobol points, one launch per rank: {sum, sumsq} x 8 or 16 slots, n   count = 17 / 33
+ *   olmc_multi_gpu_european_qmc_cv   the five control-variate moments of the rank's block of Sobol points, n   count = 6
  * Prices agree with the one-GPU entry points to the rounding of the sums' association (same paths whatever n_gpus is: the Philox
  * counter carries the global path index, the Sobol kernels take the global point index).
  *
@@ -423,6 +427,12 @@ int olmc_multi_gpu_european_cv(double S, double K, double T, double r, double si
 int olmc_multi_gpu_european_qmc(double S, double K, double T, double r, double sigma, double q, int is_call,
                                 int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
                                 int n_gpus, olmc_stats* out);
+int olmc_multi_gpu_european_qmc_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                          int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
+                                          int second_order, int n_gpus, double* out9, olmc_stats* evals /* [14] or NULL */);
+int olmc_multi_gpu_european_qmc_cv(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                   int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
+                                   int n_gpus, olmc_cv_moments* out);
 /* Host microseconds of the calling thread's last multi-GPU call: out8 = {launch phase (launch job posted -> every rank's kernel
  * queued), collective queued, result fetched (contains the kernels' run time), other ranks drained, total, the latest launcher's start
  * after the post (wake latency; 0 in the serial form), the longest and the shortest single rank's own launch}. */

@@ -93,6 +93,8 @@ PROTOTYPES = {
     "olmc_multi_gpu_greeks_fd": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(_D), C.POINTER(Stats)]),
     "olmc_multi_gpu_european_cv": (_I, _SIX + [_I, _I64, _I32, _U64T, _I, _I, C.POINTER(CvMoments)]),
     "olmc_multi_gpu_european_qmc": (_I, _SIX + [_I, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, _I, C.POINTER(Stats)]),
+    "olmc_multi_gpu_european_qmc_greeks_fd": (_I, _SIX + [_I, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, _I, _I, C.POINTER(_D), C.POINTER(Stats)]),
+    "olmc_multi_gpu_european_qmc_cv": (_I, _SIX + [_I, _I64, _I32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), _I32, _I, C.POINTER(CvMoments)]),
     "olmc_multi_gpu_spans": (_I, [C.POINTER(_D)]),
     "olmc_combine_stats": (_I, [C.POINTER(Stats), _I32, _D, _D, C.POINTER(Stats)]),
     "olmc_philox_words": (_I, [_U64T, _I64, _I64, _I32, _I32, C.c_uint32, C.POINTER(C.c_uint32)]),
@@ -557,6 +559,27 @@ def multi_gpu_european_qmc(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv
     out = Stats()
     _check(lib().olmc_multi_gpu_european_qmc(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(sv.shape[0]), psv, psh, int(sv.shape[1]),
                                              int(n_gpus), C.byref(out)))
+    return out
+
+
+def multi_gpu_european_qmc_greeks_fd(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv: np.ndarray, shift: np.ndarray, second_order: bool,
+                                     n_gpus: int, want_evals: bool = True) -> Tuple[List[float], List[Stats]]:
+    """As european_qmc_greeks_fd over n_gpus devices of this process: every rank prices the 8 / 14 contracts on its block of the
+    Sobol points in one launch, one all-reduce of 17 / 33 sums."""
+    sv, psv, shift, psh = _sobol_args(sv, shift, 0, n_paths)
+    out9 = (C.c_double * 9)()
+    evals = (Stats * 14)() if want_evals else None
+    _check(lib().olmc_multi_gpu_european_qmc_greeks_fd(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(sv.shape[0]), psv, psh,
+                                                       int(sv.shape[1]), int(second_order), int(n_gpus), out9, evals))
+    return list(out9), (list(evals) if want_evals else [])
+
+
+def multi_gpu_european_qmc_cv(S, K, T, r, sigma, q, is_call: bool, n_paths: int, sv: np.ndarray, shift: np.ndarray, n_gpus: int) -> CvMoments:
+    """As european_qmc_cv over n_gpus devices of this process: one all-reduce of the five moments and n."""
+    sv, psv, shift, psh = _sobol_args(sv, shift, 0, n_paths)
+    out = CvMoments()
+    _check(lib().olmc_multi_gpu_european_qmc_cv(S, K, T, r, sigma, q, int(is_call), int(n_paths), int(sv.shape[0]), psv, psh, int(sv.shape[1]),
+                                                int(n_gpus), C.byref(out)))
     return out
 
 

@@ -1837,7 +1837,7 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
             int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
             olmc_stats* out, double* terminal_host, int mirror = 0, olmc_cv_moments* cv = nullptr,
             double* d_triple = nullptr /* a shard of a multi-GPU call: {sum, sumsq, n} are LEFT here, on `shard_stream`, nothing is waited for */,
-            hipStream_t shard_stream = nullptr) {
+            hipStream_t shard_stream = nullptr, bool shard_cv = false /* with d_triple: the five control-variate moments and n instead */) {
     int rc = qmc_check(sv, shift, bits, dims, point_offset, n_paths);
     if (rc) return rc;
     CtxLease lease;
@@ -1881,16 +1881,18 @@ int run_qmc(double S, double K, double T, double r, double sigma, double q, int 
     EventPair ep{};
     const EventPair* timed = nullptr;
     double* const no_terminal = nullptr;
-    if (cv) {
-        rc = make_ws(c, c->stream, grid, 5, c->d_result, -1.0, &ws);
+    if (cv || (d_triple && shard_cv)) {
+        hipStream_t s = d_triple ? shard_stream : c->stream;
+        rc = make_ws(c, s, grid, 5, d_triple ? d_triple : c->d_result, d_triple ? static_cast<double>(n_paths) : -1.0, &ws);
         if (rc) return rc;
         rc = prof_pair(c, &ep, &timed);
         if (rc) return rc;
-        if (blocks && sh.aligned8) launch_timed(european_qmc_block_kernel<kControlVariate, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
-        else if (blocks) launch_timed(european_qmc_block_kernel<kControlVariate, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
-        else if (sh.split && sh.aligned) launch_timed(european_qmc_kernel<kControlVariate, true, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
-        else if (sh.split) launch_timed(european_qmc_kernel<kControlVariate, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
-        else launch_timed(european_qmc_kernel<kControlVariate, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        if (blocks && sh.aligned8) launch_timed(european_qmc_block_kernel<kControlVariate, true>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else if (blocks) launch_timed(european_qmc_block_kernel<kControlVariate, false>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else if (sh.split && sh.aligned) launch_timed(european_qmc_kernel<kControlVariate, true, true>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else if (sh.split) launch_timed(european_qmc_kernel<kControlVariate, true>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        else launch_timed(european_qmc_kernel<kControlVariate, false>, dim3(grid), dim3(kBlock), s, timed, qr, ct, d_sv, d_shift, ws, no_terminal);
+        if (d_triple) return after_launch(c, s);
     } else if (!terminal_host) {
         hipStream_t s = d_triple ? shard_stream : c->stream;
         rc = make_ws(c, s, grid, 2, d_triple ? d_triple : c->d_result, d_triple ? static_cast<double>(n_paths) : -1.0, &ws);
@@ -1955,14 +1957,18 @@ namespace {
 // k contracts on the same Sobol points, ONE launch (european_qmc_batch_kernel); falls back to k launches beyond the size one
 // grid covers.  out[i] = stats of opts[i].
 int run_qmc_batch(const olmc_option* opts, int32_t k, int64_t point_offset, int64_t n_paths, int32_t dims, const uint32_t* sv,
-                  const uint32_t* shift, int32_t bits, olmc_stats* out) {
-    if (!opts || !out) return fail(OLMC_ERR_ARG, "null pointer");
+                  const uint32_t* shift, int32_t bits, olmc_stats* out,
+                  double* d_sums = nullptr /* a shard of a multi-GPU call: the 2 nsets sums and n are LEFT here, on `shard_stream`, nothing is waited for */,
+                  hipStream_t shard_stream = nullptr, int* pos_out = nullptr /* with d_sums: slot of contract i */) {
+    if (!opts || (!out && !d_sums)) return fail(OLMC_ERR_ARG, "null pointer");
     if (k < 1 || k > OLMC_MAX_BATCH) return fail(OLMC_ERR_ARG, "batch size must be in [1, OLMC_MAX_BATCH]");
     int rc = qmc_check(sv, shift, bits, dims, point_offset, n_paths);
     if (rc) return rc;
     const QmcShape sh = qmc_shape(point_offset, n_paths, dims);
     const bool blocks = sh.blocks;
     const int64_t units = sh.units;
+    if (d_sums && (k < 2 || (units + kBlock - 1) / kBlock > kMaxGrid))
+        return fail(OLMC_ERR_ARG, "a shard of fused Sobol contracts needs 2 .. 16 contracts and points one grid covers");
     if (k == 1 || (units + kBlock - 1) / kBlock > kMaxGrid) {             // one contract, or more points than a grid covers: literal launches
         for (int i = 0; i < k; ++i) {
             rc = run_qmc(opts[i].S, opts[i].K, opts[i].T, opts[i].r, opts[i].sigma, opts[i].q, opts[i].is_call, point_offset, n_paths, dims, sv, shift,
@@ -1975,8 +1981,11 @@ int run_qmc_batch(const olmc_option* opts, int32_t k, int64_t point_offset, int6
     rc = ctx_lease(&lease);
     if (rc) return rc;
     DeviceCtx* const c = lease.c;
-    rc = qmc_table(c, sv, shift, dims);
+    bool uploaded = false;
+    rc = qmc_table(c, sv, shift, dims, &uploaded);
     if (rc) return rc;
+    if (d_sums && uploaded) HIP_TRY(hipStreamSynchronize(c->stream));        // the table travelled on the context's stream, the kernel runs on the rank's
+    hipStream_t const st = d_sums ? shard_stream : c->stream;
     const size_t sv_words = static_cast<size_t>(dims) * kSobolBits;
     uint32_t* d_sv = c->d_sobol;
     uint32_t* d_shift = d_sv + sv_words;
@@ -1988,7 +1997,7 @@ int run_qmc_batch(const olmc_option* opts, int32_t k, int64_t point_offset, int6
     const int32_t grid = sh.split ? sh.grid : static_cast<int32_t>((units + kBlock - 1) / kBlock);     // the grid covers every point / block
     const int nsets = k <= 8 ? 8 : 16;
     ReduceWs ws;
-    rc = make_ws(c, c->stream, grid, 2 * nsets, c->d_result, -1.0, &ws);
+    rc = make_ws(c, st, grid, 2 * nsets, d_sums ? d_sums : c->d_result, d_sums ? static_cast<double>(n_paths) : -1.0, &ws);
     if (rc) return rc;
     EventPair ep{};
     const EventPair* timed = nullptr;
@@ -1999,19 +2008,23 @@ int run_qmc_batch(const olmc_option* opts, int32_t k, int64_t point_offset, int6
     if (nsets == 8) {
         ContractSet<8> cs;
         group_contracts<8>(opts, k, dims, &cs, pos);
-        if (blocks && sh.aligned8) launch_timed(european_qmc_batch_kernel<8, true, false, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
-        else if (blocks) launch_timed(european_qmc_batch_kernel<8, true, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
-        else if (sh.split && sh.aligned) launch_timed(european_qmc_batch_kernel<8, false, true, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
-        else if (sh.split) launch_timed(european_qmc_batch_kernel<8, false, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
-        else launch_timed(european_qmc_batch_kernel<8, false, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+        if (blocks && sh.aligned8) launch_timed(european_qmc_batch_kernel<8, true, false, true>, dim3(grid), dim3(kBlock), st, timed, qr, cs, d_sv, d_shift, ws);
+        else if (blocks) launch_timed(european_qmc_batch_kernel<8, true, false>, dim3(grid), dim3(kBlock), st, timed, qr, cs, d_sv, d_shift, ws);
+        else if (sh.split && sh.aligned) launch_timed(european_qmc_batch_kernel<8, false, true, true>, dim3(grid), dim3(kBlock), st, timed, qr, cs, d_sv, d_shift, ws);
+        else if (sh.split) launch_timed(european_qmc_batch_kernel<8, false, true>, dim3(grid), dim3(kBlock), st, timed, qr, cs, d_sv, d_shift, ws);
+        else launch_timed(european_qmc_batch_kernel<8, false, false>, dim3(grid), dim3(kBlock), st, timed, qr, cs, d_sv, d_shift, ws);
     } else {
         ContractSet<16> cs;
         group_contracts<16>(opts, k, dims, &cs, pos);
-        if (blocks && sh.aligned8) launch_timed(european_qmc_batch_kernel<16, true, false, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
-        else if (blocks) launch_timed(european_qmc_batch_kernel<16, true, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
-        else if (sh.split && sh.aligned) launch_timed(european_qmc_batch_kernel<16, false, true, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
-        else if (sh.split) launch_timed(european_qmc_batch_kernel<16, false, true>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
-        else launch_timed(european_qmc_batch_kernel<16, false, false>, dim3(grid), dim3(kBlock), c->stream, timed, qr, cs, d_sv, d_shift, ws);
+        if (blocks && sh.aligned8) launch_timed(european_qmc_batch_kernel<16, true, false, true>, dim3(grid), dim3(kBlock), st, timed, qr, cs, d_sv, d_shift, ws);
+        else if (blocks) launch_timed(european_qmc_batch_kernel<16, true, false>, dim3(grid), dim3(kBlock), st, timed, qr, cs, d_sv, d_shift, ws);
+        else if (sh.split && sh.aligned) launch_timed(european_qmc_batch_kernel<16, false, true, true>, dim3(grid), dim3(kBlock), st, timed, qr, cs, d_sv, d_shift, ws);
+        else if (sh.split) launch_timed(european_qmc_batch_kernel<16, false, true>, dim3(grid), dim3(kBlock), st, timed, qr, cs, d_sv, d_shift, ws);
+        else launch_timed(european_qmc_batch_kernel<16, false, false>, dim3(grid), dim3(kBlock), st, timed, qr, cs, d_sv, d_shift, ws);
+    }
+    if (d_sums) {
+        if (pos_out) std::copy(pos, pos + k, pos_out);
+        return after_launch(c, st);
     }
     rc = after_launch(c, c->stream);
     if (rc) return rc;
@@ -2594,6 +2607,53 @@ extern "C" int olmc_multi_gpu_european_qmc(double S, double K, double T, double 
     if (rc) return rc;
     finish_stats(host[0], host[1], static_cast<int64_t>(host[2]), r, T, out);
     if (poisoned(S, K, T, r, sigma, q)) nan_stats(out->n, out);
+    return OLMC_OK;
+}
+
+// The 8 / 14 bumped contracts of compute_greeks_unified on a MCMethod.QMC pricer (unified_greeks.py:295-358 over gbm_qmc.py:14-46)
+// over n_gpus devices: every rank prices ALL contracts on its block of the Sobol points in one launch (european_qmc_batch_kernel),
+// the 2 nsets sums and n meet in the one all-reduce (count 17 / 33, as olmc_multi_gpu_greeks_fd).
+extern "C" int olmc_multi_gpu_european_qmc_greeks_fd(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                                     int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift,
+                                                     int32_t bits, int second_order, int n_gpus, double* out9, olmc_stats* evals) {
+    if (!out9) return fail(OLMC_ERR_ARG, "null pointer");
+    if (!(T > 0.0)) return fail(OLMC_ERR_ARG, "T must be > 0 (price() returns intrinsic value without simulating)");
+    int rc = qmc_check(sv, shift, bits, dims, 0, n_paths);
+    if (rc) return rc;
+    const GreeksSet gs(S, K, T, r, sigma, q, is_call, second_order);
+    const int nsets = gs.k <= 8 ? 8 : 16;
+    int pos[OLMC_MAX_BATCH] = {};
+    double host[kMultiValues] = {};
+    rc = multi_gpu_run(n_gpus, n_paths, dims, 2 * nsets + 1, [&](int rank, int64_t lo, int64_t n_local, hipStream_t s, double* d_send) {
+        int other[OLMC_MAX_BATCH];                                                               // every rank lays the set out alike: rank 0's
+        return run_qmc_batch(gs.o, gs.k, lo, n_local, dims, sv, shift, bits, nullptr, d_send, s, rank == 0 ? pos : other);      // layout is the one kept
+    }, host, true);
+    if (rc) return rc;
+    const int64_t n = static_cast<int64_t>(host[2 * nsets]);
+    olmc_stats st[OLMC_MAX_BATCH];
+    for (int i = 0; i < gs.k; ++i) {
+        finish_stats(host[2 * pos[i]], host[2 * pos[i] + 1], n, gs.o[i].r, gs.o[i].T, &st[i]);
+        if (poisoned(gs.o[i].S, gs.o[i].K, gs.o[i].T, gs.o[i].r, gs.o[i].sigma, gs.o[i].q)) nan_stats(n, &st[i]);
+    }
+    gs.finish(st, T, out9, evals);
+    return OLMC_OK;
+}
+
+// price_with_control_variate on a MCMethod.QMC pricer (monte_carlo.py:154-186 over gbm_qmc.py:14-46) over n_gpus devices: the five
+// moments of the rank's block of Sobol points and n (count 6, as olmc_multi_gpu_european_cv).
+extern "C" int olmc_multi_gpu_european_qmc_cv(double S, double K, double T, double r, double sigma, double q, int is_call,
+                                              int64_t n_paths, int32_t dims, const uint32_t* sv, const uint32_t* shift, int32_t bits,
+                                              int n_gpus, olmc_cv_moments* out) {
+    if (!out) return fail(OLMC_ERR_ARG, "null pointer");
+    int rc = qmc_check(sv, shift, bits, dims, 0, n_paths);
+    if (rc) return rc;
+    double host[6] = {};
+    rc = multi_gpu_run(n_gpus, n_paths, dims, 6, [&](int, int64_t lo, int64_t n_local, hipStream_t s, double* d_send) {
+        return run_qmc(S, K, T, r, sigma, q, is_call, lo, n_local, dims, sv, shift, bits, nullptr, nullptr, 0, nullptr, d_send, s, true);
+    }, host, true);
+    if (rc) return rc;
+    cv_from_device(host, static_cast<int64_t>(host[5]), S, T, r, q, out);
+    if (poisoned(S, K, T, r, sigma, q)) out->value = std::nan("");
     return OLMC_OK;
 }
 

@@ -205,7 +205,8 @@ class MonteCarloPricer:
     price(), greeks() and price_with_control_variate() shard `num_simulations` over the first n_gpus devices of THIS process
     (contiguous global path ranges, one launch per device, ONE RCCL all-reduce of the sums over xGMI: olmc_multi_gpu_*, no
     torch); the paths, hence the results up to the association of the sums, do not depend on n_gpus.  MCMethod.QMC shards its
-    price() the same way (contiguous blocks of Sobol POINTS); its Greeks, control variate and terminal array stay on one device."""
+    price(), greeks() and price_with_control_variate() the same way (contiguous blocks of Sobol POINTS, cut on multiples of 512); its
+    terminal array stays on one device."""
 
     __slots__ = ("num_simulations", "num_steps", "seed", "method", "_use_numba", "n_gpus")
 
@@ -270,6 +271,8 @@ class MonteCarloPricer:
         actual_seed = seed if seed is not None else self.seed
         if self.method == MCMethod.QMC:   # the same five-moment reduction on the Sobol points (N samples, no mirror)
             sv, shift = sobol_tables(self.num_steps, actual_seed, self.num_simulations)
+            if self.n_gpus > 1:
+                return float(_hip.multi_gpu_european_qmc_cv(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift, self.n_gpus).value)
             return float(_hip.european_qmc_cv(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift).value)
         if self.n_gpus > 1:
             m = _hip.multi_gpu_european_cv(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(), actual_seed, True,
@@ -301,8 +304,12 @@ class MonteCarloPricer:
         actual_seed = seed if seed is not None else self.seed
         if self.method == MCMethod.QMC:   # the bumped contracts share the Sobol points (same dims, same seed): one launch prices them all
             sv, shift = sobol_tables(self._steps(), actual_seed, self.num_simulations)
-            vals, _ = _hip.european_qmc_greeks_fd(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift,
-                                                  include_second_order, want_evals=False)
+            if self.n_gpus > 1:
+                vals, _ = _hip.multi_gpu_european_qmc_greeks_fd(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift,
+                                                                include_second_order, self.n_gpus, want_evals=False)
+            else:
+                vals, _ = _hip.european_qmc_greeks_fd(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, sv, shift,
+                                                      include_second_order, want_evals=False)
         elif self.n_gpus > 1:
             vals, _ = _hip.multi_gpu_greeks_fd(S, K, T, r, sigma, q, option_type == "call", self.num_simulations, self._steps(), actual_seed,
                                                include_second_order, self.n_gpus, want_evals=False)

@@ -7,6 +7,7 @@
     price_sharded               any entry point that takes (path_offset, n_local): Asian, barrier, lookback,
                                 autocallable, cliquet, Heston, jump diffusion               count = 3
     qmc_sharded                 MCMethod.QMC: contiguous blocks of Sobol POINTS (gbm_qmc.py:14-46)        count = 3
+    qmc_greeks_sharded, qmc_control_variate_sharded   the same two on blocks of Sobol points (cut by qmc_shard_bounds)   count = 2k + 1, 6
 
 Global path index g in [0, N); rank k of P owns the contiguous block
 [k*N/P, (k+1)*N/P).  The Philox counter carries g, so every path's normals are
@@ -163,7 +164,7 @@ def _device_batch(contracts, is_call, lo, n_local, n_steps, seed, antithetic):
 
 
 def greeks_sharded(S, K, T, r, sigma, option_type, q, n_paths_global: int, n_steps: int, seed: int,
-                   include_second_order: bool = True, antithetic: bool = True, group=None, batch_fn=None):
+                   include_second_order: bool = True, antithetic: bool = True, group=None, batch_fn=None, bounds=shard_bounds):
     """compute_greeks_unified (src/greeks/unified_greeks.py:235-367) over sharded paths: every rank prices the
     8 / 14 bumped contracts on ITS block of the common normals in one launch, ONE all-reduce carries the 2k sums
     and n, and every rank evaluates the same finite differences.  `batch_fn(contracts, is_call, lo, n_local,
@@ -175,7 +176,7 @@ def greeks_sharded(S, K, T, r, sigma, option_type, q, n_paths_global: int, n_ste
     compute_greeks_unified(rec, S, K, T, r, sigma, option_type, q, include_second_order, fused=False)
     contracts = list(dict.fromkeys(rec.contracts))              # the reference memoises on the same key
     rank, world = _group_info(group)
-    lo, hi = shard_bounds(n_paths_global, rank, world)
+    lo, hi = bounds(n_paths_global, rank, world)
     local = (batch_fn or _device_batch)(contracts, option_type == "call", lo, hi - lo, n_steps, seed, antithetic)
     flat = [v for (sx, sxx, _n) in local for v in (sx, sxx)] + [float(local[0][2])]
     red = _allreduce_list(flat, group)
@@ -185,12 +186,12 @@ def greeks_sharded(S, K, T, r, sigma, option_type, q, n_paths_global: int, n_ste
 
 
 def control_variate_sharded(S, K, T, r, sigma, option_type, q, n_paths_global: int, n_steps: int, seed: int,
-                            antithetic: bool = True, group=None, shard_fn=None):
+                            antithetic: bool = True, group=None, shard_fn=None, bounds=shard_bounds):
     """MonteCarloPricer.price_with_control_variate (monte_carlo.py:154-186) over sharded paths: the five moments
     and n are summed over ranks, beta and the estimate follow on every rank.  `shard_fn(lo, n_local)` -> an object
     with the olmc_cv_moments fields (default: the device kernel)."""
     rank, world = _group_info(group)
-    lo, hi = shard_bounds(n_paths_global, rank, world)
+    lo, hi = bounds(n_paths_global, rank, world)
     fn = shard_fn or (lambda lo_, n_: _hip.european_cv_shard(S, K, T, r, sigma, q, option_type == "call", lo_, n_, n_steps, seed, antithetic))
     m = fn(lo, hi - lo)
     sd, ss, sdd, sss, sds, n = _allreduce_list([m.sum_d, m.sum_s, m.sum_dd, m.sum_ss, m.sum_ds, float(m.n)], group)
@@ -200,3 +201,32 @@ def control_variate_sharded(S, K, T, r, sigma, option_type, q, n_paths_global: i
     var_s = (sss - n * mean_s * mean_s) / (n - 1.0)
     beta = cov_ds / var_s if (n > 1.0 and var_s > 1e-10) else 0.0          # :182
     return mean_d - beta * (mean_s - S * math.exp((r - q) * T))              # :184
+
+
+def qmc_greeks_sharded(S, K, T, r, sigma, option_type, q, n_points_global: int, n_steps: int, seed: int,
+                       include_second_order: bool = True, group=None, batch_fn=None):
+    """compute_greeks_unified on a MCMethod.QMC pricer over sharded POINTS: every rank prices the 8 / 14 bumped contracts on its block
+    of the one Sobol sequence (qmc_shard_bounds) in one launch, one all-reduce of the 2k sums and n.  `batch_fn` as in greeks_sharded
+    (its `antithetic` argument is False: no mirror, gbm_qmc.py:44-46).  The single-process form is olmc_multi_gpu_european_qmc_greeks_fd."""
+    if batch_fn is None:
+        from .monte_carlo import sobol_tables
+
+        sv, shift = sobol_tables(n_steps, seed, n_points_global)
+
+        def batch_fn(contracts, is_call, lo, n_local, _n_steps, _seed, _antithetic):
+            options = [(S_, K_, T_, r_, v_, q_, is_call) for (S_, K_, T_, r_, v_, q_) in contracts]
+            return [(st.sum, st.sumsq, st.n) for st in _hip.european_qmc_batch(options, n_local, sv, shift, point_offset=lo)]
+    return greeks_sharded(S, K, T, r, sigma, option_type, q, n_points_global, n_steps, seed, include_second_order, False, group, batch_fn,
+                          bounds=qmc_shard_bounds)
+
+
+def qmc_control_variate_sharded(S, K, T, r, sigma, option_type, q, n_points_global: int, n_steps: int, seed: int, group=None, shard_fn=None):
+    """price_with_control_variate on a MCMethod.QMC pricer over sharded POINTS (qmc_shard_bounds): the five moments of every rank's
+    block and n meet in one all-reduce.  The single-process form is olmc_multi_gpu_european_qmc_cv."""
+    if shard_fn is None:
+        from .monte_carlo import sobol_tables
+
+        sv, shift = sobol_tables(n_steps, seed, n_points_global)
+        shard_fn = lambda lo, n: _hip.european_qmc_cv(S, K, T, r, sigma, q, option_type == "call", n, sv, shift, point_offset=lo)   # noqa: E731
+    return control_variate_sharded(S, K, T, r, sigma, option_type, q, n_points_global, n_steps, seed, False, group, shard_fn,
+                                   bounds=qmc_shard_bounds)

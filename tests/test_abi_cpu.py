@@ -86,7 +86,7 @@ def test_struct_layouts_match_the_header():
 
 
 def test_abi_version_and_error_string(library):
-    assert library.olmc_abi_version() == 5
+    assert library.olmc_abi_version() == 6
     assert isinstance(library.olmc_last_error(), bytes)
 
 

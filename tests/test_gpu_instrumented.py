@@ -176,12 +176,48 @@ def test_n_rank_sobol_price_is_the_one_device_sobol_price(rehearsal, n_ranks):
         assert (got.sum, got.sumsq, got.n, got.price, got.std_error) == (want.sum, want.sumsq, want.n, want.price, want.std_error)
 
 
+@pytest.mark.parametrize("n_ranks", [1, 3, 8])
+def test_n_rank_sobol_greeks_and_control_variate_are_the_one_device_ones(rehearsal, n_ranks):
+    """olmc_multi_gpu_european_qmc_greeks_fd / _cv: every rank prices all 8 / 14 bumped contracts (the five control-variate moments)
+    on ITS block of the Sobol points -- the same points as the one-device call, the sums in another association (1e-13), and the
+    finite differences evaluated from them (differences of nearly equal prices: 1e-8 of the price scale) -- through split
+    workgroups, their aligned form and eight points per thread."""
+    S, K, T, r, v = ATM
+    for n, dims in ((1 << 14, 16), (300_001, 64), (1 << 19, 16)):
+        sv, shift = ol.monte_carlo.sobol_tables(dims, 42, n)
+        for second in (False, True):
+            g1, e1 = hip.european_qmc_greeks_fd(S, K, T, r, v, 0.01, True, n, sv, shift, second)
+            gn, en = hip.multi_gpu_european_qmc_greeks_fd(S, K, T, r, v, 0.01, True, n, sv, shift, second, n_ranks)
+            for a, b in zip(e1[:14 if second else 8], en):
+                assert b.n == a.n == n and b.sum == pytest.approx(a.sum, rel=1e-13, abs=1e-300) and b.sumsq == pytest.approx(a.sumsq, rel=1e-13, abs=1e-300)
+            assert gn[0] == pytest.approx(g1[0], rel=1e-13)
+            for a, b in zip(g1[1:], gn[1:]):
+                assert b == pytest.approx(a, rel=1e-7, abs=1e-7)
+        c1 = hip.european_qmc_cv(S, K, T, r, v, 0.01, False, n, sv, shift)
+        cn = hip.multi_gpu_european_qmc_cv(S, K, T, r, v, 0.01, False, n, sv, shift, n_ranks)
+        assert cn.n == c1.n == n
+        for f in ("sum_d", "sum_s", "sum_dd", "sum_ss", "sum_ds"):
+            assert getattr(cn, f) == pytest.approx(getattr(c1, f), rel=1e-13), f
+        assert cn.value == pytest.approx(c1.value, rel=1e-10)
+        parts = []
+        for d in range(n_ranks):                                     # the rank-ordered combination of the shards priced one by one (the discount
+            lo, hi = ol.sharding.qmc_shard_bounds(n, d, n_ranks)    # applied per shard there, once to the sums here: an ulp)
+            parts.append(hip.european_qmc_cv(S, K, T, r, v, 0.01, False, hi - lo, sv, shift, point_offset=lo))
+        want = hip.combine_cv(parts, S, T, r, 0.01)
+        for f in ("sum_d", "sum_s", "sum_dd", "sum_ss", "sum_ds"):
+            assert getattr(cn, f) == pytest.approx(getattr(want, f), rel=4e-16), f
+        assert cn.value == pytest.approx(want.value, rel=1e-11)
+
+
 def test_the_qmc_pricer_with_n_gpus_prices_what_the_one_gpu_qmc_pricer_prices(rehearsal, monkeypatch):
     monkeypatch.setattr(ol.monte_carlo, "_hip", hip)
     one = ol.MonteCarloPricer(1 << 15, 32, 42, ol.MCMethod.QMC)
     many = ol.MonteCarloPricer(1 << 15, 32, 42, ol.MCMethod.QMC, n_gpus=3)
     a, b = one.price(*ATM, "call", return_error=True), many.price(*ATM, "call", return_error=True)
     assert b.n_paths == a.n_paths == 1 << 15 and b.price == pytest.approx(a.price, rel=1e-13) and b.std_error == pytest.approx(a.std_error, rel=1e-10)
+    g1, gn = one.greeks(*ATM, "call"), many.greeks(*ATM, "call")
+    assert list(g1) == list(gn) and all(gn[k] == pytest.approx(g1[k], rel=1e-7, abs=1e-7) for k in g1)
+    assert many.price_with_control_variate(*ATM, "call") == pytest.approx(one.price_with_control_variate(*ATM, "call"), rel=1e-10)
 
 
 def test_engines_come_and_go_without_touching_dead_streams(rehearsal):

@@ -66,6 +66,12 @@ def test_one_rank_goes_through_the_real_all_reduce_for_every_payload():
     assert (q1.sum, q1.sumsq, q1.n, q1.price) == (q0.sum, q0.sumsq, q0.n, q0.price)
     p = ol.MonteCarloPricer(1 << 16, 16, 42, ol.MCMethod.QMC, n_gpus=1).price(*ATM, "call")
     assert p == q0.price
+    for second in (False, True):
+        g1, e1 = _hip.multi_gpu_european_qmc_greeks_fd(S, K, T, r, v, 0.0, True, 1 << 16, sv, shift, second, 1)
+        g0, e0 = _hip.european_qmc_greeks_fd(S, K, T, r, v, 0.0, True, 1 << 16, sv, shift, second)
+        assert g1 == g0 and [(x.sum, x.sumsq) for x in e1] == [(x.sum, x.sumsq) for x in e0]
+    k1, k0 = _hip.multi_gpu_european_qmc_cv(S, K, T, r, v, 0.01, False, 1 << 16, sv, shift, 1), _hip.european_qmc_cv(S, K, T, r, v, 0.01, False, 1 << 16, sv, shift)
+    assert (k1.sum_d, k1.sum_s, k1.sum_dd, k1.sum_ss, k1.sum_ds, k1.value) == (k0.sum_d, k0.sum_s, k0.sum_dd, k0.sum_ss, k0.sum_ds, k0.value)
 
 
 def _child_n_devices_price_what_one_device_prices(rank_counts):
@@ -75,6 +81,8 @@ def _child_n_devices_price_what_one_device_prices(rank_counts):
     cv0 = _hip.european_cv(S, K, T, r, v, 0.01, False, N, M, seed, True)
     sv, shift = ol.monte_carlo.sobol_tables(32, 42, 1 << 20)
     q0 = _hip.european_qmc(S, K, T, r, v, 0.0, True, 1 << 20, sv, shift)
+    qg0, _ = _hip.european_qmc_greeks_fd(S, K, T, r, v, 0.0, True, 1 << 20, sv, shift, True, want_evals=False)
+    qc0 = _hip.european_qmc_cv(S, K, T, r, v, 0.01, False, 1 << 20, sv, shift)
     for n_gpus in rank_counts:
         for launch in (0, -1):                          # launcher threads, then the serial form: the same bits
             _hip.tune(_hip.TUNE_MULTI_LAUNCH, launch)
@@ -100,6 +108,10 @@ def _child_n_devices_price_what_one_device_prices(rank_counts):
                 assert cv.n == cv0.n and cv.value == pytest.approx(cv0.value, rel=1e-11)
                 q = _hip.multi_gpu_european_qmc(S, K, T, r, v, 0.0, True, 1 << 20, sv, shift, n_gpus)
                 assert q.n == q0.n and q.sum == pytest.approx(q0.sum, rel=1e-13) and q.price == pytest.approx(q0.price, rel=1e-13)
+                qg, _ = _hip.multi_gpu_european_qmc_greeks_fd(S, K, T, r, v, 0.0, True, 1 << 20, sv, shift, True, n_gpus, want_evals=False)
+                assert qg[0] == pytest.approx(qg0[0], rel=1e-13) and qg[1] == pytest.approx(qg0[1], abs=1e-9)
+                qc = _hip.multi_gpu_european_qmc_cv(S, K, T, r, v, 0.01, False, 1 << 20, sv, shift, n_gpus)
+                assert qc.n == qc0.n and qc.value == pytest.approx(qc0.value, rel=1e-11)
             finally:
                 _hip.tune(_hip.TUNE_MULTI_LAUNCH, 0)
     assert _hip.device_info()["device"] == 0            # the thread's library device came back

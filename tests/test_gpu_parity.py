@@ -922,6 +922,15 @@ def test_sharded_price_through_process_group_single_rank():
         qp, qse, qn = ol.sharding.qmc_sharded(*ATM, "call", 0.0, 1 << 15, 16, 42)          # Sobol points through the same helpers (device kernel)
         qwant = ol.MonteCarloPricer(1 << 15, 16, 42, ol.MCMethod.QMC).price(*ATM, "call", return_error=True)
         assert (qp, qn) == (qwant.price, qwant.n_paths) and qse == pytest.approx(qwant.std_error, rel=1e-12)
+        qpricer = ol.MonteCarloPricer(1 << 15, 16, 42, ol.MCMethod.QMC)
+        for second in (False, True):                                                    # Sobol Greeks and control variate through the same helpers
+            got = ol.sharding.qmc_greeks_sharded(*ATM, "call", 0.0, 1 << 15, 16, 42, include_second_order=second)
+            want = qpricer.greeks(*ATM, "call", include_second_order=second)
+            assert list(got) == list(want)
+            for key in want:
+                assert got[key] == pytest.approx(want[key], rel=1e-9, abs=1e-9), key
+        assert ol.sharding.qmc_control_variate_sharded(*ATM, "call", 0.0, 1 << 15, 16, 42) == pytest.approx(
+            qpricer.price_with_control_variate(*ATM, "call"), rel=1e-12)
     finally:
         dist.destroy_process_group()
 

@@ -60,6 +60,42 @@ def _oracle_qmc_shard(lo, n_local):
     return _Triple(float(x.sum()), float((x * x).sum()), n_local)
 
 
+def _oracle_qmc_batch(contracts, is_call, lo, n_local, n_steps, seed, antithetic):
+    """Stand-in for the device's fused Sobol contracts: every bumped contract on the points [lo, lo + n_local) of the oracle's sequence."""
+    import warnings
+
+    import numpy as np
+
+    from oracle import numpy_reference as orc
+    assert antithetic is False
+    out = []
+    for (S, K, T, r, v, q) in contracts:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            st = orc.terminal_sobol(S, T, r, v, q, QMC_N, n_steps, seed)[lo:lo + n_local]
+        x = np.maximum(st - K, 0.0) if is_call else np.maximum(K - st, 0.0)
+        out.append((float(x.sum()), float((x * x).sum()), n_local))
+    return out
+
+
+class _Cv:
+    def __init__(self, d, s, n):
+        self.sum_d, self.sum_s, self.sum_dd, self.sum_ss, self.sum_ds, self.n = float(d.sum()), float(s.sum()), float((d * d).sum()), float((s * s).sum()), float((d * s).sum()), n
+
+
+def _oracle_qmc_cv_shard(lo, n_local):
+    import warnings
+
+    import numpy as np
+
+    from oracle import numpy_reference as orc
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        st = orc.terminal_sobol(ARGS["S"], ARGS["T"], ARGS["r"], ARGS["sigma"], ARGS["q"], QMC_N, QMC_M, SEED)[lo:lo + n_local]
+    d = math.exp(-ARGS["r"] * ARGS["T"]) * np.maximum(st - ARGS["K"], 0.0)
+    return _Cv(d, st, n_local)
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     import torch
@@ -89,8 +125,12 @@ def _worker(rank, world, port, out_dir):
     # oracle -- SciPy's own engine -- stands in for the device kernel's point offset)
     qmc = sharding.qmc_sharded(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], "call", ARGS["q"], QMC_N, QMC_M, SEED,
                                shard_fn=_oracle_qmc_shard)
+    qmc_greeks = sharding.qmc_greeks_sharded(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], "call", ARGS["q"], QMC_N, QMC_M, SEED,
+                                             batch_fn=_oracle_qmc_batch)
+    qmc_cv = sharding.qmc_control_variate_sharded(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], "call", ARGS["q"], QMC_N, QMC_M, SEED,
+                                                  shard_fn=_oracle_qmc_cv_shard)
     with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
-        f.write(repr((lo, hi, price, se, int(t[2].item()), dict(greeks), cv, asian, qmc)))
+        f.write(repr((lo, hi, price, se, int(t[2].item()), dict(greeks), cv, asian, qmc, dict(qmc_greeks), qmc_cv)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -146,6 +186,23 @@ def test_two_rank_gloo_allreduce_reproduces_unsharded_price(tmp_path):
                                      shard_fn=_oracle_qmc_shard)                  # world = 1: the whole sequence in one block
     assert got[0][8][2] == whole_qmc[2] == QMC_N and got[0][8][0] == pytest.approx(whole_qmc[0], rel=1e-13) and got[0][8][1] == pytest.approx(whole_qmc[1], rel=1e-10)
     assert abs(whole_qmc[0] - 10.450583572185565) < 0.5
+    # Sobol Greeks and control variate over two ranks == the same helpers over one (world = 1 here), == the oracle's own pricer
+    assert got[0][9] == got[1][9] and got[0][10] == got[1][10]
+    whole_greeks = sharding.qmc_greeks_sharded(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], "call", ARGS["q"], QMC_N, QMC_M, SEED,
+                                               batch_fn=_oracle_qmc_batch)
+    assert list(got[0][9]) == list(whole_greeks)
+    for key, want in whole_greeks.items():
+        assert got[0][9][key] == pytest.approx(want, rel=1e-9, abs=1e-9), key
+    from oracle import numpy_reference as orc
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref_cv = orc.OraclePricer(QMC_N, QMC_M, SEED, "qmc").price_with_control_variate(ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], "call", ARGS["q"])
+        ref_greeks = orc.fd_greeks(orc.OraclePricer(QMC_N, QMC_M, SEED, "qmc").price, ARGS["S"], ARGS["K"], ARGS["T"], ARGS["r"], ARGS["sigma"], "call", ARGS["q"],
+                                   include_second_order=True)
+    assert got[0][10] == pytest.approx(ref_cv, rel=1e-10)
+    for key, want in ref_greeks.items():
+        assert got[0][9][key] == pytest.approx(want, rel=1e-7, abs=1e-7), key
 
 
 def test_finalize_matches_reference_formula():

@@ -1139,28 +1139,31 @@ def single_process_child(args):
     S, K, T, r, sigma, q = (WORK[k] for k in ("S", "K", "T", "r", "sigma", "q"))
     bs = ol.black_scholes(S, K, T, r, sigma, "call", q)
     step = lambda k: _hip.multi_gpu_european(S, K, T, r, sigma, q, True, n_global, N_STEPS, SEED + k, True, n_gpus)
-    t0 = time.perf_counter()
-    first = step(0)
-    setup_s = time.perf_counter() - t0                  # contexts, rank streams, ncclCommInitAll
-    for k in range(max(args.warmup, 20)):
-        step(1000 + k)
-    passes, worst, spans = [], 0.0, []
-    while len(passes) < 3 or (sum(passes) < 0.5 and len(passes) < 200):
+    try:                                                # the threaded form has never run on more than one real GPU: if it fails, the serial form below still reports
         t0 = time.perf_counter()
-        res = [step(len(passes) * args.steps + k) for k in range(args.steps)]
-        passes.append(time.perf_counter() - t0)
-        spans.append(_hip.multi_gpu_spans())              # host spans of the pass's last call (olmc_multi_gpu_spans)
-        for st in res:
-            assert st.n == 2 * n_global
-            worst = max(worst, abs(st.price - bs) / st.std_error)
-    med = statistics.median(passes)
-    span = {k: round(statistics.median(sp[k] for sp in spans), 2) for k in spans[0]}
-    out = {"value": n_global * N_STEPS * args.steps / med, "unit": "path-steps/s", "ms_per_step": med / args.steps * 1e3, "n_gpus": n_gpus, "paths_per_gpu": per_gpu,
-           "global_paths": n_global, "steps": args.steps, "passes": len(passes), "max_abs_err_over_sigma": worst, "first_call_s": setup_s, "price": first.price,
-           "enqueue_us": span["launch_us"], "spans_us": span,
-           "what": "olmc_multi_gpu_european: one process, a launcher thread and a stream per device (every rank's kernel queued at once), ONE grouped "
-                   "RCCL all-reduce of (sum, sumsq, n) per blocking pricing, result by rank 0's polled completion word; no torch.  enqueue_us = host "
-                   "time from posting the launch to the last rank's kernel being queued"}
+        first = step(0)
+        setup_s = time.perf_counter() - t0                  # contexts, rank streams, ncclCommInitAll
+        for k in range(max(args.warmup, 20)):
+            step(1000 + k)
+        passes, worst, spans = [], 0.0, []
+        while len(passes) < 3 or (sum(passes) < 0.5 and len(passes) < 200):
+            t0 = time.perf_counter()
+            res = [step(len(passes) * args.steps + k) for k in range(args.steps)]
+            passes.append(time.perf_counter() - t0)
+            spans.append(_hip.multi_gpu_spans())              # host spans of the pass's last call (olmc_multi_gpu_spans)
+            for st in res:
+                assert st.n == 2 * n_global
+                worst = max(worst, abs(st.price - bs) / st.std_error)
+        med = statistics.median(passes)
+        span = {k: round(statistics.median(sp[k] for sp in spans), 2) for k in spans[0]}
+        out = {"value": n_global * N_STEPS * args.steps / med, "unit": "path-steps/s", "ms_per_step": med / args.steps * 1e3, "n_gpus": n_gpus, "paths_per_gpu": per_gpu,
+               "global_paths": n_global, "steps": args.steps, "passes": len(passes), "max_abs_err_over_sigma": worst, "first_call_s": setup_s, "price": first.price,
+               "enqueue_us": span["launch_us"], "spans_us": span,
+               "what": "olmc_multi_gpu_european: one process, a launcher thread and a stream per device (every rank's kernel queued at once), ONE grouped "
+                       "RCCL all-reduce of (sum, sumsq, n) per blocking pricing, result by rank 0's polled completion word; no torch.  enqueue_us = host "
+                       "time from posting the launch to the last rank's kernel being queued"}
+    except Exception as e:
+        out = {"n_gpus": n_gpus, "paths_per_gpu": per_gpu, "errors": [f"launcher-thread form: {type(e).__name__}: {e}"]}
     # the serial form of the launch phase beside it (round 4's: the calling thread queues the ranks one after the other), so that the
     # first run on real multi-GPU hardware carries its own A/B; with one rank the two forms are the same code
     if n_gpus > 1:
@@ -1195,7 +1198,7 @@ def single_process_child(args):
                 ts.append(time.perf_counter() - t0)
             out[name] = {"ms_per_call": statistics.median(ts) * 1e3, "path_steps_per_s": PATHS_PER_GPU * n_gpus * N_STEPS / statistics.median(ts)}
     except Exception as e:
-        out["errors"] = [f"{type(e).__name__}: {e}"]
+        out.setdefault("errors", []).append(f"{type(e).__name__}: {e}")
     print(json.dumps(out), flush=True)
     _hip.shutdown()
     return 0

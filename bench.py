@@ -1139,6 +1139,33 @@ def single_process_child(args):
     S, K, T, r, sigma, q = (WORK[k] for k in ("S", "K", "T", "r", "sigma", "q"))
     bs = ol.black_scholes(S, K, T, r, sigma, "call", q)
     step = lambda k: _hip.multi_gpu_european(S, K, T, r, sigma, q, True, n_global, N_STEPS, SEED + k, True, n_gpus)
+    # N > 1 has never run on real multi-GPU hardware, so the child reports in STAGES, a JSON line after each (the parent takes the
+    # last one, also from a child it had to kill): first the serial form of the launch phase (round 4's: the calling thread queues the
+    # ranks one after the other), then the launcher-thread form (the default), then the other payloads.  With one rank the two
+    # forms are the same code.
+    out = {"n_gpus": n_gpus, "paths_per_gpu": per_gpu, "global_paths": n_global}
+    if n_gpus > 1:
+        try:
+            _hip.tune(_hip.TUNE_MULTI_LAUNCH, -1)
+            t0 = time.perf_counter()
+            step(2000)
+            serial_setup_s = time.perf_counter() - t0
+            for k in range(10):
+                step(2001 + k)
+            sp, ssp = [], []
+            for p_ in range(5):
+                t0 = time.perf_counter()
+                for k in range(args.steps):
+                    step(3000 + p_ * args.steps + k)
+                sp.append(time.perf_counter() - t0)
+                ssp.append(_hip.multi_gpu_spans())
+            out["serial_launch_form"] = {"ms_per_step": statistics.median(sp) / args.steps * 1e3, "value": n_global * N_STEPS * args.steps / statistics.median(sp),
+                                         "first_call_s": serial_setup_s, "spans_us": {k: round(statistics.median(x[k] for x in ssp), 2) for k in ssp[0]}}
+        except Exception as e:
+            out["serial_launch_form"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            _hip.tune(_hip.TUNE_MULTI_LAUNCH, 0)
+        print(json.dumps({**out, "partial": "stage 1 of 3: the launcher-thread form had not reported when this line was taken"}), flush=True)
     try:                                                # the threaded form has never run on more than one real GPU: if it fails, the serial form below still reports
         t0 = time.perf_counter()
         first = step(0)
@@ -1156,34 +1183,16 @@ def single_process_child(args):
                 worst = max(worst, abs(st.price - bs) / st.std_error)
         med = statistics.median(passes)
         span = {k: round(statistics.median(sp[k] for sp in spans), 2) for k in spans[0]}
-        out = {"value": n_global * N_STEPS * args.steps / med, "unit": "path-steps/s", "ms_per_step": med / args.steps * 1e3, "n_gpus": n_gpus, "paths_per_gpu": per_gpu,
+        out.update({"value": n_global * N_STEPS * args.steps / med, "unit": "path-steps/s", "ms_per_step": med / args.steps * 1e3, "n_gpus": n_gpus, "paths_per_gpu": per_gpu,
                "global_paths": n_global, "steps": args.steps, "passes": len(passes), "max_abs_err_over_sigma": worst, "first_call_s": setup_s, "price": first.price,
                "enqueue_us": span["launch_us"], "spans_us": span,
                "what": "olmc_multi_gpu_european: one process, a launcher thread and a stream per device (every rank's kernel queued at once), ONE grouped "
                        "RCCL all-reduce of (sum, sumsq, n) per blocking pricing, result by rank 0's polled completion word; no torch.  enqueue_us = host "
-                       "time from posting the launch to the last rank's kernel being queued"}
+                       "time from posting the launch to the last rank's kernel being queued"})
     except Exception as e:
-        out = {"n_gpus": n_gpus, "paths_per_gpu": per_gpu, "errors": [f"launcher-thread form: {type(e).__name__}: {e}"]}
-    # the serial form of the launch phase beside it (round 4's: the calling thread queues the ranks one after the other), so that the
-    # first run on real multi-GPU hardware carries its own A/B; with one rank the two forms are the same code
+        out.setdefault("errors", []).append(f"launcher-thread form: {type(e).__name__}: {e}")
     if n_gpus > 1:
-        try:
-            _hip.tune(_hip.TUNE_MULTI_LAUNCH, -1)
-            for k in range(10):
-                step(2000 + k)
-            sp, ssp = [], []
-            for p_ in range(5):
-                t0 = time.perf_counter()
-                for k in range(args.steps):
-                    step(3000 + p_ * args.steps + k)
-                sp.append(time.perf_counter() - t0)
-                ssp.append(_hip.multi_gpu_spans())
-            out["serial_launch_form"] = {"ms_per_step": statistics.median(sp) / args.steps * 1e3,
-                                         "spans_us": {k: round(statistics.median(x[k] for x in ssp), 2) for k in ssp[0]}}
-        except Exception as e:
-            out["serial_launch_form"] = {"error": f"{type(e).__name__}: {e}"}
-        finally:
-            _hip.tune(_hip.TUNE_MULTI_LAUNCH, 0)
+        print(json.dumps({**out, "partial": "stage 2 of 3: the Greeks / control-variate payloads had not reported when this line was taken"}), flush=True)
     # the other two payloads of the same engine (count 33 and 6), at 1M paths per GPU
     try:
         g = lambda: _hip.multi_gpu_greeks_fd(S, K, T, r, sigma, q, True, PATHS_PER_GPU * n_gpus, N_STEPS, SEED, True, n_gpus, want_evals=False)
@@ -1234,10 +1243,21 @@ def c5_single_process(child, dist, use_dist, rehearsal, world, rank, gloo_group)
             res = {"error": "the child was not started"}
         else:
             try:
-                out, err = child.communicate("go\n", timeout=240)
+                try:
+                    out, err = child.communicate("go\n", timeout=240)
+                    timed_out = False
+                except subprocess.TimeoutExpired:
+                    child.kill()                                    # this child, by its handle
+                    out, err = child.communicate()                  # what it had printed: the child reports in stages
+                    timed_out = True
                 line = next((l for l in reversed(out.splitlines()) if l.startswith("{")), None)
-                res = json.loads(line) if (child.returncode == 0 and line) else {"error": f"child rc {child.returncode}: {(err or out)[-300:]}"}
-            except (OSError, subprocess.TimeoutExpired, ValueError) as e:
+                if line and (timed_out or child.returncode == 0):
+                    res = json.loads(line)
+                    if timed_out:
+                        res.setdefault("errors", []).append("the child did not finish within 240 s and was killed; " + str(res.get("partial", "")))
+                else:
+                    res = {"error": f"child rc {child.returncode}{' (killed after 240 s)' if timed_out else ''}: {(err or out)[-300:]}"}
+            except (OSError, ValueError) as e:
                 child.kill()
                 res = {"error": f"{type(e).__name__}: {e}"}
     cpu_barrier()
